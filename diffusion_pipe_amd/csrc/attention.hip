@@ -1,0 +1,487 @@
+// attention.hip -- K4: flash-style scaled-dot-product attention, forward + backward, bf16 on the CDNA4 matrix cores.
+//
+// Replaces flash_attn_varlen_func / SDPA of models/wan/attention.py:91-122,159-174, the diffusers attention
+// processors behind models/sdxl.py:797-865 and the joint attention of utils/patches.py:325-340.
+//
+// Layout: q [B, Sq, H, D], k/v [B, Sk, H, D], o [B, Sq, H, D] (head dim contiguous, D in {64, 128});
+// lse [B, H, Sq] fp32 (natural log).  Non-causal; optional per-batch valid key count.
+//
+// MI355X design.  Everything is built from v_mfma_f32_32x32x16_bf16 with the *transposed* score tile
+// S^T = K . Q^T, so that each lane owns one query column of the 32x32 accumulator: running max / sum and the
+// rescale of O^T are lane-local (one cross-lane exchange with lane^32 per row reduction), and the exponentiated
+// tile is already in MFMA B-operand order for O^T += V^T . P^T -- no LDS round trip, no permutes.  V^T (and K^T,
+// Q^T, dO^T in the backward) fragments come from row-major LDS tiles through the hardware transpose read
+// ds_read_b64_tr_b16.  K/V tiles are staged global -> registers -> LDS with 16-byte accesses, the next tile's
+// loads being issued before the current tile's MFMAs.  Backward = three kernels without atomics (deterministic):
+// delta = rowsum(dO * O); a query-outer kernel for dQ; a key-outer kernel for dK and dV.
+#include "dpipe_common.h"
+#include "../../include/dpipe_hip.h"
+
+using namespace dpipe;
+
+namespace {
+
+typedef __attribute__((address_space(3))) bf16x4_t lds_bf16x4_t;
+
+struct AttnParams {
+    const bf16_t *q, *k, *v, *o, *dout;
+    bf16_t *out, *dq, *dk, *dv;
+    float* lse; float* delta; const int* kv_len;
+    int B, H, Sq, Sk;
+    long q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, o_sb, o_ss, o_sh;
+    long do_sb, do_ss, do_sh, dq_sb, dq_ss, dq_sh, dk_sb, dk_ss, dk_sh, dv_sb, dv_ss, dv_sh;
+    float scale;
+};
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+__device__ __forceinline__ f32x16 mfma16(bf16x8_t a, bf16x8_t b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_mfma, a), __builtin_bit_cast(bf16x8_mfma, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) z[e] = 0.f;
+    return z;
+}
+__device__ __forceinline__ bf16x8_t zero_frag() {
+    bf16x8_t z;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = 0;
+    return z;
+}
+// 8 consecutive accumulator entries (e0 .. e0+7) -> bf16 MFMA operand
+__device__ __forceinline__ bf16x8_t pack_frag(const f32x16& s, int e0) {
+    uint4 u;
+    u.x = pack_bf16x2(s[e0 + 0], s[e0 + 1]); u.y = pack_bf16x2(s[e0 + 2], s[e0 + 3]);
+    u.z = pack_bf16x2(s[e0 + 4], s[e0 + 5]); u.w = pack_bf16x2(s[e0 + 6], s[e0 + 7]);
+    return __builtin_bit_cast(bf16x8_t, u);
+}
+
+// ---- LDS tiles: `ROWS` rows of D bf16, row stride RS bytes ------------------------------------------------------
+// A/B fragment with the K index along the row (contiguous): lane (i, h) reads 8 bf16 at (row0 + i, col + 8h).
+template <int RS>
+__device__ __forceinline__ bf16x8_t frag_rows(const char* tile, int row0, int col, int lane) {
+    return *reinterpret_cast<const bf16x8_t*>(tile + (row0 + (lane & 31)) * RS + (col + 8 * (lane >> 5)) * 2);
+}
+// A fragment of the TRANSPOSED tile: MFMA row = tile column (col0 + i), MFMA k = tile rows
+// {r0 + 4h + 0..3, r0 + 8 + 4h + 0..3} -- exactly the row set a lane holds in entries 8u..8u+7 of a 32x32 accumulator.
+template <int RS>
+__device__ __forceinline__ bf16x8_t frag_cols_tr(const char* tile, int r0, int col0, int lane) {
+    const int t = lane & 15, g = lane >> 4;
+    const char* p = tile + (r0 + 4 * (g >> 1) + (t >> 2)) * RS + (col0 + 16 * (g & 1) + 4 * (t & 3)) * 2;
+    bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(p));
+    bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(p + 8 * RS));
+    bf16x8_t out;
+    out[0] = lo[0]; out[1] = lo[1]; out[2] = lo[2]; out[3] = lo[3];
+    out[4] = hi[0]; out[5] = hi[1]; out[6] = hi[2]; out[7] = hi[3];
+    return out;
+}
+
+template <int N> struct RowRegs { uint4 v[N]; };
+
+// Stage a [ROWS][D] tile: rows row0.. of a [*, D] matrix with row stride `ss` elements; rows >= limit read as zero.
+template <int D, int ROWS, int NT>
+__device__ __forceinline__ void load_rows(RowRegs<ROWS * (D / 8) / NT>& r, const bf16_t* __restrict__ base, long ss, int row0, int limit) {
+    constexpr int CPR = D / 8;
+#pragma unroll
+    for (int i = 0; i < ROWS * CPR / NT; ++i) {
+        const int v = threadIdx.x + i * NT;
+        const int row = v / CPR, c = v % CPR;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (row0 + row < limit) val = *reinterpret_cast<const uint4*>(base + (long)(row0 + row) * ss + c * 8);
+        r.v[i] = val;
+    }
+}
+template <int D, int ROWS, int NT, int RS>
+__device__ __forceinline__ void store_rows(const RowRegs<ROWS * (D / 8) / NT>& r, char* tile) {
+    constexpr int CPR = D / 8;
+#pragma unroll
+    for (int i = 0; i < ROWS * CPR / NT; ++i) {
+        const int v = threadIdx.x + i * NT;
+        *reinterpret_cast<uint4*>(tile + (v / CPR) * RS + (v % CPR) * 16) = r.v[i];
+    }
+}
+
+// ================================================================================================ forward
+template <int D, int NW>
+__global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnParams p) {
+    constexpr int NT = NW * 64, KT = 64;
+    constexpr int KRS = 2 * D + 16;   // K tile: row reads (ds_read_b128), conflict-free with a 16 B pad
+    constexpr int VRS = 2 * D + 64;   // V tile: transpose reads, 4 rows x 64 B windows tile the 256 B bank row
+    __shared__ __attribute__((aligned(16))) char lds[KT * KRS + KT * VRS];
+    char* Kl = lds; char* Vl = lds + KT * KRS;
+
+    const int b = blockIdx.z, hh = blockIdx.y;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+    const int qrow = blockIdx.x * 32 * NW + wid * 32 + i;
+    const int kvl = p.kv_len ? min(p.kv_len[b], p.Sk) : p.Sk;
+    const bf16_t* Q = p.q + b * p.q_sb + hh * p.q_sh;
+    const bf16_t* K = p.k + b * p.k_sb + hh * p.k_sh;
+    const bf16_t* V = p.v + b * p.v_sb + hh * p.v_sh;
+    const float sl2 = p.scale * LOG2E;
+
+    bf16x8_t qf[D / 16];
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks)
+        qf[ks] = qrow < p.Sq ? *reinterpret_cast<const bf16x8_t*>(Q + (long)qrow * p.q_ss + 16 * ks + 8 * h) : zero_frag();
+
+    f32x16 oacc[D / 32];
+#pragma unroll
+    for (int db = 0; db < D / 32; ++db) oacc[db] = zero16();
+    float m = -INFINITY, l = 0.f;
+
+    const int nkt = (kvl + KT - 1) / KT;
+    RowRegs<KT * (D / 8) / NT> rk, rv;
+    load_rows<D, KT, NT>(rk, K, p.k_ss, 0, kvl);
+    load_rows<D, KT, NT>(rv, V, p.v_ss, 0, kvl);
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        store_rows<D, KT, NT, KRS>(rk, Kl);
+        store_rows<D, KT, NT, VRS>(rv, Vl);
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            load_rows<D, KT, NT>(rk, K, p.k_ss, (kt + 1) * KT, kvl);
+            load_rows<D, KT, NT>(rv, V, p.v_ss, (kt + 1) * KT, kvl);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int key0 = kt * KT + 32 * kb;
+            if (key0 >= kvl) break;                     // wave-uniform: nothing valid in this 32-key block
+            f32x16 s = zero16();
+#pragma unroll
+            for (int ks = 0; ks < D / 16; ++ks) s = mfma16(frag_rows<KRS>(Kl, 32 * kb, 16 * ks, lane), qf[ks], s);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const float v = key < kvl ? s[e] * sl2 : -INFINITY;
+                s[e] = v; mx = fmaxf(mx, v);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m, mx);              // finite: key0 < kvl guarantees one valid key per row
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+            float rs = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { const float pe = __builtin_amdgcn_exp2f(s[e] - m_new); s[e] = pe; rs += pe; }
+            rs += __shfl_xor(rs, 32, 64);
+            l = l * alpha + rs; m = m_new;
+#pragma unroll
+            for (int db = 0; db < D / 32; ++db)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
+            const bf16x8_t pf0 = pack_frag(s, 0), pf1 = pack_frag(s, 8);
+#pragma unroll
+            for (int db = 0; db < D / 32; ++db) {
+                oacc[db] = mfma16(frag_cols_tr<VRS>(Vl, 32 * kb, 32 * db, lane), pf0, oacc[db]);
+                oacc[db] = mfma16(frag_cols_tr<VRS>(Vl, 32 * kb + 16, 32 * db, lane), pf1, oacc[db]);
+            }
+        }
+    }
+
+    if (qrow < p.Sq) {
+        const float inv = 1.f / l;
+        bf16_t* O = p.out + b * p.o_sb + hh * p.o_sh + (long)qrow * p.o_ss;
+#pragma unroll
+        for (int db = 0; db < D / 32; ++db)
+#pragma unroll
+            for (int eg = 0; eg < 4; ++eg) {
+                uint2 w;
+                w.x = pack_bf16x2(oacc[db][4 * eg] * inv, oacc[db][4 * eg + 1] * inv);
+                w.y = pack_bf16x2(oacc[db][4 * eg + 2] * inv, oacc[db][4 * eg + 3] * inv);
+                *reinterpret_cast<uint2*>(O + 32 * db + 8 * eg + 4 * h) = w;
+            }
+        if (h == 0) p.lse[((long)b * p.H + hh) * p.Sq + qrow] = (m + __builtin_amdgcn_logf(l)) * LN2;   // v_log_f32 = log2
+    }
+}
+
+// ================================================================================================ backward: delta
+// delta[b, h, q] = sum_d dO[b, q, h, d] * O[b, q, h, d]      16 lanes per row
+template <int D>
+__global__ void __launch_bounds__(256) attn_delta_kernel(const AttnParams p) {
+    const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int sub = threadIdx.x & 15;
+    const long total = (long)p.B * p.H * p.Sq;
+    const bool live = row < total;
+    const long r = live ? row : 0;
+    const int q = (int)(r % p.Sq); const int hh = (int)((r / p.Sq) % p.H); const int b = (int)(r / ((long)p.Sq * p.H));
+    const bf16_t* o = p.o + b * p.o_sb + hh * p.o_sh + (long)q * p.o_ss;
+    const bf16_t* d = p.dout + b * p.do_sb + hh * p.do_sh + (long)q * p.do_ss;
+    float acc = 0.f;
+    constexpr int PER = D / 16;   // 8 (one uint4) or 4 (one uint2)
+    if (PER == 8) {
+        Vec16<bf16_t> vo, vd; vo.load(o + sub * 8); vd.load(d + sub * 8);
+        float fo[8], fd[8]; vo.unpack(fo); vd.unpack(fd);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += fo[j] * fd[j];
+    } else {
+        const uint2 uo = *reinterpret_cast<const uint2*>(o + sub * 4), ud = *reinterpret_cast<const uint2*>(d + sub * 4);
+        acc += __uint_as_float(uo.x << 16) * __uint_as_float(ud.x << 16) + __uint_as_float(uo.x & 0xffff0000u) * __uint_as_float(ud.x & 0xffff0000u);
+        acc += __uint_as_float(uo.y << 16) * __uint_as_float(ud.y << 16) + __uint_as_float(uo.y & 0xffff0000u) * __uint_as_float(ud.y & 0xffff0000u);
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (live && sub == 0) p.delta[r] = acc;   // delta is [B, H, Sq] contiguous and r enumerates it in that order
+}
+
+// ================================================================================================ backward: dQ
+// Query-outer.  dQ^T[d][q] += K^T[d][key] . dS^T[key][q],   dS^T = P^T o (dP^T - delta[q]),  dP^T = V . dO^T
+template <int D, int NW>
+__global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(const AttnParams p) {
+    constexpr int NT = NW * 64, KT = 64;
+    constexpr int KRS = 2 * D + 16, VRS = 2 * D + 16;
+    __shared__ __attribute__((aligned(16))) char lds[KT * KRS + KT * VRS];
+    char* Kl = lds; char* Vl = lds + KT * KRS;
+
+    const int b = blockIdx.z, hh = blockIdx.y;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+    const int qrow = blockIdx.x * 32 * NW + wid * 32 + i;
+    const bool qlive = qrow < p.Sq;
+    const int kvl = p.kv_len ? min(p.kv_len[b], p.Sk) : p.Sk;
+    const bf16_t* Q = p.q + b * p.q_sb + hh * p.q_sh;
+    const bf16_t* K = p.k + b * p.k_sb + hh * p.k_sh;
+    const bf16_t* V = p.v + b * p.v_sb + hh * p.v_sh;
+    const bf16_t* DO = p.dout + b * p.do_sb + hh * p.do_sh;
+    const float sl2 = p.scale * LOG2E;
+
+    bf16x8_t qf[D / 16], dof[D / 16];
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) {
+        qf[ks] = qlive ? *reinterpret_cast<const bf16x8_t*>(Q + (long)qrow * p.q_ss + 16 * ks + 8 * h) : zero_frag();
+        dof[ks] = qlive ? *reinterpret_cast<const bf16x8_t*>(DO + (long)qrow * p.do_ss + 16 * ks + 8 * h) : zero_frag();
+    }
+    const long stat = ((long)b * p.H + hh) * p.Sq + (qlive ? qrow : 0);
+    const float lse2 = qlive ? p.lse[stat] * LOG2E : INFINITY;
+    const float dl = qlive ? p.delta[stat] : 0.f;
+
+    f32x16 dqacc[D / 32];
+#pragma unroll
+    for (int db = 0; db < D / 32; ++db) dqacc[db] = zero16();
+
+    const int nkt = (kvl + KT - 1) / KT;
+    RowRegs<KT * (D / 8) / NT> rk, rv;
+    load_rows<D, KT, NT>(rk, K, p.k_ss, 0, kvl);
+    load_rows<D, KT, NT>(rv, V, p.v_ss, 0, kvl);
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        store_rows<D, KT, NT, KRS>(rk, Kl);
+        store_rows<D, KT, NT, VRS>(rv, Vl);
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            load_rows<D, KT, NT>(rk, K, p.k_ss, (kt + 1) * KT, kvl);
+            load_rows<D, KT, NT>(rv, V, p.v_ss, (kt + 1) * KT, kvl);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int key0 = kt * KT + 32 * kb;
+            if (key0 >= kvl) break;
+            f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+            for (int ks = 0; ks < D / 16; ++ks) {
+                s = mfma16(frag_rows<KRS>(Kl, 32 * kb, 16 * ks, lane), qf[ks], s);
+                dp = mfma16(frag_rows<VRS>(Vl, 32 * kb, 16 * ks, lane), dof[ks], dp);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const float pe = key < kvl ? __builtin_amdgcn_exp2f(s[e] * sl2 - lse2) : 0.f;
+                s[e] = pe * (dp[e] - dl);
+            }
+            const bf16x8_t ds0 = pack_frag(s, 0), ds1 = pack_frag(s, 8);
+#pragma unroll
+            for (int db = 0; db < D / 32; ++db) {
+                dqacc[db] = mfma16(frag_cols_tr<KRS>(Kl, 32 * kb, 32 * db, lane), ds0, dqacc[db]);
+                dqacc[db] = mfma16(frag_cols_tr<KRS>(Kl, 32 * kb + 16, 32 * db, lane), ds1, dqacc[db]);
+            }
+        }
+    }
+    if (qlive) {
+        bf16_t* DQ = p.dq + b * p.dq_sb + hh * p.dq_sh + (long)qrow * p.dq_ss;
+#pragma unroll
+        for (int db = 0; db < D / 32; ++db)
+#pragma unroll
+            for (int eg = 0; eg < 4; ++eg) {
+                uint2 w;
+                w.x = pack_bf16x2(dqacc[db][4 * eg] * p.scale, dqacc[db][4 * eg + 1] * p.scale);
+                w.y = pack_bf16x2(dqacc[db][4 * eg + 2] * p.scale, dqacc[db][4 * eg + 3] * p.scale);
+                *reinterpret_cast<uint2*>(DQ + 32 * db + 8 * eg + 4 * h) = w;
+            }
+    }
+}
+
+// ================================================================================================ backward: dK, dV
+// Key-outer.  S[q][key] = Q . K^T (lane owns one key column);  dV^T[d][key] += dO^T[d][q] . P[q][key];
+// dK^T[d][key] += Q^T[d][q] . dS[q][key]
+template <int D, int NW>
+__global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(const AttnParams p) {
+    constexpr int NT = NW * 64, QT = 64;
+    constexpr int QRS = 2 * D + 16;
+    __shared__ __attribute__((aligned(16))) char lds[2 * QT * QRS + 2 * QT * 4];
+    char* Ql = lds; char* DOl = lds + QT * QRS;
+    float* lse_l = reinterpret_cast<float*>(lds + 2 * QT * QRS);
+    float* dl_l = lse_l + QT;
+
+    const int b = blockIdx.z, hh = blockIdx.y;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+    const int key = blockIdx.x * 32 * NW + wid * 32 + i;
+    const int kvl = p.kv_len ? min(p.kv_len[b], p.Sk) : p.Sk;
+    const bool klive = key < kvl;
+    const bf16_t* Q = p.q + b * p.q_sb + hh * p.q_sh;
+    const bf16_t* K = p.k + b * p.k_sb + hh * p.k_sh;
+    const bf16_t* V = p.v + b * p.v_sb + hh * p.v_sh;
+    const bf16_t* DO = p.dout + b * p.do_sb + hh * p.do_sh;
+    const float* LSE = p.lse + ((long)b * p.H + hh) * p.Sq;
+    const float* DL = p.delta + ((long)b * p.H + hh) * p.Sq;
+    const float sl2 = p.scale * LOG2E;
+
+    bf16x8_t kf[D / 16], vf[D / 16];
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) {
+        kf[ks] = klive ? *reinterpret_cast<const bf16x8_t*>(K + (long)key * p.k_ss + 16 * ks + 8 * h) : zero_frag();
+        vf[ks] = klive ? *reinterpret_cast<const bf16x8_t*>(V + (long)key * p.v_ss + 16 * ks + 8 * h) : zero_frag();
+    }
+    f32x16 dkacc[D / 32], dvacc[D / 32];
+#pragma unroll
+    for (int db = 0; db < D / 32; ++db) { dkacc[db] = zero16(); dvacc[db] = zero16(); }
+
+    const int nqt = (p.Sq + QT - 1) / QT;
+    RowRegs<QT * (D / 8) / NT> rq, rdo;
+    load_rows<D, QT, NT>(rq, Q, p.q_ss, 0, p.Sq);
+    load_rows<D, QT, NT>(rdo, DO, p.do_ss, 0, p.Sq);
+    float r_lse = 0.f, r_dl = 0.f;
+    if (threadIdx.x < QT) {
+        const int q = threadIdx.x;
+        r_lse = q < p.Sq ? LSE[q] * LOG2E : INFINITY; r_dl = q < p.Sq ? DL[q] : 0.f;
+    }
+    for (int qt = 0; qt < nqt; ++qt) {
+        __syncthreads();
+        store_rows<D, QT, NT, QRS>(rq, Ql);
+        store_rows<D, QT, NT, QRS>(rdo, DOl);
+        if (threadIdx.x < QT) { lse_l[threadIdx.x] = r_lse; dl_l[threadIdx.x] = r_dl; }
+        __syncthreads();
+        if (qt + 1 < nqt) {
+            load_rows<D, QT, NT>(rq, Q, p.q_ss, (qt + 1) * QT, p.Sq);
+            load_rows<D, QT, NT>(rdo, DO, p.do_ss, (qt + 1) * QT, p.Sq);
+            if (threadIdx.x < QT) {
+                const int q = (qt + 1) * QT + threadIdx.x;
+                r_lse = q < p.Sq ? LSE[q] * LOG2E : INFINITY; r_dl = q < p.Sq ? DL[q] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            if (qt * QT + 32 * qb >= p.Sq) break;
+            f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+            for (int ks = 0; ks < D / 16; ++ks) {
+                s = mfma16(frag_rows<QRS>(Ql, 32 * qb, 16 * ks, lane), kf[ks], s);
+                dp = mfma16(frag_rows<QRS>(DOl, 32 * qb, 16 * ks, lane), vf[ks], dp);
+            }
+            f32x16 pr;
+#pragma unroll
+            for (int eg = 0; eg < 4; ++eg) {
+                const float4 l4 = *reinterpret_cast<const float4*>(&lse_l[32 * qb + 8 * eg + 4 * h]);
+                const float4 d4 = *reinterpret_cast<const float4*>(&dl_l[32 * qb + 8 * eg + 4 * h]);
+                const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = 4 * eg + j;
+                    const float pe = klive ? __builtin_amdgcn_exp2f(s[e] * sl2 - ll[j]) : 0.f;
+                    pr[e] = pe; s[e] = pe * (dp[e] - dd[j]);
+                }
+            }
+            const bf16x8_t p0 = pack_frag(pr, 0), p1 = pack_frag(pr, 8), ds0 = pack_frag(s, 0), ds1 = pack_frag(s, 8);
+#pragma unroll
+            for (int db = 0; db < D / 32; ++db) {
+                dvacc[db] = mfma16(frag_cols_tr<QRS>(DOl, 32 * qb, 32 * db, lane), p0, dvacc[db]);
+                dvacc[db] = mfma16(frag_cols_tr<QRS>(DOl, 32 * qb + 16, 32 * db, lane), p1, dvacc[db]);
+                dkacc[db] = mfma16(frag_cols_tr<QRS>(Ql, 32 * qb, 32 * db, lane), ds0, dkacc[db]);
+                dkacc[db] = mfma16(frag_cols_tr<QRS>(Ql, 32 * qb + 16, 32 * db, lane), ds1, dkacc[db]);
+            }
+        }
+    }
+    if (key < p.Sk) {
+        bf16_t* DK = p.dk + b * p.dk_sb + hh * p.dk_sh + (long)key * p.dk_ss;
+        bf16_t* DV = p.dv + b * p.dv_sb + hh * p.dv_sh + (long)key * p.dv_ss;
+#pragma unroll
+        for (int db = 0; db < D / 32; ++db)
+#pragma unroll
+            for (int eg = 0; eg < 4; ++eg) {
+                uint2 wk, wv;
+                wk.x = pack_bf16x2(dkacc[db][4 * eg] * p.scale, dkacc[db][4 * eg + 1] * p.scale);
+                wk.y = pack_bf16x2(dkacc[db][4 * eg + 2] * p.scale, dkacc[db][4 * eg + 3] * p.scale);
+                wv.x = pack_bf16x2(dvacc[db][4 * eg], dvacc[db][4 * eg + 1]);
+                wv.y = pack_bf16x2(dvacc[db][4 * eg + 2], dvacc[db][4 * eg + 3]);
+                *reinterpret_cast<uint2*>(DK + 32 * db + 8 * eg + 4 * h) = wk;
+                *reinterpret_cast<uint2*>(DV + 32 * db + 8 * eg + 4 * h) = wv;
+            }
+    }
+}
+
+bool strides_ok(const void* ptr, long sb, long ss, long sh) {
+    return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0 && sb % 8 == 0 && ss % 8 == 0 && sh % 8 == 0;
+}
+
+}  // namespace
+
+#define STREAM(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" {
+
+int dpipe_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* kv_len, int B, int H,
+                   int Sq, int Sk, int D, long q_sb, long q_ss, long q_sh, long k_sb, long k_ss, long k_sh, long v_sb,
+                   long v_ss, long v_sh, long o_sb, long o_ss, long o_sh, float scale, void* stream) {
+    if (!q || !k || !v || !o || !lse || B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) { set_last_error("dpipe_attn_fwd: bad argument"); return DPIPE_ERR_ARG; }
+    if (D != 64 && D != 128) { set_last_error("dpipe_attn_fwd: head dim must be 64 or 128"); return DPIPE_ERR_UNSUPPORTED; }
+    if (!strides_ok(q, q_sb, q_ss, q_sh) || !strides_ok(k, k_sb, k_ss, k_sh) || !strides_ok(v, v_sb, v_ss, v_sh) || !strides_ok(o, o_sb, o_ss, o_sh)) {
+        set_last_error("dpipe_attn_fwd: tensors must be 16-byte aligned with strides multiple of 8 elements"); return DPIPE_ERR_ARG; }
+    AttnParams p = {};
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.out = (bf16_t*)o; p.lse = lse; p.kv_len = kv_len;
+    p.B = B; p.H = H; p.Sq = Sq; p.Sk = Sk; p.scale = scale;
+    p.q_sb = q_sb; p.q_ss = q_ss; p.q_sh = q_sh; p.k_sb = k_sb; p.k_ss = k_ss; p.k_sh = k_sh;
+    p.v_sb = v_sb; p.v_ss = v_ss; p.v_sh = v_sh; p.o_sb = o_sb; p.o_ss = o_ss; p.o_sh = o_sh;
+    constexpr int NW = 4;
+    dim3 grid((unsigned)cdiv(Sq, 32 * NW), (unsigned)H, (unsigned)B);
+    if (D == 64) attn_fwd_kernel<64, NW><<<grid, NW * 64, 0, STREAM(stream)>>>(p);
+    else attn_fwd_kernel<128, NW><<<grid, NW * 64, 0, STREAM(stream)>>>(p);
+    return check_launch("dpipe_attn_fwd");
+}
+
+int dpipe_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                   float* delta, void* dq, void* dk, void* dv, const int* kv_len, int B, int H, int Sq, int Sk, int D,
+                   long q_sb, long q_ss, long q_sh, long k_sb, long k_ss, long k_sh, long v_sb, long v_ss, long v_sh,
+                   long o_sb, long o_ss, long o_sh, long do_sb, long do_ss, long do_sh, long dq_sb, long dq_ss,
+                   long dq_sh, long dk_sb, long dk_ss, long dk_sh, long dv_sb, long dv_ss, long dv_sh, float scale,
+                   void* stream) {
+    if (!q || !k || !v || !o || !dout || !lse || !delta || !dq || !dk || !dv || B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) {
+        set_last_error("dpipe_attn_bwd: bad argument"); return DPIPE_ERR_ARG; }
+    if (D != 64 && D != 128) { set_last_error("dpipe_attn_bwd: head dim must be 64 or 128"); return DPIPE_ERR_UNSUPPORTED; }
+    if (!strides_ok(q, q_sb, q_ss, q_sh) || !strides_ok(k, k_sb, k_ss, k_sh) || !strides_ok(v, v_sb, v_ss, v_sh) || !strides_ok(o, o_sb, o_ss, o_sh) ||
+        !strides_ok(dout, do_sb, do_ss, do_sh) || !strides_ok(dq, dq_sb, dq_ss, dq_sh) || !strides_ok(dk, dk_sb, dk_ss, dk_sh) || !strides_ok(dv, dv_sb, dv_ss, dv_sh)) {
+        set_last_error("dpipe_attn_bwd: tensors must be 16-byte aligned with strides multiple of 8 elements"); return DPIPE_ERR_ARG; }
+    AttnParams p = {};
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (const bf16_t*)o; p.dout = (const bf16_t*)dout;
+    p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.lse = const_cast<float*>(lse); p.delta = delta; p.kv_len = kv_len;
+    p.B = B; p.H = H; p.Sq = Sq; p.Sk = Sk; p.scale = scale;
+    p.q_sb = q_sb; p.q_ss = q_ss; p.q_sh = q_sh; p.k_sb = k_sb; p.k_ss = k_ss; p.k_sh = k_sh;
+    p.v_sb = v_sb; p.v_ss = v_ss; p.v_sh = v_sh; p.o_sb = o_sb; p.o_ss = o_ss; p.o_sh = o_sh;
+    p.do_sb = do_sb; p.do_ss = do_ss; p.do_sh = do_sh; p.dq_sb = dq_sb; p.dq_ss = dq_ss; p.dq_sh = dq_sh;
+    p.dk_sb = dk_sb; p.dk_ss = dk_ss; p.dk_sh = dk_sh; p.dv_sb = dv_sb; p.dv_ss = dv_ss; p.dv_sh = dv_sh;
+    hipStream_t s = STREAM(stream);
+    constexpr int NW = 4;
+    const long rows = (long)B * H * Sq;
+    dim3 gq((unsigned)cdiv(Sq, 32 * NW), (unsigned)H, (unsigned)B), gk((unsigned)cdiv(Sk, 32 * NW), (unsigned)H, (unsigned)B);
+    if (D == 64) {
+        attn_delta_kernel<64><<<(unsigned)cdiv(rows, 16), 256, 0, s>>>(p);
+        attn_bwd_dq_kernel<64, NW><<<gq, NW * 64, 0, s>>>(p);
+        attn_bwd_dkv_kernel<64, NW><<<gk, NW * 64, 0, s>>>(p);
+    } else {
+        attn_delta_kernel<128><<<(unsigned)cdiv(rows, 16), 256, 0, s>>>(p);
+        attn_bwd_dq_kernel<128, NW><<<gq, NW * 64, 0, s>>>(p);
+        attn_bwd_dkv_kernel<128, NW><<<gk, NW * 64, 0, s>>>(p);
+    }
+    return check_launch("dpipe_attn_bwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,127 @@
+// dpipe_common.h -- shared device helpers for the gfx950 (CDNA4, wave64) kernels.
+// Everything here is written for MI355X only: 64-lane wavefronts, 16-byte
+// vector global accesses, fp32 accumulation.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DPIPE_BF16 0
+#define DPIPE_F32 1
+
+#define DPIPE_OK 0
+#define DPIPE_ERR_ARG -1
+#define DPIPE_ERR_UNSUPPORTED -2
+
+namespace dpipe {
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA A/B fragment, 4 VGPRs
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_mfma;
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+void set_last_error(const char* msg);
+int check_launch(const char* what);
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+    return __uint_as_float(((uint32_t)v) << 16);
+}
+// round-to-nearest-even, NaN preserved (matches torch's float->bfloat16 cast)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x0040u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// Element traits so that HBM-bound kernels can be instantiated for bf16 and fp32.
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int VEC = 4;  // elements per 16-byte access
+    __device__ static __forceinline__ float to_f(float v) { return v; }
+    __device__ static __forceinline__ float from_f(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int VEC = 8;
+    __device__ static __forceinline__ float to_f(bf16_t v) { return bf16_to_f32(v); }
+    __device__ static __forceinline__ bf16_t from_f(float v) { return f32_to_bf16(v); }
+};
+
+// 16-byte vector of T: load, convert to fp32 lanes, store back.
+template <typename T> struct Vec16 {
+    static constexpr int N = Elem<T>::VEC;
+    uint4 raw;
+    __device__ __forceinline__ void load(const T* p) { raw = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void store(T* p) const { *reinterpret_cast<uint4*>(p) = raw; }
+    __device__ __forceinline__ void unpack(float* f) const;
+    __device__ __forceinline__ void pack(const float* f);
+};
+template <> __device__ __forceinline__ void Vec16<float>::unpack(float* f) const {
+    f[0] = __uint_as_float(raw.x); f[1] = __uint_as_float(raw.y);
+    f[2] = __uint_as_float(raw.z); f[3] = __uint_as_float(raw.w);
+}
+template <> __device__ __forceinline__ void Vec16<float>::pack(const float* f) {
+    raw.x = __float_as_uint(f[0]); raw.y = __float_as_uint(f[1]);
+    raw.z = __float_as_uint(f[2]); raw.w = __float_as_uint(f[3]);
+}
+template <> __device__ __forceinline__ void Vec16<bf16_t>::unpack(float* f) const {
+    f[0] = __uint_as_float(raw.x << 16); f[1] = __uint_as_float(raw.x & 0xffff0000u);
+    f[2] = __uint_as_float(raw.y << 16); f[3] = __uint_as_float(raw.y & 0xffff0000u);
+    f[4] = __uint_as_float(raw.z << 16); f[5] = __uint_as_float(raw.z & 0xffff0000u);
+    f[6] = __uint_as_float(raw.w << 16); f[7] = __uint_as_float(raw.w & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void Vec16<bf16_t>::pack(const float* f) {
+    raw.x = pack_bf16x2(f[0], f[1]); raw.y = pack_bf16x2(f[2], f[3]);
+    raw.z = pack_bf16x2(f[4], f[5]); raw.w = pack_bf16x2(f[6], f[7]);
+}
+
+// ---- wave64 / block reductions -------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// Block-wide sum; every thread receives the result. `smem` must hold >= 16 floats.
+// blockDim.x must be a multiple of 64 and <= 1024.
+__device__ __forceinline__ float block_sum(float v, float* smem) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    v = wave_sum(v);
+    __syncthreads();  // protect smem reuse between consecutive calls
+    if (lane == 0) smem[wid] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += smem[i];  // fixed order: deterministic
+    return r;
+}
+__device__ __forceinline__ float block_max(float v, float* smem) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) smem[wid] = v;
+    __syncthreads();
+    float r = smem[0];
+    for (int i = 1; i < nw; ++i) r = fmaxf(r, smem[i]);
+    return r;
+}
+
+__host__ __device__ __forceinline__ long cdiv(long a, long b) { return (a + b - 1) / b; }
+
+// Grid size for HBM-bound grid-stride kernels: enough blocks to cover the 256 CUs
+// eight times over (guide: cap ~2048 blocks and stride the rest).
+static inline int stream_grid(long work_items, int block) {
+    long g = cdiv(work_items, block);
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;
+    return (int)g;
+}
+
+}  // namespace dpipe

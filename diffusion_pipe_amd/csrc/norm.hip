@@ -1,0 +1,493 @@
+// norm.hip -- row-wise normalisation / rotary / softmax kernels (gfx950, wave64).
+//
+//   K2  RMSNorm fwd+bwd                 (models/wan/model.py:70-86; per-head form: hunyuan_image_modeling.py:98-103)
+//   K5  LayerNorm (+affine) + AdaLN modulate fwd+bwd  (models/wan/model.py:89-99,295-309)
+//   K3  RoPE fwd+bwd (complex multiply on interleaved or split pairs)  (models/wan/model.py:40-67)
+//       row softmax fwd+bwd (used only by the fp32 unfused attention parity path)
+//       batched 2-D transpose (GEMM fallback for MN-contiguous operands)
+//
+// Row kernels: LPR lanes cooperate on one row (LPR = 16 for head-dim rows, 64 otherwise),
+// reductions by wavefront shuffles, statistics in fp32, 16-byte accesses.
+#include "dpipe_common.h"
+#include "../../include/dpipe_hip.h"
+
+using namespace dpipe;
+
+namespace {
+
+constexpr int NB = 256;  // threads per block
+
+template <int LPR> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int LPR> __device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ------------------------------------------------------------------ RMSNorm
+// y = (T)(x * rsqrt(mean(x^2) + eps)) * w        rstd saved per row for backward
+template <typename T, typename W, int LPR>
+__global__ void __launch_bounds__(NB) rmsnorm_fwd_kernel(const T* __restrict__ x, const W* __restrict__ w, T* __restrict__ y,
+                                                         float* __restrict__ rstd_out, long rows, int cols, float eps) {
+    constexpr int V = Elem<T>::VEC;
+    constexpr int RPB = NB / LPR;
+    const int sub = threadIdx.x % LPR;
+    const long row = (long)blockIdx.x * RPB + threadIdx.x / LPR;
+    const bool live = row < rows;
+    const T* xr = x + (live ? row : 0) * (long)cols;
+    float ss = 0.f;
+    for (int c = sub * V; c < cols; c += LPR * V) {
+        Vec16<T> v; v.load(xr + c);
+        float f[V]; v.unpack(f);
+#pragma unroll
+        for (int j = 0; j < V; ++j) ss += f[j] * f[j];
+    }
+    ss = group_sum<LPR>(ss);
+    const float rstd = rsqrtf(ss / (float)cols + eps);
+    if (!live) return;
+    if (sub == 0 && rstd_out) rstd_out[row] = rstd;
+    T* yr = y + row * (long)cols;
+    for (int c = sub * V; c < cols; c += LPR * V) {
+        Vec16<T> v; v.load(xr + c);
+        float f[V]; v.unpack(f);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float n = Elem<T>::to_f(Elem<T>::from_f(f[j] * rstd));  // ".type_as(x)" rounding point of the reference
+            f[j] = w ? n * Elem<W>::to_f(w[c + j]) : n;
+        }
+        v.pack(f); v.store(yr + c);
+    }
+}
+// dx = rstd * (g*w - xhat * mean(g*w*xhat)),  xhat = x*rstd
+template <typename T, typename W, int LPR>
+__global__ void __launch_bounds__(NB) rmsnorm_bwd_dx_kernel(const T* __restrict__ x, const W* __restrict__ w, const T* __restrict__ gy,
+                                                            const float* __restrict__ rstd_in, T* __restrict__ gx, long rows, int cols) {
+    constexpr int V = Elem<T>::VEC;
+    constexpr int RPB = NB / LPR;
+    const int sub = threadIdx.x % LPR;
+    const long row = (long)blockIdx.x * RPB + threadIdx.x / LPR;
+    const bool live = row < rows;
+    const long r = live ? row : 0;
+    const T* xr = x + r * (long)cols; const T* gr = gy + r * (long)cols;
+    const float rstd = rstd_in[r];
+    float dot = 0.f;
+    for (int c = sub * V; c < cols; c += LPR * V) {
+        Vec16<T> vx, vg; vx.load(xr + c); vg.load(gr + c);
+        float fx[V], fg[V]; vx.unpack(fx); vg.unpack(fg);
+#pragma unroll
+        for (int j = 0; j < V; ++j) dot += fg[j] * (w ? Elem<W>::to_f(w[c + j]) : 1.f) * fx[j] * rstd;
+    }
+    dot = group_sum<LPR>(dot) / (float)cols;
+    if (!live) return;
+    T* o = gx + row * (long)cols;
+    for (int c = sub * V; c < cols; c += LPR * V) {
+        Vec16<T> vx, vg; vx.load(xr + c); vg.load(gr + c);
+        float fx[V], fg[V]; vx.unpack(fx); vg.unpack(fg);
+#pragma unroll
+        for (int j = 0; j < V; ++j) fg[j] = rstd * (fg[j] * (w ? Elem<W>::to_f(w[c + j]) : 1.f) - fx[j] * rstd * dot);
+        vg.pack(fg); vg.store(o + c);
+    }
+}
+// column reductions over a slab of rows: partial[slab][c] = sum_r f(r, c).  grid = (colblocks, slabs, groups)
+// MODE 0: RMSNorm dw   = sum gy * x * rstd
+// MODE 1: LN (dgamma, dbeta) = (sum dn * xhat, sum dn)      with dn = gy * (1 + scale)
+// MODE 2: AdaLN (dscale, dshift) = (sum gy * n, sum gy)      n = xhat*gamma + beta
+template <typename T, typename W, typename M, int MODE>
+__global__ void __launch_bounds__(NB) colreduce_kernel(const T* __restrict__ x, const T* __restrict__ gy, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, const W* __restrict__ gamma, const W* __restrict__ beta,
+                                                       const M* __restrict__ scale, long rows_per_group, int cols, int slabs,
+                                                       float* __restrict__ p0, float* __restrict__ p1) {
+    constexpr int V = Elem<T>::VEC;
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (c >= cols) return;
+    const long grp = blockIdx.z;
+    const long rps = cdiv(rows_per_group, slabs);
+    const long r0 = blockIdx.y * rps, r1 = min(r0 + rps, rows_per_group);
+    float a0[V], a1[V], fgam[V], fbet[V], fsc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        a0[j] = 0.f; a1[j] = 0.f;
+        fgam[j] = gamma ? Elem<W>::to_f(gamma[c + j]) : 1.f;
+        fbet[j] = beta ? Elem<W>::to_f(beta[c + j]) : 0.f;
+        fsc[j] = scale ? 1.f + Elem<M>::to_f(scale[grp * cols + c + j]) : 1.f;
+    }
+    for (long r = r0; r < r1; ++r) {
+        const long row = grp * rows_per_group + r;
+        Vec16<T> vx, vg; vx.load(x + row * cols + c); vg.load(gy + row * cols + c);
+        float fx[V], fg[V]; vx.unpack(fx); vg.unpack(fg);
+        const float mu = mean ? mean[row] : 0.f, rs = rstd[row];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float xhat = (fx[j] - mu) * rs;
+            if (MODE == 0) { a0[j] += fg[j] * xhat; }
+            else if (MODE == 1) { const float dn = fg[j] * fsc[j]; a0[j] += dn * xhat; a1[j] += dn; }
+            else { a0[j] += fg[j] * (xhat * fgam[j] + fbet[j]); a1[j] += fg[j]; }
+        }
+    }
+    const long o = (grp * slabs + blockIdx.y) * cols + c;
+#pragma unroll
+    for (int j = 0; j < V; ++j) { p0[o + j] = a0[j]; if (MODE != 0) p1[o + j] = a1[j]; }
+}
+template <typename O>
+__global__ void __launch_bounds__(NB) slabsum_kernel(const float* __restrict__ partial, O* __restrict__ out, long groups, int cols, int slabs) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= groups * cols) return;
+    const long g = i / cols; const int c = (int)(i - g * cols);
+    float a = 0.f;
+    for (int s = 0; s < slabs; ++s) a += partial[(g * slabs + s) * cols + c];
+    out[i] = Elem<O>::from_f(a);
+}
+
+// ------------------------------------------------- LayerNorm + AdaLN modulate
+// n = (x - mean) * rstd [* gamma + beta] ;  y = n * (1 + scale[b]) + shift[b]
+template <typename T, typename W, typename M, int LPR>
+__global__ void __launch_bounds__(NB) lnmod_fwd_kernel(const T* __restrict__ x, const W* __restrict__ gamma, const W* __restrict__ beta,
+                                                       const M* __restrict__ scale, const M* __restrict__ shift, T* __restrict__ y,
+                                                       float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                       long rows, int cols, long rows_per_mod, float eps) {
+    constexpr int V = Elem<T>::VEC;
+    constexpr int RPB = NB / LPR;
+    const int sub = threadIdx.x % LPR;
+    const long row = (long)blockIdx.x * RPB + threadIdx.x / LPR;
+    const bool live = row < rows;
+    const T* xr = x + (live ? row : 0) * (long)cols;
+    float s = 0.f;
+    for (int c = sub * V; c < cols; c += LPR * V) {
+        Vec16<T> v; v.load(xr + c); float f[V]; v.unpack(f);
+#pragma unroll
+        for (int j = 0; j < V; ++j) s += f[j];
+    }
+    const float mu = group_sum<LPR>(s) / (float)cols;
+    float ss = 0.f;
+    for (int c = sub * V; c < cols; c += LPR * V) {
+        Vec16<T> v; v.load(xr + c); float f[V]; v.unpack(f);
+#pragma unroll
+        for (int j = 0; j < V; ++j) { float d = f[j] - mu; ss += d * d; }
+    }
+    const float rstd = rsqrtf(group_sum<LPR>(ss) / (float)cols + eps);
+    if (!live) return;
+    if (sub == 0) { if (mean_out) mean_out[row] = mu; if (rstd_out) rstd_out[row] = rstd; }
+    const long b = row / rows_per_mod;
+    T* yr = y + row * (long)cols;
+    for (int c = sub * V; c < cols; c += LPR * V) {
+        Vec16<T> v; v.load(xr + c); float f[V]; v.unpack(f);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float n = (f[j] - mu) * rstd;
+            if (gamma) n = n * Elem<W>::to_f(gamma[c + j]) + (beta ? Elem<W>::to_f(beta[c + j]) : 0.f);
+            if (scale) n = n * (1.f + Elem<M>::to_f(scale[b * cols + c + j]));
+            if (shift) n += Elem<M>::to_f(shift[b * cols + c + j]);
+            f[j] = n;
+        }
+        v.pack(f); v.store(yr + c);
+    }
+}
+// dxhat = gy * (1+scale) * gamma ;  dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat))
+template <typename T, typename W, typename M, int LPR>
+__global__ void __launch_bounds__(NB) lnmod_bwd_dx_kernel(const T* __restrict__ x, const T* __restrict__ gy, const W* __restrict__ gamma,
+                                                          const M* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          T* __restrict__ gx, long rows, int cols, long rows_per_mod) {
+    constexpr int V = Elem<T>::VEC;
+    constexpr int RPB = NB / LPR;
+    const int sub = threadIdx.x % LPR;
+    const long row = (long)blockIdx.x * RPB + threadIdx.x / LPR;
+    const bool live = row < rows;
+    const long r = live ? row : 0;
+    const T* xr = x + r * (long)cols; const T* gr = gy + r * (long)cols;
+    const float mu = mean[r], rs = rstd[r];
+    const long b = r / rows_per_mod;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = sub * V; c < cols; c += LPR * V) {
+        Vec16<T> vx, vg; vx.load(xr + c); vg.load(gr + c);
+        float fx[V], fg[V]; vx.unpack(fx); vg.unpack(fg);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float d = fg[j] * (scale ? 1.f + Elem<M>::to_f(scale[b * cols + c + j]) : 1.f) * (gamma ? Elem<W>::to_f(gamma[c + j]) : 1.f);
+            s1 += d; s2 += d * (fx[j] - mu) * rs;
+        }
+    }
+    s1 = group_sum<LPR>(s1) / (float)cols;
+    s2 = group_sum<LPR>(s2) / (float)cols;
+    if (!live) return;
+    T* o = gx + row * (long)cols;
+    for (int c = sub * V; c < cols; c += LPR * V) {
+        Vec16<T> vx, vg; vx.load(xr + c); vg.load(gr + c);
+        float fx[V], fg[V]; vx.unpack(fx); vg.unpack(fg);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float d = fg[j] * (scale ? 1.f + Elem<M>::to_f(scale[b * cols + c + j]) : 1.f) * (gamma ? Elem<W>::to_f(gamma[c + j]) : 1.f);
+            fg[j] = rs * (d - s1 - (fx[j] - mu) * rs * s2);
+        }
+        vg.pack(fg); vg.store(o + c);
+    }
+}
+
+// --------------------------------------------------------------------- RoPE
+// x: [B, S, H, D]; cos/sin: [S, D/2] fp32.  interleaved=1: pairs (2i, 2i+1) (Wan view_as_complex);
+// interleaved=0: pairs (i, i + D/2) (rotate_half).  conj=1 applies the inverse rotation (backward).
+template <typename T>
+__global__ void __launch_bounds__(NB) rope_kernel(const T* __restrict__ x, const float* __restrict__ cs, const float* __restrict__ sn,
+                                                  T* __restrict__ y, long B, long S, long H, int D, int interleaved, int conj) {
+    constexpr int V = Elem<T>::VEC;
+    const int half = D / 2;
+    if (interleaved) {
+        const int dv = D / V;
+        const long total = B * S * H * dv;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+            const int c = (int)(i % dv) * V;
+            const long row = i / dv;            // (b*S + s)*H + h
+            const long s = (row / H) % S;
+            Vec16<T> v; v.load(x + row * D + c);
+            float f[V]; v.unpack(f);
+#pragma unroll
+            for (int j = 0; j < V; j += 2) {
+                const float co = cs[s * half + (c + j) / 2];
+                float si = sn[s * half + (c + j) / 2]; if (conj) si = -si;
+                const float a = f[j], b = f[j + 1];
+                f[j] = a * co - b * si; f[j + 1] = a * si + b * co;
+            }
+            v.pack(f); v.store(y + row * D + c);
+        }
+    } else {
+        const int hv = half / V;
+        const long total = B * S * H * hv;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+            const int c = (int)(i % hv) * V;
+            const long row = i / hv;
+            const long s = (row / H) % S;
+            Vec16<T> va, vb; va.load(x + row * D + c); vb.load(x + row * D + half + c);
+            float fa[V], fb[V]; va.unpack(fa); vb.unpack(fb);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float co = cs[s * half + c + j];
+                float si = sn[s * half + c + j]; if (conj) si = -si;
+                const float a = fa[j], b = fb[j];
+                fa[j] = a * co - b * si; fb[j] = a * si + b * co;
+            }
+            va.pack(fa); va.store(y + row * D + c);
+            vb.pack(fb); vb.store(y + row * D + half + c);
+        }
+    }
+}
+
+// ------------------------------------------------------------- row softmax
+// y = softmax(scale * x) over the last dim; cols valid entries per row, ld = row stride.
+template <typename T>
+__global__ void __launch_bounds__(NB) softmax_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long rows, int cols, long ld, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (NB / 64) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* xr = x + row * ld; T* yr = y + row * ld;
+    float m = -INFINITY;
+    for (int c = lane; c < cols; c += 64) m = fmaxf(m, Elem<T>::to_f(xr[c]) * scale);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) s += __expf(Elem<T>::to_f(xr[c]) * scale - m);
+    s = wave_sum(s);
+    const float inv = 1.f / s;
+    for (int c = lane; c < cols; c += 64) yr[c] = Elem<T>::from_f(__expf(Elem<T>::to_f(xr[c]) * scale - m) * inv);
+}
+// gx = scale * y * (gy - sum(gy * y))
+template <typename T>
+__global__ void __launch_bounds__(NB) softmax_bwd_kernel(const T* __restrict__ y, const T* __restrict__ gy, T* __restrict__ gx, long rows, int cols, long ld, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (NB / 64) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* yr = y + row * ld; const T* gr = gy + row * ld; T* o = gx + row * ld;
+    float d = 0.f;
+    for (int c = lane; c < cols; c += 64) d += Elem<T>::to_f(yr[c]) * Elem<T>::to_f(gr[c]);
+    d = wave_sum(d);
+    for (int c = lane; c < cols; c += 64) o[c] = Elem<T>::from_f(scale * Elem<T>::to_f(yr[c]) * (Elem<T>::to_f(gr[c]) - d));
+}
+
+// --------------------------------------------------------- batched transpose
+// in: [batch][R][C] (row stride ldi) -> out: [batch][C][R] (row stride ldo); 64x64 tiles through LDS.
+template <typename T>
+__global__ void __launch_bounds__(NB) transpose_kernel(const T* __restrict__ in, T* __restrict__ out, int R, int C, long ldi, long ldo,
+                                                       long bsi, long bso) {
+    __shared__ T tile[64][65];
+    const T* ib = in + blockIdx.z * bsi; T* ob = out + blockIdx.z * bso;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 4 rows per pass
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        if (r < R && c < C) tile[i][tx] = ib[(long)r * ldi + c];
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (r < R && c < C) ob[(long)c * ldo + r] = tile[tx][i];
+    }
+}
+
+template <typename T> struct Tag { using type = T; };
+
+}  // namespace
+
+#define STREAM(s) reinterpret_cast<hipStream_t>(s)
+#define BAD(msg) do { set_last_error(msg); return DPIPE_ERR_ARG; } while (0)
+
+static inline int pick_lpr(int cols, int vec) { return (cols / vec) <= 16 ? 16 : 64; }
+
+// dispatch helper over (T, W) where W in {T, float}
+#define DISPATCH_TW(dtype, wdtype, ...)                                         \
+    if (dtype == DPIPE_BF16 && wdtype == DPIPE_BF16) { using T = bf16_t; using W = bf16_t; __VA_ARGS__; } \
+    else if (dtype == DPIPE_BF16 && wdtype == DPIPE_F32) { using T = bf16_t; using W = float; __VA_ARGS__; } \
+    else if (dtype == DPIPE_F32 && wdtype == DPIPE_F32) { using T = float; using W = float; __VA_ARGS__; } \
+    else { set_last_error("unsupported dtype combination"); return DPIPE_ERR_UNSUPPORTED; }
+
+extern "C" {
+
+int dpipe_norm_slabs(long rows_per_group) {
+    long s = rows_per_group / 128; if (s < 1) s = 1; if (s > 128) s = 128; return (int)s;
+}
+
+int dpipe_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, long rows, int cols, float eps, int dtype, int wdtype, void* stream) {
+    const int V = dtype == DPIPE_BF16 ? 8 : 4;
+    if (!x || !y || rows <= 0 || cols <= 0 || (cols % V) != 0) BAD("dpipe_rmsnorm_fwd: cols must be a multiple of the 16-byte vector");
+    hipStream_t s = STREAM(stream);
+    const int lpr = pick_lpr(cols, V);
+    const unsigned grid = (unsigned)cdiv(rows, NB / lpr);
+    DISPATCH_TW(dtype, wdtype, {
+        if (lpr == 16) rmsnorm_fwd_kernel<T, W, 16><<<grid, NB, 0, s>>>((const T*)x, (const W*)w, (T*)y, rstd, rows, cols, eps);
+        else rmsnorm_fwd_kernel<T, W, 64><<<grid, NB, 0, s>>>((const T*)x, (const W*)w, (T*)y, rstd, rows, cols, eps);
+    })
+    return check_launch("dpipe_rmsnorm_fwd");
+}
+
+// workspace: slabs * cols floats (only when dw != null)
+int dpipe_rmsnorm_bwd(const void* x, const void* w, const void* gy, const float* rstd, void* gx, void* dw, float* workspace,
+                      long rows, int cols, int dtype, int wdtype, void* stream) {
+    const int V = dtype == DPIPE_BF16 ? 8 : 4;
+    if (!x || !gy || !rstd || !gx || rows <= 0 || cols <= 0 || (cols % V) != 0) BAD("dpipe_rmsnorm_bwd: bad argument");
+    if (dw && !workspace) BAD("dpipe_rmsnorm_bwd: workspace required for dw");
+    hipStream_t s = STREAM(stream);
+    const int lpr = pick_lpr(cols, V);
+    const unsigned grid = (unsigned)cdiv(rows, NB / lpr);
+    const int slabs = dpipe_norm_slabs(rows);
+    DISPATCH_TW(dtype, wdtype, {
+        if (lpr == 16) rmsnorm_bwd_dx_kernel<T, W, 16><<<grid, NB, 0, s>>>((const T*)x, (const W*)w, (const T*)gy, rstd, (T*)gx, rows, cols);
+        else rmsnorm_bwd_dx_kernel<T, W, 64><<<grid, NB, 0, s>>>((const T*)x, (const W*)w, (const T*)gy, rstd, (T*)gx, rows, cols);
+        if (dw) {
+            dim3 g2((unsigned)cdiv(cols / V, NB), slabs, 1);
+            colreduce_kernel<T, W, float, 0><<<g2, NB, 0, s>>>((const T*)x, (const T*)gy, nullptr, rstd, nullptr, nullptr, nullptr, rows, cols, slabs, workspace, nullptr);
+            slabsum_kernel<W><<<(unsigned)cdiv(cols, NB), NB, 0, s>>>(workspace, (W*)dw, 1, cols, slabs);
+        }
+    })
+    return check_launch("dpipe_rmsnorm_bwd");
+}
+
+int dpipe_lnmod_fwd(const void* x, const void* gamma, const void* beta, const void* scale, const void* shift, void* y,
+                    float* mean, float* rstd, long rows, int cols, long rows_per_mod, float eps,
+                    int dtype, int wdtype, int mdtype, void* stream) {
+    const int V = dtype == DPIPE_BF16 ? 8 : 4;
+    if (!x || !y || rows <= 0 || cols <= 0 || (cols % V) != 0 || rows_per_mod <= 0) BAD("dpipe_lnmod_fwd: bad argument");
+    hipStream_t s = STREAM(stream);
+    const unsigned grid = (unsigned)cdiv(rows, NB / 64);
+#define LNFWD(TT, WW, MM) lnmod_fwd_kernel<TT, WW, MM, 64><<<grid, NB, 0, s>>>((const TT*)x, (const WW*)gamma, (const WW*)beta, (const MM*)scale, (const MM*)shift, (TT*)y, mean, rstd, rows, cols, rows_per_mod, eps)
+    if (dtype == DPIPE_BF16) {
+        if (wdtype == DPIPE_BF16 && mdtype == DPIPE_BF16) LNFWD(bf16_t, bf16_t, bf16_t);
+        else if (wdtype == DPIPE_BF16) LNFWD(bf16_t, bf16_t, float);
+        else if (mdtype == DPIPE_BF16) LNFWD(bf16_t, float, bf16_t);
+        else LNFWD(bf16_t, float, float);
+    } else if (dtype == DPIPE_F32 && wdtype == DPIPE_F32 && mdtype == DPIPE_F32) LNFWD(float, float, float);
+    else { set_last_error("dpipe_lnmod_fwd: dtype combination"); return DPIPE_ERR_UNSUPPORTED; }
+#undef LNFWD
+    return check_launch("dpipe_lnmod_fwd");
+}
+
+// workspace: 2 * max(slabs(rows) , groups*slabs(rows_per_mod)) * cols floats
+int dpipe_lnmod_bwd(const void* x, const void* gy, const void* gamma, const void* beta, const void* scale,
+                    const float* mean, const float* rstd, void* gx, void* dgamma, void* dbeta, void* dscale, void* dshift,
+                    float* workspace, long rows, int cols, long rows_per_mod, int dtype, int wdtype, int mdtype, void* stream) {
+    const int V = dtype == DPIPE_BF16 ? 8 : 4;
+    if (!x || !gy || !mean || !rstd || !gx || rows <= 0 || cols <= 0 || (cols % V) != 0 || rows_per_mod <= 0 || (rows % rows_per_mod) != 0)
+        BAD("dpipe_lnmod_bwd: bad argument");
+    if ((dgamma || dscale) && !workspace) BAD("dpipe_lnmod_bwd: workspace required");
+    hipStream_t s = STREAM(stream);
+    const unsigned grid = (unsigned)cdiv(rows, NB / 64);
+    const long groups = rows / rows_per_mod;
+    const int slabs_all = dpipe_norm_slabs(rows), slabs_mod = dpipe_norm_slabs(rows_per_mod);
+#define LNBWD(TT, WW, MM) do { \
+    lnmod_bwd_dx_kernel<TT, WW, MM, 64><<<grid, NB, 0, s>>>((const TT*)x, (const TT*)gy, (const WW*)gamma, (const MM*)scale, mean, rstd, (TT*)gx, rows, cols, rows_per_mod); \
+    if (dscale) { \
+        float* p0 = workspace; float* p1 = workspace + groups * slabs_mod * (long)cols; \
+        dim3 g2((unsigned)cdiv(cols / V, NB), slabs_mod, (unsigned)groups); \
+        colreduce_kernel<TT, WW, MM, 2><<<g2, NB, 0, s>>>((const TT*)x, (const TT*)gy, mean, rstd, (const WW*)gamma, (const WW*)beta, (const MM*)scale, rows_per_mod, cols, slabs_mod, p0, p1); \
+        slabsum_kernel<MM><<<(unsigned)cdiv(groups * cols, NB), NB, 0, s>>>(p0, (MM*)dscale, groups, cols, slabs_mod); \
+        if (dshift) slabsum_kernel<MM><<<(unsigned)cdiv(groups * cols, NB), NB, 0, s>>>(p1, (MM*)dshift, groups, cols, slabs_mod); \
+    } \
+    if (dgamma) { \
+        /* (dgamma, dbeta) need dn = gy*(1+scale[b]) which varies per modulation group: reduce per group, then over groups */ \
+        float* p0 = workspace; float* p1 = workspace + groups * slabs_mod * (long)cols; \
+        dim3 g2((unsigned)cdiv(cols / V, NB), slabs_mod, (unsigned)groups); \
+        colreduce_kernel<TT, WW, MM, 1><<<g2, NB, 0, s>>>((const TT*)x, (const TT*)gy, mean, rstd, (const WW*)gamma, (const WW*)beta, (const MM*)scale, rows_per_mod, cols, slabs_mod, p0, p1); \
+        slabsum_kernel<WW><<<(unsigned)cdiv(cols, NB), NB, 0, s>>>(p0, (WW*)dgamma, 1, cols, (int)(groups * slabs_mod)); \
+        if (dbeta) slabsum_kernel<WW><<<(unsigned)cdiv(cols, NB), NB, 0, s>>>(p1, (WW*)dbeta, 1, cols, (int)(groups * slabs_mod)); \
+    } } while (0)
+    (void)slabs_all;
+    if (dtype == DPIPE_BF16) {
+        if (wdtype == DPIPE_BF16 && mdtype == DPIPE_BF16) LNBWD(bf16_t, bf16_t, bf16_t);
+        else if (wdtype == DPIPE_BF16) LNBWD(bf16_t, bf16_t, float);
+        else if (mdtype == DPIPE_BF16) LNBWD(bf16_t, float, bf16_t);
+        else LNBWD(bf16_t, float, float);
+    } else if (dtype == DPIPE_F32 && wdtype == DPIPE_F32 && mdtype == DPIPE_F32) LNBWD(float, float, float);
+    else { set_last_error("dpipe_lnmod_bwd: dtype combination"); return DPIPE_ERR_UNSUPPORTED; }
+#undef LNBWD
+    return check_launch("dpipe_lnmod_bwd");
+}
+
+int dpipe_lnmod_workspace_floats(long rows, int cols, long rows_per_mod) {
+    long groups = rows / rows_per_mod;
+    return (int)(2 * groups * dpipe_norm_slabs(rows_per_mod) * (long)cols);
+}
+
+int dpipe_rope(const void* x, const float* cos_t, const float* sin_t, void* y, long B, long S, long H, int D,
+               int interleaved, int conj, int dtype, void* stream) {
+    const int V = dtype == DPIPE_BF16 ? 8 : 4;
+    if (!x || !cos_t || !sin_t || !y || B <= 0 || S <= 0 || H <= 0 || D <= 0) BAD("dpipe_rope: bad argument");
+    if (interleaved ? (D % V) != 0 : ((D / 2) % V) != 0) BAD("dpipe_rope: head dim not vectorisable");
+    const long work = B * S * H * (interleaved ? D / V : (D / 2) / V);
+    hipStream_t s = STREAM(stream);
+    if (dtype == DPIPE_BF16) rope_kernel<bf16_t><<<stream_grid(work, NB), NB, 0, s>>>((const bf16_t*)x, cos_t, sin_t, (bf16_t*)y, B, S, H, D, interleaved, conj);
+    else if (dtype == DPIPE_F32) rope_kernel<float><<<stream_grid(work, NB), NB, 0, s>>>((const float*)x, cos_t, sin_t, (float*)y, B, S, H, D, interleaved, conj);
+    else { set_last_error("dpipe_rope: dtype"); return DPIPE_ERR_UNSUPPORTED; }
+    return check_launch("dpipe_rope");
+}
+
+int dpipe_softmax_fwd(const void* x, void* y, long rows, int cols, long ld, float scale, int dtype, void* stream) {
+    if (!x || !y || rows <= 0 || cols <= 0 || ld < cols) BAD("dpipe_softmax_fwd: bad argument");
+    hipStream_t s = STREAM(stream);
+    const unsigned grid = (unsigned)cdiv(rows, NB / 64);
+    if (dtype == DPIPE_BF16) softmax_fwd_kernel<bf16_t><<<grid, NB, 0, s>>>((const bf16_t*)x, (bf16_t*)y, rows, cols, ld, scale);
+    else if (dtype == DPIPE_F32) softmax_fwd_kernel<float><<<grid, NB, 0, s>>>((const float*)x, (float*)y, rows, cols, ld, scale);
+    else { set_last_error("dpipe_softmax_fwd: dtype"); return DPIPE_ERR_UNSUPPORTED; }
+    return check_launch("dpipe_softmax_fwd");
+}
+
+int dpipe_softmax_bwd(const void* y, const void* gy, void* gx, long rows, int cols, long ld, float scale, int dtype, void* stream) {
+    if (!y || !gy || !gx || rows <= 0 || cols <= 0 || ld < cols) BAD("dpipe_softmax_bwd: bad argument");
+    hipStream_t s = STREAM(stream);
+    const unsigned grid = (unsigned)cdiv(rows, NB / 64);
+    if (dtype == DPIPE_BF16) softmax_bwd_kernel<bf16_t><<<grid, NB, 0, s>>>((const bf16_t*)y, (const bf16_t*)gy, (bf16_t*)gx, rows, cols, ld, scale);
+    else if (dtype == DPIPE_F32) softmax_bwd_kernel<float><<<grid, NB, 0, s>>>((const float*)y, (const float*)gy, (float*)gx, rows, cols, ld, scale);
+    else { set_last_error("dpipe_softmax_bwd: dtype"); return DPIPE_ERR_UNSUPPORTED; }
+    return check_launch("dpipe_softmax_bwd");
+}
+
+int dpipe_transpose(const void* in, void* out, int R, int C, long ldi, long ldo, long batch_stride_in, long batch_stride_out, int batch,
+                    int dtype, void* stream) {
+    if (!in || !out || R <= 0 || C <= 0 || batch <= 0 || ldi < C || ldo < R) BAD("dpipe_transpose: bad argument");
+    dim3 grid((unsigned)cdiv(C, 64), (unsigned)cdiv(R, 64), (unsigned)batch);
+    hipStream_t s = STREAM(stream);
+    if (dtype == DPIPE_BF16) transpose_kernel<bf16_t><<<grid, NB, 0, s>>>((const bf16_t*)in, (bf16_t*)out, R, C, ldi, ldo, batch_stride_in, batch_stride_out);
+    else if (dtype == DPIPE_F32) transpose_kernel<float><<<grid, NB, 0, s>>>((const float*)in, (float*)out, R, C, ldi, ldo, batch_stride_in, batch_stride_out);
+    else { set_last_error("dpipe_transpose: dtype"); return DPIPE_ERR_UNSUPPORTED; }
+    return check_launch("dpipe_transpose");
+}
+
+}  // extern "C"

@@ -1,0 +1,34 @@
+// runtime.hip -- error reporting and device probing for libdpipe_hip.so.
+#include "dpipe_common.h"
+#include "../../include/dpipe_hip.h"
+#include <string.h>
+#include <stdio.h>
+
+namespace dpipe {
+static thread_local char g_last_error[512] = "";
+
+void set_last_error(const char* msg) {
+    strncpy(g_last_error, msg ? msg : "", sizeof(g_last_error) - 1);
+    g_last_error[sizeof(g_last_error) - 1] = 0;
+}
+// Called right after a kernel launch: reports launch-configuration errors (not asynchronous faults).
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return DPIPE_OK;
+    snprintf(g_last_error, sizeof(g_last_error), "%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+}
+}  // namespace dpipe
+
+extern "C" {
+int dpipe_version(void) { return 1; }
+const char* dpipe_last_error(void) { return dpipe::g_last_error; }
+int dpipe_device_info(int dev, int* cu_count, char* arch_name, int arch_name_len) {
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) { dpipe::set_last_error(hipGetErrorString(e)); return (int)e; }
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (arch_name && arch_name_len > 0) { strncpy(arch_name, prop.gcnArchName, arch_name_len - 1); arch_name[arch_name_len - 1] = 0; }
+    return DPIPE_OK;
+}
+}

@@ -1,0 +1,128 @@
+"""ctypes binding of libdpipe_hip.so (the C-ABI HIP layer, include/dpipe_hip.h).
+
+The product path has no CPU fallback: if the shared object is missing or a symbol is absent this module raises,
+and every wrapper checks the return code of the C call (`check`).  PyTorch is used only for device memory and the
+current HIP stream.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_long, c_void_p, POINTER
+from pathlib import Path
+
+import torch
+
+LIB_PATH = Path(__file__).resolve().parent / 'libdpipe_hip.so'
+
+BF16, F32 = 0, 1
+ACT = {None: 0, 'none': 0, 'gelu_tanh': 1, 'gelu': 2, 'gelu_erf': 2, 'silu': 3}
+LOSS_KIND = {'mse': 0, 'huber': 1, 'smooth_l1': 2}
+
+P, I, L, F = c_void_p, c_int, c_long, c_float
+
+# name -> (restype, argtypes); mirrors include/dpipe_hip.h one to one.
+_SIGNATURES = {
+    'dpipe_version': (I, []),
+    'dpipe_last_error': (c_char_p, []),
+    'dpipe_device_info': (I, [I, POINTER(c_int), c_char_p, I]),
+    'dpipe_loss_workspace_floats': (I, [L, L]),
+    'dpipe_loss_fwd': (I, [P, I, P, P, P, L, L, I, F, P, P, P, P]),
+    'dpipe_loss_bwd': (I, [P, I, P, P, P, P, L, L, I, F, P, P]),
+    'dpipe_act_fwd': (I, [P, P, L, I, I, P]),
+    'dpipe_act_bwd': (I, [P, P, P, L, I, I, P]),
+    'dpipe_geglu_fwd': (I, [P, P, L, L, I, I, P]),
+    'dpipe_geglu_bwd': (I, [P, P, P, L, L, I, I, P]),
+    'dpipe_gated_residual_fwd': (I, [P, P, P, P, L, L, L, I, I, P]),
+    'dpipe_gated_residual_slabs': (I, [L]),
+    'dpipe_gated_residual_bwd': (I, [P, P, P, P, P, P, L, L, L, I, I, P]),
+    'dpipe_sinusoidal_embed': (I, [P, P, L, I, F, I, F, F, P]),
+    'dpipe_flow_match_prep': (I, [P, P, P, P, P, L, L, P]),
+    'dpipe_multi_sumsq': (I, [P, P, P, P, I, I, P, P, P]),
+    'dpipe_multi_clip_scale': (I, [P, P, P, P, I, I, P, F, P]),
+    'dpipe_rmsnorm_fwd': (I, [P, P, P, P, L, I, F, I, I, P]),
+    'dpipe_norm_slabs': (I, [L]),
+    'dpipe_rmsnorm_bwd': (I, [P, P, P, P, P, P, P, L, I, I, I, P]),
+    'dpipe_lnmod_fwd': (I, [P, P, P, P, P, P, P, P, L, I, L, F, I, I, I, P]),
+    'dpipe_lnmod_workspace_floats': (I, [L, I, L]),
+    'dpipe_lnmod_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, L, I, I, I, P]),
+    'dpipe_rope': (I, [P, P, P, P, L, L, L, I, I, I, I, P]),
+    'dpipe_softmax_fwd': (I, [P, P, L, I, L, F, I, P]),
+    'dpipe_softmax_bwd': (I, [P, P, P, L, I, L, F, I, P]),
+    'dpipe_transpose': (I, [P, P, I, I, L, L, L, L, I, I, P]),
+    'dpipe_gemm': (I, [I, I, I, I, I, I, P, L, P, L, P, L, I, I, L, L, L, L, L, L, P, I, F, I, I, I, P]),
+    'dpipe_tr16_probe': (I, [P, P, P]),
+    'dpipe_attn_fwd': (I, [P, P, P, P, P, P, I, I, I, I, I] + [L] * 12 + [F, P]),
+    'dpipe_attn_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I] + [L] * 24 + [F, P]),
+}
+
+_lib = None
+
+
+class DpipeHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises loudly when the HIP extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise DpipeHipError(
+            f'{LIB_PATH} not found: the HIP extension is required (no CPU fallback). '
+            f'Build it with `python -m diffusion_pipe_amd.build`.')
+    handle = ctypes.CDLL(str(LIB_PATH))
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:
+            raise DpipeHipError(f'{LIB_PATH} does not export {name}; rebuild the extension') from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = handle
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().dpipe_last_error()
+        raise DpipeHipError(f'{what} failed (rc={rc}): {msg.decode() if msg else ""}')
+
+
+def dtype_code(dt):
+    if dt == torch.bfloat16:
+        return BF16
+    if dt == torch.float32:
+        return F32
+    raise DpipeHipError(f'unsupported dtype {dt}: the HIP layer computes in bf16 or fp32')
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise DpipeHipError('HIP kernels need device tensors; got a CPU tensor (there is no CPU fallback)')
+
+
+def aligned16(t):
+    return t.data_ptr() % 16 == 0
+
+
+def device_info(dev=0):
+    cu = c_int(0)
+    buf = ctypes.create_string_buffer(256)
+    check(lib().dpipe_device_info(dev, ctypes.byref(cu), buf, 256), 'dpipe_device_info')
+    return cu.value, buf.value.decode()

@@ -1,0 +1,577 @@
+"""Autograd operators of the training hot path, each a thin host wrapper over the C-ABI HIP layer.
+
+Every function here launches gfx950 kernels from libdpipe_hip.so on the current HIP stream; there is no PyTorch /
+CPU fallback (a CPU tensor or a missing library raises `DpipeHipError`).  Reference semantics are cited per op.
+"""
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import hip
+from .hip import ACT, DpipeHipError, check, dtype_code, lib, ptr, require_cuda, stream
+
+
+def _contig(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _rows2d(x):
+    """View x as [rows, cols] with a contiguous last dim and uniform row stride."""
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(-1) != 1 or (x2.shape[0] > 1 and x2.stride(0) != x2.shape[1]):
+        x2 = x2.contiguous()
+    return x2
+
+
+# --------------------------------------------------------------------------------------------- GEMM (K1/K6)
+def gemm(a, b, trans_a, trans_b, M, N, K, out, *, lda, ldb, ldc, batch_outer=1, batch_inner=1,
+         stride_a=(0, 0), stride_b=(0, 0), stride_c=(0, 0), bias=None, act=None, alpha=1.0, accumulate=False,
+         tile_hint=0):
+    """Raw strided, batched MFMA GEMM:  out = act(alpha * op(a) @ op(b) + bias) (+ out)."""
+    require_cuda(a, b, out, bias)
+    if a.dtype != b.dtype:
+        raise DpipeHipError(f'gemm operand dtypes differ: {a.dtype} vs {b.dtype}')
+    dt = dtype_code(a.dtype)
+    out_f32 = int(out.dtype == torch.float32 and a.dtype == torch.bfloat16)
+    if not out_f32 and out.dtype != a.dtype:
+        raise DpipeHipError('gemm output dtype must be the operand dtype or fp32')
+    if bias is not None and bias.dtype != a.dtype:
+        bias = bias.to(a.dtype)
+    check(lib().dpipe_gemm(dt, int(trans_a), int(trans_b), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), ldc,
+                           batch_outer, batch_inner, stride_a[0], stride_a[1], stride_b[0], stride_b[1],
+                           stride_c[0], stride_c[1], ptr(bias), ACT[act], float(alpha), int(accumulate), out_f32,
+                           tile_hint, stream()), 'dpipe_gemm')
+    return out
+
+
+def mm(a, b, trans_a=False, trans_b=False, bias=None, act=None, out=None, out_dtype=None, tile_hint=0):
+    """2-D product of row-major matrices (last dim contiguous): op(a) [M,K] @ op(b) [K,N]."""
+    assert a.dim() == 2 and b.dim() == 2
+    if a.stride(1) != 1:
+        a = a.contiguous()
+    if b.stride(1) != 1:
+        b = b.contiguous()
+    M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    Kb, N = (b.shape[1], b.shape[0]) if trans_b else b.shape
+    if K != Kb:
+        raise DpipeHipError(f'mm shape mismatch: K={K} vs {Kb}')
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=out_dtype or a.dtype)
+    return gemm(a, b, trans_a, trans_b, M, N, K, out, lda=a.stride(0), ldb=b.stride(0), ldc=out.stride(0),
+                bias=bias, act=act, tile_hint=tile_hint)
+
+
+class _LinearFn(Function):
+    """y = x W^T + b  (nn.Linear; reference: models/wan/model.py:120-122,138-142,270-272)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x2 = _rows2d(x)
+        if x2.dtype != weight.dtype:
+            x2 = x2.to(weight.dtype)
+        y = mm(x2, weight, False, True, bias=bias)
+        ctx.save_for_backward(x2, weight)
+        ctx.has_bias = bias is not None
+        ctx.x_shape = x.shape
+        ctx.x_dtype = x.dtype
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, weight = ctx.saved_tensors
+        gy2 = _rows2d(gy)
+        if gy2.dtype != weight.dtype:
+            gy2 = gy2.to(weight.dtype)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = mm(gy2, weight, False, False).view(ctx.x_shape)          # dx = dy . W
+            if gx.dtype != ctx.x_dtype:
+                gx = gx.to(ctx.x_dtype)
+        if ctx.needs_input_grad[1]:
+            gw = mm(gy2, x2, True, False)                                    # dW = dy^T . x
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = column_sum(gy2)
+        return gx, gw, gb
+
+
+def linear(x, weight, bias=None):
+    return _LinearFn.apply(x, weight, bias)
+
+
+def column_sum(x2):
+    """sum over rows of a [rows, cols] matrix via the MFMA GEMM (ones^T . x), fp32 accumulate."""
+    ones = torch.ones((x2.shape[0], 8), device=x2.device, dtype=x2.dtype)
+    out = mm(ones, x2, True, False)      # [8, cols], all rows equal
+    return out[0].contiguous()
+
+
+# ------------------------------------------------------------------------------------------- activations (K6)
+class _ActFn(Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        require_cuda(x)
+        xc = _contig(x)
+        y = torch.empty_like(xc)
+        check(lib().dpipe_act_fwd(ptr(xc), ptr(y), xc.numel(), dtype_code(xc.dtype), ACT[act], stream()), 'act_fwd')
+        ctx.save_for_backward(xc)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (xc,) = ctx.saved_tensors
+        gy = _contig(gy)
+        gx = torch.empty_like(xc)
+        check(lib().dpipe_act_bwd(ptr(xc), ptr(gy), ptr(gx), xc.numel(), dtype_code(xc.dtype), ACT[ctx.act], stream()), 'act_bwd')
+        return gx, None
+
+
+def gelu_tanh(x):
+    return _ActFn.apply(x, 'gelu_tanh')
+
+
+def gelu(x):
+    return _ActFn.apply(x, 'gelu_erf')
+
+
+def silu(x):
+    return _ActFn.apply(x, 'silu')
+
+
+class _GegluFn(Function):
+    """diffusers GEGLU: h, gate = x.chunk(2, -1); h * gelu(gate)."""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        x2 = _contig(_rows2d(x))
+        H = x2.shape[1] // 2
+        y = torch.empty((x2.shape[0], H), device=x.device, dtype=x.dtype)
+        check(lib().dpipe_geglu_fwd(ptr(x2), ptr(y), x2.shape[0], H, dtype_code(x.dtype), ACT[act], stream()), 'geglu_fwd')
+        ctx.save_for_backward(x2)
+        ctx.act = act
+        ctx.shape = x.shape
+        return y.view(*x.shape[:-1], H)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x2,) = ctx.saved_tensors
+        gy2 = _contig(_rows2d(gy))
+        gx = torch.empty_like(x2)
+        check(lib().dpipe_geglu_bwd(ptr(x2), ptr(gy2), ptr(gx), x2.shape[0], x2.shape[1] // 2, dtype_code(x2.dtype), ACT[ctx.act], stream()), 'geglu_bwd')
+        return gx.view(ctx.shape), None
+
+
+def geglu(x, act='gelu_erf'):
+    return _GegluFn.apply(x, act)
+
+
+# ----------------------------------------------------------------------------------------- gated residual (K5)
+class _GatedResidualFn(Function):
+    """out = x + y * gate  with gate [B, D] broadcast over the rows of each sample (models/wan/model.py:301,308)."""
+
+    @staticmethod
+    def forward(ctx, x, y, gate):
+        require_cuda(x, y, gate)
+        xc, yc = _contig(x), _contig(y)
+        D = xc.shape[-1]
+        rows = xc.numel() // D
+        gc = None
+        rows_per_gate = rows
+        if gate is not None:
+            gc = _contig(gate).reshape(-1, D)
+            rows_per_gate = rows // gc.shape[0]
+        out = torch.empty_like(xc)
+        check(lib().dpipe_gated_residual_fwd(ptr(xc), ptr(yc), ptr(gc), ptr(out), rows, D, rows_per_gate,
+                                             dtype_code(xc.dtype), dtype_code(gc.dtype) if gc is not None else dtype_code(xc.dtype),
+                                             stream()), 'gated_residual_fwd')
+        ctx.save_for_backward(yc, gc)
+        ctx.gate_shape = None if gate is None else gate.shape
+        ctx.rows_per_gate = rows_per_gate
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        yc, gc = ctx.saved_tensors
+        gout = _contig(gout)
+        if gc is None:
+            return gout, gout, None
+        D = yc.shape[-1]
+        batches = gc.shape[0]
+        slabs = lib().dpipe_gated_residual_slabs(ctx.rows_per_gate)
+        ws = torch.empty(batches * slabs * D, device=yc.device, dtype=torch.float32)
+        gy = torch.empty_like(yc)
+        dgate = torch.empty_like(gc)
+        check(lib().dpipe_gated_residual_bwd(ptr(gout), ptr(yc), ptr(gc), ptr(gy), ptr(dgate), ptr(ws), batches,
+                                             ctx.rows_per_gate, D, dtype_code(yc.dtype), dtype_code(gc.dtype), stream()),
+              'gated_residual_bwd')
+        return gout, gy, dgate.view(ctx.gate_shape)
+
+
+def gated_residual(x, y, gate=None):
+    return _GatedResidualFn.apply(x, y, gate)
+
+
+# ------------------------------------------------------------------------------------------------ norms (K2/K5)
+class _RMSNormFn(Function):
+    """WanRMSNorm: _norm(x.float()).type_as(x) * weight  (models/wan/model.py:70-86)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, eps):
+        require_cuda(x, weight)
+        x2 = _contig(_rows2d(x))
+        rows, cols = x2.shape
+        y = torch.empty_like(x2)
+        rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+        wd = dtype_code(weight.dtype) if weight is not None else dtype_code(x.dtype)
+        check(lib().dpipe_rmsnorm_fwd(ptr(x2), ptr(weight), ptr(y), ptr(rstd), rows, cols, eps, dtype_code(x.dtype), wd, stream()), 'rmsnorm_fwd')
+        ctx.save_for_backward(x2, weight, rstd)
+        ctx.shape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, weight, rstd = ctx.saved_tensors
+        rows, cols = x2.shape
+        gy2 = _contig(_rows2d(gy))
+        gx = torch.empty_like(x2)
+        dw = ws = None
+        if weight is not None and ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            ws = torch.empty(lib().dpipe_norm_slabs(rows) * cols, device=x2.device, dtype=torch.float32)
+        wd = dtype_code(weight.dtype) if weight is not None else dtype_code(x2.dtype)
+        check(lib().dpipe_rmsnorm_bwd(ptr(x2), ptr(weight), ptr(gy2), ptr(rstd), ptr(gx), ptr(dw), ptr(ws), rows, cols,
+                                      dtype_code(x2.dtype), wd, stream()), 'rmsnorm_bwd')
+        return gx.view(ctx.shape), dw, None
+
+
+def rms_norm(x, weight=None, eps=1e-6):
+    return _RMSNormFn.apply(x, weight, eps)
+
+
+class _LNModFn(Function):
+    """LayerNorm(x) [* gamma + beta] * (1 + scale) + shift, statistics in fp32 (models/wan/model.py:89-99,295-309)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, scale, shift, eps):
+        require_cuda(x, gamma, beta, scale, shift)
+        x2 = _contig(_rows2d(x))
+        rows, cols = x2.shape
+        sc = sh = None
+        rows_per_mod = rows
+        mdt = dtype_code(x.dtype)
+        if scale is not None or shift is not None:
+            ref = scale if scale is not None else shift
+            sc = _contig(scale).reshape(-1, cols) if scale is not None else None
+            sh = _contig(shift).reshape(-1, cols) if shift is not None else None
+            rows_per_mod = rows // (ref.numel() // cols)
+            mdt = dtype_code(ref.dtype)
+            if sc is not None and sh is not None and sc.dtype != sh.dtype:
+                raise DpipeHipError('scale and shift must share a dtype')
+        wdt = dtype_code(gamma.dtype) if gamma is not None else dtype_code(x.dtype)
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+        check(lib().dpipe_lnmod_fwd(ptr(x2), ptr(gamma), ptr(beta), ptr(sc), ptr(sh), ptr(y), ptr(mean), ptr(rstd), rows, cols,
+                                    rows_per_mod, eps, dtype_code(x.dtype), wdt, mdt, stream()), 'lnmod_fwd')
+        ctx.save_for_backward(x2, gamma, beta, sc, mean, rstd)
+        ctx.meta = (x.shape, None if scale is None else scale.shape, None if shift is None else shift.shape,
+                    rows_per_mod, wdt, mdt, shift is not None)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, gamma, beta, sc, mean, rstd = ctx.saved_tensors
+        x_shape, scale_shape, shift_shape, rows_per_mod, wdt, mdt, has_shift = ctx.meta
+        rows, cols = x2.shape
+        gy2 = _contig(_rows2d(gy))
+        gx = torch.empty_like(x2)
+        groups = rows // rows_per_mod
+        mod_dtype = torch.bfloat16 if mdt == hip.BF16 else torch.float32
+        dgamma = torch.empty_like(gamma) if gamma is not None else None
+        dbeta = torch.empty_like(beta) if beta is not None else None
+        need_mod = sc is not None or has_shift
+        dscale = torch.empty((groups, cols), device=x2.device, dtype=mod_dtype) if need_mod else None
+        dshift = torch.empty((groups, cols), device=x2.device, dtype=mod_dtype) if need_mod else None
+        ws = None
+        if dgamma is not None or need_mod:
+            ws = torch.empty(lib().dpipe_lnmod_workspace_floats(rows, cols, rows_per_mod), device=x2.device, dtype=torch.float32)
+        check(lib().dpipe_lnmod_bwd(ptr(x2), ptr(gy2), ptr(gamma), ptr(beta), ptr(sc), ptr(mean), ptr(rstd), ptr(gx),
+                                    ptr(dgamma), ptr(dbeta), ptr(dscale), ptr(dshift), ptr(ws), rows, cols, rows_per_mod,
+                                    dtype_code(x2.dtype), wdt, mdt, stream()), 'lnmod_bwd')
+        g_scale = dscale.view(scale_shape) if scale_shape is not None else None
+        g_shift = dshift.view(shift_shape) if shift_shape is not None else None
+        return gx.view(x_shape), dgamma, dbeta, g_scale, g_shift, None
+
+
+def layer_norm_modulate(x, gamma=None, beta=None, scale=None, shift=None, eps=1e-6):
+    """scale/shift: [B, D] (or broadcastable [B, 1, D]) applied to the rows of sample b."""
+    return _LNModFn.apply(x, gamma, beta, scale, shift, eps)
+
+
+# ------------------------------------------------------------------------------------------------- RoPE (K3)
+class _RopeFn(Function):
+    """Rotary embedding on [B, S, H, D] with fp32 cos/sin tables [S, D/2] (models/wan/model.py:40-67)."""
+
+    @staticmethod
+    def forward(ctx, x, cos, sin, interleaved):
+        require_cuda(x, cos, sin)
+        xc = _contig(x)
+        B, S, H, D = xc.shape
+        if cos.shape != (S, D // 2) or cos.dtype != torch.float32:
+            raise DpipeHipError(f'rope tables must be fp32 [S, D/2]; got {tuple(cos.shape)} {cos.dtype}')
+        cos, sin = _contig(cos), _contig(sin)
+        y = torch.empty_like(xc)
+        check(lib().dpipe_rope(ptr(xc), ptr(cos), ptr(sin), ptr(y), B, S, H, D, int(interleaved), 0, dtype_code(xc.dtype), stream()), 'rope')
+        ctx.save_for_backward(cos, sin)
+        ctx.interleaved = interleaved
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        cos, sin = ctx.saved_tensors
+        gy = _contig(gy)
+        B, S, H, D = gy.shape
+        gx = torch.empty_like(gy)
+        check(lib().dpipe_rope(ptr(gy), ptr(cos), ptr(sin), ptr(gx), B, S, H, D, int(ctx.interleaved), 1, dtype_code(gy.dtype), stream()), 'rope_bwd')
+        return gx, None, None, None
+
+
+def rope(x, cos, sin, interleaved=True):
+    return _RopeFn.apply(x, cos, sin, interleaved)
+
+
+# -------------------------------------------------------------------------------------------- attention (K4)
+def _bshd_strides(t):
+    if t.stride(3) != 1:
+        raise DpipeHipError('attention tensors need a contiguous head dim')
+    return t.stride(0), t.stride(1), t.stride(2)
+
+
+class _FlashAttnFn(Function):
+    """softmax(q k^T * scale) v on [B, S, H, D] bf16 tensors, flash style (models/wan/attention.py:91-122)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, kv_len, scale):
+        require_cuda(q, k, v, kv_len)
+        B, Sq, H, D = q.shape
+        Sk = k.shape[1]
+        if q.dtype != torch.bfloat16 or k.dtype != q.dtype or v.dtype != q.dtype:
+            raise DpipeHipError('flash attention kernel computes in bf16')
+        o = torch.empty((B, Sq, H, D), device=q.device, dtype=q.dtype)
+        lse = torch.empty((B, H, Sq), device=q.device, dtype=torch.float32)
+        check(lib().dpipe_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(kv_len), B, H, Sq, Sk, D,
+                                   *_bshd_strides(q), *_bshd_strides(k), *_bshd_strides(v), *_bshd_strides(o),
+                                   float(scale), stream()), 'attn_fwd')
+        ctx.save_for_backward(q, k, v, o, lse, kv_len)
+        ctx.scale = scale
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse, kv_len = ctx.saved_tensors
+        B, Sq, H, D = q.shape
+        Sk = k.shape[1]
+        if do.stride(3) != 1:
+            do = do.contiguous()
+        dq = torch.empty((B, Sq, H, D), device=q.device, dtype=q.dtype)
+        dk = torch.empty((B, Sk, H, D), device=q.device, dtype=q.dtype)
+        dv = torch.empty((B, Sk, H, D), device=q.device, dtype=q.dtype)
+        delta = torch.empty((B, H, Sq), device=q.device, dtype=torch.float32)
+        check(lib().dpipe_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
+                                   ptr(kv_len), B, H, Sq, Sk, D,
+                                   *_bshd_strides(q), *_bshd_strides(k), *_bshd_strides(v), *_bshd_strides(o), *_bshd_strides(do),
+                                   *_bshd_strides(dq), *_bshd_strides(dk), *_bshd_strides(dv), float(ctx.scale), stream()), 'attn_bwd')
+        return dq, dk, dv, None, None
+
+
+class _UnfusedAttnFn(Function):
+    """Same contraction built from the batched MFMA GEMM + row-softmax kernels (exact-fp32 parity path; also the
+    on-device cross-check of the flash kernel).  Materialises the [B, H, Sq, Sk] score matrix."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale):
+        require_cuda(q, k, v)
+        B, Sq, H, D = q.shape
+        Sk = k.shape[1]
+        q, k, v = _contig(q), _contig(k), _contig(v)
+        Skp = (Sk + 7) // 8 * 8
+        p = torch.zeros((B, H, Sq, Skp), device=q.device, dtype=q.dtype)
+        o = torch.empty((B, Sq, H, D), device=q.device, dtype=q.dtype)
+        sq, sk = (Sq * H * D, D), (Sk * H * D, D)
+        sp = (H * Sq * Skp, Sq * Skp)
+        gemm(q, k, False, True, Sq, Sk, D, p, lda=H * D, ldb=H * D, ldc=Skp, batch_outer=B, batch_inner=H,
+             stride_a=sq, stride_b=sk, stride_c=sp)
+        dt = dtype_code(q.dtype)
+        check(lib().dpipe_softmax_fwd(ptr(p), ptr(p), B * H * Sq, Sk, Skp, float(scale), dt, stream()), 'softmax_fwd')
+        gemm(p, v, False, False, Sq, D, Sk, o, lda=Skp, ldb=H * D, ldc=H * D, batch_outer=B, batch_inner=H,
+             stride_a=sp, stride_b=sk, stride_c=sq)
+        ctx.save_for_backward(q, k, v, p)
+        ctx.scale = scale
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, p = ctx.saved_tensors
+        B, Sq, H, D = q.shape
+        Sk, Skp = k.shape[1], p.shape[-1]
+        do = _contig(do)
+        sq, sk = (Sq * H * D, D), (Sk * H * D, D)
+        sp = (H * Sq * Skp, Sq * Skp)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        dp = torch.zeros_like(p)
+        kw = dict(batch_outer=B, batch_inner=H)
+        gemm(p, do, True, False, Sk, D, Sq, dv, lda=Skp, ldb=H * D, ldc=H * D, stride_a=sp, stride_b=sq, stride_c=sk, **kw)
+        gemm(do, v, False, True, Sq, Sk, D, dp, lda=H * D, ldb=H * D, ldc=Skp, stride_a=sq, stride_b=sk, stride_c=sp, **kw)
+        check(lib().dpipe_softmax_bwd(ptr(p), ptr(dp), ptr(dp), B * H * Sq, Sk, Skp, float(ctx.scale), dtype_code(q.dtype), stream()), 'softmax_bwd')
+        gemm(dp, k, False, False, Sq, D, Sk, dq, lda=Skp, ldb=H * D, ldc=H * D, stride_a=sp, stride_b=sk, stride_c=sq, **kw)
+        gemm(dp, q, True, False, Sk, D, Sq, dk, lda=Skp, ldb=H * D, ldc=H * D, stride_a=sp, stride_b=sq, stride_c=sk, **kw)
+        return dq, dk, dv, None
+
+
+def attention(q, k, v, kv_len=None, scale=None, impl='auto'):
+    """q: [B, Sq, H, D], k/v: [B, Sk, H, D] -> [B, Sq, H, D].  kv_len: optional int32 [B] of valid keys.
+    impl: 'flash' (bf16 MFMA flash kernel), 'unfused' (GEMM + softmax kernels), 'auto' = flash for bf16."""
+    D = q.shape[-1]
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    if impl == 'auto':
+        impl = 'flash' if (q.dtype == torch.bfloat16 and D in (64, 128)) else 'unfused'
+    if impl == 'flash':
+        if kv_len is not None and kv_len.dtype != torch.int32:
+            kv_len = kv_len.to(torch.int32)
+        return _FlashAttnFn.apply(q, k, v, kv_len, scale)
+    if kv_len is not None:
+        raise DpipeHipError('the unfused attention path has no key-length masking')
+    return _UnfusedAttnFn.apply(q, k, v, scale)
+
+
+# ------------------------------------------------------------------------------------------------- loss (K9)
+class _LossFn(Function):
+    @staticmethod
+    def forward(ctx, out, target, mask, row_weight, rows, kind, param):
+        require_cuda(out, target, mask, row_weight)
+        oc = _contig(out)
+        tc = _contig(target.to(device=out.device, dtype=torch.float32))
+        mc = None
+        if mask is not None and mask.numel() > 0:
+            mc = mask.to(device=out.device, dtype=torch.float32)
+            if mc.shape != oc.shape:
+                mc = mc.expand_as(oc)
+            mc = _contig(mc)
+        cols = oc.numel() // rows
+        ws = torch.empty(lib().dpipe_loss_workspace_floats(rows, cols), device=out.device, dtype=torch.float32)
+        loss = torch.empty((), device=out.device, dtype=torch.float32)
+        rw = _contig(row_weight.to(device=out.device, dtype=torch.float32)) if row_weight is not None else None
+        check(lib().dpipe_loss_fwd(ptr(oc), dtype_code(oc.dtype), ptr(tc), ptr(mc), ptr(rw), rows, cols, hip.LOSS_KIND[kind],
+                                   float(param), ptr(ws), ptr(loss), None, stream()), 'loss_fwd')
+        ctx.save_for_backward(oc, tc, mc, rw)
+        ctx.meta = (rows, cols, kind, param, out.shape)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        oc, tc, mc, rw = ctx.saved_tensors
+        rows, cols, kind, param, shape = ctx.meta
+        gl = gl.to(dtype=torch.float32).contiguous()
+        go = torch.empty_like(oc)
+        check(lib().dpipe_loss_bwd(ptr(oc), dtype_code(oc.dtype), ptr(tc), ptr(mc), ptr(rw), ptr(gl), rows, cols,
+                                   hip.LOSS_KIND[kind], float(param), ptr(go), stream()), 'loss_bwd')
+        return go.view(shape), None, None, None, None, None, None
+
+
+def fused_loss(output, target, mask=None, row_weight=None, per_sample=False, kind='mse', param=0.0):
+    """mean(elem(output - target) * mask); with per_sample: mean_b(row_weight[b] * mean_chw(...)).
+    Reference: models/base.py:418-436 (default), models/sdxl.py:632-651 (per-sample x SNR weights)."""
+    rows = output.shape[0] if per_sample else 1
+    return _LossFn.apply(output, target, mask, row_weight, rows, kind, param)
+
+
+# ------------------------------------------------------------------------------- grad-norm + clip (K10)
+_CHUNK = 1 << 16
+_table_cache = {}
+
+
+def _chunk_table(tensors):
+    key = tuple((t.data_ptr(), t.numel()) for t in tensors)
+    hit = _table_cache.get(key)
+    if hit is not None:
+        return hit
+    ptrs, ctens, coff, clen = [], [], [], []
+    for i, t in enumerate(tensors):
+        ptrs.append(t.data_ptr())
+        n = t.numel()
+        for off in range(0, n, _CHUNK):
+            ctens.append(i); coff.append(off); clen.append(min(_CHUNK, n - off))
+    dev = tensors[0].device
+    table = (torch.tensor(ptrs, dtype=torch.int64, device=dev), torch.tensor(ctens, dtype=torch.int32, device=dev),
+             torch.tensor(coff, dtype=torch.int64, device=dev), torch.tensor(clen, dtype=torch.int32, device=dev), len(ctens))
+    if len(_table_cache) > 64:
+        _table_cache.clear()
+    _table_cache[key] = table
+    return table
+
+
+def grads_sumsq(grads):
+    """fp32 device scalar: sum over all tensors of sum(g^2) (utils/patches.py:211-221)."""
+    dev = grads[0].device
+    total = torch.zeros((), device=dev, dtype=torch.float32)
+    for dt in (torch.bfloat16, torch.float32):
+        group = [g for g in grads if g.dtype == dt]
+        if not group:
+            continue
+        for g in group:
+            if not g.is_contiguous():
+                raise DpipeHipError('gradients must be contiguous')
+        ptrs, ctens, coff, clen, n = _chunk_table(group)
+        partials = torch.empty(max(n, 1), device=dev, dtype=torch.float32)
+        out = torch.empty((), device=dev, dtype=torch.float32)
+        check(lib().dpipe_multi_sumsq(ptr(ptrs), ptr(ctens), ptr(coff), ptr(clen), n, dtype_code(dt), ptr(partials), ptr(out), stream()), 'multi_sumsq')
+        total = total + out
+    rest = [g for g in grads if g.dtype not in (torch.bfloat16, torch.float32)]
+    if rest:
+        raise DpipeHipError(f'unsupported gradient dtype {rest[0].dtype}')
+    return total
+
+
+def grads_clip_scale_(grads, total_sumsq, max_norm):
+    """g *= min(1, max_norm / (sqrt(total_sumsq) + 1e-6)) in place, no host sync (utils/patches.py:240-245)."""
+    for dt in (torch.bfloat16, torch.float32):
+        group = [g for g in grads if g.dtype == dt]
+        if not group:
+            continue
+        ptrs, ctens, coff, clen, n = _chunk_table(group)
+        check(lib().dpipe_multi_clip_scale(ptr(ptrs), ptr(ctens), ptr(coff), ptr(clen), n, dtype_code(dt), ptr(total_sumsq),
+                                           float(max_norm), stream()), 'multi_clip_scale')
+
+
+# ----------------------------------------------------------------------------------------- small helpers (K7/K8)
+def sinusoidal_embedding(t, dim, max_period=10000.0, sin_first=False, downscale_shift=0.0, scale=1.0):
+    """[cos | sin] (Wan, models/wan/model.py:15-25) or [sin | cos] (sin_first) timestep embedding, fp32."""
+    require_cuda(t)
+    tc = _contig(t.to(torch.float32).reshape(-1))
+    out = torch.empty((tc.numel(), dim), device=t.device, dtype=torch.float32)
+    check(lib().dpipe_sinusoidal_embed(ptr(tc), ptr(out), tc.numel(), dim, float(max_period), int(sin_first), float(downscale_shift),
+                                       float(scale), stream()), 'sinusoidal_embed')
+    return out
+
+
+def flow_match_prep(x1, x0, t):
+    """x_t = (1-t) x1 + t x0, target = x0 - x1  (models/flux.py:368-372).  fp32 tensors, t: [B]."""
+    require_cuda(x1, x0, t)
+    x1, x0, t = _contig(x1.float()), _contig(x0.float()), _contig(t.float())
+    xt, target = torch.empty_like(x1), torch.empty_like(x1)
+    B = x1.shape[0]
+    check(lib().dpipe_flow_match_prep(ptr(x1), ptr(x0), ptr(t), ptr(xt), ptr(target), B, x1.numel() // B, stream()), 'flow_match_prep')
+    return xt, target
+
+
+def transpose2d(x):
+    """[..., R, C] -> [..., C, R] materialised by the LDS tile-transpose kernel."""
+    require_cuda(x)
+    xc = _contig(x)
+    R, C = xc.shape[-2:]
+    batch = xc.numel() // (R * C)
+    out = torch.empty(*xc.shape[:-2], C, R, device=x.device, dtype=x.dtype)
+    check(lib().dpipe_transpose(ptr(xc), ptr(out), R, C, C, R, R * C, R * C, batch, dtype_code(x.dtype), stream()), 'transpose')
+    return out

@@ -1,0 +1,154 @@
+/* dpipe_hip.h -- C ABI of libdpipe_hip.so, the MI355X (gfx950) kernel layer of the pipeline-parallel training step.
+ *
+ * Boundary B3 of SURVEY.md section 8(b).  The reference (tdrussell/diffusion-pipe) has no native layer: every op
+ * below replaces a PyTorch / flash-attn / DeepSpeed call made from Python on the train_batch path.  Each entry
+ * point cites the reference call site it stands in for.  Conventions:
+ *   - plain pointers and sizes only; PyTorch (or any host) owns every buffer; no ownership transfer;
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on that stream;
+ *   - return 0 on success, negative on argument / support errors, positive = hipError_t of the failed launch;
+ *     dpipe_last_error() returns a thread-local description;
+ *   - dtype codes: 0 = bf16, 1 = fp32; all reductions / statistics are fp32;
+ *   - "16-byte vector" requirements: pointers 16-byte aligned, innermost extents multiples of 8 (bf16) / 4 (fp32)
+ *     unless stated otherwise.  Host wrappers check and fail loudly rather than fall back.
+ */
+#ifndef DPIPE_HIP_H
+#define DPIPE_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPIPE_DTYPE_BF16 0
+#define DPIPE_DTYPE_F32 1
+
+#define DPIPE_ACT_NONE 0
+#define DPIPE_ACT_GELU_TANH 1
+#define DPIPE_ACT_GELU_ERF 2
+#define DPIPE_ACT_SILU 3
+
+#define DPIPE_LOSS_MSE 0
+#define DPIPE_LOSS_HUBER 1
+#define DPIPE_LOSS_SMOOTH_L1 2
+
+int dpipe_version(void);
+const char* dpipe_last_error(void);
+/* Number of compute units / name of device `dev`; used by the host to sanity-check it runs on gfx950. */
+int dpipe_device_info(int dev, int* cu_count, char* arch_name, int arch_name_len);
+
+/* ---- K9 loss -------------------------------------------------------------------------------------------------
+ * loss = (1/rows) * sum_r row_weight[r] * (1/cols) * sum_c elem(out[r,c] - target[r,c]) * mask[r,c]
+ * Replaces F.mse_loss/huber_loss/smooth_l1_loss(reduction='none') * mask -> mean of models/base.py:418-436 (rows=1)
+ * and the per-sample mean over (1,2,3) x SNR weight -> mean of models/sdxl.py:632-651 (rows=batch).
+ * mask / row_weight / row_loss may be NULL.  workspace: dpipe_loss_workspace_floats(rows, cols) floats. */
+int dpipe_loss_workspace_floats(long rows, long cols);
+int dpipe_loss_fwd(const void* out, int dtype, const float* target, const float* mask, const float* row_weight,
+                   long rows, long cols, int kind, float param, float* workspace, float* loss, float* row_loss,
+                   void* stream);
+/* grad_out[r,c] = grad_loss[0] * row_weight[r] * elem'(out - target) * mask / (rows * cols) ; autograd of the above. */
+int dpipe_loss_bwd(const void* out, int dtype, const float* target, const float* mask, const float* row_weight,
+                   const float* grad_loss, long rows, long cols, int kind, float param, void* grad_out, void* stream);
+
+/* ---- K6 activations ------------------------------------------------------------------------------------------
+ * nn.GELU(approximate='tanh') of models/wan/model.py:270-272, nn.SiLU of wan.py time_embedding, diffusers GEGLU. */
+int dpipe_act_fwd(const void* x, void* y, long n, int dtype, int act, void* stream);
+int dpipe_act_bwd(const void* x, const void* gy, void* gx, long n, int dtype, int act, void* stream);
+/* x: [rows, 2H] -> y[rows, H] = x[:, :H] * act(x[:, H:]) */
+int dpipe_geglu_fwd(const void* x, void* y, long rows, long H, int dtype, int act, void* stream);
+int dpipe_geglu_bwd(const void* x, const void* gy, void* gx, long rows, long H, int dtype, int act, void* stream);
+
+/* ---- K5 gated residual ---------------------------------------------------------------------------------------
+ * out[r,:] = x[r,:] + y[r,:] * gate[r / rows_per_gate, :]   ("x + y * e[2]" of models/wan/model.py:301,308;
+ * apply_gate of models/hunyuan_image_modeling.py:222-237).  gate == NULL => plain residual add. */
+int dpipe_gated_residual_fwd(const void* x, const void* y, const void* gate, void* out, long rows, long D,
+                             long rows_per_gate, int dtype, int gate_dtype, void* stream);
+int dpipe_gated_residual_slabs(long rows_per_gate);
+/* gy = gout * gate ; dgate[b,:] = sum_rows gout * y.  workspace: batches * slabs * D floats. */
+int dpipe_gated_residual_bwd(const void* gout, const void* y, const void* gate, void* gy, void* dgate,
+                             float* workspace, long batches, long rows_per_gate, long D, int dtype, int gate_dtype,
+                             void* stream);
+
+/* ---- K7 timestep embedding: sinusoidal_embedding_1d (models/wan/model.py:15-25; diffusers Timesteps) ---------- */
+int dpipe_sinusoidal_embed(const float* t, float* out, long n, int dim, float max_period, int sin_first,
+                           float downscale_shift, float scale, void* stream);
+
+/* ---- K8 flow-matching prep: x_t = (1-t) x1 + t x0, target = x0 - x1 (models/flux.py:368-372, wan.py:363-367) --- */
+int dpipe_flow_match_prep(const float* x1, const float* x0, const float* t, float* xt, float* target, long batch,
+                          long per_sample, void* stream);
+
+/* ---- K10 gradient norm + clip (utils/patches.py:175-246) ------------------------------------------------------
+ * Chunk table (device memory): chunk c = elements [chunk_off[c], chunk_off[c]+chunk_len[c]) of tensor
+ * ptrs[chunk_tensor[c]].  sumsq: out_sumsq[0] = sum over all chunks of x^2 (fp32, deterministic two-stage).
+ * clip_scale: every element *= min(1, max_norm / (sqrt(total_sumsq[0]) + 1e-6)); no host synchronisation. */
+int dpipe_multi_sumsq(const void* const* ptrs, const int* chunk_tensor, const long* chunk_off, const int* chunk_len,
+                      int nchunks, int dtype, float* partials, float* out_sumsq, void* stream);
+int dpipe_multi_clip_scale(void* const* ptrs, const int* chunk_tensor, const long* chunk_off, const int* chunk_len,
+                           int nchunks, int dtype, const float* total_sumsq, float max_norm, void* stream);
+
+/* ---- K2 RMSNorm (models/wan/model.py:70-86; per-head form models/hunyuan_image_modeling.py:98-103) ------------
+ * y = cast(x * rsqrt(mean(x^2) + eps)) * w ; w may be NULL; rstd [rows] saved for backward (may be NULL). */
+int dpipe_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, long rows, int cols, float eps, int dtype,
+                      int wdtype, void* stream);
+int dpipe_norm_slabs(long rows_per_group);
+/* workspace: dpipe_norm_slabs(rows) * cols floats, needed only when dw != NULL. */
+int dpipe_rmsnorm_bwd(const void* x, const void* w, const void* gy, const float* rstd, void* gx, void* dw,
+                      float* workspace, long rows, int cols, int dtype, int wdtype, void* stream);
+
+/* ---- K5 LayerNorm (+affine) + AdaLN modulate (models/wan/model.py:89-99,295-309,332-343) ----------------------
+ * n = (x - mean) * rstd [* gamma + beta] ; y = n * (1 + scale[r / rows_per_mod]) + shift[r / rows_per_mod].
+ * gamma/beta/scale/shift may each be NULL.  wdtype: dtype of gamma/beta; mdtype: dtype of scale/shift. */
+int dpipe_lnmod_fwd(const void* x, const void* gamma, const void* beta, const void* scale, const void* shift,
+                    void* y, float* mean, float* rstd, long rows, int cols, long rows_per_mod, float eps, int dtype,
+                    int wdtype, int mdtype, void* stream);
+int dpipe_lnmod_workspace_floats(long rows, int cols, long rows_per_mod);
+int dpipe_lnmod_bwd(const void* x, const void* gy, const void* gamma, const void* beta, const void* scale,
+                    const float* mean, const float* rstd, void* gx, void* dgamma, void* dbeta, void* dscale,
+                    void* dshift, float* workspace, long rows, int cols, long rows_per_mod, int dtype, int wdtype,
+                    int mdtype, void* stream);
+
+/* ---- K3 RoPE (models/wan/model.py:40-67 rope_apply; Flux/HunyuanVideo cos/sin tables) -------------------------
+ * x, y: [B, S, H, D] contiguous; cos/sin: [S, D/2] fp32.  interleaved=1 rotates pairs (2i, 2i+1) (view_as_complex),
+ * interleaved=0 rotates (i, i + D/2).  conj=1 applies the inverse rotation (the backward pass). */
+int dpipe_rope(const void* x, const float* cos_t, const float* sin_t, void* y, long B, long S, long H, int D,
+               int interleaved, int conj, int dtype, void* stream);
+
+/* ---- row softmax (only the fp32 unfused attention parity path uses it) ---------------------------------------- */
+int dpipe_softmax_fwd(const void* x, void* y, long rows, int cols, long ld, float scale, int dtype, void* stream);
+int dpipe_softmax_bwd(const void* y, const void* gy, void* gx, long rows, int cols, long ld, float scale, int dtype,
+                      void* stream);
+
+/* ---- batched 2-D transpose: in [batch][R][C] -> out [batch][C][R] ---------------------------------------------- */
+int dpipe_transpose(const void* in, void* out, int R, int C, long ldi, long ldo, long batch_stride_in,
+                    long batch_stride_out, int batch, int dtype, void* stream);
+
+/* ---- K1/K6 GEMM on MFMA (nn.Linear fwd / dgrad / wgrad: models/wan/model.py:120-122,138-142,270-272) ----------
+ * C[z] = act(alpha * op(A[z]) . op(B[z]) + bias) (+ C[z] if accumulate); z = (zo, zi), zi < batch_inner.
+ * transA=0: A is [M][K] row-major (lda); transA=1: A is [K][M].  transB=1: B is [N][K]; transB=0: B is [K][N].
+ * bias: [N] in the operand dtype or NULL.  out_f32: write fp32 C from bf16 operands.  tile_hint: 0 auto, 64, 128. */
+int dpipe_gemm(int dtype, int transA, int transB, int M, int N, int K, const void* A, long lda, const void* B,
+               long ldb, void* C, long ldc, int batch_outer, int batch_inner, long strideA_outer, long strideA_inner,
+               long strideB_outer, long strideB_inner, long strideC_outer, long strideC_inner, const void* bias,
+               int act, float alpha, int accumulate, int out_f32, int tile_hint, void* stream);
+/* Test probe: runs ds_read_b64_tr_b16 over a 256-element i16 LDS image so the GPU tests can pin the lane mapping
+ * the transposed-operand paths rely on. */
+int dpipe_tr16_probe(const void* in256_i16, void* out256_i16, void* stream);
+
+/* ---- K4 scaled-dot-product attention, flash style (models/wan/attention.py:91-122 flash_attn_varlen_func;
+ *      diffusers attention processors behind models/sdxl.py:797-865; joint attention of utils/patches.py:325-340)
+ * q: [B, Sq, H, D], k/v: [B, Sk, H, D], o: [B, Sq, H, D]; bf16; strides in elements (innermost D contiguous).
+ * kv_len: optional int32 [B] valid key counts (NULL => Sk); lse: [B, H, Sq] fp32 (log-sum-exp, natural log).
+ * D in {64, 128}. */
+int dpipe_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* kv_len, int B, int H,
+                   int Sq, int Sk, int D, long q_sb, long q_ss, long q_sh, long k_sb, long k_ss, long k_sh, long v_sb,
+                   long v_ss, long v_sh, long o_sb, long o_ss, long o_sh, float scale, void* stream);
+/* delta: [B, H, Sq] fp32 workspace.  dq/dk/dv have the layouts (and strides) of q/k/v. */
+int dpipe_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                   float* delta, void* dq, void* dk, void* dv, const int* kv_len, int B, int H, int Sq, int Sk, int D,
+                   long q_sb, long q_ss, long q_sh, long k_sb, long k_ss, long k_sh, long v_sb, long v_ss, long v_sh,
+                   long o_sb, long o_ss, long o_sh, long do_sb, long do_ss, long do_sh, long dq_sb, long dq_ss,
+                   long dq_sh, long dk_sb, long dk_ss, long dk_sh, long dv_sb, long dv_ss, long dv_sh, float scale,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPIPE_HIP_H */

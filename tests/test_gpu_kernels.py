@@ -1,0 +1,327 @@
+"""GPU parity tests of the HIP kernels (call through the C ABI via diffusion_pipe_amd.ops).
+
+Each kernel is compared with a plain PyTorch fp32 evaluation of the same op on the same seeded inputs.
+Tolerances: fp32 kernels 1e-4 relative (exact-fp32 MFMA / fp32 VALU math, different summation order);
+bf16 kernels: inputs are rounded to bf16 first, the reference is computed in fp32 from those rounded inputs,
+and the result must agree to bf16 output rounding (rel 1.6e-2 of the output scale).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel_err(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+def _tol(dtype):
+    return 1.6e-2 if dtype == torch.bfloat16 else 2e-4
+
+
+def test_tr16_probe_pins_lds_transpose_read_semantics(gpu):
+    from diffusion_pipe_amd import hip
+    src = torch.arange(256, dtype=torch.int16, device=gpu)
+    out = torch.full((256,), -1, dtype=torch.int16, device=gpu)
+    hip.check(hip.lib().dpipe_tr16_probe(hip.ptr(src), hip.ptr(out), hip.stream()))
+    torch.cuda.synchronize()
+    lane = torch.arange(64).repeat_interleave(4)
+    j = torch.arange(4).repeat(64)
+    expect = (64 * (lane // 16) + 16 * j + (lane % 16)).to(torch.int16)
+    got = out.cpu()
+    assert torch.equal(got, expect), f'ds_read_b64_tr_b16 mapping differs:\n{got.view(64, 4)[:20]}'
+
+
+GEMM_SHAPES = [(128, 128, 64), (256, 384, 192), (100, 72, 40), (77, 130, 64), (33, 1000, 520), (1024, 1280, 1280)]
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('trans', [(False, True), (False, False), (True, False), (True, True)])
+@pytest.mark.parametrize('shape', GEMM_SHAPES)
+@pytest.mark.parametrize('tile', [64, 128])
+def test_gemm_matches_fp32_matmul(gpu, dtype, trans, shape, tile):
+    from diffusion_pipe_amd import ops
+    ta, tb = trans
+    M, N, K = shape
+    g = torch.Generator(device='cpu').manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn((K, M) if ta else (M, K), generator=g).to(gpu, dtype)
+    b = torch.randn((N, K) if tb else (K, N), generator=g).to(gpu, dtype)
+    ref = (a.float().t() if ta else a.float()) @ (b.float().t() if tb else b.float())
+    out = ops.mm(a, b, ta, tb, tile_hint=tile)
+    torch.cuda.synchronize()
+    assert out.shape == (M, N)
+    assert _rel_err(out, ref) < _tol(dtype)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_gemm_bias_act_accumulate_batched(gpu, dtype):
+    from diffusion_pipe_amd import ops
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(200, 96, generator=g).to(gpu, dtype)
+    w = torch.randn(160, 96, generator=g).to(gpu, dtype)
+    bias = torch.randn(160, generator=g).to(gpu, dtype)
+    ref = F.gelu(a.float() @ w.float().t() + bias.float(), approximate='tanh')
+    out = ops.mm(a, w, False, True, bias=bias, act='gelu_tanh')
+    assert _rel_err(out, ref) < _tol(dtype)
+    # accumulate into an fp32 / same-dtype buffer
+    c0 = torch.randn(200, 160, generator=g).to(gpu, dtype)
+    c = c0.clone()
+    ops.gemm(a, w, False, True, 200, 160, 96, c, lda=96, ldb=96, ldc=160, accumulate=True)
+    assert _rel_err(c, c0.float() + a.float() @ w.float().t()) < _tol(dtype)
+    # two-level batch with strides: [B, S, H, D] attention-style operands
+    B, S, H, D = 2, 72, 3, 64
+    q = torch.randn(B, S, H, D, generator=g).to(gpu, dtype)
+    k = torch.randn(B, S, H, D, generator=g).to(gpu, dtype)
+    p = torch.zeros(B, H, S, S, device=gpu, dtype=dtype)
+    ops.gemm(q, k, False, True, S, S, D, p, lda=H * D, ldb=H * D, ldc=S, batch_outer=B, batch_inner=H,
+             stride_a=(S * H * D, D), stride_b=(S * H * D, D), stride_c=(H * S * S, S * S))
+    ref = torch.einsum('bqhd,bkhd->bhqk', q.float(), k.float())
+    assert _rel_err(p, ref) < _tol(dtype)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_linear_autograd(gpu, dtype):
+    from diffusion_pipe_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 150, 192, generator=g).to(gpu, dtype).requires_grad_(True)
+    w = (torch.randn(320, 192, generator=g) / 14).to(gpu, dtype).requires_grad_(True)
+    b = torch.randn(320, generator=g).to(gpu, dtype).requires_grad_(True)
+    gy = torch.randn(2, 150, 320, generator=g).to(gpu, dtype)
+    y = ops.linear(x, w, b)
+    y.backward(gy)
+    xr, wr, br = (t.detach().float().requires_grad_(True) for t in (x, w, b))
+    yr = F.linear(xr, wr, br)
+    yr.backward(gy.float())
+    tol = _tol(dtype)
+    assert _rel_err(y, yr) < tol
+    assert _rel_err(x.grad, xr.grad) < tol
+    assert _rel_err(w.grad, wr.grad) < tol
+    assert _rel_err(b.grad, br.grad) < tol
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('act', ['gelu_tanh', 'gelu_erf', 'silu'])
+def test_activations(gpu, dtype, act):
+    from diffusion_pipe_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(37, 1000 + 3, generator=g) * 2).to(gpu, dtype).requires_grad_(True)
+    gy = torch.randn(37, 1003, generator=g).to(gpu, dtype)
+    fn = {'gelu_tanh': ops.gelu_tanh, 'gelu_erf': ops.gelu, 'silu': ops.silu}[act]
+    rf = {'gelu_tanh': lambda t: F.gelu(t, approximate='tanh'), 'gelu_erf': F.gelu, 'silu': F.silu}[act]
+    y = fn(x)
+    y.backward(gy)
+    xr = x.detach().float().requires_grad_(True)
+    yr = rf(xr)
+    yr.backward(gy.float())
+    assert _rel_err(y, yr) < _tol(dtype)
+    assert _rel_err(x.grad, xr.grad) < _tol(dtype)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_geglu(gpu, dtype):
+    from diffusion_pipe_amd import ops
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(3, 50, 2 * 640, generator=g).to(gpu, dtype).requires_grad_(True)
+    gy = torch.randn(3, 50, 640, generator=g).to(gpu, dtype)
+    y = ops.geglu(x)
+    y.backward(gy)
+    xr = x.detach().float().requires_grad_(True)
+    h, gate = xr.chunk(2, dim=-1)
+    yr = h * F.gelu(gate)
+    yr.backward(gy.float())
+    assert _rel_err(y, yr) < _tol(dtype)
+    assert _rel_err(x.grad, xr.grad) < _tol(dtype)
+
+
+@pytest.mark.parametrize('dtype,gdtype', [(torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32), (torch.float32, torch.float32)])
+def test_gated_residual(gpu, dtype, gdtype):
+    from diffusion_pipe_amd import ops
+    g = torch.Generator().manual_seed(6)
+    B, S, D = 2, 700, 256
+    x = torch.randn(B, S, D, generator=g).to(gpu, dtype).requires_grad_(True)
+    y = torch.randn(B, S, D, generator=g).to(gpu, dtype).requires_grad_(True)
+    gate = torch.randn(B, 1, D, generator=g).to(gpu, gdtype).requires_grad_(True)
+    go = torch.randn(B, S, D, generator=g).to(gpu, dtype)
+    out = ops.gated_residual(x, y, gate)
+    out.backward(go)
+    xr, yr, gr = (t.detach().float().requires_grad_(True) for t in (x, y, gate))
+    outr = xr + yr * gr
+    outr.backward(go.float())
+    tol = _tol(dtype)
+    assert _rel_err(out, outr) < tol
+    assert _rel_err(x.grad, xr.grad) < tol
+    assert _rel_err(y.grad, yr.grad) < tol
+    assert _rel_err(gate.grad, gr.grad) < (3e-2 if gdtype == torch.bfloat16 else 2e-3)
+    # plain residual (gate=None)
+    out2 = ops.gated_residual(x.detach(), y.detach(), None)
+    assert _rel_err(out2, x.detach().float() + y.detach().float()) < tol
+
+
+@pytest.mark.parametrize('dtype,wdtype', [(torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32), (torch.float32, torch.float32)])
+@pytest.mark.parametrize('cols', [128, 1536])
+def test_rmsnorm(gpu, dtype, wdtype, cols):
+    from diffusion_pipe_amd import ops
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(3, 333, cols, generator=g).to(gpu, dtype).requires_grad_(True)
+    w = (1 + 0.1 * torch.randn(cols, generator=g)).to(gpu, wdtype).requires_grad_(True)
+    gy = torch.randn(3, 333, cols, generator=g).to(gpu, dtype)
+    y = ops.rms_norm(x, w, 1e-6)
+    y.backward(gy)
+    xr, wr = x.detach().float().requires_grad_(True), w.detach().float().requires_grad_(True)
+    yr = xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6) * wr
+    yr.backward(gy.float())
+    tol = _tol(dtype)
+    assert _rel_err(y, yr) < tol
+    assert _rel_err(x.grad, xr.grad) < tol
+    assert _rel_err(w.grad, wr.grad) < (3e-2 if wdtype == torch.bfloat16 else 2e-3)
+
+
+@pytest.mark.parametrize('dtype,wdtype,mdtype', [(torch.bfloat16, torch.bfloat16, torch.float32), (torch.bfloat16, torch.float32, torch.bfloat16),
+                                                 (torch.float32, torch.float32, torch.float32)])
+@pytest.mark.parametrize('affine,mod', [(False, True), (True, False), (True, True), (False, False)])
+def test_layernorm_modulate(gpu, dtype, wdtype, mdtype, affine, mod):
+    from diffusion_pipe_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, S, D = 2, 515, 384
+    x = torch.randn(B, S, D, generator=g).to(gpu, dtype).requires_grad_(True)
+    gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(gpu, wdtype).requires_grad_(True) if affine else None
+    beta = (0.1 * torch.randn(D, generator=g)).to(gpu, wdtype).requires_grad_(True) if affine else None
+    scale = (0.3 * torch.randn(B, 1, D, generator=g)).to(gpu, mdtype).requires_grad_(True) if mod else None
+    shift = (0.3 * torch.randn(B, 1, D, generator=g)).to(gpu, mdtype).requires_grad_(True) if mod else None
+    gy = torch.randn(B, S, D, generator=g).to(gpu, dtype)
+    y = ops.layer_norm_modulate(x, gamma, beta, scale, shift, 1e-6)
+    y.backward(gy)
+    f = lambda t: None if t is None else t.detach().float().requires_grad_(True)
+    xr, gr, br, sr, hr = f(x), f(gamma), f(beta), f(scale), f(shift)
+    n = F.layer_norm(xr, (D,), gr, br, 1e-6)
+    yr = n * (1 + sr) + hr if mod else n
+    yr.backward(gy.float())
+    tol = _tol(dtype)
+    assert _rel_err(y, yr) < tol
+    assert _rel_err(x.grad, xr.grad) < tol
+    if affine:
+        assert _rel_err(gamma.grad, gr.grad) < (3e-2 if wdtype == torch.bfloat16 else 2e-3)
+        assert _rel_err(beta.grad, br.grad) < (3e-2 if wdtype == torch.bfloat16 else 2e-3)
+    if mod:
+        assert _rel_err(scale.grad, sr.grad) < (3e-2 if mdtype == torch.bfloat16 else 2e-3)
+        assert _rel_err(shift.grad, hr.grad) < (3e-2 if mdtype == torch.bfloat16 else 2e-3)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('interleaved', [True, False])
+def test_rope(gpu, dtype, interleaved):
+    from diffusion_pipe_amd import ops
+    g = torch.Generator().manual_seed(10)
+    B, S, H, D = 2, 130, 5, 128
+    x = torch.randn(B, S, H, D, generator=g).to(gpu, dtype).requires_grad_(True)
+    ang = torch.rand(S, D // 2, generator=g) * 6.28
+    cos, sin = ang.cos().to(gpu), ang.sin().to(gpu)
+    gy = torch.randn(B, S, H, D, generator=g).to(gpu, dtype)
+    y = ops.rope(x, cos, sin, interleaved)
+    y.backward(gy)
+    xr = x.detach().float().requires_grad_(True)
+    if interleaved:
+        xc = torch.view_as_complex(xr.reshape(B, S, H, D // 2, 2))
+        fr = torch.polar(torch.ones_like(ang), ang).to(gpu).view(1, S, 1, D // 2)
+        yr = torch.view_as_real(xc * fr).flatten(3)
+    else:
+        a, b = xr[..., :D // 2], xr[..., D // 2:]
+        c, s = cos.view(1, S, 1, -1), sin.view(1, S, 1, -1)
+        yr = torch.cat([a * c - b * s, a * s + b * c], dim=-1)
+    yr.backward(gy.float())
+    assert _rel_err(y, yr) < _tol(dtype)
+    assert _rel_err(x.grad, xr.grad) < _tol(dtype)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('per_sample', [False, True])
+@pytest.mark.parametrize('kind', ['mse', 'huber', 'smooth_l1'])
+def test_fused_loss(gpu, dtype, per_sample, kind):
+    from diffusion_pipe_amd import ops
+    g = torch.Generator().manual_seed(12)
+    shape = (3, 4, 64, 66)
+    out = torch.randn(shape, generator=g).to(gpu, dtype).requires_grad_(True)
+    target = torch.randn(shape, generator=g).to(gpu)
+    mask = (torch.rand((3, 1, 64, 66), generator=g) > 0.3).float().to(gpu)
+    w = torch.rand(3, generator=g).to(gpu) if per_sample else None
+    param = 0.7
+    loss = ops.fused_loss(out, target, mask, w, per_sample=per_sample, kind=kind, param=param)
+    (loss * 1.5).backward()
+    o = out.detach().float().requires_grad_(True)
+    if kind == 'mse':
+        el = F.mse_loss(o, target, reduction='none')
+    elif kind == 'huber':
+        el = F.huber_loss(o, target, reduction='none', delta=param)
+    else:
+        el = F.smooth_l1_loss(o, target, reduction='none', beta=param)
+    el = el * mask
+    ref = (el.mean([1, 2, 3]) * w).mean() if per_sample else el.mean()
+    (ref * 1.5).backward()
+    assert abs(loss.item() - ref.item()) / abs(ref.item()) < 1e-5
+    assert _rel_err(out.grad, o.grad) < _tol(dtype)
+    # no mask, empty-mask tensor behaves as "no mask" (utils/dataset.py:1277-1279 turns None into an empty tensor)
+    l2 = ops.fused_loss(out.detach(), target, torch.tensor([], device=gpu), None, per_sample=False, kind='mse')
+    assert abs(l2.item() - F.mse_loss(out.detach().float(), target).item()) < 1e-5 * l2.item() + 1e-7
+
+
+def test_grad_norm_and_clip(gpu):
+    from diffusion_pipe_amd import ops
+    g = torch.Generator().manual_seed(13)
+    grads = [torch.randn(n, generator=g).to(gpu, dt) for n, dt in
+             [(70001, torch.bfloat16), (5, torch.bfloat16), (1 << 17, torch.float32), (333, torch.float32), (1280 * 1280, torch.bfloat16)]]
+    ref_ss = sum(x.float().norm(2).square() for x in grads)
+    ss = ops.grads_sumsq(grads)
+    assert abs(ss.item() - ref_ss.item()) / ref_ss.item() < 1e-5
+    max_norm = 1.0
+    coef = min(1.0, max_norm / (math.sqrt(ref_ss.item()) + 1e-6))
+    expect = [x.float() * coef for x in grads]
+    ops.grads_clip_scale_(grads, ss, max_norm)
+    for x, e in zip(grads, expect):
+        assert _rel_err(x, e) < _tol(x.dtype)
+    # norm below the threshold: gradients untouched bit for bit
+    small = [torch.full((1000,), 1e-4, device=gpu, dtype=torch.bfloat16)]
+    before = small[0].clone()
+    ops.grads_clip_scale_(small, ops.grads_sumsq(small), 1.0)
+    assert torch.equal(small[0], before)
+
+
+def test_sinusoidal_and_flow_match(gpu):
+    from diffusion_pipe_amd import ops
+    t = torch.tensor([0.0, 17.0, 999.0], device=gpu)
+    e = ops.sinusoidal_embedding(t, 256)
+    half = 128
+    sinusoid = torch.outer(t.float(), torch.pow(10000, -torch.arange(half, device=gpu).float().div(half)))
+    ref = torch.cat([torch.cos(sinusoid), torch.sin(sinusoid)], dim=1)
+    assert (e - ref).abs().max().item() < 2e-3      # fp32 trig of arguments up to 1e3
+    g = torch.Generator().manual_seed(2)
+    x1, x0 = torch.randn(2, 16, 8, 8, generator=g).to(gpu), torch.randn(2, 16, 8, 8, generator=g).to(gpu)
+    tt = torch.tensor([0.25, 0.9], device=gpu)
+    xt, tgt = ops.flow_match_prep(x1, x0, tt)
+    tv = tt.view(-1, 1, 1, 1)
+    assert torch.allclose(xt, (1 - tv) * x1 + tv * x0, atol=1e-6)
+    assert torch.allclose(tgt, x0 - x1, atol=1e-6)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_unfused_attention_path(gpu, dtype):
+    from diffusion_pipe_amd import ops
+    g = torch.Generator().manual_seed(14)
+    B, Sq, Sk, H, D = 2, 200, 77, 3, 64
+    q = torch.randn(B, Sq, H, D, generator=g).to(gpu, dtype).requires_grad_(True)
+    k = torch.randn(B, Sk, H, D, generator=g).to(gpu, dtype).requires_grad_(True)
+    v = torch.randn(B, Sk, H, D, generator=g).to(gpu, dtype).requires_grad_(True)
+    go = torch.randn(B, Sq, H, D, generator=g).to(gpu, dtype)
+    o = ops.attention(q, k, v, impl='unfused')
+    o.backward(go)
+    qr, kr, vr = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+    orf = F.scaled_dot_product_attention(qr.transpose(1, 2), kr.transpose(1, 2), vr.transpose(1, 2)).transpose(1, 2)
+    orf.backward(go.float())
+    tol = 3e-2 if dtype == torch.bfloat16 else 5e-4
+    assert _rel_err(o, orf) < tol
+    assert _rel_err(q.grad, qr.grad) < tol
+    assert _rel_err(k.grad, kr.grad) < tol
+    assert _rel_err(v.grad, vr.grad) < tol
