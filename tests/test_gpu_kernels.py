@@ -15,8 +15,9 @@ pytestmark = pytest.mark.gpu
 
 
 def _rel_err(a, b):
+    """max |a-b| relative to the scale of the reference (floored so analytically-zero results compare absolutely)."""
     a, b = a.float(), b.float()
-    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-3)).item()
 
 
 def _tol(dtype):
@@ -325,3 +326,75 @@ def test_unfused_attention_path(gpu, dtype):
     assert _rel_err(q.grad, qr.grad) < tol
     assert _rel_err(k.grad, kr.grad) < tol
     assert _rel_err(v.grad, vr.grad) < tol
+
+
+def _sdpa_ref(q, k, v, kv_len=None):
+    """fp32 reference on [B, S, H, D] tensors with optional per-batch key-length mask."""
+    B, Sq, H, D = q.shape
+    Sk = k.shape[1]
+    mask = None
+    if kv_len is not None:
+        mask = (torch.arange(Sk, device=q.device)[None, :] < kv_len[:, None].to(q.device)).view(B, 1, 1, Sk)
+    return F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), attn_mask=mask).transpose(1, 2)
+
+
+ATTN_CASES = [  # (B, Sq, Sk, H, D, kv_len)
+    (2, 200, 200, 3, 64, None), (2, 200, 200, 3, 128, None), (1, 300, 77, 5, 64, None), (2, 130, 96, 2, 128, [77, 50]),
+    (1, 1024, 1024, 4, 128, None), (1, 64, 1, 2, 64, None), (1, 33, 513, 2, 128, None)]
+
+
+@pytest.mark.parametrize('case', ATTN_CASES)
+def test_flash_attention_fwd_bwd(gpu, case):
+    from diffusion_pipe_amd import ops
+    B, Sq, Sk, H, D, kvl = case
+    g = torch.Generator().manual_seed(B * 1000 + Sq + Sk + D)
+    dt = torch.bfloat16
+    q = torch.randn(B, Sq, H, D, generator=g).to(gpu, dt).requires_grad_(True)
+    k = torch.randn(B, Sk, H, D, generator=g).to(gpu, dt).requires_grad_(True)
+    v = torch.randn(B, Sk, H, D, generator=g).to(gpu, dt).requires_grad_(True)
+    go = torch.randn(B, Sq, H, D, generator=g).to(gpu, dt)
+    kv_len = torch.tensor(kvl, dtype=torch.int32, device=gpu) if kvl is not None else None
+    o = ops.attention(q, k, v, kv_len=kv_len, impl='flash')
+    o.backward(go)
+    torch.cuda.synchronize()
+    qr, kr, vr = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+    orf = _sdpa_ref(qr, kr, vr, kv_len)
+    orf.backward(go.float())
+    # bf16 P / dS operands inside the kernel: 2e-2 of the output scale
+    assert _rel_err(o, orf) < 2e-2
+    assert _rel_err(q.grad, qr.grad) < 3e-2
+    assert _rel_err(k.grad, kr.grad) < 3e-2
+    assert _rel_err(v.grad, vr.grad) < 3e-2
+    if kvl is not None:   # masked keys receive exactly zero gradient
+        for bi, n in enumerate(kvl):
+            assert k.grad[bi, n:].abs().max().item() == 0.0 and v.grad[bi, n:].abs().max().item() == 0.0
+
+
+def test_flash_attention_strided_views_and_rescale_spike(gpu):
+    from diffusion_pipe_amd import ops
+    g = torch.Generator().manual_seed(77)
+    B, S, H, D = 1, 260, 2, 64
+    qkv = torch.randn(B, S, 3, H, D, generator=g).to(gpu, torch.bfloat16)
+    # a key late in the sequence that dominates one query row forces the online-softmax rescale branch
+    qkv[0, 5, 0] = 4.0
+    qkv[0, 200, 1] = 4.0
+    qkv = qkv.requires_grad_(True)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]      # strided views, head dim contiguous
+    go = torch.randn(B, S, H, D, generator=g).to(gpu, torch.bfloat16)
+    o = ops.attention(q, k, v, impl='flash')
+    o.backward(go)
+    ref = qkv.detach().float().requires_grad_(True)
+    orf = _sdpa_ref(ref[:, :, 0], ref[:, :, 1], ref[:, :, 2])
+    orf.backward(go.float())
+    assert _rel_err(o, orf) < 2e-2
+    assert _rel_err(qkv.grad, ref.grad) < 3e-2
+
+
+def test_flash_matches_unfused_hip_path(gpu):
+    """The two HIP attention implementations (flash MFMA kernel, GEMM+softmax kernels) agree with each other."""
+    from diffusion_pipe_amd import ops
+    g = torch.Generator().manual_seed(21)
+    q, k, v = (torch.randn(1, 320, 4, 128, generator=g).to(gpu, torch.bfloat16) for _ in range(3))
+    a = ops.attention(q, k, v, impl='flash')
+    b = ops.attention(q, k, v, impl='unfused')
+    assert _rel_err(a, b) < 2e-2
