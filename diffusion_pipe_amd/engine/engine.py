@@ -1,0 +1,454 @@
+"""PipelineEngine: the hand-written replacement for DeepSpeed's PipelineEngine on the train_batch hot path.
+
+One process per MI355X.  `train_batch` runs the 1F1B instruction stream of `schedule.TrainSchedule`: per micro-batch
+forward / backward through the local layers (whose arithmetic runs in the HIP kernels of libdpipe_hip.so),
+activation / gradient exchange with the neighbour stages over RCCL P2P on a side stream (`p2p.StageLink`),
+data-parallel gradient all-reduce in large flat buckets, on-device gradient clipping without a host sync, optimizer
+step.  The public surface is the one the reference drives: train.py:608-627,817-823,
+862,894,916-918,183; utils/saver.py:59-128; utils/dataset.py:1389-1401.
+
+Semantics restated from DeepSpeed 0.18.4 (not vendored in the reference; see DESIGN.md "unpinned"):
+  - loss of each micro-batch is scaled by 1/GAS for backward; gradients accumulate in the parameter dtype;
+  - returned loss = mean over micro-batches, averaged over data-parallel replicas, broadcast from the last stage;
+  - step end: ReduceTiedGrads (none) -> ReduceGrads (DP average) -> clip -> optimizer.step -> zero_grad -> lr step.
+"""
+import os
+from collections import OrderedDict
+
+import torch
+import torch.distributed as dist
+
+from . import schedule as sched
+from .module import PipelineModule
+from .p2p import StageLink
+
+
+def _is_float(t):
+    return torch.is_tensor(t) and t.is_floating_point()
+
+
+def _as_list(x):
+    return list(x) if isinstance(x, (tuple, list)) else [x]
+
+
+class PipelineEngine:
+    def __init__(self, module, config, args=None, optimizer=None, lr_scheduler=None, model_parameters=None, device=None):
+        assert isinstance(module, PipelineModule), 'model must be a PipelineModule'
+        self.module = module
+        self._config = dict(config or {})
+        self.args = args
+        self.grid = module.mpu()
+        self.mpu = self.grid
+        self.global_rank = self.grid.global_rank
+        self.world_size = self.grid.world_size
+        self.num_stages = self.grid.pipe_parallel_size
+        self.stage_id = self.grid.get_stage_id()
+        self.prev_stage = self.stage_id - 1
+        self.next_stage = self.stage_id + 1
+        self.dp_world_size = self.grid.data_parallel_size
+        self.is_pipe_parallel = self.num_stages > 1
+        self.is_data_parallel = self.dp_world_size > 1
+
+        self.micro_batch_size = int(self._config.get('train_micro_batch_size_per_gpu', 1))
+        self.micro_batches = int(self._config.get('gradient_accumulation_steps', 1))
+        self._gradient_clipping = float(self._config.get('gradient_clipping', 0.0))
+        self._steps_per_print = int(self._config.get('steps_per_print', 10))
+        self.train_batch_size_ = self.micro_batch_size * self.micro_batches * self.dp_world_size
+
+        if device is None:
+            if torch.cuda.is_available():
+                local_rank = int(os.environ.get('LOCAL_RANK', 0))
+                torch.cuda.set_device(local_rank)
+                device = torch.device('cuda', local_rank)
+            else:
+                device = torch.device('cpu')
+        self.device = torch.device(device)
+        self.module.to(self.device)
+
+        self.optimizer = optimizer
+        self.lr_scheduler = lr_scheduler
+        self.client_optimizer = optimizer
+        self.communication_data_type = None
+        self._support_torch_style_backward = True
+        self.first_last_stage_group = None
+        self.global_steps = 0
+        self.global_samples = 0
+        self.skipped_steps = 0
+        # Reference-faithful gradient-norm scope under pipeline parallelism: DeepSpeed's clip only counts
+        # parameters of pipeline rank 0 (utils/patches.py:212-215).  'global' = true global norm.
+        self.clip_norm_scope = self._config.get('clip_norm_scope', 'deepspeed')
+        self.clip_grad_fn = None           # optional whole-function override (the reference patches this, patches.py:429)
+        self.grad_kernels = None           # provider of grads_sumsq / grads_clip_scale_; None = HIP kernels (ops.py)
+        self.dp_bucket_bytes = int(self._config.get('dp_bucket_bytes', 512 << 20))
+        self._last_grad_norm = None
+
+        self.link = StageLink(self.grid, self.device) if self.is_pipe_parallel else None
+        self.loss = None
+        self.total_loss = None
+        self.agg_train_loss = None
+        self._data_iter = None
+        self._eval_mode = False
+        self.pipe_buffers = {}
+        self._force_grad_boundary = False
+        if self.is_data_parallel:
+            self._broadcast_model()
+
+    # ------------------------------------------------------------------------------------------------ config
+    def train_micro_batch_size_per_gpu(self):
+        return self.micro_batch_size
+
+    def gradient_accumulation_steps(self):
+        return self.micro_batches
+
+    def train_batch_size(self):
+        return self.train_batch_size_
+
+    def gradient_clipping(self):
+        return self._gradient_clipping
+
+    def steps_per_print(self):
+        return self._steps_per_print
+
+    def is_first_stage(self):
+        return self.stage_id == 0
+
+    def is_last_stage(self):
+        return self.stage_id == self.num_stages - 1
+
+    def is_gradient_accumulation_boundary(self):
+        return True
+
+    def reset_activation_shape(self):
+        """Forget cached stage-boundary tuple layouts; the reference calls this before every batch (train.py:916)."""
+        if self.link is not None:
+            self.link.reset()
+
+    def train(self, mode=True):
+        self.module.train(mode)
+        return self
+
+    def eval(self):
+        self.module.train(False)
+        return self
+
+    def get_global_grad_norm(self):
+        return self._last_grad_norm
+
+    # -------------------------------------------------------------------------------------------- optimizer
+    def _configure_optimizer(self, client_optimizer, model_parameters):
+        """client_optimizer: an Optimizer or a factory `params -> Optimizer` (train.py:817)."""
+        if callable(client_optimizer) and not isinstance(client_optimizer, torch.optim.Optimizer):
+            self.optimizer = client_optimizer(model_parameters)
+        else:
+            self.optimizer = client_optimizer
+        self.client_optimizer = self.optimizer
+        return self.optimizer
+
+    def _broadcast_model(self):
+        """Replicas start from DP-rank 0's trainable parameters (utils/patches.py:163-172)."""
+        src = self.grid.dp_group[0]
+        for _, p in self.module.named_parameters():
+            if torch.is_tensor(p) and p.requires_grad:
+                dist.broadcast(p.data, src, group=self.grid.get_data_parallel_group())
+
+    def _trainable_params(self):
+        return [p for p in self.module.parameters() if p.requires_grad]
+
+    # ---------------------------------------------------------------------------------------- batch drivers
+    def _reserve_buffers(self, n):
+        self.pipe_buffers = {k: [None] * n for k in ('inputs', 'labels', 'outputs', 'grads')}
+
+    def train_batch(self, data_iter=None):
+        if not torch._C.is_grad_enabled():
+            raise RuntimeError('train_batch() requires gradients enabled. Use eval_batch() instead.')
+        self.module.train()
+        self._eval_mode = False
+        self.total_loss = None
+        self._data_iter = data_iter
+        schedule = sched.TrainSchedule(micro_batches=self.micro_batches, stages=self.num_stages, stage_id=self.stage_id)
+        self._reserve_buffers(schedule.num_pipe_buffers())
+        self._exec_schedule(schedule)
+        self.agg_train_loss = self._aggregate_total_loss(self.micro_batches)
+        self.global_samples += self.train_batch_size_
+        if self.link is not None:
+            self.link.flush()
+        self._data_iter = None
+        return self.agg_train_loss
+
+    def eval_batch(self, data_iter, return_logits=False, compute_loss=True, reduce_output='avg', bcast_loss=True,
+                   num_micro_batches=None):
+        self.module.eval()
+        self._eval_mode = True
+        self.total_loss = None
+        self._data_iter = data_iter
+        micro_batches = self.micro_batches if num_micro_batches is None else num_micro_batches
+        schedule = sched.InferenceSchedule(micro_batches=micro_batches, stages=self.num_stages, stage_id=self.stage_id)
+        self._reserve_buffers(schedule.num_pipe_buffers())
+        with torch.no_grad():
+            self._exec_schedule(schedule)
+            out = self._aggregate_total_loss(micro_batches)
+        if self.link is not None:
+            self.link.flush()
+        self._data_iter = None
+        self._eval_mode = False
+        return out
+
+    def _exec_schedule(self, pipe_schedule):
+        for step_cmds in pipe_schedule:
+            for cmd in step_cmds:
+                handler = self._INSTRUCTION_MAP.get(type(cmd))
+                if handler is None:
+                    raise RuntimeError(f'{self.__class__.__name__} does not understand instruction {cmd!r}')
+                handler(self, **cmd.kwargs)
+
+    # ----------------------------------------------------------------------------------------- instructions
+    def _next_batch(self):
+        if self._data_iter is None:
+            raise RuntimeError('first / last stage need a data iterator')
+        return next(self._data_iter)
+
+    def _exec_load_micro_batch(self, buffer_id):
+        batch = self._next_batch()
+        if self.is_first_stage():
+            feats = batch[0]
+            if torch.is_tensor(feats):
+                loaded = feats.clone().detach().to(self.device)
+            else:
+                loaded = tuple(x.clone().detach().to(self.device) for x in feats)
+            self.pipe_buffers['inputs'][buffer_id] = loaded
+        if self.is_last_stage():
+            labels = batch[1]
+            if torch.is_tensor(labels):
+                loaded = labels.to(self.device)
+            elif isinstance(labels, (tuple, list)):
+                loaded = tuple(x.to(self.device).detach() for x in labels)
+            else:
+                loaded = labels
+            self.pipe_buffers['labels'][buffer_id] = loaded
+
+    def _exec_forward_pass(self, buffer_id):
+        inputs = self.pipe_buffers['inputs'][buffer_id]
+        outputs = self.module(inputs)
+        if self.is_last_stage():
+            if self.module.loss_fn is not None:
+                labels = self.pipe_buffers['labels'][buffer_id]
+                self.loss = self.module.loss_fn(outputs, labels)
+            else:
+                self.loss = outputs
+            if torch.is_tensor(self.loss):
+                det = self.loss.detach()
+                self.total_loss = det.clone() if self.total_loss is None else self.total_loss + det
+            self.pipe_buffers['outputs'][buffer_id] = self.loss
+        else:
+            self.pipe_buffers['outputs'][buffer_id] = outputs
+
+    def _exec_backward_pass(self, buffer_id):
+        outputs = self.pipe_buffers['outputs'][buffer_id]
+        if self.is_last_stage():
+            (outputs / self.micro_batches).backward()
+        else:
+            out_tensors = [t for t in _as_list(outputs) if _is_float(t)]
+            grad_tensors = self.pipe_buffers['grads'][buffer_id]
+            assert len(out_tensors) == len(grad_tensors), \
+                f'stage {self.stage_id}: {len(out_tensors)} floating-point outputs but {len(grad_tensors)} received gradients'
+            torch.autograd.backward(tensors=out_tensors, grad_tensors=grad_tensors)
+            self.pipe_buffers['grads'][buffer_id] = None
+        self.pipe_buffers['outputs'][buffer_id] = None
+
+    def _exec_send_activations(self, buffer_id):
+        self.link.send_tuple(self.pipe_buffers['outputs'][buffer_id], self.next_stage, tag='act')
+        if self._eval_mode:
+            self.pipe_buffers['outputs'][buffer_id] = None
+
+    def _exec_recv_activations(self, buffer_id):
+        recvd = self.link.recv_tuple(self.prev_stage, tag='act')
+        if not self._eval_mode:
+            for t in _as_list(recvd):
+                t.requires_grad = t.is_floating_point()
+        self.pipe_buffers['inputs'][buffer_id] = recvd
+
+    def _exec_send_grads(self, buffer_id):
+        inputs = self.pipe_buffers['inputs'][buffer_id]
+        grads = []
+        for t in _as_list(inputs):
+            if _is_float(t):
+                grads.append(t.grad if t.grad is not None else torch.zeros_like(t))
+        self.link.send_plain(grads, self.prev_stage)
+        self.pipe_buffers['inputs'][buffer_id] = None
+
+    def _exec_recv_grads(self, buffer_id):
+        outputs = self.pipe_buffers['outputs'][buffer_id]
+        templates = [t for t in _as_list(outputs) if _is_float(t)]
+        self.pipe_buffers['grads'][buffer_id] = self.link.recv_like(templates, self.next_stage)
+
+    def _exec_reduce_tied_grads(self):
+        pass   # the reference's adapters register no tied layers
+
+    def _exec_reduce_grads(self):
+        """Data-parallel gradient average in large flat buckets sized for xGMI / 288 GB HBM."""
+        if not self.is_data_parallel:
+            return
+        group = self.grid.get_data_parallel_group()
+        by_dtype = OrderedDict()
+        for p in self._trainable_params():
+            if p.grad is not None:
+                dt = self.communication_data_type or p.grad.dtype
+                by_dtype.setdefault((dt, p.grad.dtype), []).append(p.grad)
+        for (comm_dt, _), grads in by_dtype.items():
+            bucket, size = [], 0
+            for g in grads + [None]:
+                if g is not None:
+                    bucket.append(g); size += g.numel() * g.element_size()
+                if bucket and (g is None or size >= self.dp_bucket_bytes):
+                    flat = torch.cat([b.reshape(-1).to(comm_dt) for b in bucket])
+                    flat.div_(self.dp_world_size)
+                    dist.all_reduce(flat, group=group)
+                    off = 0
+                    for b in bucket:
+                        b.copy_(flat[off:off + b.numel()].view_as(b)); off += b.numel()
+                    bucket, size = [], 0
+
+    def clip_fp32_gradients(self):
+        """Reference `clip_grad_norm_` (utils/patches.py:175-246) on the HIP multi-tensor kernels, no host sync."""
+        params = [p for p in self.module.parameters() if p.grad is not None]
+        if self.clip_grad_fn is not None:
+            self._last_grad_norm = self.clip_grad_fn(params, self._gradient_clipping, mpu=self.mpu)
+            return
+        ops = self.grad_kernels
+        if ops is None:
+            from .. import ops          # HIP multi-tensor kernels; raises on CPU tensors (no fallback)
+        grads = [p.grad for p in params]
+        counted = grads
+        if self.is_pipe_parallel and self.clip_norm_scope == 'deepspeed' and self.stage_id != 0:
+            counted = []
+        if counted:
+            sumsq = ops.grads_sumsq(counted)
+        else:
+            sumsq = torch.zeros((), device=self.device, dtype=torch.float32)
+        if self.is_pipe_parallel:
+            dist.all_reduce(sumsq, op=dist.ReduceOp.SUM, group=self.grid.get_model_parallel_group())
+        if self.is_data_parallel:
+            norm = sumsq.sqrt() / float(self.dp_world_size)
+            dist.all_reduce(norm, group=self.grid.get_data_parallel_group())
+            sumsq = norm * norm
+        if grads:
+            ops.grads_clip_scale_(grads, sumsq, self._gradient_clipping)
+        self._last_grad_norm = sumsq.sqrt()
+
+    def _exec_optimizer_step(self, lr_kwargs=None):
+        if self._gradient_clipping > 0.0:
+            self.clip_fp32_gradients()
+        if self.optimizer is not None:
+            self.optimizer.step()
+            self.optimizer.zero_grad()
+        for p in self.module.parameters():
+            p.grad = None
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step(**(lr_kwargs or {}))
+        self.global_steps += 1
+
+    _INSTRUCTION_MAP = {
+        sched.OptimizerStep: _exec_optimizer_step,
+        sched.ReduceGrads: _exec_reduce_grads,
+        sched.ReduceTiedGrads: _exec_reduce_tied_grads,
+        sched.LoadMicroBatch: _exec_load_micro_batch,
+        sched.ForwardPass: _exec_forward_pass,
+        sched.BackwardPass: _exec_backward_pass,
+        sched.SendActivation: _exec_send_activations,
+        sched.RecvActivation: _exec_recv_activations,
+        sched.SendGrad: _exec_send_grads,
+        sched.RecvGrad: _exec_recv_grads,
+    }
+
+    # ------------------------------------------------------------------------------------------------ loss
+    def _aggregate_total_loss(self, micro_batches):
+        """mean over micro-batches -> mean over DP replicas -> broadcast from the last stage."""
+        if self.is_last_stage():
+            if self.total_loss is None:
+                loss = torch.zeros((), device=self.device, dtype=torch.float32)
+            else:
+                loss = (self.total_loss / micro_batches).to(torch.float32)
+            if self.is_data_parallel:
+                loss = loss.clone()
+                dist.all_reduce(loss, group=self.grid.get_data_parallel_group())
+                loss /= self.dp_world_size
+        else:
+            loss = torch.zeros((), device=self.device, dtype=torch.float32)
+        if self.is_pipe_parallel:
+            loss = loss.clone().reshape(1)
+            src = self.grid.stage_to_global(self.num_stages - 1)
+            dist.broadcast(loss, src=src, group=self.grid.get_pipe_parallel_group())
+            loss = loss.reshape(())
+        return loss
+
+    # ------------------------------------------------------------------------------------------ checkpoints
+    def _ckpt_tag(self):
+        return f'global_step{self.global_steps}'
+
+    def save_checkpoint(self, save_dir, tag=None, client_state=None, save_latest=True, exclude_frozen_parameters=False):
+        """Layout: save_dir/<tag>/layer_XX-model_states.pt (one per local layer, written by DP rank 0) and
+        mp_rank_XX_model_states.pt (optimizer, lr scheduler, client_state) + save_dir/latest (utils/saver.py:118-128)."""
+        tag = tag or self._ckpt_tag()
+        path = os.path.join(save_dir, tag)
+        os.makedirs(path, exist_ok=True)
+        if self.grid.get_data_parallel_rank() == 0:
+            start, _ = self.module.local_layer_range()
+            for local_idx, layer in enumerate(self.module.forward_funcs):
+                if not isinstance(layer, torch.nn.Module):
+                    continue
+                sd = OrderedDict()
+                trainable = {n for n, p in layer.named_parameters() if p.requires_grad}
+                for k, v in layer.state_dict().items():
+                    if exclude_frozen_parameters and k not in trainable:
+                        continue
+                    sd[k] = v.detach().cpu()
+                torch.save(sd, os.path.join(path, f'layer_{local_idx + start:02d}-model_states.pt'))
+            state = {
+                'optimizer': self.optimizer.state_dict() if self.optimizer is not None else None,
+                'lr_scheduler': self.lr_scheduler.state_dict() if self.lr_scheduler is not None else None,
+                'global_steps': self.global_steps, 'global_samples': self.global_samples,
+                'client_state': dict(client_state or {}), 'num_stages': self.num_stages,
+            }
+            torch.save(state, os.path.join(path, f'mp_rank_{self.stage_id:02d}_model_states.pt'))
+        if dist.is_available() and dist.is_initialized():
+            dist.barrier()
+        if save_latest and self.global_rank == 0:
+            with open(os.path.join(save_dir, 'latest'), 'w') as f:
+                f.write(tag)
+        return True
+
+    def load_checkpoint(self, load_dir, tag=None, load_module_strict=True, load_optimizer_states=True,
+                        load_lr_scheduler_states=True, load_module_only=False):
+        if tag is None:
+            latest = os.path.join(load_dir, 'latest')
+            if not os.path.isfile(latest):
+                return None, None
+            with open(latest) as f:
+                tag = f.read().strip()
+        path = os.path.join(load_dir, tag)
+        start, _ = self.module.local_layer_range()
+        for local_idx, layer in enumerate(self.module.forward_funcs):
+            if not isinstance(layer, torch.nn.Module):
+                continue
+            fn = os.path.join(path, f'layer_{local_idx + start:02d}-model_states.pt')
+            if os.path.isfile(fn):
+                layer.load_state_dict(torch.load(fn, map_location='cpu'), strict=load_module_strict)
+        state = torch.load(os.path.join(path, f'mp_rank_{self.stage_id:02d}_model_states.pt'), map_location='cpu', weights_only=False)
+        if not load_module_only:
+            if load_optimizer_states and self.optimizer is not None and state.get('optimizer') is not None:
+                self.optimizer.load_state_dict(state['optimizer'])
+            if load_lr_scheduler_states and self.lr_scheduler is not None and state.get('lr_scheduler') is not None:
+                self.lr_scheduler.load_state_dict(state['lr_scheduler'])
+        self.global_steps = state.get('global_steps', 0)
+        self.global_samples = state.get('global_samples', 0)
+        return path, state.get('client_state', {})
+
+
+def initialize(args=None, model=None, optimizer=None, model_parameters=None, training_data=None, lr_scheduler=None,
+               config=None, config_params=None, device=None, **kwargs):
+    """Same call shape and return tuple as `deepspeed.initialize` (train.py:623-627):
+    returns (engine, optimizer, training_dataloader=None, lr_scheduler)."""
+    cfg = config if config is not None else config_params
+    engine = PipelineEngine(module=model, config=cfg, args=args, optimizer=optimizer, lr_scheduler=lr_scheduler,
+                            model_parameters=model_parameters, device=device)
+    return engine, engine.optimizer, None, engine.lr_scheduler

@@ -1,0 +1,147 @@
+"""Stage-to-stage exchange of activation / gradient tuples.
+
+On MI355X each neighbour pair talks over its direct xGMI link through RCCL point-to-point (torch.distributed
+backend 'nccl').  All P2P traffic is issued on one side HIP stream, ordered against the compute stream with
+events: a send waits only for the kernel that produced its payload, a receive is ordered before the first kernel
+that consumes it, so transfers overlap with the compute of other micro-batches.  The per-step instruction order of
+the 1F1B schedule makes adjacent stages post complementary send/recv sequences, which keeps the single in-order
+communication stream deadlock-free.  On CPU tensors (gloo, used by the tests) the same code runs without streams.
+
+Wire format (dynamic shapes, like DeepSpeed's `_send_tensor_meta`): the first tuple sent across a boundary after
+`reset_activation_shape()` is preceded by one int64 header [n, (dtype_id, ndim, *shape) * n]; later tuples reuse it.
+"""
+import torch
+import torch.distributed as dist
+
+_DTYPES = [torch.float32, torch.bfloat16, torch.float16, torch.float64, torch.int64, torch.int32, torch.int16, torch.int8,
+           torch.uint8, torch.bool, torch.complex64, torch.complex128]
+_DTYPE_ID = {dt: i for i, dt in enumerate(_DTYPES)}
+_MAX_META = 512
+
+
+def encode_meta(tensors, is_tuple=True):
+    meta = [len(tensors), int(is_tuple)]
+    for t in tensors:
+        meta += [_DTYPE_ID[t.dtype], t.dim(), *t.shape]
+    if len(meta) + 1 > _MAX_META:
+        raise RuntimeError('activation tuple too large for the P2P header')
+    return [len(meta)] + meta + [0] * (_MAX_META - 1 - len(meta))
+
+
+def decode_meta(words):
+    n, is_tuple = words[1], bool(words[2])
+    pos = 3
+    out = []
+    for _ in range(n):
+        dtype, ndim = _DTYPES[words[pos]], words[pos + 1]
+        shape = tuple(words[pos + 2: pos + 2 + ndim])
+        pos += 2 + ndim
+        out.append((dtype, shape))
+    return out, is_tuple
+
+
+def _wire(t):
+    """View of `t` in a dtype every backend can move (RCCL has no complex / bool types)."""
+    if t.is_complex():
+        return torch.view_as_real(t)
+    if t.dtype == torch.bool:
+        return t.view(torch.uint8)
+    return t
+
+
+class StageLink:
+    """P2P endpoint of one pipeline stage."""
+
+    def __init__(self, grid, device):
+        self.grid = grid
+        self.device = torch.device(device)
+        self.on_gpu = self.device.type == 'cuda'
+        self.comm_stream = torch.cuda.Stream(self.device) if self.on_gpu else None
+        self._pending = []          # (work, tensors) of sends not yet waited for
+        self.reset()
+
+    def reset(self):
+        """Forget cached tuple layouts (engine.reset_activation_shape)."""
+        self._sent_meta = {}        # (peer, tag) -> layout already announced
+        self._recv_meta = {}        # (peer, tag) -> layout received
+
+    # ------------------------------------------------------------------------------------------ raw transfers
+    def _isend(self, tensors, peer):
+        if self.on_gpu:
+            ev = torch.cuda.current_stream(self.device).record_event()
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                works = [dist.isend(_wire(t), dst=peer) for t in tensors]
+            for t in tensors:
+                t.record_stream(self.comm_stream)
+        else:
+            works = [dist.isend(_wire(t), dst=peer) for t in tensors]
+        self._pending.append((works, tensors))
+
+    def _recv(self, buffers, peer):
+        if self.on_gpu:
+            with torch.cuda.stream(self.comm_stream):
+                works = [dist.irecv(_wire(b), src=peer) for b in buffers]
+                for w in works:
+                    w.wait()                          # comm stream ordered after the transfers
+                done = self.comm_stream.record_event()
+            for b in buffers:
+                b.record_stream(self.comm_stream)
+            torch.cuda.current_stream(self.device).wait_event(done)   # consumers run after the payload landed
+        else:
+            for w in [dist.irecv(_wire(b), src=peer) for b in buffers]:
+                w.wait()
+
+    def flush(self):
+        """Complete outstanding sends (end of a batch)."""
+        for works, _ in self._pending:
+            for w in works:
+                w.wait()
+        self._pending.clear()
+
+    # ------------------------------------------------------------------------------------------ tuple protocol
+    def send_tuple(self, payload, peer_stage, tag):
+        """payload: a tensor or a tuple/list of tensors (the value a layer returned)."""
+        peer = self.grid.stage_to_global(peer_stage)
+        is_tuple = not torch.is_tensor(payload)
+        tensors = list(payload) if is_tuple else [payload]
+        tensors = [t if t.is_contiguous() else t.contiguous() for t in tensors]
+        layout = ([(t.dtype, tuple(t.shape)) for t in tensors], is_tuple)
+        key = (peer, tag)
+        if self._sent_meta.get(key) != layout:
+            if key in self._sent_meta:
+                raise RuntimeError('activation shapes changed without reset_activation_shape()')
+            header = torch.tensor(encode_meta(tensors, is_tuple), dtype=torch.int64, device=self.device)
+            self._isend([header], peer)
+            self._sent_meta[key] = layout
+        if tensors:
+            self._isend(tensors, peer)
+
+    def recv_tuple(self, peer_stage, tag):
+        peer = self.grid.stage_to_global(peer_stage)
+        key = (peer, tag)
+        layout = self._recv_meta.get(key)
+        if layout is None:
+            header = torch.empty(_MAX_META, dtype=torch.int64, device=self.device)
+            self._recv([header], peer)
+            layout = decode_meta(header.tolist())     # host read: once per boundary per shape epoch
+            self._recv_meta[key] = layout
+        specs, is_tuple = layout
+        buffers = [torch.empty(shape, dtype=dtype, device=self.device) for dtype, shape in specs]
+        if buffers:
+            self._recv(buffers, peer)
+        return tuple(buffers) if is_tuple else buffers[0]
+
+    def recv_like(self, templates, peer_stage):
+        """Receive tensors whose layouts are known locally (gradients of tensors this stage sent)."""
+        peer = self.grid.stage_to_global(peer_stage)
+        buffers = [torch.empty_like(t, memory_format=torch.contiguous_format) for t in templates]
+        if buffers:
+            self._recv(buffers, peer)
+        return buffers
+
+    def send_plain(self, tensors, peer_stage):
+        peer = self.grid.stage_to_global(peer_stage)
+        tensors = [t if t.is_contiguous() else t.contiguous() for t in tensors]
+        if tensors:
+            self._isend(tensors, peer)

@@ -1,0 +1,232 @@
+"""Engine host logic on CPU (gloo): pp=1, pp=2 and dp=2 runs of the 1F1B engine reproduce the oracle's sequential
+eager step (loss, parameters after the optimizer step, clipped gradients).  world_size-2 processes over 127.0.0.1."""
+import os
+import socket
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+from diffusion_pipe_amd.engine import ManualPipelineModule, PipelineModule, initialize
+from diffusion_pipe_amd import data as dpdata
+from oracle import eager_step as oracle
+
+D = 16
+
+
+class First(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.lin = nn.Linear(D, D)
+
+    def forward(self, inputs):
+        for t in inputs:
+            if torch.is_floating_point(t):
+                t.requires_grad_(True)          # adapter convention (models/sdxl.py:677-679)
+        x, ids = inputs
+        return torch.tanh(self.lin(x)), ids, x * 0.5   # carries an int tensor and a float skip tensor downstream
+
+
+class Mid(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.lin = nn.Linear(D, D)
+
+    def forward(self, inputs):
+        x, ids, skip = inputs
+        return torch.tanh(self.lin(x)) + 0.1 * skip, ids, skip
+
+
+class Last(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.lin = nn.Linear(D, D)
+
+    def forward(self, inputs):
+        x, ids, skip = inputs
+        return self.lin(x + skip) * (1 + ids.float().mean() * 0)
+
+
+def make_layers(seed=0):
+    torch.manual_seed(seed)
+    return [First(), Mid(), Mid(), Mid(), Mid(), Last()]
+
+
+def make_batches(n, bs, seed):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n):
+        x = torch.randn(bs, D, generator=g)
+        ids = torch.randint(0, 10, (bs, 3), generator=g)
+        target = torch.randn(bs, D, generator=g)
+        out.append(((x, ids), (target, torch.tensor([]))))
+    return out
+
+
+def oracle_run(steps, gas, clip, batches_per_step):
+    layers = make_layers()
+    params = [p for l in layers for p in l.parameters()]
+    opt = torch.optim.AdamW(params, lr=1e-2)
+    losses = []
+    for s in range(steps):
+        loss, _ = oracle.eager_train_step(layers, oracle.default_loss_fn(), batches_per_step[s], opt, gradient_clipping=clip, params=params)
+        losses.append(loss.item())
+    return losses, [p.detach().clone() for p in params]
+
+
+def engine_run(steps, gas, clip, batches_for_rank, num_stages, partition_method='uniform', split=None, scope='global'):
+    layers = make_layers()
+    all_params = [p for l in layers for p in l.parameters()]
+    module = ManualPipelineModule(layers=layers, num_stages=num_stages, partition_method=partition_method,
+                                  manual_partition_split=split, loss_fn=oracle.default_loss_fn(), dynamic_shape=True)
+    engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 2, 'gradient_accumulation_steps': gas,
+                                                         'gradient_clipping': clip, 'clip_norm_scope': scope}, device='cpu')
+    engine.grad_kernels = oracle.TorchGradKernels
+    local = [p for p in module.parameters() if p.requires_grad]
+    engine._configure_optimizer(lambda ps: torch.optim.AdamW(ps, lr=1e-2), local)
+    losses = []
+    for s in range(steps):
+        engine.reset_activation_shape()
+        it = iter(batches_for_rank[s]) if (engine.is_first_stage() or engine.is_last_stage()) else None
+        losses.append(engine.train_batch(it).item())
+    return losses, all_params, engine
+
+
+def test_engine_pp1_matches_oracle():
+    steps, gas = 3, 4
+    batches = [make_batches(gas, 2, 100 + s) for s in range(steps)]
+    want_l, want_p = oracle_run(steps, gas, 0.5, batches)
+    got_l, got_p, engine = engine_run(steps, gas, 0.5, batches, num_stages=1)
+    assert got_l == pytest.approx(want_l, rel=1e-6)
+    for a, b in zip(got_p, want_p):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+    # eval path: forward-only schedule returns the mean micro-batch loss
+    ev = engine.eval_batch(iter(batches[0]), num_micro_batches=gas).item()
+    assert ev == pytest.approx(oracle.eager_eval(list(engine.module.forward_funcs), oracle.default_loss_fn(), batches[0]).item(), rel=1e-6)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, mode, outdir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        steps, gas = 2, 4
+        if mode == 'pp2':
+            batches = [make_batches(gas, 2, 100 + s) for s in range(steps)]
+            losses, params, engine = engine_run(steps, gas, 0.5, batches, num_stages=2, partition_method='manual', split=[2], scope='global')
+            assert engine.module.parts == [0, 2, 6]
+        elif mode == 'pp2_dsclip':
+            batches = [make_batches(gas, 2, 100)]
+            losses, params, engine = engine_run(1, gas, 0.05, batches, num_stages=2, partition_method='uniform', scope='deepspeed')
+        else:  # dp2: each replica sees its own micro-batches
+            batches = [make_batches(2 * gas, 2, 100 + s)[rank * gas:(rank + 1) * gas] for s in range(steps)]
+            losses, params, engine = engine_run(steps, gas, 0.5, batches, num_stages=1)
+        start, stop = engine.module.local_layer_range()
+        torch.save({'losses': losses, 'range': (start, stop), 'params': [p.detach() for p in params]}, os.path.join(outdir, f'r{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(mode):
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(2, _free_port(), mode, d), nprocs=2, join=True)
+        return [torch.load(os.path.join(d, f'r{r}.pt')) for r in range(2)]
+
+
+def _stage_params(res, layer_param_counts):
+    """Assemble the full parameter list from the stage that owns each layer."""
+    out = []
+    idx = 0
+    for layer, n in enumerate(layer_param_counts):
+        owner = next(r for r in res if r['range'][0] <= layer < r['range'][1])
+        out += owner['params'][idx:idx + n]
+        idx += n
+    return out
+
+
+def test_engine_pp2_gloo_matches_oracle():
+    steps, gas = 2, 4
+    batches = [make_batches(gas, 2, 100 + s) for s in range(steps)]
+    want_l, want_p = oracle_run(steps, gas, 0.5, batches)
+    res = _spawn('pp2')
+    for r in res:
+        assert r['losses'] == pytest.approx(want_l, rel=1e-6)      # loss broadcast from the last stage to every rank
+    got = _stage_params(res, [2] * 6)
+    for a, b in zip(got, want_p):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+
+
+def test_engine_pp2_deepspeed_clip_scope_counts_stage0_only():
+    """Reference quirk: with pp>1 DeepSpeed's clip only counts pipeline-rank-0 parameters."""
+    steps, gas, clip = 1, 4, 0.05
+    batches = [make_batches(gas, 2, 100)]
+    layers = make_layers()
+    params = [p for l in layers for p in l.parameters()]
+    for f, l in batches[0]:
+        (oracle.default_loss_fn()(oracle.run_layers(layers, f), l) / gas).backward()
+    stage0 = [p for l in layers[:3] for p in l.parameters()]
+    norm0 = torch.stack([p.grad.float().norm(2) for p in stage0]).square().sum().sqrt()
+    coef = min(1.0, clip / (norm0.item() + 1e-6))
+    opt = torch.optim.AdamW(params, lr=1e-2)
+    for p in params:
+        p.grad.mul_(coef)
+    opt.step()
+    res = _spawn('pp2_dsclip')
+    got = _stage_params(res, [2] * 6)
+    for a, b in zip(got, params):
+        assert torch.allclose(a, b.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_engine_dp2_gloo_matches_oracle():
+    steps, gas = 2, 4
+    # two replicas x gas micro-batches == one process with 2*gas micro-batches (mean of means with equal sizes)
+    batches = [make_batches(2 * gas, 2, 100 + s) for s in range(steps)]
+    want_l, want_p = oracle_run(steps, 2 * gas, 0.5, batches)
+    res = _spawn('dp2')
+    for r in res:
+        assert r['losses'] == pytest.approx(want_l, rel=1e-5)
+        for a, b in zip(r['params'], want_p):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    steps, gas = 1, 2
+    batches = [make_batches(gas, 2, 5)]
+    _, params, engine = engine_run(steps, gas, 0.0, batches, num_stages=1)
+    engine.save_checkpoint(str(tmp_path), client_state={'step': 1, 'examples': 4}, save_latest=True, exclude_frozen_parameters=True)
+    assert (tmp_path / 'latest').read_text() == 'global_step1'
+    _, params2, engine2 = engine_run(0, gas, 0.0, [], num_stages=1)
+    path, client = engine2.load_checkpoint(str(tmp_path), load_module_strict=False)
+    assert client == {'step': 1, 'examples': 4} and path.endswith('global_step1')
+    for a, b in zip(params, params2):
+        assert torch.equal(a, b)
+    assert engine2.global_steps == 1
+
+
+def test_microbatch_loader_epoch_tracking():
+    class FakeEngine:
+        is_pipe_parallel = False
+    dataset = [{'i': i} for i in range(3)]
+
+    def prepare_inputs(batch, timestep_quantile=None):
+        x = torch.full((4, 2), float(batch['i']))
+        return (x, None), (x + 1, None)
+
+    loader = dpdata.MicroBatchLoader(dataset, FakeEngine(), 2, prepare_inputs)
+    assert len(loader) == 6
+    seen = []
+    for _ in range(6):
+        (f, l) = next(loader)
+        seen.append(f[0][0, 0].item())
+        assert f[1].numel() == 0 and l[1].numel() == 0
+    assert seen == [0, 0, 1, 1, 2, 2]
+    assert loader.epoch == 2                         # epoch advances as soon as the final micro-batch is returned
+    assert next(loader)[0][0][0, 0].item() == 0

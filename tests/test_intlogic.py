@@ -1,0 +1,145 @@
+"""Bit-exact integer / index logic: product (diffusion_pipe_amd.engine, .data) vs the scalar oracle restatement
+(oracle/intlogic.py), plus the reference's own worked examples.  CPU only."""
+import math
+import random
+
+import numpy as np
+import pytest
+
+from diffusion_pipe_amd import data
+from diffusion_pipe_amd.engine import module as pm
+from diffusion_pipe_amd.engine import schedule as ps
+from diffusion_pipe_amd.engine.topology import PipeDataParallelTopology
+from oracle import intlogic as ol
+
+
+def _names(steps):
+    return [[(c.name, c.kwargs.get('buffer_id')) for c in step] for step in steps]
+
+
+def test_train_schedule_worked_example_s2_m4():
+    """S=2, M=4, stage 0 starts [Load0 Fwd0] [SendAct0] [Load1 Fwd1] [RecvGrad0 SendAct1 Bwd0]."""
+    steps = _names(ps.TrainSchedule(micro_batches=4, stages=2, stage_id=0).steps())
+    assert len(steps) == 2 * (4 + 2 - 1)
+    assert steps[0] == [('LoadMicroBatch', 0), ('ForwardPass', 0)]
+    assert steps[1] == [('SendActivation', 0)]
+    assert steps[2] == [('LoadMicroBatch', 1), ('ForwardPass', 1)]
+    assert steps[3] == [('RecvGrad', 0), ('SendActivation', 1), ('BackwardPass', 0)]
+    assert steps[-1][-3:] == [('ReduceTiedGrads', None), ('ReduceGrads', None), ('OptimizerStep', None)]
+
+
+@pytest.mark.parametrize('stages', [1, 2, 3, 4, 8])
+@pytest.mark.parametrize('mbs', [1, 2, 4, 7, 16])
+def test_schedules_match_oracle(stages, mbs):
+    for stage in range(stages):
+        assert _names(ps.TrainSchedule(mbs, stages, stage).steps()) == ol.train_schedule(mbs, stages, stage)
+        assert _names(ps.InferenceSchedule(mbs, stages, stage).steps()) == ol.inference_schedule(mbs, stages, stage)
+
+
+@pytest.mark.parametrize('stages', [2, 4, 8])
+def test_train_schedule_is_a_valid_pipeline(stages):
+    """Size-independent properties: every micro-batch is forwarded then backwarded exactly once per stage, sends
+    and receives pair up between neighbours in the same step order."""
+    M = 8
+    per_stage = [ol.train_schedule(M, stages, s) for s in range(stages)]
+    for s, steps in enumerate(per_stage):
+        flat = [c for st in steps for c in st]
+        assert sum(1 for c in flat if c[0] == 'ForwardPass') == M
+        assert sum(1 for c in flat if c[0] == 'BackwardPass') == M
+        if s + 1 < stages:
+            sends = [i for i, st in enumerate(steps) for c in st if c[0] == 'SendActivation']
+            recvs = [i for i, st in enumerate(per_stage[s + 1]) for c in st if c[0] == 'RecvActivation']
+            assert sends == recvs                      # same step index on both sides => no deadlock
+            gs = [i for i, st in enumerate(per_stage[s + 1]) for c in st if c[0] == 'SendGrad']
+            gr = [i for i, st in enumerate(steps) for c in st if c[0] == 'RecvGrad']
+            assert gs == gr
+
+
+def test_partition_uniform_and_balanced_match_oracle():
+    rng = random.Random(0)
+    for _ in range(300):
+        n, m = rng.randint(1, 40), rng.randint(1, 9)
+        assert pm.partition_uniform(n, m) == ol.partition_uniform(n, m)
+        w = [rng.choice([0, 1, 5, 1000, 123456789, 2_600_000_000]) * rng.randint(0, 3) for _ in range(n)]
+        assert pm.partition_balanced(w, m) == ol.partition_balanced(w, m), (w, m)
+
+
+def test_partition_layer_counts_of_the_baseline_models():
+    # SDXL 23 layers (models/sdxl.py:591-602), Flux 59, Wan-14B 42, HunyuanVideo 63
+    for L in (23, 59, 42, 63):
+        for S in (1, 2, 4, 8):
+            parts = pm.partition_uniform(L, S)
+            assert parts[0] == 0 and parts[-1] == L and len(parts) == S + 1
+            assert all(b >= a for a, b in zip(parts, parts[1:]))
+            assert ol.manual_partition(L, S, parts[1:-1]) == parts
+
+
+def test_topology_rank_layout():
+    topo = PipeDataParallelTopology(num_pp=4, num_dp=2)
+    for s in range(4):
+        for d in range(2):
+            assert topo.get_rank(s, d) == ol.rank_of(s, d, 4, 2)
+            assert topo.get_coord(topo.get_rank(s, d)) == (s, d)
+    assert topo.get_axis_comm_lists('pipe') == [[0, 2, 4, 6], [1, 3, 5, 7]]
+    assert topo.get_axis_comm_lists('data') == [[0, 1], [2, 3], [4, 5], [6, 7]]
+
+
+def test_bucket_arithmetic_matches_oracle():
+    rng = random.Random(1)
+    ars = data.make_ar_buckets(0.5, 2.0, 7)
+    assert np.array_equal(ars, ol.dedup_and_sort(np.geomspace(0.5, 2.0, num=7)))
+    fb = np.array([1, 33, 65])
+    for _ in range(500):
+        w, h, frames = rng.randint(64, 4000), rng.randint(64, 4000), rng.choice([1, 1, 20, 33, 50, 65, 200])
+        log_ar = np.log(w / h)
+        for is_video in (False, True):
+            assert data.find_closest_ar_bucket(log_ar, frames, is_video, ars, fb) == ol.find_closest_ar_bucket(log_ar, frames, is_video, ars, fb)
+        res, mult = rng.choice([512, 768, 1024]), rng.choice([16, 32, 64])
+        for ar in ars:
+            assert data.size_bucket_for(ar, frames, res, mult) == ol.size_bucket(ar, frames, res, mult)
+    sbs = [(1024, 1024, 1), (1280, 768, 1), (768, 1280, 1), (512, 512, 33), (640, 384, 65)]
+    for _ in range(200):
+        log_ar, frames = math.log(rng.uniform(0.3, 3.0)), rng.choice([1, 10, 33, 40, 65, 100])
+        for is_video in (False, True):
+            a, b = data.find_closest_size_bucket(log_ar, frames, is_video, sbs), ol.find_closest_size_bucket(log_ar, frames, is_video, sbs)
+            assert (a is None and b is None) or np.array_equal(a, b)
+    for x in [0.5, 1.5, 2.5, 1023.9, 1040.0, 1008.0, 24.0, 8.0]:
+        assert data.round_to_nearest_multiple(x, 16) == ol.round_to_nearest_multiple(x, 16)
+    assert data.round_to_nearest_multiple(24.0, 16) == 32 and data.round_to_nearest_multiple(8.0, 16) == 0   # banker's rounding
+    assert data.seed_from_hash('some/path.png') == ol.seed_from_hash('some/path.png')
+    a, b = list(range(50)), list(range(50))
+    data.shuffle_with_seed(a, 7); ol.shuffle_with_seed(b, 7)
+    assert a == b
+
+
+def test_iteration_order_and_dp_slices():
+    state = random.getstate()
+    for lens, gbs in [([5, 9, 3], 4), ([100], 8), ([1, 1, 1], 4), ([0, 7], 2)]:
+        got = data.batched_iteration_order(lens, gbs)
+        want = ol.iteration_order(lens, gbs)
+        assert [tuple(r) for r in got.tolist()] == want
+        assert len(got) % gbs == 0
+    assert random.getstate() == state               # global RNG untouched (utils/dataset.py:41-45)
+    for idx in range(3):
+        covered = []
+        for r in range(4):
+            s, e = data.dp_batch_slice(idx, 8, r, 4)
+            assert (s, e) == ol.dp_slice(idx, 8, r, 4)
+            covered += list(range(s, e))
+        assert covered == list(range(idx * 8, idx * 8 + 8))
+    assert data.pick_global_batch_size((1024, 1024, 1), {None: 4}) == 4
+    d = {512: 8, 1024: 2}
+    for sb in [(512, 512, 1), (1280, 768, 1), (768, 768, 1)]:
+        assert data.pick_global_batch_size(sb, d) == ol.pick_global_batch_size(sb, d)
+
+
+def test_split_batch_edge_cases():
+    import torch
+    feats = (torch.arange(8.).view(4, 2), None, torch.arange(4))
+    label = (torch.ones(4, 3), None)
+    mbs = data.split_batch((feats, label), 2)
+    assert len(mbs) == 2
+    (f0, l0), (f1, l1) = mbs
+    assert torch.equal(f0[0], feats[0][:2]) and torch.equal(f1[2], feats[2][2:])
+    assert f0[1].numel() == 0 and l1[1].numel() == 0        # None -> empty tensor
+    assert all(torch.is_tensor(t) for t in f0 + l0)
