@@ -31,6 +31,7 @@ struct AttnParams {
     long q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, o_sb, o_ss, o_sh;
     long do_sb, do_ss, do_sh, dq_sb, dq_ss, dq_sh, dk_sb, dk_ss, dk_sh, dv_sb, dv_ss, dv_sh;
     float scale;
+    int causal;
 };
 
 constexpr float LOG2E = 1.4426950408889634f;
@@ -150,6 +151,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnParams p) {
         for (int kb = 0; kb < 2; ++kb) {
             const int key0 = kt * KT + 32 * kb;
             if (key0 >= kvl) break;                     // wave-uniform: nothing valid in this 32-key block
+            if (p.causal && key0 > qrow - i + 31) break; // whole block above the diagonal for every row of the wave
             f32x16 s = zero16();
 #pragma unroll
             for (int ks = 0; ks < D / 16; ++ks) s = mfma16(frag_rows<KRS>(Kl, 32 * kb, 16 * ks, lane), qf[ks], s);
@@ -157,7 +159,8 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const float v = key < kvl ? s[e] * sl2 : -INFINITY;
+                const bool ok = key < kvl && (!p.causal || key <= qrow);
+                const float v = ok ? s[e] * sl2 : -INFINITY;
                 s[e] = v; mx = fmaxf(mx, v);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -277,6 +280,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(const AttnParams p
         for (int kb = 0; kb < 2; ++kb) {
             const int key0 = kt * KT + 32 * kb;
             if (key0 >= kvl) break;
+            if (p.causal && key0 > qrow - i + 31) break;
             f32x16 s = zero16(), dp = zero16();
 #pragma unroll
             for (int ks = 0; ks < D / 16; ++ks) {
@@ -286,7 +290,8 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(const AttnParams p
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const float pe = key < kvl ? __builtin_amdgcn_exp2f(s[e] * sl2 - lse2) : 0.f;
+                const bool ok = key < kvl && (!p.causal || key <= qrow);
+                const float pe = ok ? __builtin_amdgcn_exp2f(s[e] * sl2 - lse2) : 0.f;
                 s[e] = pe * (dp[e] - dl);
             }
             const bf16x8_t ds0 = pack_frag(s, 0), ds1 = pack_frag(s, 8);
@@ -387,7 +392,9 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(const AttnParams 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int e = 4 * eg + j;
-                    const float pe = klive ? __builtin_amdgcn_exp2f(s[e] * sl2 - ll[j]) : 0.f;
+                    const int qq = qt * QT + 32 * qb + 8 * eg + 4 * h + j;
+                    const bool ok = klive && (!p.causal || key <= qq);
+                    const float pe = ok ? __builtin_amdgcn_exp2f(s[e] * sl2 - ll[j]) : 0.f;
                     pr[e] = pe; s[e] = pe * (dp[e] - dd[j]);
                 }
             }
@@ -431,14 +438,14 @@ extern "C" {
 
 int dpipe_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* kv_len, int B, int H,
                    int Sq, int Sk, int D, long q_sb, long q_ss, long q_sh, long k_sb, long k_ss, long k_sh, long v_sb,
-                   long v_ss, long v_sh, long o_sb, long o_ss, long o_sh, float scale, void* stream) {
+                   long v_ss, long v_sh, long o_sb, long o_ss, long o_sh, float scale, int causal, void* stream) {
     if (!q || !k || !v || !o || !lse || B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) { set_last_error("dpipe_attn_fwd: bad argument"); return DPIPE_ERR_ARG; }
     if (D != 64 && D != 128) { set_last_error("dpipe_attn_fwd: head dim must be 64 or 128"); return DPIPE_ERR_UNSUPPORTED; }
     if (!strides_ok(q, q_sb, q_ss, q_sh) || !strides_ok(k, k_sb, k_ss, k_sh) || !strides_ok(v, v_sb, v_ss, v_sh) || !strides_ok(o, o_sb, o_ss, o_sh)) {
         set_last_error("dpipe_attn_fwd: tensors must be 16-byte aligned with strides multiple of 8 elements"); return DPIPE_ERR_ARG; }
     AttnParams p = {};
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.out = (bf16_t*)o; p.lse = lse; p.kv_len = kv_len;
-    p.B = B; p.H = H; p.Sq = Sq; p.Sk = Sk; p.scale = scale;
+    p.B = B; p.H = H; p.Sq = Sq; p.Sk = Sk; p.scale = scale; p.causal = causal;
     p.q_sb = q_sb; p.q_ss = q_ss; p.q_sh = q_sh; p.k_sb = k_sb; p.k_ss = k_ss; p.k_sh = k_sh;
     p.v_sb = v_sb; p.v_ss = v_ss; p.v_sh = v_sh; p.o_sb = o_sb; p.o_ss = o_ss; p.o_sh = o_sh;
     constexpr int NW = 4;
@@ -453,7 +460,7 @@ int dpipe_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
                    long q_sb, long q_ss, long q_sh, long k_sb, long k_ss, long k_sh, long v_sb, long v_ss, long v_sh,
                    long o_sb, long o_ss, long o_sh, long do_sb, long do_ss, long do_sh, long dq_sb, long dq_ss,
                    long dq_sh, long dk_sb, long dk_ss, long dk_sh, long dv_sb, long dv_ss, long dv_sh, float scale,
-                   void* stream) {
+                   int causal, void* stream) {
     if (!q || !k || !v || !o || !dout || !lse || !delta || !dq || !dk || !dv || B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) {
         set_last_error("dpipe_attn_bwd: bad argument"); return DPIPE_ERR_ARG; }
     if (D != 64 && D != 128) { set_last_error("dpipe_attn_bwd: head dim must be 64 or 128"); return DPIPE_ERR_UNSUPPORTED; }
@@ -463,7 +470,7 @@ int dpipe_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
     AttnParams p = {};
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (const bf16_t*)o; p.dout = (const bf16_t*)dout;
     p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.lse = const_cast<float*>(lse); p.delta = delta; p.kv_len = kv_len;
-    p.B = B; p.H = H; p.Sq = Sq; p.Sk = Sk; p.scale = scale;
+    p.B = B; p.H = H; p.Sq = Sq; p.Sk = Sk; p.scale = scale; p.causal = causal;
     p.q_sb = q_sb; p.q_ss = q_ss; p.q_sh = q_sh; p.k_sb = k_sb; p.k_ss = k_ss; p.k_sh = k_sh;
     p.v_sb = v_sb; p.v_ss = v_ss; p.v_sh = v_sh; p.o_sb = o_sb; p.o_ss = o_ss; p.o_sh = o_sh;
     p.do_sb = do_sb; p.do_ss = do_ss; p.do_sh = do_sh; p.dq_sb = dq_sb; p.dq_ss = dq_ss; p.dq_sh = dq_sh;

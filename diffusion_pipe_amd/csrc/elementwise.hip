@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(EW_BLOCK) loss_bwd_kernel(
 }
 
 // ------------------------------------------------------------- activations (K6)
-enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_SILU = 3 };
+enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_SILU = 3, ACT_QUICK_GELU = 4 };
 
 __device__ __forceinline__ float act_fwd(float x, int act) {
     switch (act) {
@@ -137,6 +137,7 @@ __device__ __forceinline__ float act_fwd(float x, int act) {
     }
     case ACT_GELU_ERF: return 0.5f * x * (1.f + erff(x * 0.7071067811865476f));
     case ACT_SILU: return x / (1.f + __expf(-x));
+    case ACT_QUICK_GELU: return x / (1.f + __expf(-1.702f * x));       // HF CLIP quick_gelu: x * sigmoid(1.702 x)
     default: return x;
     }
 }
@@ -157,6 +158,10 @@ __device__ __forceinline__ float act_bwd(float x, int act) {  // d act / dx
     case ACT_SILU: {
         float s = 1.f / (1.f + __expf(-x));
         return s * (1.f + x * (1.f - s));
+    }
+    case ACT_QUICK_GELU: {
+        float s = 1.f / (1.f + __expf(-1.702f * x));
+        return s * (1.f + 1.702f * x * (1.f - s));
     }
     default: return 1.f;
     }

@@ -37,12 +37,13 @@ struct GemmParams {
     int tiles_m, tiles_n;
 };
 
-enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_SILU = 3 };
+enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_SILU = 3, ACT_QUICK_GELU = 4 };
 __device__ __forceinline__ float epilogue_act(float x, int act) {
     switch (act) {
     case ACT_GELU_TANH: { const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x); return 0.5f * x * (1.f + tanhf(u)); }
     case ACT_GELU_ERF: return 0.5f * x * (1.f + erff(x * 0.7071067811865476f));
     case ACT_SILU: return x / (1.f + __expf(-x));
+    case ACT_QUICK_GELU: return x / (1.f + __expf(-1.702f * x));
     default: return x;
     }
 }

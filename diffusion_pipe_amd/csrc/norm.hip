@@ -277,11 +277,14 @@ __global__ void __launch_bounds__(NB) rope_kernel(const T* __restrict__ x, const
 // ------------------------------------------------------------- row softmax
 // y = softmax(scale * x) over the last dim; cols valid entries per row, ld = row stride.
 template <typename T>
-__global__ void __launch_bounds__(NB) softmax_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long rows, int cols, long ld, float scale) {
+__global__ void __launch_bounds__(NB) softmax_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long rows, int cols_all, long ld, float scale, int causal_rows) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * (NB / 64) + (threadIdx.x >> 6);
     if (row >= rows) return;
     const T* xr = x + row * ld; T* yr = y + row * ld;
+    // causal_rows > 0: rows come in matrices of `causal_rows` rows; row r of a matrix attends to columns <= r
+    const int cols = causal_rows > 0 ? min(cols_all, (int)(row % causal_rows) + 1) : cols_all;
+    for (int c = cols + lane; c < cols_all; c += 64) yr[c] = Elem<T>::from_f(0.f);
     float m = -INFINITY;
     for (int c = lane; c < cols; c += 64) m = fmaxf(m, Elem<T>::to_f(xr[c]) * scale);
     m = wave_max(m);
@@ -459,12 +462,12 @@ int dpipe_rope(const void* x, const float* cos_t, const float* sin_t, void* y, l
     return check_launch("dpipe_rope");
 }
 
-int dpipe_softmax_fwd(const void* x, void* y, long rows, int cols, long ld, float scale, int dtype, void* stream) {
+int dpipe_softmax_fwd(const void* x, void* y, long rows, int cols, long ld, float scale, int causal_rows, int dtype, void* stream) {
     if (!x || !y || rows <= 0 || cols <= 0 || ld < cols) BAD("dpipe_softmax_fwd: bad argument");
     hipStream_t s = STREAM(stream);
     const unsigned grid = (unsigned)cdiv(rows, NB / 64);
-    if (dtype == DPIPE_BF16) softmax_fwd_kernel<bf16_t><<<grid, NB, 0, s>>>((const bf16_t*)x, (bf16_t*)y, rows, cols, ld, scale);
-    else if (dtype == DPIPE_F32) softmax_fwd_kernel<float><<<grid, NB, 0, s>>>((const float*)x, (float*)y, rows, cols, ld, scale);
+    if (dtype == DPIPE_BF16) softmax_fwd_kernel<bf16_t><<<grid, NB, 0, s>>>((const bf16_t*)x, (bf16_t*)y, rows, cols, ld, scale, causal_rows);
+    else if (dtype == DPIPE_F32) softmax_fwd_kernel<float><<<grid, NB, 0, s>>>((const float*)x, (float*)y, rows, cols, ld, scale, causal_rows);
     else { set_last_error("dpipe_softmax_fwd: dtype"); return DPIPE_ERR_UNSUPPORTED; }
     return check_launch("dpipe_softmax_fwd");
 }

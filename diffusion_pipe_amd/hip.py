@@ -14,7 +14,7 @@ import torch
 LIB_PATH = Path(__file__).resolve().parent / 'libdpipe_hip.so'
 
 BF16, F32 = 0, 1
-ACT = {None: 0, 'none': 0, 'gelu_tanh': 1, 'gelu': 2, 'gelu_erf': 2, 'silu': 3}
+ACT = {None: 0, 'none': 0, 'gelu_tanh': 1, 'gelu': 2, 'gelu_erf': 2, 'silu': 3, 'quick_gelu': 4}
 LOSS_KIND = {'mse': 0, 'huber': 1, 'smooth_l1': 2}
 
 P, I, L, F = c_void_p, c_int, c_long, c_float
@@ -45,13 +45,13 @@ _SIGNATURES = {
     'dpipe_lnmod_workspace_floats': (I, [L, I, L]),
     'dpipe_lnmod_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, L, I, I, I, P]),
     'dpipe_rope': (I, [P, P, P, P, L, L, L, I, I, I, I, P]),
-    'dpipe_softmax_fwd': (I, [P, P, L, I, L, F, I, P]),
+    'dpipe_softmax_fwd': (I, [P, P, L, I, L, F, I, I, P]),
     'dpipe_softmax_bwd': (I, [P, P, P, L, I, L, F, I, P]),
     'dpipe_transpose': (I, [P, P, I, I, L, L, L, L, I, I, P]),
     'dpipe_gemm': (I, [I, I, I, I, I, I, P, L, P, L, P, L, I, I, L, L, L, L, L, L, P, I, F, I, I, I, P]),
     'dpipe_tr16_probe': (I, [P, P, P]),
-    'dpipe_attn_fwd': (I, [P, P, P, P, P, P, I, I, I, I, I] + [L] * 12 + [F, P]),
-    'dpipe_attn_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I] + [L] * 24 + [F, P]),
+    'dpipe_attn_fwd': (I, [P, P, P, P, P, P, I, I, I, I, I] + [L] * 12 + [F, I, P]),
+    'dpipe_attn_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I] + [L] * 24 + [F, I, P]),
 }
 
 _lib = None

@@ -1,0 +1,154 @@
+"""nn.Module building blocks whose arithmetic runs in the HIP kernels (ops.py).  Parameter names follow the
+libraries the reference adapters wrap (diffusers / HF transformers), so state dicts line up with theirs.
+
+Compute dtype = parameter dtype (bf16 for training, fp32 for the exact-parity mode): there is no autocast layer;
+inputs are cast to the weight dtype at the first GEMM of a block, norms keep fp32 statistics.
+Convolutions and GroupNorm stay on PyTorch-ROCm (MIOpen / native kernels) as SURVEY.md section 0 allows.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import ops
+
+
+class Linear(nn.Module):
+    def __init__(self, in_features, out_features, bias=True, device=None, dtype=None):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features, device=device, dtype=dtype))
+        self.bias = nn.Parameter(torch.empty(out_features, device=device, dtype=dtype)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            bound = 1 / math.sqrt(self.in_features)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x):
+        return ops.linear(x, self.weight, self.bias)
+
+    def extra_repr(self):
+        return f'in_features={self.in_features}, out_features={self.out_features}, bias={self.bias is not None}'
+
+
+class LayerNorm(nn.Module):
+    def __init__(self, dim, eps=1e-5, elementwise_affine=True, bias=True, device=None, dtype=None):
+        super().__init__()
+        self.dim, self.eps = dim, eps
+        self.weight = nn.Parameter(torch.ones(dim, device=device, dtype=dtype)) if elementwise_affine else None
+        self.bias = nn.Parameter(torch.zeros(dim, device=device, dtype=dtype)) if (elementwise_affine and bias) else None
+
+    def forward(self, x, scale=None, shift=None):
+        """Optionally fused AdaLN modulation: LN(x) * (1 + scale) + shift."""
+        return ops.layer_norm_modulate(x, self.weight, self.bias, scale, shift, self.eps)
+
+
+class RMSNorm(nn.Module):
+    def __init__(self, dim, eps=1e-6, elementwise_affine=True, device=None, dtype=None):
+        super().__init__()
+        self.dim, self.eps = dim, eps
+        self.weight = nn.Parameter(torch.ones(dim, device=device, dtype=dtype)) if elementwise_affine else None
+
+    def forward(self, x):
+        return ops.rms_norm(x, self.weight, self.eps)
+
+
+class SiLU(nn.Module):
+    def forward(self, x):
+        return ops.silu(x)
+
+
+class GELU(nn.Module):
+    def __init__(self, approximate='none'):
+        super().__init__()
+        self.approximate = approximate
+
+    def forward(self, x):
+        return ops.gelu_tanh(x) if self.approximate == 'tanh' else ops.gelu(x)
+
+
+class QuickGELU(nn.Module):
+    def forward(self, x):
+        return ops.quick_gelu(x)
+
+
+class Identity(nn.Module):
+    def forward(self, x):
+        return x
+
+
+class GEGLU(nn.Module):
+    """diffusers.models.activations.GEGLU: proj to 2*inner, hidden * gelu(gate)."""
+
+    def __init__(self, dim_in, dim_out, device=None, dtype=None):
+        super().__init__()
+        self.proj = Linear(dim_in, dim_out * 2, device=device, dtype=dtype)
+
+    def forward(self, x):
+        return ops.geglu(self.proj(x))
+
+
+class FeedForward(nn.Module):
+    """diffusers FeedForward(activation_fn='geglu'): net = [GEGLU, Dropout, Linear]."""
+
+    def __init__(self, dim, mult=4, device=None, dtype=None):
+        super().__init__()
+        inner = dim * mult
+        self.net = nn.ModuleList([GEGLU(dim, inner, device=device, dtype=dtype), Identity(), Linear(inner, dim, device=device, dtype=dtype)])
+
+    def forward(self, x):
+        for m in self.net:
+            x = m(x)
+        return x
+
+
+class Attention(nn.Module):
+    """diffusers.models.attention_processor.Attention (self- or cross-attention, no qk-norm, no mask)."""
+
+    def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64, bias=False, out_bias=True, device=None, dtype=None):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads, self.dim_head = heads, dim_head
+        kv_dim = cross_attention_dim if cross_attention_dim is not None else query_dim
+        kw = dict(device=device, dtype=dtype)
+        self.to_q = Linear(query_dim, inner, bias=bias, **kw)
+        self.to_k = Linear(kv_dim, inner, bias=bias, **kw)
+        self.to_v = Linear(kv_dim, inner, bias=bias, **kw)
+        self.to_out = nn.ModuleList([Linear(inner, query_dim, bias=out_bias, **kw), Identity()])
+        self.attn_impl = 'auto'
+
+    def forward(self, hidden_states, encoder_hidden_states=None):
+        ctx = hidden_states if encoder_hidden_states is None else encoder_hidden_states
+        B, S, _ = hidden_states.shape
+        q = self.to_q(hidden_states).view(B, S, self.heads, self.dim_head)
+        k = self.to_k(ctx).view(B, ctx.shape[1], self.heads, self.dim_head)
+        v = self.to_v(ctx).view(B, ctx.shape[1], self.heads, self.dim_head)
+        o = ops.attention(q, k, v, impl=self.attn_impl)
+        return self.to_out[0](o.reshape(B, S, self.heads * self.dim_head))
+
+
+class Timesteps(nn.Module):
+    """diffusers Timesteps / get_timestep_embedding: fp32 sinusoidal features, [cos | sin] when flip_sin_to_cos."""
+
+    def __init__(self, num_channels, flip_sin_to_cos=True, downscale_freq_shift=0.0, scale=1.0):
+        super().__init__()
+        self.num_channels, self.flip_sin_to_cos = num_channels, flip_sin_to_cos
+        self.downscale_freq_shift, self.scale = downscale_freq_shift, scale
+
+    def forward(self, timesteps):
+        return ops.sinusoidal_embedding(timesteps, self.num_channels, 10000.0, sin_first=not self.flip_sin_to_cos,
+                                        downscale_shift=self.downscale_freq_shift, scale=self.scale)
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, in_channels, time_embed_dim, device=None, dtype=None):
+        super().__init__()
+        self.linear_1 = Linear(in_channels, time_embed_dim, device=device, dtype=dtype)
+        self.act = SiLU()
+        self.linear_2 = Linear(time_embed_dim, time_embed_dim, device=device, dtype=dtype)
+
+    def forward(self, sample, condition=None):
+        return self.linear_2(self.act(self.linear_1(sample)))

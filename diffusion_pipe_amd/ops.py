@@ -139,6 +139,10 @@ def silu(x):
     return _ActFn.apply(x, 'silu')
 
 
+def quick_gelu(x):
+    return _ActFn.apply(x, 'quick_gelu')
+
+
 class _GegluFn(Function):
     """diffusers GEGLU: h, gate = x.chunk(2, -1); h * gelu(gate)."""
 
@@ -352,7 +356,7 @@ class _FlashAttnFn(Function):
     """softmax(q k^T * scale) v on [B, S, H, D] bf16 tensors, flash style (models/wan/attention.py:91-122)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, kv_len, scale):
+    def forward(ctx, q, k, v, kv_len, scale, causal):
         require_cuda(q, k, v, kv_len)
         B, Sq, H, D = q.shape
         Sk = k.shape[1]
@@ -362,9 +366,10 @@ class _FlashAttnFn(Function):
         lse = torch.empty((B, H, Sq), device=q.device, dtype=torch.float32)
         check(lib().dpipe_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(kv_len), B, H, Sq, Sk, D,
                                    *_bshd_strides(q), *_bshd_strides(k), *_bshd_strides(v), *_bshd_strides(o),
-                                   float(scale), stream()), 'attn_fwd')
+                                   float(scale), int(causal), stream()), 'attn_fwd')
         ctx.save_for_backward(q, k, v, o, lse, kv_len)
         ctx.scale = scale
+        ctx.causal = causal
         return o
 
     @staticmethod
@@ -381,8 +386,8 @@ class _FlashAttnFn(Function):
         check(lib().dpipe_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
                                    ptr(kv_len), B, H, Sq, Sk, D,
                                    *_bshd_strides(q), *_bshd_strides(k), *_bshd_strides(v), *_bshd_strides(o), *_bshd_strides(do),
-                                   *_bshd_strides(dq), *_bshd_strides(dk), *_bshd_strides(dv), float(ctx.scale), stream()), 'attn_bwd')
-        return dq, dk, dv, None, None
+                                   *_bshd_strides(dq), *_bshd_strides(dk), *_bshd_strides(dv), float(ctx.scale), int(ctx.causal), stream()), 'attn_bwd')
+        return dq, dk, dv, None, None, None
 
 
 class _UnfusedAttnFn(Function):
@@ -390,7 +395,7 @@ class _UnfusedAttnFn(Function):
     on-device cross-check of the flash kernel).  Materialises the [B, H, Sq, Sk] score matrix."""
 
     @staticmethod
-    def forward(ctx, q, k, v, scale):
+    def forward(ctx, q, k, v, scale, causal):
         require_cuda(q, k, v)
         B, Sq, H, D = q.shape
         Sk = k.shape[1]
@@ -403,7 +408,7 @@ class _UnfusedAttnFn(Function):
         gemm(q, k, False, True, Sq, Sk, D, p, lda=H * D, ldb=H * D, ldc=Skp, batch_outer=B, batch_inner=H,
              stride_a=sq, stride_b=sk, stride_c=sp)
         dt = dtype_code(q.dtype)
-        check(lib().dpipe_softmax_fwd(ptr(p), ptr(p), B * H * Sq, Sk, Skp, float(scale), dt, stream()), 'softmax_fwd')
+        check(lib().dpipe_softmax_fwd(ptr(p), ptr(p), B * H * Sq, Sk, Skp, float(scale), Sq if causal else 0, dt, stream()), 'softmax_fwd')
         gemm(p, v, False, False, Sq, D, Sk, o, lda=Skp, ldb=H * D, ldc=H * D, batch_outer=B, batch_inner=H,
              stride_a=sp, stride_b=sk, stride_c=sq)
         ctx.save_for_backward(q, k, v, p)
@@ -426,10 +431,10 @@ class _UnfusedAttnFn(Function):
         check(lib().dpipe_softmax_bwd(ptr(p), ptr(dp), ptr(dp), B * H * Sq, Sk, Skp, float(ctx.scale), dtype_code(q.dtype), stream()), 'softmax_bwd')
         gemm(dp, k, False, False, Sq, D, Sk, dq, lda=Skp, ldb=H * D, ldc=H * D, stride_a=sp, stride_b=sk, stride_c=sq, **kw)
         gemm(dp, q, True, False, Sk, D, Sq, dk, lda=Skp, ldb=H * D, ldc=H * D, stride_a=sp, stride_b=sq, stride_c=sk, **kw)
-        return dq, dk, dv, None
+        return dq, dk, dv, None, None
 
 
-def attention(q, k, v, kv_len=None, scale=None, impl='auto'):
+def attention(q, k, v, kv_len=None, scale=None, impl='auto', causal=False):
     """q: [B, Sq, H, D], k/v: [B, Sk, H, D] -> [B, Sq, H, D].  kv_len: optional int32 [B] of valid keys.
     impl: 'flash' (bf16 MFMA flash kernel), 'unfused' (GEMM + softmax kernels), 'auto' = flash for bf16."""
     D = q.shape[-1]
@@ -440,10 +445,10 @@ def attention(q, k, v, kv_len=None, scale=None, impl='auto'):
     if impl == 'flash':
         if kv_len is not None and kv_len.dtype != torch.int32:
             kv_len = kv_len.to(torch.int32)
-        return _FlashAttnFn.apply(q, k, v, kv_len, scale)
+        return _FlashAttnFn.apply(q, k, v, kv_len, scale, causal)
     if kv_len is not None:
         raise DpipeHipError('the unfused attention path has no key-length masking')
-    return _UnfusedAttnFn.apply(q, k, v, scale)
+    return _UnfusedAttnFn.apply(q, k, v, scale, causal)
 
 
 # ------------------------------------------------------------------------------------------------- loss (K9)

@@ -25,6 +25,7 @@ extern "C" {
 #define DPIPE_ACT_GELU_TANH 1
 #define DPIPE_ACT_GELU_ERF 2
 #define DPIPE_ACT_SILU 3
+#define DPIPE_ACT_QUICK_GELU 4
 
 #define DPIPE_LOSS_MSE 0
 #define DPIPE_LOSS_HUBER 1
@@ -112,7 +113,9 @@ int dpipe_rope(const void* x, const float* cos_t, const float* sin_t, void* y, l
                int interleaved, int conj, int dtype, void* stream);
 
 /* ---- row softmax (only the fp32 unfused attention parity path uses it) ---------------------------------------- */
-int dpipe_softmax_fwd(const void* x, void* y, long rows, int cols, long ld, float scale, int dtype, void* stream);
+/* causal_rows > 0: rows form matrices of that many rows; row r only sees columns <= r (masked outputs are 0). */
+int dpipe_softmax_fwd(const void* x, void* y, long rows, int cols, long ld, float scale, int causal_rows, int dtype,
+                      void* stream);
 int dpipe_softmax_bwd(const void* y, const void* gy, void* gx, long rows, int cols, long ld, float scale, int dtype,
                       void* stream);
 
@@ -136,17 +139,18 @@ int dpipe_tr16_probe(const void* in256_i16, void* out256_i16, void* stream);
  *      diffusers attention processors behind models/sdxl.py:797-865; joint attention of utils/patches.py:325-340)
  * q: [B, Sq, H, D], k/v: [B, Sk, H, D], o: [B, Sq, H, D]; bf16; strides in elements (innermost D contiguous).
  * kv_len: optional int32 [B] valid key counts (NULL => Sk); lse: [B, H, Sq] fp32 (log-sum-exp, natural log).
- * D in {64, 128}. */
+ * D in {64, 128}.  causal != 0 masks keys with index > query index (CLIP text encoders inside SDXL stage 0,
+ * models/sdxl.py:738-784). */
 int dpipe_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* kv_len, int B, int H,
                    int Sq, int Sk, int D, long q_sb, long q_ss, long q_sh, long k_sb, long k_ss, long k_sh, long v_sb,
-                   long v_ss, long v_sh, long o_sb, long o_ss, long o_sh, float scale, void* stream);
+                   long v_ss, long v_sh, long o_sb, long o_ss, long o_sh, float scale, int causal, void* stream);
 /* delta: [B, H, Sq] fp32 workspace.  dq/dk/dv have the layouts (and strides) of q/k/v. */
 int dpipe_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                    float* delta, void* dq, void* dk, void* dv, const int* kv_len, int B, int H, int Sq, int Sk, int D,
                    long q_sb, long q_ss, long q_sh, long k_sb, long k_ss, long k_sh, long v_sb, long v_ss, long v_sh,
                    long o_sb, long o_ss, long o_sh, long do_sb, long do_ss, long do_sh, long dq_sb, long dq_ss,
                    long dq_sh, long dk_sb, long dk_ss, long dk_sh, long dv_sb, long dv_ss, long dv_sh, float scale,
-                   void* stream);
+                   int causal, void* stream);
 
 #ifdef __cplusplus
 }

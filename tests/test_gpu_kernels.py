@@ -398,3 +398,35 @@ def test_flash_matches_unfused_hip_path(gpu):
     a = ops.attention(q, k, v, impl='flash')
     b = ops.attention(q, k, v, impl='unfused')
     assert _rel_err(a, b) < 2e-2
+
+
+@pytest.mark.parametrize('impl,dtype', [('flash', torch.bfloat16), ('unfused', torch.bfloat16), ('unfused', torch.float32)])
+@pytest.mark.parametrize('S', [77, 200])
+def test_causal_attention(gpu, impl, dtype, S):
+    """Causal masking used by the CLIP text encoders that run inside SDXL's first pipeline layer."""
+    from diffusion_pipe_amd import ops
+    g = torch.Generator().manual_seed(31 + S)
+    B, H, D = 2, 3, 64
+    q, k, v = (torch.randn(B, S, H, D, generator=g).to(gpu, dtype).requires_grad_(True) for _ in range(3))
+    go = torch.randn(B, S, H, D, generator=g).to(gpu, dtype)
+    o = ops.attention(q, k, v, impl=impl, causal=True)
+    o.backward(go)
+    qr, kr, vr = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+    orf = F.scaled_dot_product_attention(qr.transpose(1, 2), kr.transpose(1, 2), vr.transpose(1, 2), is_causal=True).transpose(1, 2)
+    orf.backward(go.float())
+    tol = 3e-2 if dtype == torch.bfloat16 else 5e-4
+    assert _rel_err(o, orf) < tol
+    for a, b in ((q.grad, qr.grad), (k.grad, kr.grad), (v.grad, vr.grad)):
+        assert _rel_err(a, b) < tol
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_quick_gelu(gpu, dtype):
+    from diffusion_pipe_amd import ops
+    x = torch.linspace(-6, 6, 4096).to(gpu, dtype).requires_grad_(True)
+    y = ops.quick_gelu(x)
+    y.sum().backward()
+    xr = x.detach().float().requires_grad_(True)
+    yr = xr * torch.sigmoid(1.702 * xr)
+    yr.sum().backward()
+    assert _rel_err(y, yr) < _tol(dtype) and _rel_err(x.grad, xr.grad) < _tol(dtype)
