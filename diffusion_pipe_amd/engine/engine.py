@@ -82,6 +82,11 @@ class PipelineEngine:
         self.dp_bucket_bytes = int(self._config.get('dp_bucket_bytes', 512 << 20))
         self._last_grad_norm = None
 
+        # hipGraph mode: one captured graph per micro-batch shape replaces ~10^4 per-op launches (static shapes only;
+        # single-stage for now -- P2P stays outside graphs).  Gradients then live in persistent buffers.
+        self.use_graph = bool(self._config.get('hip_graph', False)) and self.device.type == 'cuda' and not self.is_pipe_parallel
+        self._graphs = {}
+        self._g_total_loss = None
         self.link = StageLink(self.grid, self.device) if self.is_pipe_parallel else None
         self.loss = None
         self.total_loss = None
@@ -165,9 +170,12 @@ class PipelineEngine:
         self._eval_mode = False
         self.total_loss = None
         self._data_iter = data_iter
-        schedule = sched.TrainSchedule(micro_batches=self.micro_batches, stages=self.num_stages, stage_id=self.stage_id)
-        self._reserve_buffers(schedule.num_pipe_buffers())
-        self._exec_schedule(schedule)
+        if self.use_graph:
+            self._train_batch_graphed()
+        else:
+            schedule = sched.TrainSchedule(micro_batches=self.micro_batches, stages=self.num_stages, stage_id=self.stage_id)
+            self._reserve_buffers(schedule.num_pipe_buffers())
+            self._exec_schedule(schedule)
         self.agg_train_loss = self._aggregate_total_loss(self.micro_batches)
         self.global_samples += self.train_batch_size_
         if self.link is not None:
@@ -200,6 +208,64 @@ class PipelineEngine:
                 if handler is None:
                     raise RuntimeError(f'{self.__class__.__name__} does not understand instruction {cmd!r}')
                 handler(self, **cmd.kwargs)
+
+    # ------------------------------------------------------------------------------------------- hipGraph path
+    def _train_batch_graphed(self):
+        """Single-stage 1F1B degenerates to [Load, Forward, Backward] x GAS, then reduce / clip / step; each
+        micro-batch's forward + loss + backward is ONE graph replay."""
+        if self._g_total_loss is None:
+            self._g_total_loss = torch.zeros((), device=self.device, dtype=torch.float32)
+        self._g_total_loss.zero_()
+        for _ in range(self.micro_batches):
+            feats, labels = self._next_batch()
+            feats = (feats,) if torch.is_tensor(feats) else tuple(feats)
+            labels = (labels,) if torch.is_tensor(labels) else tuple(labels)
+            sig = tuple((tuple(t.shape), t.dtype) for t in feats + labels)
+            entry = self._graphs.get(sig)
+            if entry is None:
+                entry = self._capture_micro_batch(feats, labels)
+                self._graphs[sig] = entry
+            for dst, src in zip(entry['inputs'] + entry['labels'], feats + labels):
+                if src.numel() > 0:
+                    dst.copy_(src, non_blocking=True)
+            entry['graph'].replay()
+        self.total_loss = self._g_total_loss
+        self._exec_reduce_tied_grads()
+        self._exec_reduce_grads()
+        self._exec_optimizer_step()
+
+    def _capture_micro_batch(self, feats, labels):
+        static_in = tuple(t.clone().detach().to(self.device) for t in feats)
+        static_lab = tuple(t.clone().detach().to(self.device) for t in labels)
+        single = len(static_in) == 1
+        single_label = len(static_lab) == 1
+
+        def body():
+            x = static_in[0].detach() if single else tuple(t.detach() for t in static_in)
+            out = self.module(x)
+            loss = self.module.loss_fn(out, static_lab[0] if single_label else static_lab)
+            self._g_total_loss.add_(loss.detach().to(torch.float32))
+            (loss / self.micro_batches).backward()
+
+        had_grad = {id(p) for p in self.module.parameters() if p.grad is not None}
+        cur = torch.cuda.current_stream(self.device)
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(2):                      # eager warm-up (library autotuning, allocator pools)
+                body()
+        cur.wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            body()
+        # undo the warm-up's side effects: gradient buffers stay allocated (persistent, addresses baked into the
+        # graph) but are zeroed; parameters that receive no gradient keep grad = None like the eager path.
+        fresh = [p.grad for p in self.module.parameters() if p.grad is not None and id(p) not in had_grad]
+        if fresh:
+            torch._foreach_zero_(fresh)
+        self._g_total_loss.zero_()
+        return {'graph': graph, 'inputs': static_in, 'labels': static_lab}
 
     # ----------------------------------------------------------------------------------------- instructions
     def _next_batch(self):
@@ -340,9 +406,15 @@ class PipelineEngine:
             self.clip_fp32_gradients()
         if self.optimizer is not None:
             self.optimizer.step()
-            self.optimizer.zero_grad()
-        for p in self.module.parameters():
-            p.grad = None
+        if self.use_graph:
+            grads = [p.grad for p in self.module.parameters() if p.grad is not None]
+            if grads:
+                torch._foreach_zero_(grads)         # buffers are referenced by the captured graphs: zero, never free
+        else:
+            if self.optimizer is not None:
+                self.optimizer.zero_grad()
+            for p in self.module.parameters():
+                p.grad = None
         if self.lr_scheduler is not None:
             self.lr_scheduler.step(**(lr_kwargs or {}))
         self.global_steps += 1

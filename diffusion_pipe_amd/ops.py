@@ -25,6 +25,11 @@ def _rows2d(x):
 
 
 # --------------------------------------------------------------------------------------------- GEMM (K1/K6)
+# bench.py sets this to a list to record the signature of every GEMM launch of a step (shape, layout, batch); the
+# distinct signatures are then timed with HIP events on the launch stream for the `roofline` object.
+GEMM_TRACE = None
+
+
 def gemm(a, b, trans_a, trans_b, M, N, K, out, *, lda, ldb, ldc, batch_outer=1, batch_inner=1,
          stride_a=(0, 0), stride_b=(0, 0), stride_c=(0, 0), bias=None, act=None, alpha=1.0, accumulate=False,
          tile_hint=0):
@@ -38,6 +43,8 @@ def gemm(a, b, trans_a, trans_b, M, N, K, out, *, lda, ldb, ldc, batch_outer=1, 
         raise DpipeHipError('gemm output dtype must be the operand dtype or fp32')
     if bias is not None and bias.dtype != a.dtype:
         bias = bias.to(a.dtype)
+    if GEMM_TRACE is not None:
+        GEMM_TRACE.append((dt, int(trans_a), int(trans_b), M, N, K, batch_outer * batch_inner, bias is not None, act, int(accumulate), out_f32, tile_hint))
     check(lib().dpipe_gemm(dt, int(trans_a), int(trans_b), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), ldc,
                            batch_outer, batch_inner, stride_a[0], stride_a[1], stride_b[0], stride_b[1],
                            stride_c[0], stride_c[1], ptr(bias), ACT[act], float(alpha), int(accumulate), out_f32,

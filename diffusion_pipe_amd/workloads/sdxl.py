@@ -158,7 +158,7 @@ class CLIPTextModel(nn.Module):
         if want_pooled:
             last = tm.final_layer_norm(x)
             eos_pos = input_ids.to(torch.int).argmax(dim=-1)             # EOS carries the largest token id
-            pooled = last[torch.arange(last.shape[0], device=last.device), eos_pos]
+            pooled = last.gather(1, eos_pos.long()[:, None, None].expand(-1, 1, last.shape[-1])).squeeze(1)
             if self.text_projection is not None:
                 pooled = self.text_projection(pooled)
         return penultimate, pooled
@@ -328,7 +328,7 @@ class InitialLayer(nn.Module):
                 t.requires_grad_(True)
         sample, timestep, input_ids, input_ids_2, add_time_ids = inputs
         factor = 2 ** self.num_upsamplers
-        forward_upsample_size = torch.tensor(any(d % factor != 0 for d in sample.shape[-2:])).to(sample.device)
+        forward_upsample_size = torch.full((), any(d % factor != 0 for d in sample.shape[-2:]), dtype=torch.bool, device=sample.device)
 
         encoder_hidden_states, pooled = self.get_text_conditioning(input_ids, input_ids_2)
         wdtype = self.conv_in.weight.dtype
@@ -353,7 +353,7 @@ class InitialLayer(nn.Module):
         for i, chunk in enumerate(torch.split(input_ids, self.max_len - 2, dim=-1)):
             chunk = torch.cat([torch.full((bs, 1), c.bos, device=device), chunk, torch.full((bs, 1), c.pad, device=device)], dim=-1)
             first_pad = torch.argmax((chunk == c.pad).to(torch.int32), dim=-1)
-            chunk[torch.arange(bs, device=device), first_pad] = c.eos
+            chunk.scatter_(1, first_pad[:, None], c.eos)        # chunk[b, first_pad[b]] = EOS without a host-side scalar copy
             hidden, p = text_encoder(chunk, want_pooled=want_pooled and i == 0)
             if i == 0:
                 pooled = p
@@ -520,7 +520,9 @@ class SDXLWorkload:
         """Per-sample loss weights of models/sdxl.py:333-355; None when neither option is set."""
         if self.min_snr_gamma is None and self.debiased_estimation_loss is None:
             return None
-        snr = self.all_snr.to(timesteps.device)[timesteps]
+        if self.all_snr.device != timesteps.device:
+            self.all_snr = self.all_snr.to(timesteps.device)        # one-time move (keeps graph capture free of H2D copies)
+        snr = self.all_snr[timesteps]
         w = torch.ones_like(snr)
         if self.min_snr_gamma is not None:
             m = torch.minimum(snr, torch.full_like(snr, self.min_snr_gamma))
