@@ -18,35 +18,12 @@
 // that are MN-contiguous in memory are stored as [k][mn] rows padded by 64 B and consumed with the LDS
 // transpose-read ds_read_b64_tr_b16, so no transposed copy of dy / x / W is ever materialised in HBM.
 // Workgroup ids are remapped so that each XCD (private 4 MiB L2) works on a contiguous band of tiles.
-#include "dpipe_common.h"
+#include "gemm_internal.h"
 #include "../../include/dpipe_hip.h"
 
 using namespace dpipe;
 
 namespace {
-
-struct GemmParams {
-    const void* A; const void* B; void* C; const void* bias;
-    int M, N, K;
-    long lda, ldb, ldc;
-    long sAo, sAi, sBo, sBi, sCo, sCi;  // outer / inner batch strides (elements)
-    int batch_inner;                      // batch index z -> (z / batch_inner, z % batch_inner)
-    float alpha;
-    int act, accumulate, out_f32;
-    int vecA, vecB;                       // 16-byte global loads legal for A / B
-    int tiles_m, tiles_n;
-};
-
-enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_SILU = 3, ACT_QUICK_GELU = 4 };
-__device__ __forceinline__ float epilogue_act(float x, int act) {
-    switch (act) {
-    case ACT_GELU_TANH: { const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x); return 0.5f * x * (1.f + tanhf(u)); }
-    case ACT_GELU_ERF: return 0.5f * x * (1.f + erff(x * 0.7071067811865476f));
-    case ACT_SILU: return x / (1.f + __expf(-x));
-    case ACT_QUICK_GELU: return x / (1.f + __expf(-1.702f * x));
-    default: return x;
-    }
-}
 
 typedef __attribute__((address_space(3))) bf16x4_t lds_bf16x4_t;
 
@@ -274,12 +251,13 @@ __global__ void tr16_probe_kernel(const short* __restrict__ in, short* __restric
 
 extern "C" {
 
-int dpipe_gemm(int dtype, int transA, int transB, int M, int N, int K,
-               const void* A, long lda, const void* B, long ldb, void* C, long ldc,
-               int batch_outer, int batch_inner,
-               long strideA_outer, long strideA_inner, long strideB_outer, long strideB_inner,
-               long strideC_outer, long strideC_inner,
-               const void* bias, int act, float alpha, int accumulate, int out_f32, int tile_hint, void* stream) {
+int dpipe_gemm_ex(int dtype, int transA, int transB, int M, int N, int K,
+                  const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                  int batch_outer, int batch_inner,
+                  long strideA_outer, long strideA_inner, long strideB_outer, long strideB_inner,
+                  long strideC_outer, long strideC_inner,
+                  const void* bias, int act, float alpha, int accumulate, int out_f32, int tile_hint,
+                  void* splitk_ws, long splitk_ws_bytes, void* stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch_outer <= 0 || batch_inner <= 0) { set_last_error("dpipe_gemm: bad argument"); return DPIPE_ERR_ARG; }
     if (dtype != DPIPE_BF16 && dtype != DPIPE_F32) { set_last_error("dpipe_gemm: dtype"); return DPIPE_ERR_UNSUPPORTED; }
     const int V = dtype == DPIPE_BF16 ? 8 : 4;
@@ -287,19 +265,42 @@ int dpipe_gemm(int dtype, int transA, int transB, int M, int N, int K,
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.sAo = strideA_outer; p.sAi = strideA_inner; p.sBo = strideB_outer; p.sBi = strideB_inner; p.sCo = strideC_outer; p.sCi = strideC_inner;
     p.batch_inner = batch_inner; p.alpha = alpha; p.act = act; p.accumulate = accumulate; p.out_f32 = out_f32;
+    p.splitk = 1; p.ksteps = 0; p.ksteps_per_split = 0; p.slabs = nullptr; p.counters = nullptr;
+    const int batch = batch_outer * batch_inner;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // tile_hint: 0 = auto (pipelined bf16 kernel when eligible, else generic); 64 / 128 = generic kernel with that tile;
+    // 1000 + S = pipelined kernel, S K-slices forced (S = 0: its own choice), 2000 + S / 3000 + S = the same with the
+    // 64 x 64 / 128 x 128 tile forced -- an error when the problem is not eligible.
+    if (dtype == DPIPE_BF16 && (tile_hint == 0 || tile_hint >= 1000)) {
+        int rc = 0;
+        const int force_tile = tile_hint >= 3000 ? 128 : tile_hint >= 2000 ? 64 : 0;
+        const int force_s = tile_hint >= 1000 ? tile_hint % 1000 : 0;
+        if (gemm_pipe_try(p, transA, transB, batch, splitk_ws, splitk_ws_bytes, force_s, force_tile, s, &rc)) return rc;
+        if (tile_hint >= 1000) { set_last_error("dpipe_gemm: problem not eligible for the pipelined kernel"); return DPIPE_ERR_UNSUPPORTED; }
+    }
+    if (tile_hint >= 1000) { set_last_error("dpipe_gemm: pipelined kernel is bf16 only"); return DPIPE_ERR_UNSUPPORTED; }
     // 16-byte loads need an aligned base and vector-multiple strides; ragged edges are handled per vector in load_tile.
     auto vec_ok = [&](const void* ptr, long ld, long so, long si) {
         return ((reinterpret_cast<uintptr_t>(ptr) & 15) == 0) && (ld % V == 0) && (so % V == 0) && (si % V == 0);
     };
     p.vecA = vec_ok(A, lda, strideA_outer, strideA_inner);
     p.vecB = vec_ok(B, ldb, strideB_outer, strideB_inner);
-    const int batch = batch_outer * batch_inner;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     // Tile choice: 128x128 when it yields at least ~one wave of workgroups over the 256 CUs, else 64x64.
     long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
     bool big = tile_hint == 128 || (tile_hint == 0 && t128 >= 192);
     if (dtype == DPIPE_BF16) return big ? launch_cfg<bf16_t, 128, 128>(p, transA, transB, batch, s) : launch_cfg<bf16_t, 64, 64>(p, transA, transB, batch, s);
     return big ? launch_cfg<float, 128, 128>(p, transA, transB, batch, s) : launch_cfg<float, 64, 64>(p, transA, transB, batch, s);
+}
+
+int dpipe_gemm(int dtype, int transA, int transB, int M, int N, int K,
+               const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+               int batch_outer, int batch_inner,
+               long strideA_outer, long strideA_inner, long strideB_outer, long strideB_inner,
+               long strideC_outer, long strideC_inner,
+               const void* bias, int act, float alpha, int accumulate, int out_f32, int tile_hint, void* stream) {
+    return dpipe_gemm_ex(dtype, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, batch_outer, batch_inner, strideA_outer, strideA_inner,
+                         strideB_outer, strideB_inner, strideC_outer, strideC_inner, bias, act, alpha, accumulate, out_f32, tile_hint,
+                         nullptr, 0, stream);
 }
 
 int dpipe_tr16_probe(const void* in256_i16, void* out256_i16, void* stream) {

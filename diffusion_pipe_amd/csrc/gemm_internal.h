@@ -1,0 +1,40 @@
+// gemm_internal.h -- argument block shared by the two bf16/fp32 GEMM back ends of dpipe_gemm (gemm.hip: generic
+// register-staged kernel; gemm_pipe.hip: LDS-DMA pipelined bf16 kernel with in-launch split-K).
+#pragma once
+#include "dpipe_common.h"
+
+namespace dpipe {
+
+struct GemmParams {
+    const void* A; const void* B; void* C; const void* bias;
+    int M, N, K;
+    long lda, ldb, ldc;
+    long sAo, sAi, sBo, sBi, sCo, sCi;  // outer / inner batch strides (elements)
+    int batch_inner;                      // batch index z -> (z / batch_inner, z % batch_inner)
+    float alpha;
+    int act, accumulate, out_f32;
+    int vecA, vecB;                       // 16-byte global loads legal for A / B
+    int tiles_m, tiles_n;
+    // split-K (pipelined kernel only)
+    int splitk, ksteps, ksteps_per_split;
+    float* slabs; int* counters;
+};
+
+enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_SILU = 3, ACT_QUICK_GELU = 4 };
+__device__ __forceinline__ float epilogue_act(float x, int act) {
+    switch (act) {
+    case ACT_GELU_TANH: { const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x); return 0.5f * x * (1.f + tanhf(u)); }
+    case ACT_GELU_ERF: return 0.5f * x * (1.f + erff(x * 0.7071067811865476f));
+    case ACT_SILU: return x / (1.f + __expf(-x));
+    case ACT_QUICK_GELU: return x / (1.f + __expf(-1.702f * x));
+    default: return x;
+    }
+}
+
+// Pipelined bf16 path.  Returns true when it launched the GEMM (*rc_out = launch status), false when the problem is
+// not eligible (caller falls through to the generic kernel).  `ws` = [counters: 4 KiB][fp32 slabs ...], zero-initialised
+// once by the host and private to one stream; NULL disables split-K.
+bool gemm_pipe_try(GemmParams& p, int transA, int transB, int batch, void* ws, long ws_bytes, int force_splitk, int force_tile,
+                   hipStream_t s, int* rc_out);
+
+}  // namespace dpipe

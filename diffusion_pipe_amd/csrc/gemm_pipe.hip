@@ -1,0 +1,403 @@
+// gemm_pipe.hip -- the bf16 hot-path GEMM of the training step: LDS-DMA pipelined MFMA kernel with in-launch split-K.
+//
+//   C[z] = act(alpha * op(A[z]) . op(B[z]) + bias) (+ C[z])        (same contract as dpipe_gemm, bf16 operands)
+//
+// Why a second kernel: at micro-batch 1 the SDXL / DiT linears are small (M = 77 .. 4096 tokens, N, K = 640 .. 10240):
+// a 128 x 128 tiling yields 10 .. 100 workgroups for 256 CUs and every workgroup walks K serially, so the generic
+// register-staged kernel (gemm.hip) is bound by one global-load latency per K-step, not by MFMA or HBM.  This kernel
+//   * streams operand tiles global -> LDS with `buffer_load_dwordx4 ... lds` (no staging VGPRs, no ds_write pass) into
+//     a ring of STAGES x 32 KiB buffers, keeps STAGES-1 K-steps in flight across ONE raw s_barrier per K-step and
+//     drains them with counted `s_waitcnt vmcnt(N)` (never 0 in steady state);
+//   * lays the LDS images out bank-conflict-free by permuting the per-lane SOURCE address (the DMA destination is
+//     lane-linear): K-contiguous operands as [128 rows][8 x 16 B] with chunk ^= (row >> 1) & 7 for ds_read_b128,
+//     MN-contiguous operands (dgrad's W, wgrad's dy and x) as [64 k-rows][4 x 64 B] with granule ^= krow & 3 for
+//     ds_read_b64_tr_b16 -- so no transposed copy of any operand is ever materialised;
+//   * uses the buffer descriptor's bounds check for ragged tiles (out-of-range rows read as zero);
+//   * splits K over up to 16 workgroups per tile when the tile count alone cannot fill the chip: each slice stores an
+//     fp32 slab in MFMA-native order (coalesced 16-B stores), publishes it with an agent-scope release + ticket counter,
+//     and the last arriver acquires, sums the slabs in slice order (deterministic) and runs the epilogue;
+//   * computes C^T tiles (operands swapped in the MFMA) so each lane owns 4 consecutive N elements of one row:
+//     8-byte bf16 / 16-byte fp32 stores and vector bias loads instead of 2-byte scatter.
+// Workgroup = 256 threads = 4 waves (2 x 2), 64 x 64 per wave, v_mfma_f32_32x32x16_bf16, fp32 accumulate.
+#include "gemm_internal.h"
+#include "../../include/dpipe_hip.h"
+
+using namespace dpipe;
+
+namespace dpipe_pipe {   // named: a kernel template argument may not have internal linkage (its host stub would be dropped)
+
+constexpr int BK = 64;
+constexpr int COUNTER_BYTES = 4096;
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(3))) bf16x4_t lds_bf16x4_t;
+
+// Tile geometry.  T64: 64 x 64 tile, 4 waves (2 x 2, 32 x 32 each), 4-deep ring of 16 KiB stages -> 2 workgroups per CU;
+// the small-problem configuration (4 x the workgroups of T128: aggregate L1/L2 bandwidth of more CUs is what bounds a
+// GEMM whose whole operand set is a few MB).  T128: 128 x 128 tile, 8 waves (2 x 4, 64 x 32 each) = 2 waves per SIMD so
+// one wave's DMA issue (60..180 cycles per 1 KiB piece, MI355X_MICROARCH.md) hides under the other's MFMAs; 3 x 32 KiB.
+template <int BM_, int BN_, int WM_, int WN_, int STAGES_> struct Tile {
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, STAGES = STAGES_;
+    static constexpr int NW = WM * WN, NT = NW * 64;
+    static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;       // 32x32 MFMA tiles per wave
+    static constexpr int IMG_A = BM * BK * 2, IMG_B = BN * BK * 2, STAGE_BYTES = IMG_A + IMG_B;
+    static constexpr int PA = IMG_A / 1024 / NW, PB = IMG_B / 1024 / NW;   // 1 KiB DMA pieces per wave per operand
+    static constexpr int NLOAD = PA + PB;
+    static constexpr int SLAB_F4 = BM * BN / 4;
+    static constexpr int ACC_F4 = TM * TN * 4;                        // float4 per thread in a slab
+    static_assert(IMG_A % (1024 * NW) == 0 && IMG_B % (1024 * NW) == 0, "pieces must split evenly over the waves");
+};
+using T64 = Tile<64, 64, 2, 2, 4>;
+using T128 = Tile<128, 128, 2, 4, 3>;
+
+// Byte offset (from the operand base of this batch) of the 16 bytes lane `lane` fetches for DMA piece q of an image of
+// ROWS mn-rows at K-step 0.  The DMA writes lane L of piece q to LDS byte (q * 1024 + 16 L); the logical chunk fetched
+// is the inverse of the read-side swizzle.
+template <bool MC, int ROWS>
+__device__ __forceinline__ unsigned dma_voffset(int q, int lane, int mn0, long ld) {
+    if (!MC) {   // image [ROWS mn-rows][128 B]: physical 16-B chunk pc of row holds logical chunk pc ^ ((row >> 1) & 7)
+        const int row = 8 * q + (lane >> 3);
+        const int pc = lane & 7;
+        const int lc = pc ^ ((row >> 1) & 7);
+        return (unsigned)(((long)(mn0 + row) * ld + lc * 8) * 2);
+    } else {     // image [64 k-rows][ROWS * 2 B]: physical 64-B granule pg of a k-row holds logical granule pg ^ f(krow)
+        constexpr int CPR = ROWS / 8;            // 16-B chunks per k-row (16 or 8)
+        constexpr int G = ROWS / 32;             // 64-B granules per k-row (4 or 2)
+        const int krow = q * (64 / CPR) + lane / CPR;
+        const int pc = lane % CPR;
+        const int f = G == 4 ? (krow & 3) : ((krow >> 1) & 1);
+        const int lc = (((pc >> 2) ^ f) << 2) | (pc & 3);
+        return (unsigned)(((long)krow * ld + mn0 + lc * 8) * 2);
+    }
+}
+
+// MFMA operand fragment (32 mn-rows x 16 k): lane (i = lane & 31, h = lane >> 5) gets k = 16 ks + 8 h .. + 8 of row mn + i.
+template <bool MC, int ROWS>
+__device__ __forceinline__ bf16x8_t read_frag(const char* img, int mn, int ks, int lane) {
+    if (!MC) {
+        const int row = mn + (lane & 31);
+        const int pc = (2 * ks + (lane >> 5)) ^ ((row >> 1) & 7);
+        return *reinterpret_cast<const bf16x8_t*>(img + row * 128 + pc * 16);
+    } else {
+        // ds_read_b64_tr_b16: in a 16-lane group lane t supplies the address of 4 contiguous bf16 of k-row (t >> 2) at
+        // columns 4 (t & 3) of a [4][16] block and receives column t of it (the 4 k values of one mn index).
+        constexpr int RB = ROWS * 2, G = ROWS / 32;
+        const int t = lane & 15, g = lane >> 4;
+        const int krow = 16 * ks + 8 * (g >> 1) + (t >> 2);
+        const int col_b = (16 * (g & 1) + 4 * (t & 3)) * 2;          // byte column inside the 64-B granule
+        const int f = G == 4 ? (krow & 3) : ((krow >> 1) & 1);       // identical for krow + 4
+        const char* p = img + krow * RB + ((mn >> 5) ^ f) * 64 + col_b;
+        const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(p));
+        const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(p + 4 * RB));
+        bf16x8_t out;
+        out[0] = lo[0]; out[1] = lo[1]; out[2] = lo[2]; out[3] = lo[3];
+        out[4] = hi[0]; out[5] = hi[1]; out[6] = hi[2]; out[7] = hi[3];
+        return out;
+    }
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N == 0 || N == 4 || N == 8 || N == 12, "counted waits of this file");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
+
+template <int BM_, int BN_, int WM_, int WN_, int STAGES_, bool A_MC, bool B_MC>
+__global__ void __launch_bounds__(512) gemm_pipe_kernel(const GemmParams p) {
+    using TL = Tile<BM_, BN_, WM_, WN_, STAGES_>;
+    constexpr int BM = TL::BM, BN = TL::BN, STAGES = TL::STAGES, TM = TL::TM, TN = TL::TN, NLOAD = TL::NLOAD;
+    static_assert(NLOAD == 4 && (STAGES == 3 || STAGES == 4), "vmcnt ladder below assumes 4 pieces per wave per stage");
+    __shared__ __attribute__((aligned(1024))) char lds[STAGES * TL::STAGE_BYTES];
+
+    // XCD-aware bijective remap (consecutive ids round-robin over the 8 XCDs): each XCD owns a contiguous run of
+    // (tile, slice) pairs; slices of one tile are adjacent, so a tile's slabs stay in one L2.
+    const int nt = p.tiles_m * p.tiles_n;
+    const int nwg = nt * p.splitk;
+    const int orig = blockIdx.x;
+    const int xq = nwg / 8, xr = nwg % 8, xcd = orig % 8;
+    const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + orig / 8;
+    const int split = wg % p.splitk, tile = wg / p.splitk;
+    // grouped rasterisation: consecutive tiles walk 8 tile-rows before moving one tile-column over, so the ~32 tiles an
+    // XCD works on at any moment form an 8 x 4 block sharing 8 + 4 operand panels (instead of 32 + 1): ~2.7x less
+    // L2 miss traffic once the operands outgrow the 4 MiB L2.
+    constexpr int GR = 8;
+    const int gsz = GR * p.tiles_n;
+    const int grp = tile / gsz, first_m = grp * GR;
+    const int rows_in = min(p.tiles_m - first_m, GR);
+    const int tile_m = first_m + (tile - grp * gsz) % rows_in, tile_n = (tile - grp * gsz) / rows_in;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int z = blockIdx.y;
+    const long zo = z / p.batch_inner, zi = z % p.batch_inner;
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + zo * p.sAo + zi * p.sAi;
+    const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B) + zo * p.sBo + zi * p.sBi;
+    const unsigned a_bytes = (unsigned)((A_MC ? (long)(p.K - 1) * p.lda + p.M : (long)(p.M - 1) * p.lda + p.K) * 2);
+    const unsigned b_bytes = (unsigned)((B_MC ? (long)(p.K - 1) * p.ldb + p.N : (long)(p.N - 1) * p.ldb + p.K) * 2);
+    // (hipcc's host pass drops a kernel's launch stub -- silently -- when a target builtin is called with type-dependent
+    // operands: the DMA builtin below only ever sees non-dependent locals, hence the ISSUE_STAGE macro)
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), (short)0, (int)a_bytes, 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), (short)0, (int)b_bytes, 0x00020000);
+
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm0 = (wid / TL::WN) * (BM / TL::WM), wn0 = (wid % TL::WN) * (BN / TL::WN);
+
+    const int kbeg = split * p.ksteps_per_split;
+    const int kend = min(p.ksteps, kbeg + p.ksteps_per_split);
+    const int nk = kend - kbeg;
+
+    // per-lane source offsets of this wave's DMA pieces (piece q = j * NW + wid), advanced by one K-step per issue
+    const unsigned stepA = A_MC ? (unsigned)(BK * p.lda * 2) : (unsigned)(BK * 2);
+    const unsigned stepB = B_MC ? (unsigned)(BK * p.ldb * 2) : (unsigned)(BK * 2);
+    unsigned voA[TL::PA], voB[TL::PB];
+#pragma unroll
+    for (int j = 0; j < TL::PA; ++j) voA[j] = dma_voffset<A_MC, BM>(j * TL::NW + wid, lane, m0, p.lda) + (unsigned)kbeg * stepA;
+#pragma unroll
+    for (int j = 0; j < TL::PB; ++j) voB[j] = dma_voffset<B_MC, BN>(j * TL::NW + wid, lane, n0, p.ldb) + (unsigned)kbeg * stepB;
+    // One K-step of this wave's DMA pieces into ring buffer `buf` (piece j of an operand lands at LDS byte
+    // (j * NW + wid) * 1024 of its image); advances the per-lane source offsets by one K-step.
+#define ISSUE_STAGE(buf)                                                                                                      \
+    do {                                                                                                                      \
+        char* base_ = lds + (buf) * TL::STAGE_BYTES + wid * 1024;                                                             \
+        _Pragma("unroll") for (int j = 0; j < TL::PA; ++j) {                                                                  \
+            char* dst_ = base_ + j * TL::NW * 1024; const unsigned off_ = voA[j];   /* non-dependent builtin operands */      \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)dst_, 16, off_, 0, 0, 0);                              \
+            voA[j] += stepA;                                                                                                  \
+        }                                                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < TL::PB; ++j) {                                                                  \
+            char* dst_ = base_ + TL::IMG_A + j * TL::NW * 1024; const unsigned off_ = voB[j];                                 \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)dst_, 16, off_, 0, 0, 0);                              \
+            voB[j] += stepB;                                                                                                  \
+        }                                                                                                                     \
+    } while (0)
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // ---- prologue: STAGES - 1 K-steps in flight
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) ISSUE_STAGE(s);
+
+    int cur = 0, nxt = STAGES - 1;
+    for (int it = 0; it < nk; ++it) {
+        // retire this wave's DMA of K-step `it` (later steps stay in flight), then one barrier: every wave's share of
+        // step `it` has landed AND every wave has finished reading buffer `nxt` (it computed step it-1 from it).
+        const int ahead = nk - it - 1;
+        if (STAGES == 4 && ahead >= 2) wait_vmcnt<2 * NLOAD>();
+        else if (ahead >= 1) wait_vmcnt<NLOAD>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (it + STAGES - 1 < nk) ISSUE_STAGE(nxt);
+        const char* imgA = lds + cur * TL::STAGE_BYTES;
+        const char* imgB = imgA + TL::IMG_A;
+        // all fragment reads of the K-step are issued up front: the MFMAs of k-slice ks start as soon as their
+        // fragments land while the later slices are still in flight (counted lgkmcnt by the compiler)
+        bf16x8_t fa[4][TM], fb[4][TN];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[ks][i] = read_frag<A_MC, BM>(imgA, wm0 + i * 32, ks, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[ks][j] = read_frag<B_MC, BN>(imgB, wn0 + j * 32, ks, lane);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)   // operands swapped: D[row = n][col = m]
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8_mfma, fb[ks][j]), __builtin_bit_cast(bf16x8_mfma, fa[ks][i]), acc[i][j], 0, 0, 0);
+        cur = (cur + 1 == STAGES) ? 0 : cur + 1;
+        nxt = (nxt + 1 == STAGES) ? 0 : nxt + 1;
+    }
+
+#undef ISSUE_STAGE
+    // ---- split-K: publish this slice's slab; the last arriver of the tile reduces all slabs in slice order
+    if (p.splitk > 1) {
+        float4* slab0 = reinterpret_cast<float4*>(p.slabs) + ((long)(z * nt + tile) * p.splitk) * TL::SLAB_F4;
+        float4* mine = slab0 + (long)split * TL::SLAB_F4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    mine[((i * TN + j) * 4 + q) * TL::NT + threadIdx.x] =
+                        make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                       // all slab stores of this workgroup issued and waited for
+        int* flag = reinterpret_cast<int*>(lds);               // the one LDS array doubles as the broadcast word
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int ticket = __hip_atomic_fetch_add(&p.counters[z * nt + tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = (ticket == p.splitk - 1);
+        }
+        __syncthreads();
+        if (!*flag) return;
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(&p.counters[z * nt + tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int s = 0; s < p.splitk; ++s) {
+            const float4* sl = slab0 + (long)s * TL::SLAB_F4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = sl[((i * TN + j) * 4 + q) * TL::NT + threadIdx.x];
+                        acc[i][j][4 * q] += v.x; acc[i][j][4 * q + 1] += v.y; acc[i][j][4 * q + 2] += v.z; acc[i][j][4 * q + 3] += v.w;
+                    }
+        }
+    }
+
+    // ---- epilogue.  D layout of the swapped 32x32 MFMA: m = lane & 31, n = (e & 3) + 8 (e >> 2) + 4 (lane >> 5):
+    // for each q = e >> 2 the lane holds 4 consecutive n of one output row.
+    const long coff = zo * p.sCo + zi * p.sCi;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm0 + i * 32 + (lane & 31);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn0 + j * 32 + 8 * q + 4 * h;
+                if (n >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = p.alpha * acc[i][j][4 * q + r];
+                const bool full = n + 3 < p.N;
+                if (p.bias) {
+                    const bf16_t* bp = reinterpret_cast<const bf16_t*>(p.bias) + n;
+                    if (full && p.vecB >= 2) {
+                        const uint2 bv = *reinterpret_cast<const uint2*>(bp);
+                        v[0] += __uint_as_float(bv.x << 16); v[1] += __uint_as_float(bv.x & 0xffff0000u);
+                        v[2] += __uint_as_float(bv.y << 16); v[3] += __uint_as_float(bv.y & 0xffff0000u);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += bf16_to_f32(bp[r]);
+                    }
+                }
+                if (p.act != ACT_NONE) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = epilogue_act(v[r], p.act);
+                }
+                const long idx = coff + (long)m * p.ldc + n;
+                if (p.out_f32) {
+                    float* c = reinterpret_cast<float*>(p.C) + idx;
+                    if (full && p.vecA >= 2) {
+                        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                        if (p.accumulate) { const float4 old = *reinterpret_cast<const float4*>(c); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+                        *reinterpret_cast<float4*>(c) = o;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (n + r < p.N) c[r] = p.accumulate ? c[r] + v[r] : v[r];
+                    }
+                } else {
+                    bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + idx;
+                    if (full && p.vecA >= 2) {
+                        if (p.accumulate) {
+                            const uint2 old = *reinterpret_cast<const uint2*>(c);
+                            v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
+                            v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
+                        }
+                        *reinterpret_cast<uint2*>(c) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (n + r < p.N) c[r] = f32_to_bf16(p.accumulate ? bf16_to_f32(c[r]) + v[r] : v[r]);
+                    }
+                }
+            }
+    }
+}
+
+template <typename TL>
+int launch_pipe(const GemmParams& p, bool a_mc, bool b_mc, int batch, hipStream_t s) {
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n * p.splitk), (unsigned)batch);
+#define DPIPE_PIPE_LAUNCH(AM, BMC) gemm_pipe_kernel<TL::BM, TL::BN, TL::WM, TL::WN, TL::STAGES, AM, BMC><<<grid, TL::NT, 0, s>>>(p)
+    if (!a_mc && !b_mc) DPIPE_PIPE_LAUNCH(false, false);
+    else if (!a_mc && b_mc) DPIPE_PIPE_LAUNCH(false, true);
+    else if (a_mc && b_mc) DPIPE_PIPE_LAUNCH(true, true);
+    else DPIPE_PIPE_LAUNCH(true, false);
+#undef DPIPE_PIPE_LAUNCH
+    return check_launch("dpipe_gemm(pipe)");
+}
+
+}  // namespace dpipe_pipe
+
+using namespace dpipe_pipe;
+
+namespace dpipe {
+
+bool gemm_pipe_try(GemmParams& p, int transA, int transB, int batch, void* ws, long ws_bytes, int force_splitk, int force_tile,
+                   hipStream_t s, int* rc_out) {
+    const bool a_mc = transA != 0, b_mc = transB == 0;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    // eligibility: 16-byte DMA pieces, K-contiguous operands need whole K-steps, 32-bit offsets
+    if (!al16(p.A) || !al16(p.B)) return false;
+    if (p.lda % 8 || p.ldb % 8 || p.sAo % 8 || p.sAi % 8 || p.sBo % 8 || p.sBi % 8) return false;
+    if ((!a_mc || !b_mc) && (p.K % BK) != 0) return false;
+    const long kpad = (long)((p.K + BK - 1) / BK) * BK, mpad = (long)((p.M + 127) / 128) * 128, npad = (long)((p.N + 127) / 128) * 128;
+    const long ext_a = a_mc ? kpad * p.lda + mpad : mpad * p.lda + kpad;
+    const long ext_b = b_mc ? kpad * p.ldb + npad : npad * p.ldb + kpad;
+    if (ext_a * 2 >= (1L << 31) || ext_b * 2 >= (1L << 31)) return false;
+
+    p.ksteps = (p.K + BK - 1) / BK;
+    const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
+    const long tiles64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64) * batch;
+    // tile (measured on the SDXL shapes, tools/kernel_timing.py): 128 x 128 from ~half a wave of workgroups on, or when a
+    // long K can be split three ways over few tiles; else 64 x 64 (4 x the workgroups, 2 resident per CU)
+    const bool long_k = p.ksteps >= 96;
+    const bool big = force_tile ? force_tile == 128 : (tiles128 >= 128 || (long_k && tiles128 >= 48));
+    const int bm = big ? 128 : 64;
+    p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bm - 1) / bm;
+    const long tiles = big ? tiles128 : tiles64;
+    const long slab_bytes = (long)bm * bm * 4;
+    int S = 1;
+    if (ws && ws_bytes > COUNTER_BYTES) {
+        if (force_splitk > 0) S = force_splitk;
+        else if (!big && tiles <= 128 && p.ksteps >= 32) {   // every slice pays an agent-scope release: only few, long tiles split
+            S = (int)(512 / tiles); const int cap = p.ksteps / 8; if (S > cap) S = cap; if (S > 4) S = 4;
+        } else if (big && tiles < 128 && long_k) S = 3;
+        if (S < 1) S = 1;
+        if (S > p.ksteps) S = p.ksteps;
+        const long max_slabs = (ws_bytes - COUNTER_BYTES) / slab_bytes;
+        if (tiles * S > max_slabs) S = (int)(max_slabs / tiles);
+        if (tiles > COUNTER_BYTES / 4 || S < 1) S = 1;
+    }
+    p.ksteps_per_split = (p.ksteps + S - 1) / S;
+    p.splitk = (p.ksteps + p.ksteps_per_split - 1) / p.ksteps_per_split;
+    p.counters = reinterpret_cast<int*>(ws);
+    p.slabs = ws ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + COUNTER_BYTES) : nullptr;
+    // vector epilogue flags (re-using the generic kernel's fields): vecA >= 2 -> C rows allow 4-element vector accesses,
+    // vecB >= 2 -> bias allows 8-byte loads
+    const int celt = p.out_f32 ? 4 : 2;
+    const bool c_ok = (reinterpret_cast<uintptr_t>(p.C) % (4 * celt) == 0) && p.ldc % 4 == 0 && p.sCo % 4 == 0 && p.sCi % 4 == 0;
+    p.vecA = c_ok ? 2 : 0;
+    p.vecB = (p.bias && reinterpret_cast<uintptr_t>(p.bias) % 8 == 0) ? 2 : 0;
+    *rc_out = big ? launch_pipe<T128>(p, a_mc, b_mc, batch, s) : launch_pipe<T64>(p, a_mc, b_mc, batch, s);
+    return true;
+}
+
+}  // namespace dpipe

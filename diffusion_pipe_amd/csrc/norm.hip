@@ -96,14 +96,20 @@ __global__ void __launch_bounds__(NB) rmsnorm_bwd_dx_kernel(const T* __restrict_
 // MODE 0: RMSNorm dw   = sum gy * x * rstd
 // MODE 1: LN (dgamma, dbeta) = (sum dn * xhat, sum dn)      with dn = gy * (1 + scale)
 // MODE 2: AdaLN (dscale, dshift) = (sum gy * n, sum gy)      n = xhat*gamma + beta
+// MODE 3: plain column sum of x (bias gradients); gy / statistics unused
+// Block = 32 column vectors (512 B of a row: whole cache lines) x 8 row lanes; a slab is ~32 rows so a [1024, 1280]
+// operand launches 5 x 32 blocks with 4 independent row loads per thread in flight; row lanes combine through LDS.
+constexpr int CR_CT = 32, CR_RT = 8;
 template <typename T, typename W, typename M, int MODE>
 __global__ void __launch_bounds__(NB) colreduce_kernel(const T* __restrict__ x, const T* __restrict__ gy, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, const W* __restrict__ gamma, const W* __restrict__ beta,
-                                                       const M* __restrict__ scale, long rows_per_group, int cols, int slabs,
+                                                       const M* __restrict__ scale, long rows_per_group, int cols, long ld, int slabs,
                                                        float* __restrict__ p0, float* __restrict__ p1) {
     constexpr int V = Elem<T>::VEC;
-    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * V;
-    if (c >= cols) return;
+    __shared__ float red[2][CR_RT][CR_CT * V];
+    const int ct = threadIdx.x % CR_CT, rl = threadIdx.x / CR_CT;
+    const int c = (blockIdx.x * CR_CT + ct) * V;
+    const bool live = c < cols;
     const long grp = blockIdx.z;
     const long rps = cdiv(rows_per_group, slabs);
     const long r0 = blockIdx.y * rps, r1 = min(r0 + rps, rows_per_group);
@@ -111,34 +117,60 @@ __global__ void __launch_bounds__(NB) colreduce_kernel(const T* __restrict__ x, 
 #pragma unroll
     for (int j = 0; j < V; ++j) {
         a0[j] = 0.f; a1[j] = 0.f;
-        fgam[j] = gamma ? Elem<W>::to_f(gamma[c + j]) : 1.f;
-        fbet[j] = beta ? Elem<W>::to_f(beta[c + j]) : 0.f;
-        fsc[j] = scale ? 1.f + Elem<M>::to_f(scale[grp * cols + c + j]) : 1.f;
+        fgam[j] = (live && gamma) ? Elem<W>::to_f(gamma[c + j]) : 1.f;
+        fbet[j] = (live && beta) ? Elem<W>::to_f(beta[c + j]) : 0.f;
+        fsc[j] = (live && scale) ? 1.f + Elem<M>::to_f(scale[grp * cols + c + j]) : 1.f;
     }
-    for (long r = r0; r < r1; ++r) {
-        const long row = grp * rows_per_group + r;
-        Vec16<T> vx, vg; vx.load(x + row * cols + c); vg.load(gy + row * cols + c);
-        float fx[V], fg[V]; vx.unpack(fx); vg.unpack(fg);
-        const float mu = mean ? mean[row] : 0.f, rs = rstd[row];
+    if (live) {
+        for (long r = r0 + rl; r < r1; r += CR_RT) {
+            const long row = grp * rows_per_group + r;
+            Vec16<T> vx; vx.load(x + row * ld + c);
+            float fx[V]; vx.unpack(fx);
+            if (MODE == 3) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-            const float xhat = (fx[j] - mu) * rs;
-            if (MODE == 0) { a0[j] += fg[j] * xhat; }
-            else if (MODE == 1) { const float dn = fg[j] * fsc[j]; a0[j] += dn * xhat; a1[j] += dn; }
-            else { a0[j] += fg[j] * (xhat * fgam[j] + fbet[j]); a1[j] += fg[j]; }
+                for (int j = 0; j < V; ++j) a0[j] += fx[j];
+            } else {
+                Vec16<T> vg; vg.load(gy + row * ld + c);
+                float fg[V]; vg.unpack(fg);
+                const float mu = mean ? mean[row] : 0.f, rs = rstd[row];
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const float xhat = (fx[j] - mu) * rs;
+                    if (MODE == 0) { a0[j] += fg[j] * xhat; }
+                    else if (MODE == 1) { const float dn = fg[j] * fsc[j]; a0[j] += dn * xhat; a1[j] += dn; }
+                    else { a0[j] += fg[j] * (xhat * fgam[j] + fbet[j]); a1[j] += fg[j]; }
+                }
+            }
         }
     }
-    const long o = (grp * slabs + blockIdx.y) * cols + c;
 #pragma unroll
-    for (int j = 0; j < V; ++j) { p0[o + j] = a0[j]; if (MODE != 0) p1[o + j] = a1[j]; }
+    for (int j = 0; j < V; ++j) {
+        red[0][rl][ct * V + j] = a0[j];
+        if (MODE == 1 || MODE == 2) red[1][rl][ct * V + j] = a1[j];
+    }
+    __syncthreads();
+    // CR_CT * V columns, one per thread (bf16: 256 columns = 256 threads; fp32: 128 columns)
+    const int col_in = threadIdx.x;
+    if (col_in < CR_CT * V) {
+        const int cc = blockIdx.x * CR_CT * V + col_in;
+        if (cc < cols) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < CR_RT; ++r) { s0 += red[0][r][col_in]; if (MODE == 1 || MODE == 2) s1 += red[1][r][col_in]; }
+            const long o = (grp * slabs + blockIdx.y) * cols + cc;
+            p0[o] = s0;
+            if (MODE == 1 || MODE == 2) p1[o] = s1;
+        }
+    }
 }
 template <typename O>
-__global__ void __launch_bounds__(NB) slabsum_kernel(const float* __restrict__ partial, O* __restrict__ out, long groups, int cols, int slabs) {
+__global__ void __launch_bounds__(NB) slabsum_kernel(const float* __restrict__ partial, O* __restrict__ out, long groups, int cols, int slabs, int accumulate) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= groups * cols) return;
     const long g = i / cols; const int c = (int)(i - g * cols);
     float a = 0.f;
     for (int s = 0; s < slabs; ++s) a += partial[(g * slabs + s) * cols + c];
+    if (accumulate) a += Elem<O>::to_f(out[i]);
     out[i] = Elem<O>::from_f(a);
 }
 
@@ -346,7 +378,7 @@ static inline int pick_lpr(int cols, int vec) { return (cols / vec) <= 16 ? 16 :
 extern "C" {
 
 int dpipe_norm_slabs(long rows_per_group) {
-    long s = rows_per_group / 128; if (s < 1) s = 1; if (s > 128) s = 128; return (int)s;
+    long s = rows_per_group / 32; if (s < 1) s = 1; if (s > 256) s = 256; return (int)s;
 }
 
 int dpipe_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, long rows, int cols, float eps, int dtype, int wdtype, void* stream) {
@@ -364,7 +396,7 @@ int dpipe_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, long r
 
 // workspace: slabs * cols floats (only when dw != null)
 int dpipe_rmsnorm_bwd(const void* x, const void* w, const void* gy, const float* rstd, void* gx, void* dw, float* workspace,
-                      long rows, int cols, int dtype, int wdtype, void* stream) {
+                      long rows, int cols, int dtype, int wdtype, int accumulate_params, void* stream) {
     const int V = dtype == DPIPE_BF16 ? 8 : 4;
     if (!x || !gy || !rstd || !gx || rows <= 0 || cols <= 0 || (cols % V) != 0) BAD("dpipe_rmsnorm_bwd: bad argument");
     if (dw && !workspace) BAD("dpipe_rmsnorm_bwd: workspace required for dw");
@@ -376,9 +408,9 @@ int dpipe_rmsnorm_bwd(const void* x, const void* w, const void* gy, const float*
         if (lpr == 16) rmsnorm_bwd_dx_kernel<T, W, 16><<<grid, NB, 0, s>>>((const T*)x, (const W*)w, (const T*)gy, rstd, (T*)gx, rows, cols);
         else rmsnorm_bwd_dx_kernel<T, W, 64><<<grid, NB, 0, s>>>((const T*)x, (const W*)w, (const T*)gy, rstd, (T*)gx, rows, cols);
         if (dw) {
-            dim3 g2((unsigned)cdiv(cols / V, NB), slabs, 1);
-            colreduce_kernel<T, W, float, 0><<<g2, NB, 0, s>>>((const T*)x, (const T*)gy, nullptr, rstd, nullptr, nullptr, nullptr, rows, cols, slabs, workspace, nullptr);
-            slabsum_kernel<W><<<(unsigned)cdiv(cols, NB), NB, 0, s>>>(workspace, (W*)dw, 1, cols, slabs);
+            dim3 g2((unsigned)cdiv(cols / V, CR_CT), slabs, 1);
+            colreduce_kernel<T, W, float, 0><<<g2, NB, 0, s>>>((const T*)x, (const T*)gy, nullptr, rstd, nullptr, nullptr, nullptr, rows, cols, cols, slabs, workspace, nullptr);
+            slabsum_kernel<W><<<(unsigned)cdiv(cols, NB), NB, 0, s>>>(workspace, (W*)dw, 1, cols, slabs, accumulate_params);
         }
     })
     return check_launch("dpipe_rmsnorm_bwd");
@@ -406,7 +438,8 @@ int dpipe_lnmod_fwd(const void* x, const void* gamma, const void* beta, const vo
 // workspace: 2 * max(slabs(rows) , groups*slabs(rows_per_mod)) * cols floats
 int dpipe_lnmod_bwd(const void* x, const void* gy, const void* gamma, const void* beta, const void* scale,
                     const float* mean, const float* rstd, void* gx, void* dgamma, void* dbeta, void* dscale, void* dshift,
-                    float* workspace, long rows, int cols, long rows_per_mod, int dtype, int wdtype, int mdtype, void* stream) {
+                    float* workspace, long rows, int cols, long rows_per_mod, int dtype, int wdtype, int mdtype, int accumulate_params,
+                    void* stream) {
     const int V = dtype == DPIPE_BF16 ? 8 : 4;
     if (!x || !gy || !mean || !rstd || !gx || rows <= 0 || cols <= 0 || (cols % V) != 0 || rows_per_mod <= 0 || (rows % rows_per_mod) != 0)
         BAD("dpipe_lnmod_bwd: bad argument");
@@ -419,18 +452,18 @@ int dpipe_lnmod_bwd(const void* x, const void* gy, const void* gamma, const void
     lnmod_bwd_dx_kernel<TT, WW, MM, 64><<<grid, NB, 0, s>>>((const TT*)x, (const TT*)gy, (const WW*)gamma, (const MM*)scale, mean, rstd, (TT*)gx, rows, cols, rows_per_mod); \
     if (dscale) { \
         float* p0 = workspace; float* p1 = workspace + groups * slabs_mod * (long)cols; \
-        dim3 g2((unsigned)cdiv(cols / V, NB), slabs_mod, (unsigned)groups); \
-        colreduce_kernel<TT, WW, MM, 2><<<g2, NB, 0, s>>>((const TT*)x, (const TT*)gy, mean, rstd, (const WW*)gamma, (const WW*)beta, (const MM*)scale, rows_per_mod, cols, slabs_mod, p0, p1); \
-        slabsum_kernel<MM><<<(unsigned)cdiv(groups * cols, NB), NB, 0, s>>>(p0, (MM*)dscale, groups, cols, slabs_mod); \
-        if (dshift) slabsum_kernel<MM><<<(unsigned)cdiv(groups * cols, NB), NB, 0, s>>>(p1, (MM*)dshift, groups, cols, slabs_mod); \
+        dim3 g2((unsigned)cdiv(cols / V, CR_CT), slabs_mod, (unsigned)groups); \
+        colreduce_kernel<TT, WW, MM, 2><<<g2, NB, 0, s>>>((const TT*)x, (const TT*)gy, mean, rstd, (const WW*)gamma, (const WW*)beta, (const MM*)scale, rows_per_mod, cols, cols, slabs_mod, p0, p1); \
+        slabsum_kernel<MM><<<(unsigned)cdiv(groups * cols, NB), NB, 0, s>>>(p0, (MM*)dscale, groups, cols, slabs_mod, 0); \
+        if (dshift) slabsum_kernel<MM><<<(unsigned)cdiv(groups * cols, NB), NB, 0, s>>>(p1, (MM*)dshift, groups, cols, slabs_mod, 0); \
     } \
     if (dgamma) { \
         /* (dgamma, dbeta) need dn = gy*(1+scale[b]) which varies per modulation group: reduce per group, then over groups */ \
         float* p0 = workspace; float* p1 = workspace + groups * slabs_mod * (long)cols; \
-        dim3 g2((unsigned)cdiv(cols / V, NB), slabs_mod, (unsigned)groups); \
-        colreduce_kernel<TT, WW, MM, 1><<<g2, NB, 0, s>>>((const TT*)x, (const TT*)gy, mean, rstd, (const WW*)gamma, (const WW*)beta, (const MM*)scale, rows_per_mod, cols, slabs_mod, p0, p1); \
-        slabsum_kernel<WW><<<(unsigned)cdiv(cols, NB), NB, 0, s>>>(p0, (WW*)dgamma, 1, cols, (int)(groups * slabs_mod)); \
-        if (dbeta) slabsum_kernel<WW><<<(unsigned)cdiv(cols, NB), NB, 0, s>>>(p1, (WW*)dbeta, 1, cols, (int)(groups * slabs_mod)); \
+        dim3 g2((unsigned)cdiv(cols / V, CR_CT), slabs_mod, (unsigned)groups); \
+        colreduce_kernel<TT, WW, MM, 1><<<g2, NB, 0, s>>>((const TT*)x, (const TT*)gy, mean, rstd, (const WW*)gamma, (const WW*)beta, (const MM*)scale, rows_per_mod, cols, cols, slabs_mod, p0, p1); \
+        slabsum_kernel<WW><<<(unsigned)cdiv(cols, NB), NB, 0, s>>>(p0, (WW*)dgamma, 1, cols, (int)(groups * slabs_mod), accumulate_params); \
+        if (dbeta) slabsum_kernel<WW><<<(unsigned)cdiv(cols, NB), NB, 0, s>>>(p1, (WW*)dbeta, 1, cols, (int)(groups * slabs_mod), accumulate_params); \
     } } while (0)
     (void)slabs_all;
     if (dtype == DPIPE_BF16) {
@@ -447,6 +480,21 @@ int dpipe_lnmod_bwd(const void* x, const void* gy, const void* gamma, const void
 int dpipe_lnmod_workspace_floats(long rows, int cols, long rows_per_mod) {
     long groups = rows / rows_per_mod;
     return (int)(2 * groups * dpipe_norm_slabs(rows_per_mod) * (long)cols);
+}
+
+// out[c] (+)= sum_r x[r, c]: bias gradients of nn.Linear (db = column sums of dy).  workspace: dpipe_norm_slabs(rows) * cols floats.
+int dpipe_colsum(const void* x, long rows, int cols, long ld, void* out, float* workspace, int dtype, int out_dtype, int accumulate,
+                 void* stream) {
+    const int V = dtype == DPIPE_BF16 ? 8 : 4;
+    if (!x || !out || !workspace || rows <= 0 || cols <= 0 || (cols % V) != 0 || (ld % V) != 0) BAD("dpipe_colsum: bad argument");
+    hipStream_t s = STREAM(stream);
+    const int slabs = dpipe_norm_slabs(rows);
+    DISPATCH_TW(dtype, out_dtype, {
+        dim3 g2((unsigned)cdiv(cols / V, CR_CT), slabs, 1);
+        colreduce_kernel<T, W, float, 3><<<g2, NB, 0, s>>>((const T*)x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, rows, cols, ld, slabs, workspace, nullptr);
+        slabsum_kernel<W><<<(unsigned)cdiv(cols, NB), NB, 0, s>>>(workspace, (W*)out, 1, cols, slabs, accumulate);
+    });
+    return check_launch("dpipe_colsum");
 }
 
 int dpipe_rope(const void* x, const float* cos_t, const float* sin_t, void* y, long B, long S, long H, int D,

@@ -87,6 +87,9 @@ class PipelineEngine:
         self.use_graph = bool(self._config.get('hip_graph', False)) and self.device.type == 'cuda' and not self.is_pipe_parallel
         self._graphs = {}
         self._g_total_loss = None
+        if self.device.type == 'cuda' and self._config.get('fuse_grad_accumulation', True):
+            from .. import ops as _ops
+            _ops.FUSE_GRAD_ACCUM = True     # wgrad / bias / norm-weight kernels add straight into existing .grad buffers
         self.link = StageLink(self.grid, self.device) if self.is_pipe_parallel else None
         self.loss = None
         self.total_loss = None

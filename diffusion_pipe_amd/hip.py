@@ -40,15 +40,17 @@ _SIGNATURES = {
     'dpipe_multi_clip_scale': (I, [P, P, P, P, I, I, P, F, P]),
     'dpipe_rmsnorm_fwd': (I, [P, P, P, P, L, I, F, I, I, P]),
     'dpipe_norm_slabs': (I, [L]),
-    'dpipe_rmsnorm_bwd': (I, [P, P, P, P, P, P, P, L, I, I, I, P]),
+    'dpipe_rmsnorm_bwd': (I, [P, P, P, P, P, P, P, L, I, I, I, I, P]),
+    'dpipe_colsum': (I, [P, L, I, L, P, P, I, I, I, P]),
     'dpipe_lnmod_fwd': (I, [P, P, P, P, P, P, P, P, L, I, L, F, I, I, I, P]),
     'dpipe_lnmod_workspace_floats': (I, [L, I, L]),
-    'dpipe_lnmod_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, L, I, I, I, P]),
+    'dpipe_lnmod_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, L, I, I, I, I, P]),
     'dpipe_rope': (I, [P, P, P, P, L, L, L, I, I, I, I, P]),
     'dpipe_softmax_fwd': (I, [P, P, L, I, L, F, I, I, P]),
     'dpipe_softmax_bwd': (I, [P, P, P, L, I, L, F, I, P]),
     'dpipe_transpose': (I, [P, P, I, I, L, L, L, L, I, I, P]),
     'dpipe_gemm': (I, [I, I, I, I, I, I, P, L, P, L, P, L, I, I, L, L, L, L, L, L, P, I, F, I, I, I, P]),
+    'dpipe_gemm_ex': (I, [I, I, I, I, I, I, P, L, P, L, P, L, I, I, L, L, L, L, L, L, P, I, F, I, I, I, P, L, P]),
     'dpipe_tr16_probe': (I, [P, P, P]),
     'dpipe_attn_fwd': (I, [P, P, P, P, P, P, I, I, I, I, I] + [L] * 12 + [F, I, P]),
     'dpipe_attn_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I] + [L] * 24 + [F, I, P]),

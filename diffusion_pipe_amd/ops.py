@@ -29,6 +29,20 @@ def _rows2d(x):
 # distinct signatures are then timed with HIP events on the launch stream for the `roofline` object.
 GEMM_TRACE = None
 
+# Split-K workspace of the pipelined bf16 GEMM: [4 KiB ticket counters][272 fp32 slabs of 64 KiB], zero-filled once and
+# private to one (device, stream) -- launches on one stream are ordered, so slices of two GEMMs never share counters.
+_SPLITK_WS = {}
+_SPLITK_WS_BYTES = 4096 + 272 * 65536
+
+
+def _splitk_workspace(device):
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _SPLITK_WS.get(key)
+    if ws is None:
+        ws = torch.zeros(_SPLITK_WS_BYTES, dtype=torch.uint8, device=device)
+        _SPLITK_WS[key] = ws
+    return ws
+
 
 def gemm(a, b, trans_a, trans_b, M, N, K, out, *, lda, ldb, ldc, batch_outer=1, batch_inner=1,
          stride_a=(0, 0), stride_b=(0, 0), stride_c=(0, 0), bias=None, act=None, alpha=1.0, accumulate=False,
@@ -45,14 +59,15 @@ def gemm(a, b, trans_a, trans_b, M, N, K, out, *, lda, ldb, ldc, batch_outer=1, 
         bias = bias.to(a.dtype)
     if GEMM_TRACE is not None:
         GEMM_TRACE.append((dt, int(trans_a), int(trans_b), M, N, K, batch_outer * batch_inner, bias is not None, act, int(accumulate), out_f32, tile_hint))
-    check(lib().dpipe_gemm(dt, int(trans_a), int(trans_b), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), ldc,
-                           batch_outer, batch_inner, stride_a[0], stride_a[1], stride_b[0], stride_b[1],
-                           stride_c[0], stride_c[1], ptr(bias), ACT[act], float(alpha), int(accumulate), out_f32,
-                           tile_hint, stream()), 'dpipe_gemm')
+    ws = _splitk_workspace(a.device) if dt == hip.BF16 else None
+    check(lib().dpipe_gemm_ex(dt, int(trans_a), int(trans_b), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), ldc,
+                              batch_outer, batch_inner, stride_a[0], stride_a[1], stride_b[0], stride_b[1],
+                              stride_c[0], stride_c[1], ptr(bias), ACT[act], float(alpha), int(accumulate), out_f32,
+                              tile_hint, ptr(ws), ws.numel() if ws is not None else 0, stream()), 'dpipe_gemm')
     return out
 
 
-def mm(a, b, trans_a=False, trans_b=False, bias=None, act=None, out=None, out_dtype=None, tile_hint=0):
+def mm(a, b, trans_a=False, trans_b=False, bias=None, act=None, out=None, out_dtype=None, tile_hint=0, accumulate=False):
     """2-D product of row-major matrices (last dim contiguous): op(a) [M,K] @ op(b) [K,N]."""
     assert a.dim() == 2 and b.dim() == 2
     if a.stride(1) != 1:
@@ -66,7 +81,24 @@ def mm(a, b, trans_a=False, trans_b=False, bias=None, act=None, out=None, out_dt
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=out_dtype or a.dtype)
     return gemm(a, b, trans_a, trans_b, M, N, K, out, lda=a.stride(0), ldb=b.stride(0), ldc=out.stride(0),
-                bias=bias, act=act, tile_hint=tile_hint)
+                bias=bias, act=act, tile_hint=tile_hint, accumulate=accumulate)
+
+
+# Gradient-accumulation fusion (set by the engine): when a parameter already owns a .grad buffer (micro-batch > 0 of a
+# step, or the persistent buffers of the hipGraph path) the parameter-gradient kernels add into it in their epilogue
+# (wgrad GEMM `accumulate`, column-sum / slab-sum `accumulate`) and autograd receives None -- this removes one
+# elementwise add launch per parameter per micro-batch (DeepSpeed accumulates the same way into .grad in the
+# parameter dtype).
+FUSE_GRAD_ACCUM = False
+
+
+def _accum_target(param):
+    if not FUSE_GRAD_ACCUM or param is None:
+        return None
+    g = param.grad
+    if g is None or g.dtype != param.dtype or not g.is_contiguous() or g.shape != param.shape:
+        return None
+    return g
 
 
 class _LinearFn(Function):
@@ -78,7 +110,7 @@ class _LinearFn(Function):
         if x2.dtype != weight.dtype:
             x2 = x2.to(weight.dtype)
         y = mm(x2, weight, False, True, bias=bias)
-        ctx.save_for_backward(x2, weight)
+        ctx.save_for_backward(x2, weight, bias)
         ctx.has_bias = bias is not None
         ctx.x_shape = x.shape
         ctx.x_dtype = x.dtype
@@ -86,7 +118,7 @@ class _LinearFn(Function):
 
     @staticmethod
     def backward(ctx, gy):
-        x2, weight = ctx.saved_tensors
+        x2, weight, bias = ctx.saved_tensors
         gy2 = _rows2d(gy)
         if gy2.dtype != weight.dtype:
             gy2 = gy2.to(weight.dtype)
@@ -96,9 +128,16 @@ class _LinearFn(Function):
             if gx.dtype != ctx.x_dtype:
                 gx = gx.to(ctx.x_dtype)
         if ctx.needs_input_grad[1]:
-            gw = mm(gy2, x2, True, False)                                    # dW = dy^T . x
+            tgt = _accum_target(weight)
+            if tgt is not None:
+                mm(gy2, x2, True, False, out=tgt, accumulate=True)          # dW += dy^T . x  (fused accumulation)
+            else:
+                gw = mm(gy2, x2, True, False)                                # dW = dy^T . x
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = column_sum(gy2)
+            tgt = _accum_target(bias)
+            gb = column_sum(gy2, out=tgt)
+            if tgt is not None:
+                gb = None
         return gx, gw, gb
 
 
@@ -106,11 +145,20 @@ def linear(x, weight, bias=None):
     return _LinearFn.apply(x, weight, bias)
 
 
-def column_sum(x2):
-    """sum over rows of a [rows, cols] matrix via the MFMA GEMM (ones^T . x), fp32 accumulate."""
-    ones = torch.ones((x2.shape[0], 8), device=x2.device, dtype=x2.dtype)
-    out = mm(ones, x2, True, False)      # [8, cols], all rows equal
-    return out[0].contiguous()
+def column_sum(x2, out=None, out_dtype=None):
+    """sum over the rows of a [rows, cols] matrix (fp32 accumulate, two-stage slab reduction).  `out` given: out += sum
+    (the fused gradient-accumulation form); else a new [cols] tensor in x2's dtype (or out_dtype)."""
+    require_cuda(x2, out)
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    rows, cols = x2.shape
+    accumulate = out is not None
+    if out is None:
+        out = torch.empty(cols, device=x2.device, dtype=out_dtype or x2.dtype)
+    ws = torch.empty(lib().dpipe_norm_slabs(rows) * cols, device=x2.device, dtype=torch.float32)
+    check(lib().dpipe_colsum(ptr(x2), rows, cols, x2.stride(0), ptr(out), ptr(ws), dtype_code(x2.dtype), dtype_code(out.dtype),
+                             int(accumulate), stream()), 'colsum')
+    return out
 
 
 # ------------------------------------------------------------------------------------------- activations (K6)
@@ -247,13 +295,17 @@ class _RMSNormFn(Function):
         gy2 = _contig(_rows2d(gy))
         gx = torch.empty_like(x2)
         dw = ws = None
+        fused = False
         if weight is not None and ctx.needs_input_grad[1]:
-            dw = torch.empty_like(weight)
+            dw = _accum_target(weight)
+            fused = dw is not None
+            if dw is None:
+                dw = torch.empty_like(weight)
             ws = torch.empty(lib().dpipe_norm_slabs(rows) * cols, device=x2.device, dtype=torch.float32)
         wd = dtype_code(weight.dtype) if weight is not None else dtype_code(x2.dtype)
         check(lib().dpipe_rmsnorm_bwd(ptr(x2), ptr(weight), ptr(gy2), ptr(rstd), ptr(gx), ptr(dw), ptr(ws), rows, cols,
-                                      dtype_code(x2.dtype), wd, stream()), 'rmsnorm_bwd')
-        return gx.view(ctx.shape), dw, None
+                                      dtype_code(x2.dtype), wd, int(fused), stream()), 'rmsnorm_bwd')
+        return gx.view(ctx.shape), (None if fused else dw), None
 
 
 def rms_norm(x, weight=None, eps=1e-6):
@@ -299,8 +351,15 @@ class _LNModFn(Function):
         gx = torch.empty_like(x2)
         groups = rows // rows_per_mod
         mod_dtype = torch.bfloat16 if mdt == hip.BF16 else torch.float32
-        dgamma = torch.empty_like(gamma) if gamma is not None else None
-        dbeta = torch.empty_like(beta) if beta is not None else None
+        fused = False
+        dgamma = dbeta = None
+        if gamma is not None:
+            tg, tb = _accum_target(gamma), _accum_target(beta)
+            if tg is not None and (beta is None or tb is not None):
+                dgamma, dbeta, fused = tg, tb, True
+            else:
+                dgamma = torch.empty_like(gamma)
+                dbeta = torch.empty_like(beta) if beta is not None else None
         need_mod = sc is not None or has_shift
         dscale = torch.empty((groups, cols), device=x2.device, dtype=mod_dtype) if need_mod else None
         dshift = torch.empty((groups, cols), device=x2.device, dtype=mod_dtype) if need_mod else None
@@ -309,9 +368,11 @@ class _LNModFn(Function):
             ws = torch.empty(lib().dpipe_lnmod_workspace_floats(rows, cols, rows_per_mod), device=x2.device, dtype=torch.float32)
         check(lib().dpipe_lnmod_bwd(ptr(x2), ptr(gy2), ptr(gamma), ptr(beta), ptr(sc), ptr(mean), ptr(rstd), ptr(gx),
                                     ptr(dgamma), ptr(dbeta), ptr(dscale), ptr(dshift), ptr(ws), rows, cols, rows_per_mod,
-                                    dtype_code(x2.dtype), wdt, mdt, stream()), 'lnmod_bwd')
+                                    dtype_code(x2.dtype), wdt, mdt, int(fused), stream()), 'lnmod_bwd')
         g_scale = dscale.view(scale_shape) if scale_shape is not None else None
         g_shift = dshift.view(shift_shape) if shift_shape is not None else None
+        if fused:
+            dgamma = dbeta = None
         return gx.view(x_shape), dgamma, dbeta, g_scale, g_shift, None
 
 
@@ -441,10 +502,15 @@ class _UnfusedAttnFn(Function):
         return dq, dk, dv, None, None
 
 
+ATTN_TRACE = None     # like GEMM_TRACE: (B, Sq, Sk, H, D, causal) of every attention call of a step
+
+
 def attention(q, k, v, kv_len=None, scale=None, impl='auto', causal=False):
     """q: [B, Sq, H, D], k/v: [B, Sk, H, D] -> [B, Sq, H, D].  kv_len: optional int32 [B] of valid keys.
     impl: 'flash' (bf16 MFMA flash kernel), 'unfused' (GEMM + softmax kernels), 'auto' = flash for bf16."""
     D = q.shape[-1]
+    if ATTN_TRACE is not None:
+        ATTN_TRACE.append((q.shape[0], q.shape[1], k.shape[1], q.shape[2], D, int(causal)))
     if scale is None:
         scale = 1.0 / math.sqrt(D)
     if impl == 'auto':

@@ -90,9 +90,14 @@ int dpipe_multi_clip_scale(void* const* ptrs, const int* chunk_tensor, const lon
 int dpipe_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, long rows, int cols, float eps, int dtype,
                       int wdtype, void* stream);
 int dpipe_norm_slabs(long rows_per_group);
-/* workspace: dpipe_norm_slabs(rows) * cols floats, needed only when dw != NULL. */
+/* workspace: dpipe_norm_slabs(rows) * cols floats, needed only when dw != NULL.  accumulate_params != 0: dw += (the
+ * gradient-accumulation step of the micro-batch loop fused into the reduction; dw then is the persistent .grad). */
 int dpipe_rmsnorm_bwd(const void* x, const void* w, const void* gy, const float* rstd, void* gx, void* dw,
-                      float* workspace, long rows, int cols, int dtype, int wdtype, void* stream);
+                      float* workspace, long rows, int cols, int dtype, int wdtype, int accumulate_params, void* stream);
+/* out[c] (+)= sum_r x[r, c], x: [rows, cols] with row stride ld -- the bias gradient of nn.Linear (column sums of dy).
+ * dtype: x; out_dtype: out (bf16 x -> bf16 or fp32 out; fp32 x -> fp32 out).  workspace as above. */
+int dpipe_colsum(const void* x, long rows, int cols, long ld, void* out, float* workspace, int dtype, int out_dtype,
+                 int accumulate, void* stream);
 
 /* ---- K5 LayerNorm (+affine) + AdaLN modulate (models/wan/model.py:89-99,295-309,332-343) ----------------------
  * n = (x - mean) * rstd [* gamma + beta] ; y = n * (1 + scale[r / rows_per_mod]) + shift[r / rows_per_mod].
@@ -104,7 +109,7 @@ int dpipe_lnmod_workspace_floats(long rows, int cols, long rows_per_mod);
 int dpipe_lnmod_bwd(const void* x, const void* gy, const void* gamma, const void* beta, const void* scale,
                     const float* mean, const float* rstd, void* gx, void* dgamma, void* dbeta, void* dscale,
                     void* dshift, float* workspace, long rows, int cols, long rows_per_mod, int dtype, int wdtype,
-                    int mdtype, void* stream);
+                    int mdtype, int accumulate_params, void* stream);   /* accumulate_params: dgamma / dbeta += */
 
 /* ---- K3 RoPE (models/wan/model.py:40-67 rope_apply; Flux/HunyuanVideo cos/sin tables) -------------------------
  * x, y: [B, S, H, D] contiguous; cos/sin: [S, D/2] fp32.  interleaved=1 rotates pairs (2i, 2i+1) (view_as_complex),
@@ -131,6 +136,18 @@ int dpipe_gemm(int dtype, int transA, int transB, int M, int N, int K, const voi
                long ldb, void* C, long ldc, int batch_outer, int batch_inner, long strideA_outer, long strideA_inner,
                long strideB_outer, long strideB_inner, long strideC_outer, long strideC_inner, const void* bias,
                int act, float alpha, int accumulate, int out_f32, int tile_hint, void* stream);
+/* Same contract plus the split-K workspace of the pipelined bf16 kernel (csrc/gemm_pipe.hip): `splitk_ws` =
+ * [4 KiB ticket counters][64 KiB fp32 slabs ...], zero-filled ONCE by the host and then private to one stream (the
+ * kernel re-arms the counters itself); >= 4 KiB + 256 slabs makes every split decision available; NULL = never split.
+ * tile_hint: 0 = auto, 64 / 128 = generic register-staged kernel with that tile, 1000 + S = pipelined kernel with S
+ * K-slices forced (S = 0: its own choice), 2000 + S / 3000 + S = pipelined kernel with the 64 x 64 / 128 x 128 tile
+ * forced; forced forms fail when the problem is not eligible: bf16, 16-byte aligned operands, leading dims multiples
+ * of 8, K % 64 == 0 unless both operands are K-major. */
+int dpipe_gemm_ex(int dtype, int transA, int transB, int M, int N, int K, const void* A, long lda, const void* B,
+                  long ldb, void* C, long ldc, int batch_outer, int batch_inner, long strideA_outer,
+                  long strideA_inner, long strideB_outer, long strideB_inner, long strideC_outer, long strideC_inner,
+                  const void* bias, int act, float alpha, int accumulate, int out_f32, int tile_hint, void* splitk_ws,
+                  long splitk_ws_bytes, void* stream);
 /* Test probe: runs ds_read_b64_tr_b16 over a 256-element i16 LDS image so the GPU tests can pin the lane mapping
  * the transposed-operand paths rely on. */
 int dpipe_tr16_probe(const void* in256_i16, void* out256_i16, void* stream);

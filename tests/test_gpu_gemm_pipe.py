@@ -1,0 +1,147 @@
+"""GPU parity tests of the LDS-DMA pipelined bf16 GEMM (csrc/gemm_pipe.hip) through the C ABI (dpipe_gemm_ex):
+every operand layout (fwd NT, dgrad NN, wgrad TN, TT), ragged tiles served by the buffer bounds check, forced and
+automatic split-K (slab reduction, ticket re-arm, determinism), epilogue variants, strided batches.
+Reference: fp32 matmul of the bf16-rounded operands; tolerance = bf16 output rounding (1.6e-2 of the output scale),
+fp32-output cases 2e-3 (fp32 accumulation of bf16 products in a different order)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+PIPE = 1000          # tile_hint: pipelined kernel, its own tile / split choice; PIPE + S forces S slices
+T64, T128 = 2000, 3000   # ... with the 64 x 64 / 128 x 128 tile forced (+ S)
+
+
+def _rel_err(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-3)).item()
+
+
+def _operands(gpu, ta, tb, M, N, K, seed):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    a = torch.randn((K, M) if ta else (M, K), generator=g).to(gpu, torch.bfloat16)
+    b = torch.randn((N, K) if tb else (K, N), generator=g).to(gpu, torch.bfloat16)
+    ref = (a.float().t() if ta else a.float()) @ (b.float().t() if tb else b.float())
+    return a, b, ref
+
+
+# (M, N, K): K is a multiple of 64 (needed whenever an operand is K-contiguous); M / N ragged against the 128-tile
+SHAPES = [(128, 128, 64), (256, 384, 192), (77, 1280, 1280), (100, 72, 128), (1000, 136, 320), (1024, 1280, 1280), (130, 8, 4096)]
+
+
+@pytest.mark.parametrize('trans', [(False, True), (False, False), (True, False), (True, True)])
+@pytest.mark.parametrize('shape', SHAPES)
+@pytest.mark.parametrize('split', [0, 1, 2, 5])
+@pytest.mark.parametrize('tile', [T64, T128])
+def test_pipe_gemm_matches_fp32_matmul(gpu, trans, shape, split, tile):
+    from diffusion_pipe_amd import ops
+    from diffusion_pipe_amd.hip import DpipeHipError
+    ta, tb = trans
+    M, N, K = shape
+    a, b, ref = _operands(gpu, ta, tb, M, N, K, M * 7 + N * 3 + K)
+    if (ta and M % 8) or (not tb and N % 8):          # MN-contiguous operand whose row pitch is not 16-byte aligned
+        with pytest.raises(DpipeHipError):
+            ops.mm(a, b, ta, tb, tile_hint=tile + split)
+        return
+    out = ops.mm(a, b, ta, tb, tile_hint=tile + split)
+    torch.cuda.synchronize()
+    assert out.shape == (M, N)
+    assert _rel_err(out, ref) < 1.6e-2
+
+
+@pytest.mark.parametrize('K', [77, 8, 200, 1024, 4100])
+@pytest.mark.parametrize('split', [0, 1, 3, T64 + 3, T128 + 2])
+def test_pipe_wgrad_any_k(gpu, K, split):
+    """dW = dy^T x: both operands K-major ([tokens][features]) -> any token count; rows >= K read as zero."""
+    from diffusion_pipe_amd import ops
+    M, N = 320, 200
+    a, b, ref = _operands(gpu, True, False, M, N, K, K)
+    out = ops.mm(a, b, True, False, tile_hint=PIPE + split)
+    assert _rel_err(out, ref) < 1.6e-2
+
+
+def test_pipe_not_eligible_is_an_error_and_auto_falls_back(gpu):
+    from diffusion_pipe_amd import ops
+    from diffusion_pipe_amd.hip import DpipeHipError
+    a, b, ref = _operands(gpu, False, True, 100, 72, 40, 3)          # K % 64 != 0 with K-contiguous operands
+    with pytest.raises(DpipeHipError):
+        ops.mm(a, b, False, True, tile_hint=PIPE)
+    out = ops.mm(a, b, False, True)                                    # auto: generic kernel
+    assert _rel_err(out, ref) < 1.6e-2
+
+
+@pytest.mark.parametrize('split', [1, 4, T128 - PIPE + 1, T128 - PIPE + 3])
+def test_pipe_epilogue_bias_act_accumulate_f32(gpu, split):
+    from diffusion_pipe_amd import ops
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 200, 164, 256
+    a = torch.randn(M, K, generator=g).to(gpu, torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / 16).to(gpu, torch.bfloat16)
+    bias = torch.randn(N, generator=g).to(gpu, torch.bfloat16)
+    lin = a.float() @ w.float().t()
+    out = ops.mm(a, w, False, True, bias=bias, act='gelu_tanh', tile_hint=PIPE + split)
+    assert _rel_err(out, F.gelu(lin + bias.float(), approximate='tanh')) < 1.6e-2
+    # unaligned bias pointer / odd ldc take the scalar epilogue
+    bias2 = torch.randn(N + 1, generator=g).to(gpu, torch.bfloat16)[1:]
+    cbuf = torch.zeros(M, N + 3, device=gpu, dtype=torch.bfloat16)
+    ops.gemm(a, w, False, True, M, N, K, cbuf, lda=K, ldb=K, ldc=N + 3, bias=bias2, tile_hint=PIPE + split)
+    assert _rel_err(cbuf[:, :N], lin + bias2.float()) < 1.6e-2
+    assert torch.count_nonzero(cbuf[:, N:]) == 0
+    # accumulate: bf16 and fp32 outputs
+    c0 = torch.randn(M, N, generator=g).to(gpu, torch.bfloat16)
+    c = c0.clone()
+    ops.gemm(a, w, False, True, M, N, K, c, lda=K, ldb=K, ldc=N, accumulate=True, alpha=0.5, tile_hint=PIPE + split)
+    assert _rel_err(c, c0.float() + 0.5 * lin) < 1.6e-2
+    cf0 = torch.randn(M, N, generator=g).to(gpu)
+    cf = cf0.clone()
+    ops.gemm(a, w, False, True, M, N, K, cf, lda=K, ldb=K, ldc=N, accumulate=True, tile_hint=PIPE + split)
+    assert _rel_err(cf, cf0 + lin) < 2e-3
+
+
+def test_pipe_batched_strided(gpu):
+    from diffusion_pipe_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, S, H, D = 2, 200, 3, 64
+    q = torch.randn(B, S, H, D, generator=g).to(gpu, torch.bfloat16)
+    k = torch.randn(B, S, H, D, generator=g).to(gpu, torch.bfloat16)
+    Sp = 208
+    p = torch.zeros(B, H, S, Sp, device=gpu, dtype=torch.bfloat16)
+    for hint in (PIPE, T64 + 1, T128 + 1):
+        p.zero_()
+        ops.gemm(q, k, False, True, S, S, D, p, lda=H * D, ldb=H * D, ldc=Sp, batch_outer=B, batch_inner=H,
+                 stride_a=(S * H * D, D), stride_b=(S * H * D, D), stride_c=(H * S * Sp, S * Sp), tile_hint=hint)
+        ref = torch.einsum('bqhd,bkhd->bhqk', q.float(), k.float())
+        assert _rel_err(p[..., :S], ref) < 1.6e-2
+        assert torch.count_nonzero(p[..., S:]) == 0
+    # K-contiguous A with K = 208 (not a multiple of 64): not eligible -> the forced hint must refuse
+    from diffusion_pipe_amd.hip import DpipeHipError
+    pv = torch.empty(B, S, H, D, device=gpu, dtype=torch.bfloat16)
+    with pytest.raises(DpipeHipError):
+        ops.gemm(p, k, False, False, S, D, Sp, pv, lda=Sp, ldb=H * D, ldc=H * D, batch_outer=B, batch_inner=H,
+                 stride_a=(H * S * Sp, S * Sp), stride_b=(S * H * D, D), stride_c=(S * H * D, D), tile_hint=PIPE)
+
+
+def test_pipe_splitk_is_deterministic_and_rearms_counters(gpu):
+    from diffusion_pipe_amd import ops
+    a, b, ref = _operands(gpu, False, False, 1024, 1280, 2560, 77)
+    first = ops.mm(a, b, False, False, tile_hint=T64 + 4)
+    assert _rel_err(first, ref) < 1.6e-2
+    for i in range(40):                       # every launch must find its ticket counters at zero
+        again = ops.mm(a, b, False, False, tile_hint=(T64 + 4 if i % 2 == 0 else T128 + 7))
+        if i % 2 == 0:
+            assert torch.equal(again, first), f'launch {i}: split-K result changed between launches'
+        else:
+            assert _rel_err(again, ref) < 1.6e-2
+    torch.cuda.synchronize()
+
+
+def test_pipe_agrees_with_generic_kernel_on_sdxl_shapes(gpu):
+    from diffusion_pipe_amd import ops
+    for (ta, tb, M, N, K) in [(0, 1, 1024, 10240, 1280), (0, 0, 1024, 1280, 10240), (1, 0, 640, 640, 4096), (0, 1, 77, 1280, 2048),
+                              (1, 0, 10240, 1280, 1024), (0, 1, 4096, 640, 2560)]:
+        a, b, ref = _operands(gpu, bool(ta), bool(tb), M, N, K, M + N + K)
+        auto = ops.mm(a, b, bool(ta), bool(tb))
+        generic = ops.mm(a, b, bool(ta), bool(tb), tile_hint=128)
+        assert _rel_err(auto, ref) < 1.6e-2
+        assert _rel_err(auto, generic) < 1.6e-2

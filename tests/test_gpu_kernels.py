@@ -430,3 +430,45 @@ def test_quick_gelu(gpu, dtype):
     yr = xr * torch.sigmoid(1.702 * xr)
     yr.sum().backward()
     assert _rel_err(y, yr) < _tol(dtype) and _rel_err(x.grad, xr.grad) < _tol(dtype)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('shape', [(1, 320), (77, 1280), (1024, 1280), (4096, 640), (333, 200)])
+def test_column_sum_and_accumulate(gpu, dtype, shape):
+    from diffusion_pipe_amd import ops
+    rows, cols = shape
+    g = torch.Generator().manual_seed(rows + cols)
+    x = torch.randn(rows, cols, generator=g).to(gpu, dtype)
+    ref = x.float().sum(0)
+    out = ops.column_sum(x)
+    assert out.dtype == dtype and _rel_err(out, ref) < _tol(dtype)
+    acc0 = torch.randn(cols, generator=g).to(gpu, dtype)
+    acc = acc0.clone()
+    ops.column_sum(x, out=acc)
+    assert _rel_err(acc, acc0.float() + ref) < _tol(dtype)
+    # row-strided view (a column block of a wider matrix)
+    wide = torch.randn(rows, cols + 64, generator=g).to(gpu, dtype)
+    view = wide[:, 32:32 + cols] if dtype == torch.float32 else wide[:, 64:64 + cols]
+    assert _rel_err(ops.column_sum(view), view.float().sum(0)) < _tol(dtype)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_fused_gradient_accumulation_matches_autograd_accumulation(gpu, dtype):
+    """Two micro-batches through Linear + LayerNorm + RMSNorm: with ops.FUSE_GRAD_ACCUM the second backward adds into the
+    existing .grad inside the kernels; the result must equal plain autograd accumulation (up to one bf16 rounding)."""
+    from diffusion_pipe_amd import nn as dnn, ops
+
+    def run(fuse):
+        torch.manual_seed(3)
+        lin, ln, rms = dnn.Linear(192, 320).to(gpu, dtype), dnn.LayerNorm(320).to(gpu, dtype), dnn.RMSNorm(320).to(gpu, dtype)
+        ops.FUSE_GRAD_ACCUM = fuse
+        try:
+            for mb in range(3):
+                x = torch.randn(2, 150, 192, generator=torch.Generator().manual_seed(mb)).to(gpu, dtype)
+                (rms(ln(lin(x))).float() * torch.linspace(-1, 1, 320, device=gpu)).sum().backward()
+        finally:
+            ops.FUSE_GRAD_ACCUM = False
+        return [p.grad.clone() for m in (lin, ln, rms) for p in m.parameters()]
+
+    for a, b in zip(run(True), run(False)):
+        assert _rel_err(a, b) < (2e-2 if dtype == torch.bfloat16 else 1e-4)

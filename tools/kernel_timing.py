@@ -1,0 +1,90 @@
+"""In-graph kernel timing on the GPU box: each op is captured N times into one hipGraph and replayed, so the number is
+GPU time per launch (no host launch gaps).  Prints JSON lines: the pipelined GEMM vs the generic kernel vs the
+PyTorch-ROCm library (hipBLASLt) on the SDXL shapes of one micro-batch, plus the column-sum / LayerNorm-backward kernels."""
+import json
+import sys
+
+import torch
+
+sys.path.insert(0, '.')
+from diffusion_pipe_amd import ops  # noqa: E402
+
+
+def graph_time(fn, n=20, reps=5):
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn(); fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (reps * n) * 1e3     # us
+
+
+SHAPES = [  # (ta, tb, M, N, K, count per micro-batch)
+    (0, 0, 1024, 1280, 1280, 372), (0, 0, 1024, 1280, 10240, 60), (1, 0, 1280, 1280, 1024, 372), (1, 0, 10240, 1280, 1024, 60),
+    (0, 1, 1024, 1280, 1280, 372), (0, 1, 1024, 1280, 5120, 60), (0, 1, 1024, 10240, 1280, 60), (1, 0, 640, 640, 4096, 70),
+    (0, 0, 1024, 5120, 1280, 60), (1, 0, 1280, 5120, 1024, 60), (0, 1, 77, 1280, 2048, 120), (0, 0, 77, 1280, 1280, 128),
+    (0, 1, 77, 1280, 1280, 128), (0, 0, 77, 2048, 1280, 120), (0, 0, 77, 1280, 5120, 32), (0, 1, 77, 1280, 5120, 32),
+    (1, 0, 1280, 1280, 77, 128), (1, 0, 1280, 2048, 77, 120), (0, 0, 4096, 640, 640, 70), (0, 1, 4096, 640, 640, 70),
+    (1, 0, 5120, 640, 4096, 10), (0, 1, 4096, 5120, 640, 10), (0, 0, 4096, 640, 5120, 10), (0, 1, 4096, 640, 2560, 10),
+    (0, 0, 4096, 2560, 640, 10), (1, 0, 640, 2560, 4096, 10), (0, 1, 77, 768, 768, 48), (0, 1, 1024, 3840, 1280, 0),
+    (0, 1, 8192, 8192, 8192, 0), (0, 1, 4608, 9216, 3072, 0)]
+
+
+def main():
+    dev = torch.device('cuda:0')
+    tot = {'pipe': 0.0, 'g64': 0.0, 'g128': 0.0, 'torch': 0.0, 'best_generic': 0.0}
+    for (ta, tb, M, N, K, cnt) in SHAPES:
+        a = torch.randn((K, M) if ta else (M, K), device=dev, dtype=torch.bfloat16)
+        b = torch.randn((N, K) if tb else (K, N), device=dev, dtype=torch.bfloat16)
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        aa, bb = (a.t() if ta else a), (b.t() if tb else b)
+        rec = {'op': 'gemm', 'ta': ta, 'tb': tb, 'M': M, 'N': N, 'K': K, 'cnt': cnt}
+        fl = 2.0 * M * N * K
+        for name, hint in (('pipe', 1000), ('t64s1', 2001), ('t64s2', 2002), ('t64s4', 2004), ('t64s8', 2008), ('t128s1', 3001), ('t128s3', 3003),
+                           ('g64', 64), ('g128', 128)):
+            try:
+                us = graph_time(lambda: ops.mm(a, b, bool(ta), bool(tb), out=out, tile_hint=hint))
+            except Exception as e:  # not eligible
+                us = float('nan')
+            rec[name + '_us'] = round(us, 1)
+        us = graph_time(lambda: torch.matmul(aa, bb, out=out))
+        rec['torch_us'] = round(us, 1)
+        rec['pipe_TF'] = round(fl / rec['pipe_us'] / 1e6, 1) if rec['pipe_us'] == rec['pipe_us'] else None
+        rec['torch_TF'] = round(fl / us / 1e6, 1)
+        for k in ('pipe', 'g64', 'g128', 'torch'):
+            v = rec[k + '_us']
+            tot[k] += cnt * (v if v == v else min(rec['g64_us'], rec['g128_us'])) / 1e3
+        tot['best_generic'] += cnt * min(rec['g64_us'], rec['g128_us']) / 1e3
+        print(json.dumps(rec), flush=True)
+    print(json.dumps({'summary_ms_per_microbatch': {k: round(v, 2) for k, v in tot.items()}}), flush=True)
+    # column sums / LayerNorm backward
+    for rows, cols in [(1024, 1280), (4096, 640), (1024, 10240), (77, 1280)]:
+        x = torch.randn(rows, cols, device=dev, dtype=torch.bfloat16)
+        gy = torch.randn(rows, cols, device=dev, dtype=torch.bfloat16)
+        acc = torch.zeros(cols, device=dev, dtype=torch.bfloat16)
+        us = graph_time(lambda: ops.column_sum(x, out=acc))
+        w = torch.ones(cols, device=dev, dtype=torch.bfloat16, requires_grad=True)
+        bz = torch.zeros(cols, device=dev, dtype=torch.bfloat16, requires_grad=True)
+        xr = x.clone().requires_grad_(True)
+
+        def ln_fwd_bwd():                       # forward inside the captured region too (backward runs on the forward's stream)
+            ops.layer_norm_modulate(xr, w, bz, None, None, 1e-5).backward(gy)
+        us_lnf = graph_time(lambda: ops.layer_norm_modulate(x, w, bz, None, None, 1e-5))
+        us_ln = graph_time(ln_fwd_bwd) - us_lnf
+        print(json.dumps({'op': 'colsum/ln', 'rows': rows, 'cols': cols, 'colsum_us': round(us, 1), 'ln_bwd_us': round(us_ln, 1), 'ln_fwd_us': round(us_lnf, 1)}), flush=True)
+
+
+main()
