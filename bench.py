@@ -38,6 +38,7 @@ def parse():
     ap.add_argument('--activation-checkpointing', action='store_true')
     ap.add_argument('--partition', default='parameters')
     ap.add_argument('--no-graph', action='store_true', help='disable hipGraph capture of the micro-batch fwd+bwd')
+    ap.add_argument('--parallel-wgrad', action='store_true', help='fork wgrad onto a side stream (A/B switch; measured slower)')
     return ap.parse_args()
 
 
@@ -106,7 +107,8 @@ def main():
     module = ManualPipelineModule(layers=layers, num_stages=pp, partition_method=args.partition, loss_fn=work.get_loss_fn(),
                                   dynamic_shape=True, **kwargs)
     engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 1, 'gradient_accumulation_steps': gas,
-                                                         'gradient_clipping': 1.0, 'steps_per_print': 1 << 30, 'hip_graph': not args.no_graph}, device=device)
+                                                         'gradient_clipping': 1.0, 'steps_per_print': 1 << 30, 'hip_graph': not args.no_graph,
+                                                         'parallel_wgrad': args.parallel_wgrad}, device=device)
     params = [p for p in module.parameters() if p.requires_grad]
 
     def make_opt(ps):

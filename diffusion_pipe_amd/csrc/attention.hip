@@ -32,6 +32,8 @@ struct AttnParams {
     long do_sb, do_ss, do_sh, dq_sb, dq_ss, dq_sh, dk_sb, dk_ss, dk_sh, dv_sb, dv_ss, dv_sh;
     float scale;
     int causal;
+    int qsplit;            // dK/dV kernel: query tiles are split over `qsplit` workgroups per key block (short-key cross attention)
+    float* part;           // fp32 partials [B][H][qsplit][2][Sk][D] when qsplit > 1
 };
 
 constexpr float LOG2E = 1.4426950408889634f;
@@ -330,7 +332,8 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(const AttnParams 
 
     const int b = blockIdx.z, hh = blockIdx.y;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
-    const int key = blockIdx.x * 32 * NW + wid * 32 + i;
+    const int kblock = blockIdx.x / p.qsplit, qs = blockIdx.x % p.qsplit;
+    const int key = kblock * 32 * NW + wid * 32 + i;
     const int kvl = p.kv_len ? min(p.kv_len[b], p.Sk) : p.Sk;
     const bool klive = key < kvl;
     const bf16_t* Q = p.q + b * p.q_sb + hh * p.q_sh;
@@ -351,16 +354,18 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(const AttnParams 
 #pragma unroll
     for (int db = 0; db < D / 32; ++db) { dkacc[db] = zero16(); dvacc[db] = zero16(); }
 
-    const int nqt = (p.Sq + QT - 1) / QT;
+    const int nqt_all = (p.Sq + QT - 1) / QT;
+    const int per = (nqt_all + p.qsplit - 1) / p.qsplit;
+    const int qt0 = qs * per, nqt = min(nqt_all, qt0 + per);      // this workgroup's query tiles [qt0, nqt)
     RowRegs<QT * (D / 8) / NT> rq, rdo;
-    load_rows<D, QT, NT>(rq, Q, p.q_ss, 0, p.Sq);
-    load_rows<D, QT, NT>(rdo, DO, p.do_ss, 0, p.Sq);
+    load_rows<D, QT, NT>(rq, Q, p.q_ss, qt0 * QT, p.Sq);
+    load_rows<D, QT, NT>(rdo, DO, p.do_ss, qt0 * QT, p.Sq);
     float r_lse = 0.f, r_dl = 0.f;
     if (threadIdx.x < QT) {
-        const int q = threadIdx.x;
+        const int q = qt0 * QT + threadIdx.x;
         r_lse = q < p.Sq ? LSE[q] * LOG2E : INFINITY; r_dl = q < p.Sq ? DL[q] : 0.f;
     }
-    for (int qt = 0; qt < nqt; ++qt) {
+    for (int qt = qt0; qt < nqt; ++qt) {
         __syncthreads();
         store_rows<D, QT, NT, QRS>(rq, Ql);
         store_rows<D, QT, NT, QRS>(rdo, DOl);
@@ -408,6 +413,22 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(const AttnParams 
             }
         }
     }
+    if (p.qsplit > 1) {
+        if (key < p.Sk) {            // fp32 partial of this query slice; attn_dkv_reduce_kernel sums the slices in order
+            float* PK = p.part + ((((long)b * p.H + hh) * p.qsplit + qs) * 2) * p.Sk * D + (long)key * D;
+            float* PV = PK + (long)p.Sk * D;
+#pragma unroll
+            for (int db = 0; db < D / 32; ++db)
+#pragma unroll
+                for (int eg = 0; eg < 4; ++eg) {
+                    *reinterpret_cast<float4*>(PK + 32 * db + 8 * eg + 4 * h) =
+                        make_float4(dkacc[db][4 * eg], dkacc[db][4 * eg + 1], dkacc[db][4 * eg + 2], dkacc[db][4 * eg + 3]);
+                    *reinterpret_cast<float4*>(PV + 32 * db + 8 * eg + 4 * h) =
+                        make_float4(dvacc[db][4 * eg], dvacc[db][4 * eg + 1], dvacc[db][4 * eg + 2], dvacc[db][4 * eg + 3]);
+                }
+        }
+        return;
+    }
     if (key < p.Sk) {
         bf16_t* DK = p.dk + b * p.dk_sb + hh * p.dk_sh + (long)key * p.dk_ss;
         bf16_t* DV = p.dv + b * p.dv_sb + hh * p.dv_sh + (long)key * p.dv_ss;
@@ -424,6 +445,38 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(const AttnParams 
                 *reinterpret_cast<uint2*>(DV + 32 * db + 8 * eg + 4 * h) = wv;
             }
     }
+}
+
+// dK / dV = sum over query slices of the fp32 partials (slice order: deterministic), one thread per 4 head-dim elements
+template <int D>
+__global__ void __launch_bounds__(256) attn_dkv_reduce_kernel(const AttnParams p) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)p.B * p.H * p.Sk * (D / 4);
+    if (idx >= total) return;
+    const int d4 = (int)(idx % (D / 4)); const int key = (int)((idx / (D / 4)) % p.Sk);
+    const int hh = (int)((idx / ((long)(D / 4) * p.Sk)) % p.H); const int b = (int)(idx / ((long)(D / 4) * p.Sk * p.H));
+    const float* base = p.part + (((long)b * p.H + hh) * p.qsplit * 2) * p.Sk * D + (long)key * D + 4 * d4;
+    float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = k4;
+    for (int s = 0; s < p.qsplit; ++s) {
+        const float4 a = *reinterpret_cast<const float4*>(base + (long)s * 2 * p.Sk * D);
+        const float4 c = *reinterpret_cast<const float4*>(base + ((long)s * 2 + 1) * p.Sk * D);
+        k4.x += a.x; k4.y += a.y; k4.z += a.z; k4.w += a.w; v4.x += c.x; v4.y += c.y; v4.z += c.z; v4.w += c.w;
+    }
+    bf16_t* DK = p.dk + b * p.dk_sb + hh * p.dk_sh + (long)key * p.dk_ss + 4 * d4;
+    bf16_t* DV = p.dv + b * p.dv_sb + hh * p.dv_sh + (long)key * p.dv_ss + 4 * d4;
+    *reinterpret_cast<uint2*>(DK) = make_uint2(pack_bf16x2(k4.x * p.scale, k4.y * p.scale), pack_bf16x2(k4.z * p.scale, k4.w * p.scale));
+    *reinterpret_cast<uint2*>(DV) = make_uint2(pack_bf16x2(v4.x, v4.y), pack_bf16x2(v4.z, v4.w));
+}
+
+// Query-slice count of the dK/dV kernel: fill ~256 workgroups when the key blocks x heads alone cannot (cross attention
+// to 77 text tokens: one key block per head), at least one 64-query tile per slice.
+int dkv_qsplit(int B, int H, int Sq, int Sk, int NW) {
+    const long wgs = (long)cdiv(Sk, 32 * NW) * H * B;
+    const int nqt = (int)cdiv(Sq, 64);
+    long qs = wgs >= 192 ? 1 : 256 / wgs;
+    if (qs > nqt) qs = nqt;
+    if (qs > 64) qs = 64;
+    return qs < 1 ? 1 : (int)qs;
 }
 
 bool strides_ok(const void* ptr, long sb, long ss, long sh) {
@@ -448,11 +501,23 @@ int dpipe_attn_fwd(const void* q, const void* k, const void* v, void* o, float* 
     p.B = B; p.H = H; p.Sq = Sq; p.Sk = Sk; p.scale = scale; p.causal = causal;
     p.q_sb = q_sb; p.q_ss = q_ss; p.q_sh = q_sh; p.k_sb = k_sb; p.k_ss = k_ss; p.k_sh = k_sh;
     p.v_sb = v_sb; p.v_ss = v_ss; p.v_sh = v_sh; p.o_sb = o_sb; p.o_ss = o_ss; p.o_sh = o_sh;
-    constexpr int NW = 4;
-    dim3 grid((unsigned)cdiv(Sq, 32 * NW), (unsigned)H, (unsigned)B);
-    if (D == 64) attn_fwd_kernel<64, NW><<<grid, NW * 64, 0, STREAM(stream)>>>(p);
-    else attn_fwd_kernel<128, NW><<<grid, NW * 64, 0, STREAM(stream)>>>(p);
+    // 128 queries per workgroup (4 waves) when that alone fills the chip, else 64 (2 waves): twice the workgroups
+    const bool small = cdiv(Sq, 128) * H * B < 256;
+    if (small) {
+        dim3 grid((unsigned)cdiv(Sq, 64), (unsigned)H, (unsigned)B);
+        if (D == 64) attn_fwd_kernel<64, 2><<<grid, 128, 0, STREAM(stream)>>>(p);
+        else attn_fwd_kernel<128, 2><<<grid, 128, 0, STREAM(stream)>>>(p);
+    } else {
+        dim3 grid((unsigned)cdiv(Sq, 128), (unsigned)H, (unsigned)B);
+        if (D == 64) attn_fwd_kernel<64, 4><<<grid, 256, 0, STREAM(stream)>>>(p);
+        else attn_fwd_kernel<128, 4><<<grid, 256, 0, STREAM(stream)>>>(p);
+    }
     return check_launch("dpipe_attn_fwd");
+}
+
+long dpipe_attn_bwd_partial_floats(int B, int H, int Sq, int Sk, int D) {
+    const int qs = dkv_qsplit(B, H, Sq, Sk, 4);
+    return qs > 1 ? (long)B * H * qs * 2 * Sk * D : 0;
 }
 
 int dpipe_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
@@ -460,7 +525,7 @@ int dpipe_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
                    long q_sb, long q_ss, long q_sh, long k_sb, long k_ss, long k_sh, long v_sb, long v_ss, long v_sh,
                    long o_sb, long o_ss, long o_sh, long do_sb, long do_ss, long do_sh, long dq_sb, long dq_ss,
                    long dq_sh, long dk_sb, long dk_ss, long dk_sh, long dv_sb, long dv_ss, long dv_sh, float scale,
-                   int causal, void* stream) {
+                   int causal, float* dkv_partial, long dkv_partial_floats, void* stream) {
     if (!q || !k || !v || !o || !dout || !lse || !delta || !dq || !dk || !dv || B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) {
         set_last_error("dpipe_attn_bwd: bad argument"); return DPIPE_ERR_ARG; }
     if (D != 64 && D != 128) { set_last_error("dpipe_attn_bwd: head dim must be 64 or 128"); return DPIPE_ERR_UNSUPPORTED; }
@@ -478,16 +543,19 @@ int dpipe_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
     hipStream_t s = STREAM(stream);
     constexpr int NW = 4;
     const long rows = (long)B * H * Sq;
-    dim3 gq((unsigned)cdiv(Sq, 32 * NW), (unsigned)H, (unsigned)B), gk((unsigned)cdiv(Sk, 32 * NW), (unsigned)H, (unsigned)B);
-    if (D == 64) {
-        attn_delta_kernel<64><<<(unsigned)cdiv(rows, 16), 256, 0, s>>>(p);
-        attn_bwd_dq_kernel<64, NW><<<gq, NW * 64, 0, s>>>(p);
-        attn_bwd_dkv_kernel<64, NW><<<gk, NW * 64, 0, s>>>(p);
-    } else {
-        attn_delta_kernel<128><<<(unsigned)cdiv(rows, 16), 256, 0, s>>>(p);
-        attn_bwd_dq_kernel<128, NW><<<gq, NW * 64, 0, s>>>(p);
-        attn_bwd_dkv_kernel<128, NW><<<gk, NW * 64, 0, s>>>(p);
-    }
+    p.qsplit = dkv_qsplit(B, H, Sq, Sk, NW);
+    if (p.qsplit > 1 && (!dkv_partial || dkv_partial_floats < (long)B * H * p.qsplit * 2 * Sk * D)) p.qsplit = 1;   // no workspace: unsplit
+    p.part = dkv_partial;
+    const bool small_q = cdiv(Sq, 128) * H * B < 256;
+    dim3 gq((unsigned)cdiv(Sq, small_q ? 64 : 128), (unsigned)H, (unsigned)B), gk((unsigned)(cdiv(Sk, 32 * NW) * p.qsplit), (unsigned)H, (unsigned)B);
+    const unsigned gred = (unsigned)cdiv((long)B * H * Sk * (D / 4), 256);
+#define ATTN_BWD(DD) do { \
+        attn_delta_kernel<DD><<<(unsigned)cdiv(rows, 16), 256, 0, s>>>(p); \
+        if (small_q) attn_bwd_dq_kernel<DD, 2><<<gq, 128, 0, s>>>(p); else attn_bwd_dq_kernel<DD, 4><<<gq, 256, 0, s>>>(p); \
+        attn_bwd_dkv_kernel<DD, NW><<<gk, NW * 64, 0, s>>>(p); \
+        if (p.qsplit > 1) attn_dkv_reduce_kernel<DD><<<gred, 256, 0, s>>>(p); } while (0)
+    if (D == 64) ATTN_BWD(64); else ATTN_BWD(128);
+#undef ATTN_BWD
     return check_launch("dpipe_attn_bwd");
 }
 

@@ -133,8 +133,12 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const GemmParams p) {
     const long zo = z / p.batch_inner, zi = z % p.batch_inner;
     const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + zo * p.sAo + zi * p.sAi;
     const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B) + zo * p.sBo + zi * p.sBi;
-    const unsigned a_bytes = (unsigned)((A_MC ? (long)(p.K - 1) * p.lda + p.M : (long)(p.M - 1) * p.lda + p.K) * 2);
-    const unsigned b_bytes = (unsigned)((B_MC ? (long)(p.K - 1) * p.ldb + p.N : (long)(p.N - 1) * p.ldb + p.K) * 2);
+    // Buffer extents for the bounds check (out-of-range dwords read as zero).  An MN-contiguous operand's last row is
+    // rounded up to whole 16-byte pieces: the check is per dword, and an odd MN count would otherwise zero the last
+    // element of the last K-row (its row pitch is a multiple of 8 elements, so those bytes exist; they only feed
+    // output indices >= M / N, which are never stored).
+    const unsigned a_bytes = (unsigned)((A_MC ? (long)(p.K - 1) * p.lda + ((p.M + 7) & ~7) : (long)(p.M - 1) * p.lda + p.K) * 2);
+    const unsigned b_bytes = (unsigned)((B_MC ? (long)(p.K - 1) * p.ldb + ((p.N + 7) & ~7) : (long)(p.N - 1) * p.ldb + p.K) * 2);
     // (hipcc's host pass drops a kernel's launch stub -- silently -- when a target builtin is called with type-dependent
     // operands: the DMA builtin below only ever sees non-dependent locals, hence the ISSUE_STAGE macro)
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), (short)0, (int)a_bytes, 0x00020000);

@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(NB) rmsnorm_bwd_dx_kernel(const T* __restrict_
 // MODE 2: AdaLN (dscale, dshift) = (sum gy * n, sum gy)      n = xhat*gamma + beta
 // MODE 3: plain column sum of x (bias gradients); gy / statistics unused
 // Block = 32 column vectors (512 B of a row: whole cache lines) x 8 row lanes; a slab is ~32 rows so a [1024, 1280]
-// operand launches 5 x 32 blocks with 4 independent row loads per thread in flight; row lanes combine through LDS.
+// operand launches 5 x 8 blocks of 128 rows, 16 rows per thread (unrolled 4x for loads in flight); row lanes combine through LDS.
 constexpr int CR_CT = 32, CR_RT = 8;
 template <typename T, typename W, typename M, int MODE>
 __global__ void __launch_bounds__(NB) colreduce_kernel(const T* __restrict__ x, const T* __restrict__ gy, const float* __restrict__ mean,
@@ -122,6 +122,7 @@ __global__ void __launch_bounds__(NB) colreduce_kernel(const T* __restrict__ x, 
         fsc[j] = (live && scale) ? 1.f + Elem<M>::to_f(scale[grp * cols + c + j]) : 1.f;
     }
     if (live) {
+#pragma unroll 4
         for (long r = r0 + rl; r < r1; r += CR_RT) {
             const long row = grp * rows_per_group + r;
             Vec16<T> vx; vx.load(x + row * ld + c);
@@ -169,7 +170,8 @@ __global__ void __launch_bounds__(NB) slabsum_kernel(const float* __restrict__ p
     if (i >= groups * cols) return;
     const long g = i / cols; const int c = (int)(i - g * cols);
     float a = 0.f;
-    for (int s = 0; s < slabs; ++s) a += partial[(g * slabs + s) * cols + c];
+#pragma unroll 8
+    for (int s = 0; s < slabs; ++s) a += partial[(g * slabs + s) * cols + c];     // 8 independent loads in flight
     if (accumulate) a += Elem<O>::to_f(out[i]);
     out[i] = Elem<O>::from_f(a);
 }
@@ -378,7 +380,7 @@ static inline int pick_lpr(int cols, int vec) { return (cols / vec) <= 16 ? 16 :
 extern "C" {
 
 int dpipe_norm_slabs(long rows_per_group) {
-    long s = rows_per_group / 32; if (s < 1) s = 1; if (s > 256) s = 256; return (int)s;
+    long s = rows_per_group / 128; if (s < 1) s = 1; if (s > 64) s = 64; return (int)s;   // few slabs: the second stage walks them serially
 }
 
 int dpipe_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, long rows, int cols, float eps, int dtype, int wdtype, void* stream) {

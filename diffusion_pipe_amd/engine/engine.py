@@ -90,6 +90,7 @@ class PipelineEngine:
         if self.device.type == 'cuda' and self._config.get('fuse_grad_accumulation', True):
             from .. import ops as _ops
             _ops.FUSE_GRAD_ACCUM = True     # wgrad / bias / norm-weight kernels add straight into existing .grad buffers
+            _ops.PARALLEL_WGRAD = self.use_graph and bool(self._config.get('parallel_wgrad', False))   # dgrad || wgrad as parallel graph branches (measured: no gain on MI355X, off)
         self.link = StageLink(self.grid, self.device) if self.is_pipe_parallel else None
         self.loss = None
         self.total_loss = None

@@ -53,7 +53,8 @@ _SIGNATURES = {
     'dpipe_gemm_ex': (I, [I, I, I, I, I, I, P, L, P, L, P, L, I, I, L, L, L, L, L, L, P, I, F, I, I, I, P, L, P]),
     'dpipe_tr16_probe': (I, [P, P, P]),
     'dpipe_attn_fwd': (I, [P, P, P, P, P, P, I, I, I, I, I] + [L] * 12 + [F, I, P]),
-    'dpipe_attn_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I] + [L] * 24 + [F, I, P]),
+    'dpipe_attn_bwd_partial_floats': (L, [I, I, I, I, I]),
+    'dpipe_attn_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I] + [L] * 24 + [F, I, P, L, P]),
 }
 
 _lib = None

@@ -101,6 +101,22 @@ def _accum_target(param):
     return g
 
 
+# Backward-pass concurrency (set by the engine): dgrad (dx = dy W) and wgrad (dW = dy^T x, + the bias column sum) of a
+# Linear are independent; at micro-batch 1 each fills well under half of the 256 CUs (40 .. 320 workgroups), so wgrad is
+# forked onto a side HIP stream and joined before the function returns.  Under hipGraph capture the fork / join become
+# parallel graph branches.  The split-K workspace is per stream, so the two GEMMs never share ticket counters.
+PARALLEL_WGRAD = False
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    st = _SIDE_STREAMS.get(device.index)
+    if st is None:
+        st = torch.cuda.Stream(device)
+        _SIDE_STREAMS[device.index] = st
+    return st
+
+
 class _LinearFn(Function):
     """y = x W^T + b  (nn.Linear; reference: models/wan/model.py:120-122,138-142,270-272)."""
 
@@ -123,21 +139,36 @@ class _LinearFn(Function):
         if gy2.dtype != weight.dtype:
             gy2 = gy2.to(weight.dtype)
         gx = gw = gb = None
+
+        def param_grads():
+            gw_ = gb_ = None
+            if ctx.needs_input_grad[1]:
+                tgt = _accum_target(weight)
+                if tgt is not None:
+                    mm(gy2, x2, True, False, out=tgt, accumulate=True)      # dW += dy^T . x  (fused accumulation)
+                else:
+                    gw_ = mm(gy2, x2, True, False)                            # dW = dy^T . x
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                tgt = _accum_target(bias)
+                gb_ = column_sum(gy2, out=tgt)
+                if tgt is not None:
+                    gb_ = None
+            return gw_, gb_
+
+        fork = PARALLEL_WGRAD and ctx.needs_input_grad[0] and (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]))
+        if fork:
+            main, side = torch.cuda.current_stream(gy2.device), _side_stream(gy2.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                gw, gb = param_grads()
         if ctx.needs_input_grad[0]:
             gx = mm(gy2, weight, False, False).view(ctx.x_shape)          # dx = dy . W
             if gx.dtype != ctx.x_dtype:
                 gx = gx.to(ctx.x_dtype)
-        if ctx.needs_input_grad[1]:
-            tgt = _accum_target(weight)
-            if tgt is not None:
-                mm(gy2, x2, True, False, out=tgt, accumulate=True)          # dW += dy^T . x  (fused accumulation)
-            else:
-                gw = mm(gy2, x2, True, False)                                # dW = dy^T . x
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            tgt = _accum_target(bias)
-            gb = column_sum(gy2, out=tgt)
-            if tgt is not None:
-                gb = None
+        if fork:
+            main.wait_stream(side)      # join before dy / x can be released (and before autograd consumes gw / gb)
+        else:
+            gw, gb = param_grads()
         return gx, gw, gb
 
 
@@ -451,10 +482,13 @@ class _FlashAttnFn(Function):
         dk = torch.empty((B, Sk, H, D), device=q.device, dtype=q.dtype)
         dv = torch.empty((B, Sk, H, D), device=q.device, dtype=q.dtype)
         delta = torch.empty((B, H, Sq), device=q.device, dtype=torch.float32)
+        npart = lib().dpipe_attn_bwd_partial_floats(B, H, Sq, Sk, D)
+        part = torch.empty(npart, device=q.device, dtype=torch.float32) if npart > 0 else None
         check(lib().dpipe_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
                                    ptr(kv_len), B, H, Sq, Sk, D,
                                    *_bshd_strides(q), *_bshd_strides(k), *_bshd_strides(v), *_bshd_strides(o), *_bshd_strides(do),
-                                   *_bshd_strides(dq), *_bshd_strides(dk), *_bshd_strides(dv), float(ctx.scale), int(ctx.causal), stream()), 'attn_bwd')
+                                   *_bshd_strides(dq), *_bshd_strides(dk), *_bshd_strides(dv), float(ctx.scale), int(ctx.causal),
+                                   ptr(part), npart, stream()), 'attn_bwd')
         return dq, dk, dv, None, None, None
 
 

@@ -161,13 +161,17 @@ int dpipe_tr16_probe(const void* in256_i16, void* out256_i16, void* stream);
 int dpipe_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* kv_len, int B, int H,
                    int Sq, int Sk, int D, long q_sb, long q_ss, long q_sh, long k_sb, long k_ss, long k_sh, long v_sb,
                    long v_ss, long v_sh, long o_sb, long o_ss, long o_sh, float scale, int causal, void* stream);
-/* delta: [B, H, Sq] fp32 workspace.  dq/dk/dv have the layouts (and strides) of q/k/v. */
+/* delta: [B, H, Sq] fp32 workspace.  dq/dk/dv have the layouts (and strides) of q/k/v.
+ * dkv_partial: fp32 workspace of dpipe_attn_bwd_partial_floats() elements (0 = not needed) -- when few key blocks x
+ * heads cannot fill the chip (cross attention to 77 text tokens) the dK/dV kernel splits the queries over workgroups
+ * and a reduce kernel sums the slices in order; NULL keeps the unsplit single-kernel form. */
+long dpipe_attn_bwd_partial_floats(int B, int H, int Sq, int Sk, int D);
 int dpipe_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                    float* delta, void* dq, void* dk, void* dv, const int* kv_len, int B, int H, int Sq, int Sk, int D,
                    long q_sb, long q_ss, long q_sh, long k_sb, long k_ss, long k_sh, long v_sb, long v_ss, long v_sh,
                    long o_sb, long o_ss, long o_sh, long do_sb, long do_ss, long do_sh, long dq_sb, long dq_ss,
                    long dq_sh, long dk_sb, long dk_ss, long dk_sh, long dv_sb, long dv_ss, long dv_sh, float scale,
-                   int causal, void* stream);
+                   int causal, float* dkv_partial, long dkv_partial_floats, void* stream);
 
 #ifdef __cplusplus
 }

@@ -61,6 +61,25 @@ def test_pipe_wgrad_any_k(gpu, K, split):
     assert _rel_err(out, ref) < 1.6e-2
 
 
+def test_pipe_last_k_row_of_a_ragged_mn_major_operand(gpu):
+    """Only the LAST K-row feeds the LAST output row / column (causal attention's dV, dK have this shape: [77][80-pitch]
+    probabilities): the buffer bounds check must not clip the odd tail of that row."""
+    from diffusion_pipe_amd import ops
+    K, M, N, pitch = 77, 77, 64, 80
+    abuf = torch.zeros(K, pitch, device=gpu, dtype=torch.bfloat16)
+    abuf[torch.arange(K), torch.arange(M)] = 1.0                       # A^T = identity (lower-triangular support)
+    b = torch.randn(K, N, generator=torch.Generator().manual_seed(1)).to(gpu, torch.bfloat16)
+    for hint in (T64 + 1, T128 + 1, PIPE):
+        out = torch.empty(M, N, device=gpu, dtype=torch.bfloat16)
+        ops.gemm(abuf, b, True, False, M, N, K, out, lda=pitch, ldb=N, ldc=N, tile_hint=hint)
+        assert torch.equal(out, b), f'hint {hint}: rows differ {(out != b).any(1).nonzero().flatten().tolist()}'
+    # same for the [K][N] operand: B = identity with an 80-element pitch, N = 77
+    a = torch.randn(K, 64, generator=torch.Generator().manual_seed(2)).to(gpu, torch.bfloat16)
+    out = torch.empty(64, M, device=gpu, dtype=torch.bfloat16)
+    ops.gemm(a, abuf, True, False, 64, M, K, out, lda=64, ldb=pitch, ldc=M, tile_hint=T64 + 1)
+    assert torch.equal(out, a.t().contiguous())
+
+
 def test_pipe_not_eligible_is_an_error_and_auto_falls_back(gpu):
     from diffusion_pipe_amd import ops
     from diffusion_pipe_amd.hip import DpipeHipError

@@ -340,7 +340,11 @@ def _sdpa_ref(q, k, v, kv_len=None):
 
 ATTN_CASES = [  # (B, Sq, Sk, H, D, kv_len)
     (2, 200, 200, 3, 64, None), (2, 200, 200, 3, 128, None), (1, 300, 77, 5, 64, None), (2, 130, 96, 2, 128, [77, 50]),
-    (1, 1024, 1024, 4, 128, None), (1, 64, 1, 2, 64, None), (1, 33, 513, 2, 128, None)]
+    (1, 1024, 1024, 4, 128, None), (1, 64, 1, 2, 64, None), (1, 33, 513, 2, 128, None),
+    # SDXL cross attention (one key block per head -> query-split dK/dV + reduce), many-head self attention (128-query
+    # workgroups), ragged query-slice counts
+    (1, 1024, 77, 20, 64, None), (1, 4096, 77, 10, 64, None), (2, 1000, 100, 3, 128, [77, 100]), (1, 1024, 1024, 20, 64, None),
+    (3, 700, 77, 30, 64, None)]
 
 
 @pytest.mark.parametrize('case', ATTN_CASES)
@@ -472,3 +476,24 @@ def test_fused_gradient_accumulation_matches_autograd_accumulation(gpu, dtype):
 
     for a, b in zip(run(True), run(False)):
         assert _rel_err(a, b) < (2e-2 if dtype == torch.bfloat16 else 1e-4)
+
+
+def test_parallel_wgrad_fork_join_matches_single_stream(gpu):
+    """dgrad on the current stream, wgrad + bias column sum forked onto the side stream and joined: same numbers."""
+    from diffusion_pipe_amd import nn as dnn, ops
+
+    def run(parallel):
+        torch.manual_seed(5)
+        lin1, lin2 = dnn.Linear(256, 384).to(gpu, torch.bfloat16), dnn.Linear(384, 128).to(gpu, torch.bfloat16)
+        ops.PARALLEL_WGRAD = parallel
+        try:
+            x = torch.randn(4, 100, 256, generator=torch.Generator().manual_seed(1)).to(gpu, torch.bfloat16).requires_grad_(True)
+            for _ in range(3):
+                lin2(ops.gelu_tanh(lin1(x))).float().square().mean().backward()
+            torch.cuda.synchronize()
+        finally:
+            ops.PARALLEL_WGRAD = False
+        return [x.grad] + [p.grad for m in (lin1, lin2) for p in m.parameters()]
+
+    for a, b in zip(run(True), run(False)):
+        assert torch.equal(a, b)

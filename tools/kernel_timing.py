@@ -87,4 +87,26 @@ def main():
         print(json.dumps({'op': 'colsum/ln', 'rows': rows, 'cols': cols, 'colsum_us': round(us, 1), 'ln_bwd_us': round(us_ln, 1), 'ln_fwd_us': round(us_lnf, 1)}), flush=True)
 
 
-main()
+def attn_main():
+    dev = torch.device('cuda:0')
+    F = torch.nn.functional
+    for (B, Sq, Sk, H, D, causal, cnt) in [(1, 1024, 1024, 20, 64, 0, 60), (1, 4096, 4096, 10, 64, 0, 10), (1, 1024, 77, 20, 64, 0, 60),
+                                           (1, 4096, 77, 10, 64, 0, 10), (1, 77, 77, 20, 64, 1, 32), (1, 77, 77, 12, 64, 1, 12)]:
+        q = torch.randn(B, Sq, H, D, device=dev, dtype=torch.bfloat16, requires_grad=True)
+        k = torch.randn(B, Sk, H, D, device=dev, dtype=torch.bfloat16, requires_grad=True)
+        v = torch.randn(B, Sk, H, D, device=dev, dtype=torch.bfloat16, requires_grad=True)
+        go = torch.randn(B, Sq, H, D, device=dev, dtype=torch.bfloat16)
+        with torch.no_grad():
+            f_us = graph_time(lambda: ops.attention(q, k, v, impl='flash', causal=bool(causal)), n=10)
+            tf_us = graph_time(lambda: F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), is_causal=bool(causal)), n=10)
+        fb_us = graph_time(lambda: ops.attention(q, k, v, impl='flash', causal=bool(causal)).backward(go), n=10)
+        tfb_us = graph_time(lambda: F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), is_causal=bool(causal)).backward(go.transpose(1, 2)), n=10)
+        print(json.dumps({'op': 'attn', 'Sq': Sq, 'Sk': Sk, 'H': H, 'causal': causal, 'cnt': cnt, 'fwd_us': round(f_us, 1), 'bwd_us': round(fb_us - f_us, 1),
+                          'torch_fwd_us': round(tf_us, 1), 'torch_bwd_us': round(tfb_us - tf_us, 1),
+                          'tot_ms': round(cnt * fb_us / 1e3, 2), 'torch_tot_ms': round(cnt * tfb_us / 1e3, 2)}), flush=True)
+
+
+if 'attn' in sys.argv[1:]:
+    attn_main()
+else:
+    main()
