@@ -38,6 +38,8 @@ def parse():
     ap.add_argument('--activation-checkpointing', action='store_true')
     ap.add_argument('--partition', default='parameters')
     ap.add_argument('--no-graph', action='store_true', help='disable hipGraph capture of the micro-batch fwd+bwd')
+    ap.add_argument('--test-single-device', action='store_true',
+                    help='TEST ONLY: all ranks share cuda:0, collectives over gloo, stage payloads staged through the host')
     ap.add_argument('--parallel-wgrad', action='store_true', help='fork wgrad onto a side stream (A/B switch; measured slower)')
     return ap.parse_args()
 
@@ -81,11 +83,16 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run for --gpus > 1')
+    if args.test_single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        if args.test_single_device:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     from diffusion_pipe_amd import hip, ops
     from diffusion_pipe_amd.data import split_batch
@@ -108,7 +115,7 @@ def main():
                                   dynamic_shape=True, **kwargs)
     engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 1, 'gradient_accumulation_steps': gas,
                                                          'gradient_clipping': 1.0, 'steps_per_print': 1 << 30, 'hip_graph': not args.no_graph,
-                                                         'parallel_wgrad': args.parallel_wgrad}, device=device)
+                                                         'parallel_wgrad': args.parallel_wgrad, 'p2p_via_host': args.test_single_device}, device=device)
     params = [p for p in module.parameters() if p.requires_grad]
 
     def make_opt(ps):

@@ -20,7 +20,7 @@ import torch.distributed as dist
 
 from . import schedule as sched
 from .module import PipelineModule
-from .p2p import StageLink
+from .p2p import HostStagedLink, StageLink
 
 
 def _is_float(t):
@@ -84,14 +84,21 @@ class PipelineEngine:
 
         # hipGraph mode: one captured graph per micro-batch shape replaces ~10^4 per-op launches (static shapes only;
         # single-stage for now -- P2P stays outside graphs).  Gradients then live in persistent buffers.
-        self.use_graph = bool(self._config.get('hip_graph', False)) and self.device.type == 'cuda' and not self.is_pipe_parallel
+        want_graph = bool(self._config.get('hip_graph', False)) and self.device.type == 'cuda'
+        self.use_graph = want_graph and not self.is_pipe_parallel
+        # pipeline-parallel form: per (pipe buffer, tuple layout) one forward graph and one backward graph of this stage's
+        # layers ("slots": 1F1B keeps up to num_pipe_buffers micro-batches in flight, each needs its own saved
+        # activations); P2P, the schedule and the step end stay outside the graphs.
+        self.use_stage_graphs = want_graph and self.is_pipe_parallel
         self._graphs = {}
+        self._stage_slots = {}
         self._g_total_loss = None
         if self.device.type == 'cuda' and self._config.get('fuse_grad_accumulation', True):
             from .. import ops as _ops
             _ops.FUSE_GRAD_ACCUM = True     # wgrad / bias / norm-weight kernels add straight into existing .grad buffers
             _ops.PARALLEL_WGRAD = self.use_graph and bool(self._config.get('parallel_wgrad', False))   # dgrad || wgrad as parallel graph branches (measured: no gain on MI355X, off)
-        self.link = StageLink(self.grid, self.device) if self.is_pipe_parallel else None
+        link_cls = HostStagedLink if (self._config.get('p2p_via_host', False) and self.device.type == 'cuda') else StageLink
+        self.link = link_cls(self.grid, self.device) if self.is_pipe_parallel else None
         self.loss = None
         self.total_loss = None
         self.agg_train_loss = None
@@ -165,7 +172,7 @@ class PipelineEngine:
 
     # ---------------------------------------------------------------------------------------- batch drivers
     def _reserve_buffers(self, n):
-        self.pipe_buffers = {k: [None] * n for k in ('inputs', 'labels', 'outputs', 'grads')}
+        self.pipe_buffers = {k: [None] * n for k in ('inputs', 'labels', 'outputs', 'grads', 'slot')}
 
     def train_batch(self, data_iter=None):
         if not torch._C.is_grad_enabled():
@@ -177,9 +184,15 @@ class PipelineEngine:
         if self.use_graph:
             self._train_batch_graphed()
         else:
+            if self.use_stage_graphs:
+                if self._g_total_loss is None:
+                    self._g_total_loss = torch.zeros((), device=self.device, dtype=torch.float32)
+                self._g_total_loss.zero_()
             schedule = sched.TrainSchedule(micro_batches=self.micro_batches, stages=self.num_stages, stage_id=self.stage_id)
             self._reserve_buffers(schedule.num_pipe_buffers())
             self._exec_schedule(schedule)
+            if self.use_stage_graphs and self.is_last_stage():
+                self.total_loss = self._g_total_loss
         self.agg_train_loss = self._aggregate_total_loss(self.micro_batches)
         self.global_samples += self.train_batch_size_
         if self.link is not None:
@@ -271,6 +284,112 @@ class PipelineEngine:
         self._g_total_loss.zero_()
         return {'graph': graph, 'inputs': static_in, 'labels': static_lab}
 
+    # ------------------------------------------------------------------------- hipGraph path, pipeline stages
+    def _stage_slot(self, buffer_id, inputs, labels):
+        ins = tuple(_as_list(inputs))
+        labs = tuple(_as_list(labels)) if labels is not None else ()
+        sig = (buffer_id, torch.is_tensor(inputs), torch.is_tensor(labels), tuple((tuple(t.shape), t.dtype) for t in ins + labs))
+        slot = self._stage_slots.get(sig)
+        if slot is None:
+            slot = self._capture_stage_slot(ins, labs, torch.is_tensor(inputs), torch.is_tensor(labels))
+            self._stage_slots[sig] = slot
+        return slot
+
+    def _capture_stage_slot(self, ins, labs, single_in, single_lab):
+        """Capture this stage's forward and backward for one pipe buffer.  The forward graph writes the stage outputs
+        (and keeps the saved activations) in the slot's private pool; the backward graph reads the gradients of the
+        outputs from static buffers, accumulates parameter gradients in place (fused into the wgrad / column-sum
+        kernels) and leaves the input gradients in static tensors for SendGrad."""
+        first, last = self.is_first_stage(), self.is_last_stage()
+        params = [p for p in self.module.parameters() if p.requires_grad]
+        saved_grads = {id(p): p.grad.clone() for p in params if p.grad is not None}     # micro-batches already accumulated
+        saved_loss = self._g_total_loss.clone()
+
+        def make_inputs():
+            xs = tuple(t.detach().clone() for t in ins)
+            if not first:
+                for t in xs:
+                    t.requires_grad_(t.is_floating_point())
+            return xs
+        static_lab = tuple(t.detach().clone() for t in labs)
+
+        def forward(xs):
+            out = self.module(xs[0] if single_in else xs)
+            if last:
+                loss = self.module.loss_fn(out, static_lab[0] if single_lab else static_lab) if self.module.loss_fn is not None else out
+                self._g_total_loss.add_(loss.detach().to(torch.float32))
+                return loss
+            return out
+
+        def backward(out, gouts):
+            if last:
+                (out / self.micro_batches).backward()
+            else:
+                torch.autograd.backward(tensors=[t for t in _as_list(out) if _is_float(t)], grad_tensors=gouts)
+
+        def grads_like(out):
+            return [torch.zeros_like(t, memory_format=torch.contiguous_format) for t in _as_list(out) if _is_float(t)]
+
+        cur = torch.cuda.current_stream(self.device)
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(2):                      # eager warm-up: library autotuning, allocator pools, .grad buffers
+                xs = make_inputs()
+                out = forward(xs)
+                backward(out, None if last else grads_like(out))
+                del xs, out
+        cur.wait_stream(side)
+        torch.cuda.synchronize(self.device)
+
+        static_in = make_inputs()
+        fwd_graph, bwd_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(fwd_graph):
+            out = forward(static_in)
+        static_gout = None if last else grads_like(out)
+        with torch.cuda.graph(bwd_graph, pool=fwd_graph.pool()):
+            backward(out, static_gout)
+        # undo the side effects of warm-up / capture on the accumulators
+        for p in params:
+            if p.grad is not None:
+                if id(p) in saved_grads:
+                    p.grad.copy_(saved_grads[id(p)])
+                else:
+                    p.grad.zero_()
+        self._g_total_loss.copy_(saved_loss)
+        return {'fwd': fwd_graph, 'bwd': bwd_graph, 'inputs': static_in, 'labels': static_lab, 'out': out, 'gout': static_gout,
+                'single_in': single_in}
+
+    def _exec_forward_pass_graphed(self, buffer_id):
+        inputs = self.pipe_buffers['inputs'][buffer_id]
+        labels = self.pipe_buffers['labels'][buffer_id] if self.is_last_stage() else None
+        slot = self._stage_slot(buffer_id, inputs, labels)
+        with torch.no_grad():
+            for dst, src in zip(slot['inputs'], _as_list(inputs)):
+                if src.numel() > 0:
+                    dst.copy_(src, non_blocking=True)
+            if labels is not None:
+                for dst, src in zip(slot['labels'], _as_list(labels)):
+                    if src.numel() > 0:
+                        dst.copy_(src, non_blocking=True)
+        slot['fwd'].replay()
+        self.pipe_buffers['inputs'][buffer_id] = slot['inputs'][0] if slot['single_in'] else slot['inputs']   # their .grad feeds SendGrad
+        self.pipe_buffers['outputs'][buffer_id] = slot['out']
+        self.pipe_buffers['slot'][buffer_id] = slot
+
+    def _exec_backward_pass_graphed(self, buffer_id):
+        slot = self.pipe_buffers['slot'][buffer_id]
+        if not self.is_last_stage():
+            grads = self.pipe_buffers['grads'][buffer_id]
+            assert len(grads) == len(slot['gout']), \
+                f'stage {self.stage_id}: {len(slot["gout"])} floating-point outputs but {len(grads)} received gradients'
+            with torch.no_grad():
+                for dst, src in zip(slot['gout'], grads):
+                    dst.copy_(src, non_blocking=True)
+            self.pipe_buffers['grads'][buffer_id] = None
+        slot['bwd'].replay()
+        self.pipe_buffers['outputs'][buffer_id] = None
+
     # ----------------------------------------------------------------------------------------- instructions
     def _next_batch(self):
         if self._data_iter is None:
@@ -297,6 +416,8 @@ class PipelineEngine:
             self.pipe_buffers['labels'][buffer_id] = loaded
 
     def _exec_forward_pass(self, buffer_id):
+        if self.use_stage_graphs and not self._eval_mode:
+            return self._exec_forward_pass_graphed(buffer_id)
         inputs = self.pipe_buffers['inputs'][buffer_id]
         outputs = self.module(inputs)
         if self.is_last_stage():
@@ -313,6 +434,8 @@ class PipelineEngine:
             self.pipe_buffers['outputs'][buffer_id] = outputs
 
     def _exec_backward_pass(self, buffer_id):
+        if self.use_stage_graphs:
+            return self._exec_backward_pass_graphed(buffer_id)
         outputs = self.pipe_buffers['outputs'][buffer_id]
         if self.is_last_stage():
             (outputs / self.micro_batches).backward()
@@ -410,7 +533,7 @@ class PipelineEngine:
             self.clip_fp32_gradients()
         if self.optimizer is not None:
             self.optimizer.step()
-        if self.use_graph:
+        if self.use_graph or self.use_stage_graphs:
             grads = [p.grad for p in self.module.parameters() if p.grad is not None]
             if grads:
                 torch._foreach_zero_(grads)         # buffers are referenced by the captured graphs: zero, never free

@@ -145,3 +145,24 @@ class StageLink:
         tensors = [t if t.is_contiguous() else t.contiguous() for t in tensors]
         if tensors:
             self._isend(tensors, peer)
+
+
+class HostStagedLink(StageLink):
+    """Test / fallback endpoint: payloads cross through host memory over a CPU-capable backend (gloo).  This is how the
+    reference runs consumer cards (`NCCL_P2P_DISABLE=1`, README.md:118-120) and what lets the pipeline-parallel engine
+    (including its per-stage hipGraphs) run as two processes sharing ONE GPU in the GPU tests; the MI355X product path
+    is `StageLink` (RCCL over xGMI)."""
+
+    def _isend(self, tensors, peer):
+        torch.cuda.current_stream(self.device).synchronize()
+        host = [_wire(t).detach().cpu() for t in tensors]
+        works = [dist.isend(h, dst=peer) for h in host]
+        self._pending.append((works, host))
+
+    def _recv(self, buffers, peer):
+        for b in buffers:
+            w = _wire(b)
+            h = torch.empty(w.shape, dtype=w.dtype)
+            dist.recv(h, src=peer)
+            with torch.no_grad():
+                w.copy_(h)

@@ -371,7 +371,8 @@ def test_flash_attention_fwd_bwd(gpu, case):
     assert _rel_err(v.grad, vr.grad) < 3e-2
     if kvl is not None:   # masked keys receive exactly zero gradient
         for bi, n in enumerate(kvl):
-            assert k.grad[bi, n:].abs().max().item() == 0.0 and v.grad[bi, n:].abs().max().item() == 0.0
+            if n < Sk:
+                assert k.grad[bi, n:].abs().max().item() == 0.0 and v.grad[bi, n:].abs().max().item() == 0.0
 
 
 def test_flash_attention_strided_views_and_rescale_spike(gpu):
