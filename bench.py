@@ -38,6 +38,7 @@ def parse():
     ap.add_argument('--activation-checkpointing', action='store_true')
     ap.add_argument('--partition', default='parameters')
     ap.add_argument('--no-graph', action='store_true', help='disable hipGraph capture of the micro-batch fwd+bwd')
+    ap.add_argument('--lanes', type=int, default=2, help='concurrent micro-batch lanes of the single-stage hipGraph path')
     ap.add_argument('--test-single-device', action='store_true',
                     help='TEST ONLY: all ranks share cuda:0, collectives over gloo, stage payloads staged through the host')
     ap.add_argument('--parallel-wgrad', action='store_true', help='fork wgrad onto a side stream (A/B switch; measured slower)')
@@ -115,7 +116,7 @@ def main():
                                   dynamic_shape=True, **kwargs)
     engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 1, 'gradient_accumulation_steps': gas,
                                                          'gradient_clipping': 1.0, 'steps_per_print': 1 << 30, 'hip_graph': not args.no_graph,
-                                                         'parallel_wgrad': args.parallel_wgrad, 'p2p_via_host': args.test_single_device}, device=device)
+                                                         'parallel_wgrad': args.parallel_wgrad, 'p2p_via_host': args.test_single_device, 'graph_lanes': args.lanes}, device=device)
     params = [p for p in module.parameters() if p.requires_grad]
 
     def make_opt(ps):
@@ -159,6 +160,8 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = t.item()
+    gnorm = engine.get_global_grad_norm()
+    gnorm = float(gnorm.item()) if gnorm is not None else float('nan')
 
     # --- roofline of the dominant kernel (the MFMA GEMM).  Inside a replayed hipGraph individual launches cannot be
     # bracketed, so one extra eager step records every GEMM launch signature of this rank's stage, and each distinct
@@ -194,8 +197,9 @@ def main():
             'config': {'workload': f'SDXL {latent * 8}x{latent * 8} full fine-tune (UNet + both CLIP text encoders trained), micro-batch 1 per stage, '
                                    f'pp={pp}, GAS={gas}, AdamW, clip 1.0' + (' [tiny test config]' if args.config != 'full' else ''),
                        'global_batch': images, 'parallelism': f'pp{pp}', 'gradient_accumulation_steps': gas,
-                       'activation_checkpointing': bool(args.activation_checkpointing), 'partition': module.parts, 'hip_graph': bool(engine.use_graph)},
-            'loss': float(loss.item()),
+                       'activation_checkpointing': bool(args.activation_checkpointing), 'partition': module.parts, 'hip_graph': bool(engine.use_graph or engine.use_stage_graphs),
+                       'concurrent_micro_batch_lanes': engine.graph_lanes},
+            'loss': float(loss.item()), 'grad_norm': float(gnorm),
             'step_tflop_algorithmic': round(step_flops / 1e12, 2),
             'mfu_vs_bf16_mfma_peak': round(step_flops / (elapsed / args.steps) / (peak * 1e12 * world), 5),
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_kernel<bf16> (dpipe_gemm: Linear fwd/dgrad/wgrad)', 'achieved': round(achieved, 2), 'peak': peak,

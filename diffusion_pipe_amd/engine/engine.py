@@ -93,6 +93,12 @@ class PipelineEngine:
         self._graphs = {}
         self._stage_slots = {}
         self._g_total_loss = None
+        # Concurrent micro-batch lanes (single-stage graph path): at micro-batch 1 most kernels of the step fill well under
+        # half of the 256 CUs, so `graph_lanes` micro-batches replay at the same time on separate HIP streams, each lane
+        # accumulating into its own gradient buffers (288 GB HBM: +5 GB per lane for SDXL); the lanes' gradients are summed
+        # once before ReduceGrads / clip / optimizer.  Same math as sequential accumulation up to fp summation order.
+        self.graph_lanes = max(1, int(self._config.get('graph_lanes', 1))) if self.use_graph else 1
+        self._lanes = []
         if self.device.type == 'cuda' and self._config.get('fuse_grad_accumulation', True):
             from .. import ops as _ops
             _ops.FUSE_GRAD_ACCUM = True     # wgrad / bias / norm-weight kernels add straight into existing .grad buffers
@@ -229,47 +235,81 @@ class PipelineEngine:
     # ------------------------------------------------------------------------------------------- hipGraph path
     def _train_batch_graphed(self):
         """Single-stage 1F1B degenerates to [Load, Forward, Backward] x GAS, then reduce / clip / step; each
-        micro-batch's forward + loss + backward is ONE graph replay."""
-        if self._g_total_loss is None:
-            self._g_total_loss = torch.zeros((), device=self.device, dtype=torch.float32)
-        self._g_total_loss.zero_()
-        for _ in range(self.micro_batches):
+        micro-batch's forward + loss + backward is ONE graph replay.  With graph_lanes = K > 1 micro-batch i replays on
+        lane i % K (own stream, own static buffers, own gradient accumulators); lanes are joined and summed at the end."""
+        from .. import ops as _ops
+        K = min(self.graph_lanes, self.micro_batches)
+        while len(self._lanes) < K:
+            self._lanes.append({'id': len(self._lanes), 'stream': torch.cuda.Stream(self.device), 'graphs': {}, 'grads': {},
+                                'loss': torch.zeros((), device=self.device, dtype=torch.float32)})
+        lanes = self._lanes[:K]
+        params = list(self.module.parameters())
+        main = torch.cuda.current_stream(self.device)
+        for lane in lanes:
+            lane['loss'].zero_()
+            lane['stream'].wait_stream(main)
+        for i in range(self.micro_batches):
+            lane = lanes[i % K]
             feats, labels = self._next_batch()
             feats = (feats,) if torch.is_tensor(feats) else tuple(feats)
             labels = (labels,) if torch.is_tensor(labels) else tuple(labels)
             sig = tuple((tuple(t.shape), t.dtype) for t in feats + labels)
-            entry = self._graphs.get(sig)
+            entry = lane['graphs'].get(sig)
             if entry is None:
-                entry = self._capture_micro_batch(feats, labels)
-                self._graphs[sig] = entry
-            for dst, src in zip(entry['inputs'] + entry['labels'], feats + labels):
-                if src.numel() > 0:
-                    dst.copy_(src, non_blocking=True)
-            entry['graph'].replay()
-        self.total_loss = self._g_total_loss
+                torch.cuda.synchronize(self.device)            # capture with every lane idle
+                entry = self._capture_micro_batch(lane, params, feats, labels)
+                lane['graphs'][sig] = entry
+                lane['stream'].wait_stream(main)
+            with torch.cuda.stream(lane['stream']):
+                for dst, src in zip(entry['inputs'] + entry['labels'], feats + labels):
+                    if src.numel() > 0:
+                        dst.copy_(src, non_blocking=True)
+                entry['graph'].replay()
+        for lane in lanes:
+            main.wait_stream(lane['stream'])
+        # lane 0 owns the step's gradients; add the other lanes' accumulators and losses into it
+        base = lanes[0]
+        for lane in lanes[1:]:
+            dst = [base['grads'][k] for k in lane['grads'] if k in base['grads']]
+            src = [lane['grads'][k] for k in lane['grads'] if k in base['grads']]
+            if dst:
+                torch._foreach_add_(dst, src)
+            base['loss'].add_(lane['loss'])
+        for p in params:
+            p.grad = base['grads'].get(id(p))
+        self.total_loss = base['loss']
+        _ops.WS_LANE = None
         self._exec_reduce_tied_grads()
         self._exec_reduce_grads()
-        self._exec_optimizer_step()
+        self._exec_optimizer_step()                              # zeroes lane 0's buffers (p.grad)
+        for lane in lanes[1:]:
+            if lane['grads']:
+                torch._foreach_zero_(list(lane['grads'].values()))
 
-    def _capture_micro_batch(self, feats, labels):
+    def _capture_micro_batch(self, lane, params, feats, labels):
+        from .. import ops as _ops
         static_in = tuple(t.clone().detach().to(self.device) for t in feats)
         static_lab = tuple(t.clone().detach().to(self.device) for t in labels)
         single = len(static_in) == 1
         single_label = len(static_lab) == 1
+        for p in params:                                  # this lane's accumulators become the parameters' .grad
+            p.grad = lane['grads'].get(id(p))
+        _ops.WS_LANE = lane['id'] if self.graph_lanes > 1 else None
+        saved = {k: g.clone() for k, g in lane['grads'].items()}      # micro-batches this lane already accumulated
+        saved_loss = lane['loss'].clone()
 
         def body():
             x = static_in[0].detach() if single else tuple(t.detach() for t in static_in)
             out = self.module(x)
             loss = self.module.loss_fn(out, static_lab[0] if single_label else static_lab)
-            self._g_total_loss.add_(loss.detach().to(torch.float32))
+            lane['loss'].add_(loss.detach().to(torch.float32))
             (loss / self.micro_batches).backward()
 
-        had_grad = {id(p) for p in self.module.parameters() if p.grad is not None}
         cur = torch.cuda.current_stream(self.device)
         side = torch.cuda.Stream(self.device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            for _ in range(2):                      # eager warm-up (library autotuning, allocator pools)
+            for _ in range(2):                      # eager warm-up (library autotuning, allocator pools, .grad buffers)
                 body()
         cur.wait_stream(side)
         torch.cuda.synchronize(self.device)
@@ -277,11 +317,17 @@ class PipelineEngine:
         with torch.cuda.graph(graph):
             body()
         # undo the warm-up's side effects: gradient buffers stay allocated (persistent, addresses baked into the
-        # graph) but are zeroed; parameters that receive no gradient keep grad = None like the eager path.
-        fresh = [p.grad for p in self.module.parameters() if p.grad is not None and id(p) not in had_grad]
-        if fresh:
-            torch._foreach_zero_(fresh)
-        self._g_total_loss.zero_()
+        # graph); parameters that receive no gradient keep grad = None like the eager path.
+        for p in params:
+            if p.grad is not None:
+                k = id(p)
+                if k in saved:
+                    p.grad.copy_(saved[k])
+                else:
+                    p.grad.zero_()
+                    lane['grads'][k] = p.grad
+        lane['loss'].copy_(saved_loss)
+        _ops.WS_LANE = None
         return {'graph': graph, 'inputs': static_in, 'labels': static_lab}
 
     # ------------------------------------------------------------------------- hipGraph path, pipeline stages

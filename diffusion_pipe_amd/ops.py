@@ -33,10 +33,13 @@ GEMM_TRACE = None
 # private to one (device, stream) -- launches on one stream are ordered, so slices of two GEMMs never share counters.
 _SPLITK_WS = {}
 _SPLITK_WS_BYTES = 4096 + 272 * 65536
+# Set by the engine while it captures / runs one of several concurrent micro-batch lanes: graphs captured on the same
+# capture stream but replayed on different streams must not share ticket counters, so the lane id replaces the stream key.
+WS_LANE = None
 
 
 def _splitk_workspace(device):
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, ('lane', WS_LANE) if WS_LANE is not None else torch.cuda.current_stream(device).cuda_stream)
     ws = _SPLITK_WS.get(key)
     if ws is None:
         ws = torch.zeros(_SPLITK_WS_BYTES, dtype=torch.uint8, device=device)

@@ -100,3 +100,35 @@ def test_sdxl_eval_batch_and_activation_checkpointing(gpu):
     eng2._configure_optimizer(lambda ps: torch.optim.SGD(ps, lr=0.0), [p for p in module.parameters()])
     assert abs(eng2.train_batch(iter(micro)).item() - base) / abs(base) < 1e-5
     assert abs(eng2.get_global_grad_norm().item() - engine.get_global_grad_norm().item()) / engine.get_global_grad_norm().item() < 1e-4
+
+
+def test_concurrent_micro_batch_lanes_match_sequential_graph_path(gpu):
+    """graph_lanes = 2 / 4: micro-batches replay concurrently on separate streams into per-lane gradient accumulators that
+    are summed before clip / step -- loss and global gradient norm must agree with the one-lane path on every step
+    (a lane sharing scratch memory with another lane would show up here as run-to-run noise)."""
+    from diffusion_pipe_amd.data import split_batch
+    from diffusion_pipe_amd.engine import ManualPipelineModule, initialize
+    from diffusion_pipe_amd.workloads import sdxl
+    cfg = sdxl.tiny_config()
+    gas = 4
+
+    def run(lanes):
+        work = sdxl.SDXLWorkload(cfg, model_config={'min_snr_gamma': 5.0}, dtype=torch.bfloat16, seed=2, device=gpu)
+        module = ManualPipelineModule(layers=work.to_layers(), num_stages=1, partition_method='parameters', loss_fn=work.get_loss_fn(), dynamic_shape=True)
+        engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 1, 'gradient_accumulation_steps': gas, 'gradient_clipping': 1.0,
+                                                             'hip_graph': True, 'graph_lanes': lanes}, device=gpu)
+        engine._configure_optimizer(lambda ps: torch.optim.SGD(ps, lr=1e-3), [p for p in module.parameters()])
+        res = []
+        for step in range(4):
+            torch.manual_seed(100 + step)
+            feats, label = work.prepare_inputs(sdxl.synthetic_batch(cfg, batch_size=gas, latent_hw=32, seed=10 + step))
+            loss = engine.train_batch(iter(split_batch((feats, label), gas)))
+            res.append((loss.item(), engine.get_global_grad_norm().item()))
+        return res
+
+    base = run(1)
+    for lanes in (2, 4):
+        got = run(lanes)
+        for (l0, n0), (l1, n1) in zip(base, got):
+            assert abs(l1 - l0) / abs(l0) < 5e-3, (lanes, base, got)
+            assert abs(n1 - n0) / n0 < 1e-2, (lanes, base, got)
