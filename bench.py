@@ -45,34 +45,12 @@ def parse():
     return ap.parse_args()
 
 
-def gemm_roofline(trace, device):
-    """Time each distinct GEMM signature of a step with HIP events; returns (flops, ms, launches) per step."""
-    from collections import Counter
-    from diffusion_pipe_amd import ops
-    counts = Counter(trace)
+def gemm_roofline(trace):
+    """(flops, ms, launches, per-kernel-config breakdown) of the GEMM launches of one step from their HIP-event pairs."""
     tot_flops = tot_ms = 0.0
-    for sig, cnt in counts.items():
-        dt, ta, tb, M, N, K, batch, has_bias, act, accumulate, out_f32, hint = sig
-        tdt = torch.bfloat16 if dt == 0 else torch.float32
-        a = torch.randn((batch, K, M) if ta else (batch, M, K), device=device, dtype=tdt)
-        b = torch.randn((batch, N, K) if tb else (batch, K, N), device=device, dtype=tdt)
-        c = torch.zeros((batch, M, N), device=device, dtype=torch.float32 if out_f32 else tdt)
-        bias = torch.randn(N, device=device, dtype=tdt) if has_bias else None
-
-        def launch():
-            ops.gemm(a, b, ta, tb, M, N, K, c, lda=a.shape[2], ldb=b.shape[2], ldc=N, batch_outer=batch, batch_inner=1,
-                     stride_a=(a.shape[1] * a.shape[2], 0), stride_b=(b.shape[1] * b.shape[2], 0), stride_c=(M * N, 0),
-                     bias=bias, act=act, accumulate=bool(accumulate), tile_hint=hint)
-        for _ in range(3):
-            launch()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            launch()
-        e1.record()
-        torch.cuda.synchronize()
-        tot_ms += cnt * e0.elapsed_time(e1) / 10
-        tot_flops += cnt * 2.0 * M * N * K * batch
+    for (dt, ta, tb, M, N, K, batch), e0, e1 in trace:
+        tot_ms += e0.elapsed_time(e1)
+        tot_flops += 2.0 * M * N * K * batch
     return tot_flops, tot_ms, len(trace)
 
 
@@ -163,20 +141,22 @@ def main():
     gnorm = engine.get_global_grad_norm()
     gnorm = float(gnorm.item()) if gnorm is not None else float('nan')
 
-    # --- roofline of the dominant kernel (the MFMA GEMM).  Inside a replayed hipGraph individual launches cannot be
-    # bracketed, so one extra eager step records every GEMM launch signature of this rank's stage, and each distinct
-    # signature is then timed with HIP events on the launch stream (operands resident in HBM, 3 warm-up + 10 timed
-    # launches).  achieved = sum(flops) / sum(count * mean duration) over the step's launches.
+    # --- roofline of the dominant kernel (the MFMA GEMM of dpipe_gemm: every Linear forward / dgrad / wgrad).  Launches inside
+    # a replayed hipGraph cannot be bracketed, so ONE extra step runs eagerly on the same data with every GEMM launch
+    # bracketed by two HIP events recorded on the launch stream (ops.GEMM_TRACE); achieved = sum(2 M N K) / sum(elapsed).
+    # Each kernel then runs alone on the chip with operands as cold as in training (all other kernels of the step run in
+    # between), which is the per-kernel figure; the graph path additionally overlaps two micro-batches (config.lanes).
     ops.GEMM_TRACE = []
-    was_graph, engine.use_graph = engine.use_graph, False
-    if was_graph:
+    was_graph, was_stage = engine.use_graph, engine.use_stage_graphs
+    engine.use_graph = engine.use_stage_graphs = False
+    if was_graph or was_stage:
         for p_ in module.parameters():
             p_.grad = None
     one_step(0)
-    engine.use_graph = was_graph
+    engine.use_graph, engine.use_stage_graphs = was_graph, was_stage
     trace, ops.GEMM_TRACE = ops.GEMM_TRACE, None
     torch.cuda.synchronize()
-    g_flops, g_ms, launches = gemm_roofline(trace, device)
+    g_flops, g_ms, launches = gemm_roofline(trace)
     rl = torch.tensor([g_flops, g_ms, launches], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(rl)
@@ -202,7 +182,7 @@ def main():
             'loss': float(loss.item()), 'grad_norm': float(gnorm),
             'step_tflop_algorithmic': round(step_flops / 1e12, 2),
             'mfu_vs_bf16_mfma_peak': round(step_flops / (elapsed / args.steps) / (peak * 1e12 * world), 5),
-            'roofline': {'bound': 'mfma', 'kernel': 'gemm_kernel<bf16> (dpipe_gemm: Linear fwd/dgrad/wgrad)', 'achieved': round(achieved, 2), 'peak': peak,
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm_pipe_kernel<bf16> (dpipe_gemm_ex: every Linear forward / dgrad / wgrad)', 'achieved': round(achieved, 2), 'peak': peak,
                          'unit': 'TFLOP/s', 'frac': round(achieved / peak, 5), 'traffic': None,
                          'launches_per_step': int(launches), 'avg_launch_us': round(g_ms * 1e3 / max(launches, 1), 2),
                          'gemm_time_share_of_step': round(g_ms / world / ms_per_step, 4)},

@@ -25,8 +25,8 @@ def _rows2d(x):
 
 
 # --------------------------------------------------------------------------------------------- GEMM (K1/K6)
-# bench.py sets this to a list to record the signature of every GEMM launch of a step (shape, layout, batch); the
-# distinct signatures are then timed with HIP events on the launch stream for the `roofline` object.
+# bench.py sets this to a list for one eager step: every GEMM launch is then bracketed by two HIP events recorded on the
+# launch stream, and (signature, start, stop) is appended -- the `roofline` object sums flops and elapsed times.
 GEMM_TRACE = None
 
 # Split-K workspace of the pipelined bf16 GEMM: [4 KiB ticket counters][272 fp32 slabs of 64 KiB], zero-filled once and
@@ -60,13 +60,18 @@ def gemm(a, b, trans_a, trans_b, M, N, K, out, *, lda, ldb, ldc, batch_outer=1, 
         raise DpipeHipError('gemm output dtype must be the operand dtype or fp32')
     if bias is not None and bias.dtype != a.dtype:
         bias = bias.to(a.dtype)
-    if GEMM_TRACE is not None:
-        GEMM_TRACE.append((dt, int(trans_a), int(trans_b), M, N, K, batch_outer * batch_inner, bias is not None, act, int(accumulate), out_f32, tile_hint))
     ws = _splitk_workspace(a.device) if dt == hip.BF16 else None
+    timed = GEMM_TRACE is not None
+    if timed:       # bench.py's roofline leg: HIP events on the launch stream around this one launch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib().dpipe_gemm_ex(dt, int(trans_a), int(trans_b), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), ldc,
                               batch_outer, batch_inner, stride_a[0], stride_a[1], stride_b[0], stride_b[1],
                               stride_c[0], stride_c[1], ptr(bias), ACT[act], float(alpha), int(accumulate), out_f32,
                               tile_hint, ptr(ws), ws.numel() if ws is not None else 0, stream()), 'dpipe_gemm')
+    if timed:
+        e1.record()
+        GEMM_TRACE.append(((dt, int(trans_a), int(trans_b), M, N, K, batch_outer * batch_inner), e0, e1))
     return out
 
 
