@@ -185,7 +185,8 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_pipe_kernel<bf16> (dpipe_gemm_ex: every Linear forward / dgrad / wgrad)', 'achieved': round(achieved, 2), 'peak': peak,
                          'unit': 'TFLOP/s', 'frac': round(achieved / peak, 5), 'traffic': None,
                          'launches_per_step': int(launches), 'avg_launch_us': round(g_ms * 1e3 / max(launches, 1), 2),
-                         'gemm_time_share_of_step': round(g_ms / world / ms_per_step, 4)},
+                         'gemm_gpu_ms_per_step': round(g_ms / world, 2),
+                         'note': 'per-launch HIP-event times of one eager step (kernels run alone); graph replays overlap 2 micro-batches'},
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle.cpu_baseline import sdxl_cpu_baseline

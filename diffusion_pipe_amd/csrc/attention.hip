@@ -109,7 +109,7 @@ __device__ __forceinline__ void store_rows(const RowRegs<ROWS * (D / 8) / NT>& r
 
 // ================================================================================================ forward
 template <int D, int NW>
-__global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnParams p) {
+__global__ void __launch_bounds__(NW * 64, D == 64 ? 2 : 1) attn_fwd_kernel(const AttnParams p) {
     constexpr int NT = NW * 64, KT = 64;
     constexpr int KRS = 2 * D + 16;   // K tile: row reads (ds_read_b128), conflict-free with a 16 B pad
     constexpr int VRS = 2 * D + 64;   // V tile: transpose reads, 4 rows x 64 B windows tile the 256 B bank row
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(256) attn_delta_kernel(const AttnParams p) {
 // ================================================================================================ backward: dQ
 // Query-outer.  dQ^T[d][q] += K^T[d][key] . dS^T[key][q],   dS^T = P^T o (dP^T - delta[q]),  dP^T = V . dO^T
 template <int D, int NW>
-__global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(const AttnParams p) {
+__global__ void __launch_bounds__(NW * 64, D == 64 ? 2 : 1) attn_bwd_dq_kernel(const AttnParams p) {
     constexpr int NT = NW * 64, KT = 64;
     constexpr int KRS = 2 * D + 16, VRS = 2 * D + 16;
     __shared__ __attribute__((aligned(16))) char lds[KT * KRS + KT * VRS];
@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(const AttnParams p
 // Key-outer.  S[q][key] = Q . K^T (lane owns one key column);  dV^T[d][key] += dO^T[d][q] . P[q][key];
 // dK^T[d][key] += Q^T[d][q] . dS[q][key]
 template <int D, int NW>
-__global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(const AttnParams p) {
+__global__ void __launch_bounds__(NW * 64, D == 64 ? 2 : 1) attn_bwd_dkv_kernel(const AttnParams p) {
     constexpr int NT = NW * 64, QT = 64;
     constexpr int QRS = 2 * D + 16;
     __shared__ __attribute__((aligned(16))) char lds[2 * QT * QRS + 2 * QT * 4];

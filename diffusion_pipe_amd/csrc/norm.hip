@@ -164,6 +164,23 @@ __global__ void __launch_bounds__(NB) colreduce_kernel(const T* __restrict__ x, 
         }
     }
 }
+// two reductions that share a shape (dgamma + dbeta, dscale + dshift) in one launch; out1 may be null
+template <typename O>
+__global__ void __launch_bounds__(NB) slabsum2_kernel(const float* __restrict__ p0, const float* __restrict__ p1, O* __restrict__ out0,
+                                                      O* __restrict__ out1, long groups, int cols, int slabs, int accumulate) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= groups * cols) return;
+    const long g = i / cols; const int c = (int)(i - g * cols);
+    float a = 0.f, b = 0.f;
+#pragma unroll 8
+    for (int s = 0; s < slabs; ++s) {
+        a += p0[(g * slabs + s) * cols + c];
+        if (out1) b += p1[(g * slabs + s) * cols + c];
+    }
+    if (accumulate) { a += Elem<O>::to_f(out0[i]); if (out1) b += Elem<O>::to_f(out1[i]); }
+    out0[i] = Elem<O>::from_f(a);
+    if (out1) out1[i] = Elem<O>::from_f(b);
+}
 template <typename O>
 __global__ void __launch_bounds__(NB) slabsum_kernel(const float* __restrict__ partial, O* __restrict__ out, long groups, int cols, int slabs, int accumulate) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -456,16 +473,14 @@ int dpipe_lnmod_bwd(const void* x, const void* gy, const void* gamma, const void
         float* p0 = workspace; float* p1 = workspace + groups * slabs_mod * (long)cols; \
         dim3 g2((unsigned)cdiv(cols / V, CR_CT), slabs_mod, (unsigned)groups); \
         colreduce_kernel<TT, WW, MM, 2><<<g2, NB, 0, s>>>((const TT*)x, (const TT*)gy, mean, rstd, (const WW*)gamma, (const WW*)beta, (const MM*)scale, rows_per_mod, cols, cols, slabs_mod, p0, p1); \
-        slabsum_kernel<MM><<<(unsigned)cdiv(groups * cols, NB), NB, 0, s>>>(p0, (MM*)dscale, groups, cols, slabs_mod, 0); \
-        if (dshift) slabsum_kernel<MM><<<(unsigned)cdiv(groups * cols, NB), NB, 0, s>>>(p1, (MM*)dshift, groups, cols, slabs_mod, 0); \
+        slabsum2_kernel<MM><<<(unsigned)cdiv(groups * cols, NB), NB, 0, s>>>(p0, p1, (MM*)dscale, (MM*)dshift, groups, cols, slabs_mod, 0); \
     } \
     if (dgamma) { \
         /* (dgamma, dbeta) need dn = gy*(1+scale[b]) which varies per modulation group: reduce per group, then over groups */ \
         float* p0 = workspace; float* p1 = workspace + groups * slabs_mod * (long)cols; \
         dim3 g2((unsigned)cdiv(cols / V, CR_CT), slabs_mod, (unsigned)groups); \
         colreduce_kernel<TT, WW, MM, 1><<<g2, NB, 0, s>>>((const TT*)x, (const TT*)gy, mean, rstd, (const WW*)gamma, (const WW*)beta, (const MM*)scale, rows_per_mod, cols, cols, slabs_mod, p0, p1); \
-        slabsum_kernel<WW><<<(unsigned)cdiv(cols, NB), NB, 0, s>>>(p0, (WW*)dgamma, 1, cols, (int)(groups * slabs_mod), accumulate_params); \
-        if (dbeta) slabsum_kernel<WW><<<(unsigned)cdiv(cols, NB), NB, 0, s>>>(p1, (WW*)dbeta, 1, cols, (int)(groups * slabs_mod), accumulate_params); \
+        slabsum2_kernel<WW><<<(unsigned)cdiv(cols, NB), NB, 0, s>>>(p0, p1, (WW*)dgamma, (WW*)dbeta, 1, cols, (int)(groups * slabs_mod), accumulate_params); \
     } } while (0)
     (void)slabs_all;
     if (dtype == DPIPE_BF16) {

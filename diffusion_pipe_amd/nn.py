@@ -119,15 +119,28 @@ class Attention(nn.Module):
         self.to_v = Linear(kv_dim, inner, bias=bias, **kw)
         self.to_out = nn.ModuleList([Linear(inner, query_dim, bias=out_bias, **kw), Identity()])
         self.attn_impl = 'auto'
+        self.fuse_projections = True      # fused QKV / KV GEMMs + packed flash attention in bf16 (fp32 parity mode: separate)
 
     def forward(self, hidden_states, encoder_hidden_states=None):
-        ctx = hidden_states if encoder_hidden_states is None else encoder_hidden_states
         B, S, _ = hidden_states.shape
-        q = self.to_q(hidden_states).view(B, S, self.heads, self.dim_head)
-        k = self.to_k(ctx).view(B, ctx.shape[1], self.heads, self.dim_head)
-        v = self.to_v(ctx).view(B, ctx.shape[1], self.heads, self.dim_head)
+        H, D = self.heads, self.dim_head
+        fused = self.fuse_projections and self.attn_impl == 'auto' and ops.flash_eligible(self.to_q.weight.dtype, D)
+        if fused and encoder_hidden_states is None:         # self attention: one QKV GEMM, packed attention
+            qkv = ops.fused_linear(hidden_states, [self.to_q.weight, self.to_k.weight, self.to_v.weight],
+                                   [self.to_q.bias, self.to_k.bias, self.to_v.bias])
+            o = ops.attention_packed(qkv, None, H, D)
+            return self.to_out[0](o)
+        if fused:                                           # cross attention: Q GEMM + one KV GEMM on the context
+            q = self.to_q(hidden_states)
+            kv = ops.fused_linear(encoder_hidden_states, [self.to_k.weight, self.to_v.weight], [self.to_k.bias, self.to_v.bias])
+            o = ops.attention_packed(q, kv, H, D)
+            return self.to_out[0](o)
+        ctx = hidden_states if encoder_hidden_states is None else encoder_hidden_states
+        q = self.to_q(hidden_states).view(B, S, H, D)
+        k = self.to_k(ctx).view(B, ctx.shape[1], H, D)
+        v = self.to_v(ctx).view(B, ctx.shape[1], H, D)
         o = ops.attention(q, k, v, impl=self.attn_impl)
-        return self.to_out[0](o.reshape(B, S, self.heads * self.dim_head))
+        return self.to_out[0](o.reshape(B, S, H * D))
 
 
 class Timesteps(nn.Module):

@@ -184,6 +184,118 @@ def linear(x, weight, bias=None):
     return _LinearFn.apply(x, weight, bias)
 
 
+# ------------------------------------------------------------------------- fused projections (K1: fused QKV)
+def packed_view(tensors):
+    """[sum rows, ...] view over tensors that sit back to back in one storage (row blocks of one matrix), else None."""
+    t0 = tensors[0]
+    nxt = t0.data_ptr()
+    for t in tensors:
+        if t is None or not t.is_contiguous() or t.data_ptr() != nxt or t.shape[1:] != t0.shape[1:] or t.dtype != t0.dtype \
+                or t.untyped_storage().data_ptr() != t0.untyped_storage().data_ptr():
+            return None
+        nxt += t.numel() * t.element_size()
+    rows = sum(t.shape[0] for t in tensors)
+    return torch.as_strided(t0.detach(), (rows, *t0.shape[1:]), t0.stride(), t0.storage_offset())
+
+
+@torch.no_grad()
+def pack_parameters(params):
+    """Re-home parameters (row blocks: [N_i, K] weights or [N_i] biases) into one buffer, in order, keeping the Parameter
+    objects (optimizers / state dicts keep working); existing gradients are packed the same way."""
+    buf = torch.cat([p.data for p in params], dim=0)
+    off = 0
+    for p in params:
+        n = p.shape[0]
+        p.data = buf[off:off + n]
+        off += n
+    if all(p.grad is not None for p in params):
+        gbuf = torch.cat([p.grad for p in params], dim=0)
+        off = 0
+        for p in params:
+            n = p.shape[0]
+            p.grad = gbuf[off:off + n]
+            off += n
+
+
+class _FusedLinearFn(Function):
+    """y = x [W_1; ...; W_n]^T + [b_1; ...; b_n] -- several nn.Linear layers that share their input (to_q / to_k / to_v of
+    self attention, to_k / to_v of cross attention, CLIP q/k/v_proj) as ONE GEMM each for forward, dgrad (K = sum N_i) and
+    wgrad, on weights packed back to back (`pack_parameters`).  The layers stay separate Parameters (LoRA / checkpoints
+    address them one by one: models/base.py:262-270)."""
+
+    @staticmethod
+    def forward(ctx, x, n, *params):
+        ws, bs = params[:n], params[n:]
+        x2 = _rows2d(x)
+        if x2.dtype != ws[0].dtype:
+            x2 = x2.to(ws[0].dtype)
+        wcat = packed_view(ws)
+        has_bias = bs[0] is not None
+        bcat = packed_view(bs) if has_bias else None
+        if wcat is None or (has_bias and bcat is None):
+            raise DpipeHipError('fused_linear: parameters are not packed (call ops.pack_parameters first)')
+        y = mm(x2, wcat, False, True, bias=bcat)
+        ctx.save_for_backward(x2, *params)
+        ctx.n, ctx.has_bias, ctx.x_shape, ctx.x_dtype = n, has_bias, x.shape, x.dtype
+        return y.view(*x.shape[:-1], wcat.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, *params = ctx.saved_tensors
+        n = ctx.n
+        ws, bs = params[:n], params[n:]
+        gy2 = _rows2d(gy)
+        if gy2.dtype != ws[0].dtype:
+            gy2 = gy2.to(ws[0].dtype)
+        wcat = packed_view(ws)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = mm(gy2, wcat, False, False).view(ctx.x_shape)                 # dx = dy . [W_1; ...; W_n], K = sum N_i
+            if gx.dtype != ctx.x_dtype:
+                gx = gx.to(ctx.x_dtype)
+
+        def grads_for(group, compute):
+            """`compute(out, accumulate)` writes the packed gradient of the group.  Returns the per-parameter gradients
+            autograd should see: None after a fused accumulation / direct .grad installation, else row-block views."""
+            if not any(ctx.needs_input_grad[2 + (0 if group is ws else n) + i] for i in range(n)):
+                return [None] * n
+            if FUSE_GRAD_ACCUM:
+                grads = [p.grad for p in group]
+                if all(g is None for g in grads):
+                    gcat = compute(None, False)                                   # first micro-batch: the packed buffer becomes .grad
+                    off = 0
+                    for p in group:
+                        p.grad = gcat[off:off + p.shape[0]]
+                        off += p.shape[0]
+                    return [None] * n
+                if all(g is not None for g in grads):
+                    gv = packed_view(grads)
+                    if gv is not None:
+                        compute(gv, True)                                          # later micro-batches: accumulate in the epilogue
+                        return [None] * n
+            gcat = compute(None, False)
+            out, off = [], 0
+            for p in group:
+                out.append(gcat[off:off + p.shape[0]])
+                off += p.shape[0]
+            return out
+
+        gws = grads_for(ws, lambda out, acc: mm(gy2, x2, True, False, out=out, accumulate=acc))
+        gbs = grads_for(bs, lambda out, acc: column_sum(gy2, out=out)) if ctx.has_bias else [None] * n
+        return (gx, None, *gws, *gbs)
+
+
+def fused_linear(x, weights, biases=None):
+    """[.., K] -> [.., sum N_i].  weights: list of [N_i, K] Parameters; biases: matching list or None."""
+    weights = list(weights)
+    biases = list(biases) if biases is not None and biases[0] is not None else [None] * len(weights)
+    if packed_view(weights) is None:
+        pack_parameters(weights)
+    if biases[0] is not None and packed_view(biases) is None:
+        pack_parameters(biases)
+    return _FusedLinearFn.apply(x, len(weights), *weights, *biases)
+
+
 def column_sum(x2, out=None, out_dtype=None):
     """sum over the rows of a [rows, cols] matrix (fp32 accumulate, two-stage slab reduction).  `out` given: out += sum
     (the fused gradient-accumulation form); else a new [cols] tensor in x2's dtype (or out_dtype)."""
@@ -459,21 +571,41 @@ def _bshd_strides(t):
     return t.stride(0), t.stride(1), t.stride(2)
 
 
+def _flash_fwd(q, k, v, kv_len, scale, causal):
+    B, Sq, H, D = q.shape
+    Sk = k.shape[1]
+    if q.dtype != torch.bfloat16 or k.dtype != q.dtype or v.dtype != q.dtype:
+        raise DpipeHipError('flash attention kernel computes in bf16')
+    o = torch.empty((B, Sq, H, D), device=q.device, dtype=q.dtype)
+    lse = torch.empty((B, H, Sq), device=q.device, dtype=torch.float32)
+    check(lib().dpipe_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(kv_len), B, H, Sq, Sk, D,
+                               *_bshd_strides(q), *_bshd_strides(k), *_bshd_strides(v), *_bshd_strides(o),
+                               float(scale), int(causal), stream()), 'attn_fwd')
+    return o, lse
+
+
+def _flash_bwd(q, k, v, o, do, lse, kv_len, dq, dk, dv, scale, causal):
+    B, Sq, H, D = q.shape
+    Sk = k.shape[1]
+    if do.stride(3) != 1:
+        do = do.contiguous()
+    delta = torch.empty((B, H, Sq), device=q.device, dtype=torch.float32)
+    npart = lib().dpipe_attn_bwd_partial_floats(B, H, Sq, Sk, D)
+    part = torch.empty(npart, device=q.device, dtype=torch.float32) if npart > 0 else None
+    check(lib().dpipe_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
+                               ptr(kv_len), B, H, Sq, Sk, D,
+                               *_bshd_strides(q), *_bshd_strides(k), *_bshd_strides(v), *_bshd_strides(o), *_bshd_strides(do),
+                               *_bshd_strides(dq), *_bshd_strides(dk), *_bshd_strides(dv), float(scale), int(causal),
+                               ptr(part), npart, stream()), 'attn_bwd')
+
+
 class _FlashAttnFn(Function):
     """softmax(q k^T * scale) v on [B, S, H, D] bf16 tensors, flash style (models/wan/attention.py:91-122)."""
 
     @staticmethod
     def forward(ctx, q, k, v, kv_len, scale, causal):
         require_cuda(q, k, v, kv_len)
-        B, Sq, H, D = q.shape
-        Sk = k.shape[1]
-        if q.dtype != torch.bfloat16 or k.dtype != q.dtype or v.dtype != q.dtype:
-            raise DpipeHipError('flash attention kernel computes in bf16')
-        o = torch.empty((B, Sq, H, D), device=q.device, dtype=q.dtype)
-        lse = torch.empty((B, H, Sq), device=q.device, dtype=torch.float32)
-        check(lib().dpipe_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(kv_len), B, H, Sq, Sk, D,
-                                   *_bshd_strides(q), *_bshd_strides(k), *_bshd_strides(v), *_bshd_strides(o),
-                                   float(scale), int(causal), stream()), 'attn_fwd')
+        o, lse = _flash_fwd(q, k, v, kv_len, scale, causal)
         ctx.save_for_backward(q, k, v, o, lse, kv_len)
         ctx.scale = scale
         ctx.causal = causal
@@ -482,22 +614,71 @@ class _FlashAttnFn(Function):
     @staticmethod
     def backward(ctx, do):
         q, k, v, o, lse, kv_len = ctx.saved_tensors
-        B, Sq, H, D = q.shape
-        Sk = k.shape[1]
-        if do.stride(3) != 1:
-            do = do.contiguous()
-        dq = torch.empty((B, Sq, H, D), device=q.device, dtype=q.dtype)
-        dk = torch.empty((B, Sk, H, D), device=q.device, dtype=q.dtype)
-        dv = torch.empty((B, Sk, H, D), device=q.device, dtype=q.dtype)
-        delta = torch.empty((B, H, Sq), device=q.device, dtype=torch.float32)
-        npart = lib().dpipe_attn_bwd_partial_floats(B, H, Sq, Sk, D)
-        part = torch.empty(npart, device=q.device, dtype=torch.float32) if npart > 0 else None
-        check(lib().dpipe_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
-                                   ptr(kv_len), B, H, Sq, Sk, D,
-                                   *_bshd_strides(q), *_bshd_strides(k), *_bshd_strides(v), *_bshd_strides(o), *_bshd_strides(do),
-                                   *_bshd_strides(dq), *_bshd_strides(dk), *_bshd_strides(dv), float(ctx.scale), int(ctx.causal),
-                                   ptr(part), npart, stream()), 'attn_bwd')
+        dq, dk, dv = torch.empty_like(q, memory_format=torch.contiguous_format), torch.empty_like(k, memory_format=torch.contiguous_format), \
+            torch.empty_like(v, memory_format=torch.contiguous_format)
+        _flash_bwd(q, k, v, o, do, lse, kv_len, dq, dk, dv, ctx.scale, ctx.causal)
         return dq, dk, dv, None, None, None
+
+
+def _split_heads(packed, parts, H, D):
+    """[B, S, parts * H * D] -> `parts` strided views [B, S, H, D] (no copies: the kernels take strides)."""
+    B, S, _ = packed.shape
+    return [packed[..., i * H * D:(i + 1) * H * D].view(B, S, H, D) for i in range(parts)]
+
+
+class _FlashAttnPackedFn(Function):
+    """The same kernels on the output of a fused projection: mode 'qkv' takes one [B, S, 3 H D] tensor, mode 'q_kv' a query
+    [B, Sq, H D] and a packed [B, Sk, 2 H D] key/value tensor.  Backward writes dq / dk / dv straight into the packed
+    gradient of the projection output (strided stores), so the fused dgrad / wgrad GEMMs consume it without any concat."""
+
+    @staticmethod
+    def forward(ctx, a, b, H, D, kv_len, scale, causal):
+        require_cuda(a, b, kv_len)
+        a = _contig(a)
+        if b is None:
+            q, k, v = _split_heads(a, 3, H, D)
+        else:
+            b = _contig(b)
+            q = a.view(a.shape[0], a.shape[1], H, D)
+            k, v = _split_heads(b, 2, H, D)
+        o, lse = _flash_fwd(q, k, v, kv_len, scale, causal)
+        ctx.save_for_backward(a, b, o, lse, kv_len)
+        ctx.meta = (H, D, scale, causal)
+        return o.view(o.shape[0], o.shape[1], H * D)
+
+    @staticmethod
+    def backward(ctx, do):
+        a, b, o, lse, kv_len = ctx.saved_tensors
+        H, D, scale, causal = ctx.meta
+        do = _contig(do).view(o.shape)
+        da = torch.empty_like(a)
+        if b is None:
+            q, k, v = _split_heads(a, 3, H, D)
+            dq, dk, dv = _split_heads(da, 3, H, D)
+            db = None
+        else:
+            db = torch.empty_like(b)
+            q, dq = a.view(a.shape[0], a.shape[1], H, D), da.view(a.shape[0], a.shape[1], H, D)
+            k, v = _split_heads(b, 2, H, D)
+            dk, dv = _split_heads(db, 2, H, D)
+        _flash_bwd(q, k, v, o, do, lse, kv_len, dq, dk, dv, scale, causal)
+        return da, db, None, None, None, None, None
+
+
+def attention_packed(qkv_or_q, kv=None, heads=1, head_dim=64, kv_len=None, scale=None, causal=False):
+    """bf16 flash attention on fused-projection outputs; returns [B, Sq, H D].  See _FlashAttnPackedFn."""
+    if scale is None:
+        scale = 1.0 / math.sqrt(head_dim)
+    if ATTN_TRACE is not None:
+        Sk = qkv_or_q.shape[1] if kv is None else kv.shape[1]
+        ATTN_TRACE.append((qkv_or_q.shape[0], qkv_or_q.shape[1], Sk, heads, head_dim, int(causal)))
+    if kv_len is not None and kv_len.dtype != torch.int32:
+        kv_len = kv_len.to(torch.int32)
+    return _FlashAttnPackedFn.apply(qkv_or_q, kv, heads, head_dim, kv_len, scale, causal)
+
+
+def flash_eligible(dtype, head_dim):
+    return dtype == torch.bfloat16 and head_dim in (64, 128)
 
 
 class _UnfusedAttnFn(Function):

@@ -82,6 +82,10 @@ class CLIPAttention(nn.Module):
 
     def forward(self, x):
         B, S, C = x.shape
+        if ops.flash_eligible(self.q_proj.weight.dtype, self.head_dim):      # fused QKV GEMM + packed causal attention
+            qkv = ops.fused_linear(x, [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight],
+                                   [self.q_proj.bias, self.k_proj.bias, self.v_proj.bias])
+            return self.out_proj(ops.attention_packed(qkv, None, self.heads, self.head_dim, causal=True))
         q = self.q_proj(x).view(B, S, self.heads, self.head_dim)
         k = self.k_proj(x).view(B, S, self.heads, self.head_dim)
         v = self.v_proj(x).view(B, S, self.heads, self.head_dim)

@@ -498,3 +498,50 @@ def test_parallel_wgrad_fork_join_matches_single_stream(gpu):
 
     for a, b in zip(run(True), run(False)):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('cross', [False, True])
+@pytest.mark.parametrize('fuse_accum', [False, True])
+def test_fused_qkv_projection_and_packed_attention_match_separate_path(gpu, cross, fuse_accum):
+    """nn.Attention with fused QKV (self) / KV (cross) GEMMs + packed flash attention vs three separate Linear layers +
+    plain flash attention on the same weights: outputs, input gradients and every parameter gradient over 3 micro-batches."""
+    from diffusion_pipe_amd import nn as dnn, ops
+
+    def run(fused):
+        torch.manual_seed(9)
+        attn = dnn.Attention(640, 2048 if cross else None, heads=10, dim_head=64).to(gpu, torch.bfloat16)
+        attn.fuse_projections = fused
+        ops.FUSE_GRAD_ACCUM = fuse_accum
+        outs = []
+        try:
+            for mb in range(3):
+                g = torch.Generator().manual_seed(mb)
+                x = torch.randn(2, 200, 640, generator=g).to(gpu, torch.bfloat16).requires_grad_(True)
+                c = torch.randn(2, 77, 2048, generator=g).to(gpu, torch.bfloat16).requires_grad_(True) if cross else None
+                y = attn(x, c)
+                (y.float() * torch.linspace(-1, 1, 640, device=gpu)).sum().backward()
+                outs += [y.detach(), x.grad] + ([c.grad] if cross else [])
+        finally:
+            ops.FUSE_GRAD_ACCUM = False
+        return outs + [p.grad.clone() for p in attn.parameters()]
+
+    for a, b in zip(run(True), run(False)):
+        assert a.shape == b.shape
+        assert _rel_err(a, b) < 2e-2
+
+
+def test_clip_attention_fused_causal_matches_reference(gpu):
+    from diffusion_pipe_amd.workloads import sdxl
+    c = sdxl.CLIPConfig(hidden=768, layers=1, heads=12, mlp=3072)
+    torch.manual_seed(3)
+    attn = sdxl.CLIPAttention(c).to(gpu, torch.bfloat16)
+    x = torch.randn(2, 77, 768, generator=torch.Generator().manual_seed(1)).to(gpu, torch.bfloat16).requires_grad_(True)
+    y = attn(x)
+    y.float().square().mean().backward()
+    xr = x.detach().float().requires_grad_(True)
+    w = {n: p.detach().float() for n, p in attn.named_parameters()}
+    q, k, v = (F.linear(xr, w[f'{n}_proj.weight'], w[f'{n}_proj.bias']).view(2, 77, 12, 64).transpose(1, 2) for n in 'qkv')
+    o = F.scaled_dot_product_attention(q, k, v, is_causal=True).transpose(1, 2).reshape(2, 77, 768)
+    yr = F.linear(o, w['out_proj.weight'], w['out_proj.bias'])
+    yr.square().mean().backward()
+    assert _rel_err(y, yr) < 3e-2 and _rel_err(x.grad, xr.grad) < 4e-2
