@@ -49,6 +49,11 @@ template <int BM_, int BN_, int WM_, int WN_, int STAGES_> struct Tile {
 };
 using T64 = Tile<64, 64, 2, 2, 4>;
 using T128 = Tile<128, 128, 2, 4, 3>;
+using T128R2 = Tile<128, 128, 2, 4, 2>;     // 2-deep ring, 64 KiB -> 2 workgroups per CU: one tile's epilogue / prologue overlaps the other's K-loop.
+                                            // Measured (tools/kernel_timing.py cold): 1.3-1.7x over T128 once there are >= 256 tiles and an
+                                            // MN-contiguous operand (dgrad / wgrad), 1.2x at 8192^3; slower with few tiles (no second workgroup).
+using T64S3 = Tile<64, 64, 2, 2, 3>;         // selectable, not chosen automatically: 3-deep ring (3 workgroups per CU)
+using T256 = Tile<256, 128, 4, 2, 3>;       // selectable, not chosen automatically: 256 x 128, 8 waves of 64 x 64, 144 KiB (T128R2 beats it)
 
 // Byte offset (from the operand base of this batch) of the 16 bytes lane `lane` fetches for DMA piece q of an image of
 // ROWS mn-rows at K-step 0.  The DMA writes lane L of piece q to LDS byte (q * 1024 + 16 L); the logical chunk fetched
@@ -65,7 +70,7 @@ __device__ __forceinline__ unsigned dma_voffset(int q, int lane, int mn0, long l
         constexpr int G = ROWS / 32;             // 64-B granules per k-row (4 or 2)
         const int krow = q * (64 / CPR) + lane / CPR;
         const int pc = lane % CPR;
-        const int f = G == 4 ? (krow & 3) : ((krow >> 1) & 1);
+        const int f = G >= 4 ? (krow & 3) : ((krow >> 1) & 1);
         const int lc = (((pc >> 2) ^ f) << 2) | (pc & 3);
         return (unsigned)(((long)krow * ld + mn0 + lc * 8) * 2);
     }
@@ -85,7 +90,7 @@ __device__ __forceinline__ bf16x8_t read_frag(const char* img, int mn, int ks, i
         const int t = lane & 15, g = lane >> 4;
         const int krow = 16 * ks + 8 * (g >> 1) + (t >> 2);
         const int col_b = (16 * (g & 1) + 4 * (t & 3)) * 2;          // byte column inside the 64-B granule
-        const int f = G == 4 ? (krow & 3) : ((krow >> 1) & 1);       // identical for krow + 4
+        const int f = G >= 4 ? (krow & 3) : ((krow >> 1) & 1);       // identical for krow + 4
         const char* p = img + krow * RB + ((mn >> 5) ^ f) * 64 + col_b;
         const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(p));
         const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(p + 4 * RB));
@@ -96,19 +101,31 @@ __device__ __forceinline__ bf16x8_t read_frag(const char* img, int mn, int ks, i
     }
 }
 
-template <int N> __device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N == 0 || N == 4 || N == 8 || N == 12, "counted waits of this file");
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+// counted wait for this wave's LDS-DMA: `ahead` later K-steps (NLOAD DMA instructions each) may stay in flight
+template <int NLOAD> __device__ __forceinline__ void wait_dma_ahead(int ahead) {
+    static_assert(NLOAD == 4 || NLOAD == 6, "DMA pieces per wave per K-step");
+    if constexpr (NLOAD == 4) {
+        switch (ahead) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        }
+    } else {
+        switch (ahead) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        }
+    }
 }
 
 template <int BM_, int BN_, int WM_, int WN_, int STAGES_, bool A_MC, bool B_MC>
 __global__ void __launch_bounds__(512) gemm_pipe_kernel(const GemmParams p) {
     using TL = Tile<BM_, BN_, WM_, WN_, STAGES_>;
     constexpr int BM = TL::BM, BN = TL::BN, STAGES = TL::STAGES, TM = TL::TM, TN = TL::TN, NLOAD = TL::NLOAD;
-    static_assert(NLOAD == 4 && (STAGES == 3 || STAGES == 4), "vmcnt ladder below assumes 4 pieces per wave per stage");
+    static_assert(STAGES >= 2 && STAGES <= 5, "ring depth (the vmcnt ladder covers <= 3 K-steps ahead)");
     __shared__ __attribute__((aligned(1024))) char lds[STAGES * TL::STAGE_BYTES];
 
     // XCD-aware bijective remap (consecutive ids round-robin over the 8 XCDs): each XCD owns a contiguous run of
@@ -194,10 +211,7 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const GemmParams p) {
     for (int it = 0; it < nk; ++it) {
         // retire this wave's DMA of K-step `it` (later steps stay in flight), then one barrier: every wave's share of
         // step `it` has landed AND every wave has finished reading buffer `nxt` (it computed step it-1 from it).
-        const int ahead = nk - it - 1;
-        if (STAGES == 4 && ahead >= 2) wait_vmcnt<2 * NLOAD>();
-        else if (ahead >= 1) wait_vmcnt<NLOAD>();
-        else wait_vmcnt<0>();
+        wait_dma_ahead<NLOAD>(min(nk - it - 1, STAGES - 2));
         __builtin_amdgcn_s_barrier();
         if (it + STAGES - 1 < nk) ISSUE_STAGE(nxt);
         const char* imgA = lds + cur * TL::STAGE_BYTES;
@@ -362,7 +376,7 @@ bool gemm_pipe_try(GemmParams& p, int transA, int transB, int batch, void* ws, l
     if (!al16(p.A) || !al16(p.B)) return false;
     if (p.lda % 8 || p.ldb % 8 || p.sAo % 8 || p.sAi % 8 || p.sBo % 8 || p.sBi % 8) return false;
     if ((!a_mc || !b_mc) && (p.K % BK) != 0) return false;
-    const long kpad = (long)((p.K + BK - 1) / BK) * BK, mpad = (long)((p.M + 127) / 128) * 128, npad = (long)((p.N + 127) / 128) * 128;
+    const long kpad = (long)((p.K + BK - 1) / BK) * BK, mpad = (long)((p.M + 255) / 256) * 256, npad = (long)((p.N + 255) / 256) * 256;
     const long ext_a = a_mc ? kpad * p.lda + mpad : mpad * p.lda + kpad;
     const long ext_b = b_mc ? kpad * p.ldb + npad : npad * p.ldb + kpad;
     if (ext_a * 2 >= (1L << 31) || ext_b * 2 >= (1L << 31)) return false;
@@ -372,18 +386,18 @@ bool gemm_pipe_try(GemmParams& p, int transA, int transB, int batch, void* ws, l
     const long tiles64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64) * batch;
     // tile (measured on the SDXL shapes, tools/kernel_timing.py): 128 x 128 from ~half a wave of workgroups on, or when a
     // long K can be split three ways over few tiles; else 64 x 64 (4 x the workgroups, 2 resident per CU)
-    const bool long_k = p.ksteps >= 96;
-    const bool big = force_tile ? force_tile == 128 : (tiles128 >= 128 || (long_k && tiles128 >= 48));
-    const int bm = big ? 128 : 64;
-    p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bm - 1) / bm;
-    const long tiles = big ? tiles128 : tiles64;
-    const long slab_bytes = (long)bm * bm * 4;
+    const bool long_k = p.ksteps >= 48;
+    const bool big = force_tile ? force_tile >= 128 : (tiles128 >= 128 || (long_k && tiles128 >= 48));
+    const int bm = force_tile == 256 ? 256 : big ? 128 : 64, bn = force_tile == 256 ? 128 : bm;
+    p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bn - 1) / bn;
+    const long tiles = (long)p.tiles_m * p.tiles_n * batch;
+    const long slab_bytes = (long)bm * bn * 4;
     int S = 1;
     if (ws && ws_bytes > COUNTER_BYTES) {
         if (force_splitk > 0) S = force_splitk;
         else if (!big && tiles <= 128 && p.ksteps >= 32) {   // every slice pays an agent-scope release: only few, long tiles split
             S = (int)(512 / tiles); const int cap = p.ksteps / 8; if (S > cap) S = cap; if (S > 4) S = 4;
-        } else if (big && tiles < 128 && long_k) S = 3;
+        } else if (big && tiles < 256 && long_k) { S = (int)(384 / tiles); if (S > 3) S = 3; }   // >= 16 K-steps per slice
         if (S < 1) S = 1;
         if (S > p.ksteps) S = p.ksteps;
         const long max_slabs = (ws_bytes - COUNTER_BYTES) / slab_bytes;
@@ -400,7 +414,11 @@ bool gemm_pipe_try(GemmParams& p, int transA, int transB, int batch, void* ws, l
     const bool c_ok = (reinterpret_cast<uintptr_t>(p.C) % (4 * celt) == 0) && p.ldc % 4 == 0 && p.sCo % 4 == 0 && p.sCi % 4 == 0;
     p.vecA = c_ok ? 2 : 0;
     p.vecB = (p.bias && reinterpret_cast<uintptr_t>(p.bias) % 8 == 0) ? 2 : 0;
-    *rc_out = big ? launch_pipe<T128>(p, a_mc, b_mc, batch, s) : launch_pipe<T64>(p, a_mc, b_mc, batch, s);
+    if (force_tile == 256) *rc_out = launch_pipe<T256>(p, a_mc, b_mc, batch, s);
+    else if (force_tile == 129 || (force_tile == 0 && big && tiles128 >= 256 && (a_mc || b_mc || tiles128 >= 1024)))
+        *rc_out = launch_pipe<T128R2>(p, a_mc, b_mc, batch, s);
+    else if (force_tile == 63) *rc_out = launch_pipe<T64S3>(p, a_mc, b_mc, batch, s);
+    else *rc_out = big ? launch_pipe<T128>(p, a_mc, b_mc, batch, s) : launch_pipe<T64>(p, a_mc, b_mc, batch, s);
     return true;
 }
 

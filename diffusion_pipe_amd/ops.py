@@ -29,10 +29,10 @@ def _rows2d(x):
 # launch stream, and (signature, start, stop) is appended -- the `roofline` object sums flops and elapsed times.
 GEMM_TRACE = None
 
-# Split-K workspace of the pipelined bf16 GEMM: [4 KiB ticket counters][272 fp32 slabs of 64 KiB], zero-filled once and
+# Split-K workspace of the pipelined bf16 GEMM: [4 KiB ticket counters][640 fp32 slabs of 64 KiB], zero-filled once and
 # private to one (device, stream) -- launches on one stream are ordered, so slices of two GEMMs never share counters.
 _SPLITK_WS = {}
-_SPLITK_WS_BYTES = 4096 + 272 * 65536
+_SPLITK_WS_BYTES = 4096 + 640 * 65536
 # Set by the engine while it captures / runs one of several concurrent micro-batch lanes: graphs captured on the same
 # capture stream but replayed on different streams must not share ticket counters, so the lane id replaces the stream key.
 WS_LANE = None

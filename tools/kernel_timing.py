@@ -106,7 +106,47 @@ def attn_main():
                           'tot_ms': round(cnt * fb_us / 1e3, 2), 'torch_tot_ms': round(cnt * tfb_us / 1e3, 2)}), flush=True)
 
 
-if 'attn' in sys.argv[1:]:
+def cold_main():
+    """GEMMs whose weight (or gradient accumulator) comes cold from HBM, as in a training step: the graph cycles through
+    enough distinct weight buffers to exceed the 256 MiB Infinity Cache; activations stay warm."""
+    dev = torch.device('cuda:0')
+    cases = [(0, 1, 1024, 1280, 1280), (0, 0, 1024, 1280, 1280), (1, 0, 1280, 1280, 1024), (0, 1, 1024, 3840, 1280), (0, 0, 1024, 1280, 3840),
+             (1, 0, 3840, 1280, 1024), (0, 1, 1024, 10240, 1280), (1, 0, 10240, 1280, 1024), (0, 0, 1024, 1280, 10240),
+             (0, 1, 1024, 1280, 5120), (0, 0, 1024, 5120, 1280), (1, 0, 1280, 5120, 1024), (0, 1, 4096, 640, 2560), (0, 0, 4096, 640, 5120),
+             (1, 0, 640, 640, 4096), (1, 0, 640, 1920, 4096)]
+    for (ta, tb, M, N, K) in cases:
+        wgrad = bool(ta)
+        wbytes = (M * N if wgrad else N * K) * 2
+        nbuf = max(2, min(256, -(-800_000_000 // wbytes)))
+        a = torch.randn((K, M) if ta else (M, K), device=dev, dtype=torch.bfloat16)
+        if wgrad:
+            b = torch.randn(K, N, device=dev, dtype=torch.bfloat16)
+            outs = [torch.zeros(M, N, device=dev, dtype=torch.bfloat16) for _ in range(nbuf)]
+            ws = [b] * nbuf
+        else:
+            ws = [torch.randn((N, K) if tb else (K, N), device=dev, dtype=torch.bfloat16) for _ in range(nbuf)]
+            outs = [torch.empty(M, N, device=dev, dtype=torch.bfloat16)] * nbuf
+        rec = {'op': 'gemm_cold', 'ta': ta, 'tb': tb, 'M': M, 'N': N, 'K': K, 'nbuf': nbuf}
+        for name, hint in (('auto', 0), ('t64', 2001), ('t128', 3001), ('t128r2', 4001), ('t128k2', 3002), ('t128k3', 3003), ('t64k2', 2002)):
+            def run():
+                for i in range(nbuf):
+                    ops.mm(a, ws[i], bool(ta), bool(tb), out=outs[i], tile_hint=hint, accumulate=wgrad)
+            rec[name + '_us'] = round(graph_time(run, n=1, reps=3) / nbuf, 1)
+        aa = a.t() if ta else a
+
+        def run_t():
+            for i in range(nbuf):
+                if wgrad:
+                    outs[i].addmm_(aa, ws[i])
+                else:
+                    torch.matmul(aa, ws[i].t() if tb else ws[i], out=outs[i])
+        rec['torch_us'] = round(graph_time(run_t, n=1, reps=3) / nbuf, 1)
+        print(json.dumps(rec), flush=True)
+
+
+if 'cold' in sys.argv[1:]:
+    cold_main()
+elif 'attn' in sys.argv[1:]:
     attn_main()
 else:
     main()
