@@ -214,6 +214,10 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
                 if (m >= p.M) continue;
                 float v = epilogue_act(p.alpha * acc[i][j][e] + bv, p.act);
                 const long idx = coff + (long)m * p.ldc + n;
+                if (p.residual) {
+                    const long ridx = coff + (long)m * p.ldr + n;
+                    v += (p.out_f32 || sizeof(T) == 4) ? reinterpret_cast<const float*>(p.residual)[ridx] : bf16_to_f32(reinterpret_cast<const bf16_t*>(p.residual)[ridx]);
+                }
                 if (p.out_f32 || sizeof(T) == 4) {
                     float* c = reinterpret_cast<float*>(p.C);
                     if (p.accumulate) v += c[idx];
@@ -257,7 +261,8 @@ int dpipe_gemm_ex(int dtype, int transA, int transB, int M, int N, int K,
                   long strideA_outer, long strideA_inner, long strideB_outer, long strideB_inner,
                   long strideC_outer, long strideC_inner,
                   const void* bias, int act, float alpha, int accumulate, int out_f32, int tile_hint,
-                  void* splitk_ws, long splitk_ws_bytes, void* stream) {
+                  void* splitk_ws, long splitk_ws_bytes, const void* residual, long ldr, void* colsum, int colsum_accumulate,
+                  void* stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch_outer <= 0 || batch_inner <= 0) { set_last_error("dpipe_gemm: bad argument"); return DPIPE_ERR_ARG; }
     if (dtype != DPIPE_BF16 && dtype != DPIPE_F32) { set_last_error("dpipe_gemm: dtype"); return DPIPE_ERR_UNSUPPORTED; }
     const int V = dtype == DPIPE_BF16 ? 8 : 4;
@@ -266,6 +271,8 @@ int dpipe_gemm_ex(int dtype, int transA, int transB, int M, int N, int K,
     p.sAo = strideA_outer; p.sAi = strideA_inner; p.sBo = strideB_outer; p.sBi = strideB_inner; p.sCo = strideC_outer; p.sCi = strideC_inner;
     p.batch_inner = batch_inner; p.alpha = alpha; p.act = act; p.accumulate = accumulate; p.out_f32 = out_f32;
     p.splitk = 1; p.ksteps = 0; p.ksteps_per_split = 0; p.slabs = nullptr; p.counters = nullptr;
+    p.residual = residual; p.ldr = ldr; p.colsum = colsum; p.colsum_acc = colsum_accumulate;
+    if (residual && residual == C && !accumulate) { set_last_error("dpipe_gemm: residual may not alias C"); return DPIPE_ERR_ARG; }
     const int batch = batch_outer * batch_inner;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     // tile_hint: 0 = auto (pipelined bf16 kernel when eligible, else generic); 64 / 128 = generic kernel with that tile;
@@ -279,6 +286,7 @@ int dpipe_gemm_ex(int dtype, int transA, int transB, int M, int N, int K,
         if (tile_hint >= 1000) { set_last_error("dpipe_gemm: problem not eligible for the pipelined kernel"); return DPIPE_ERR_UNSUPPORTED; }
     }
     if (tile_hint >= 1000) { set_last_error("dpipe_gemm: pipelined kernel is bf16 only"); return DPIPE_ERR_UNSUPPORTED; }
+    if (colsum) { set_last_error("dpipe_gemm: fused column sum needs the pipelined kernel with a K-major A operand (transA = 1)"); return DPIPE_ERR_UNSUPPORTED; }
     // 16-byte loads need an aligned base and vector-multiple strides; ragged edges are handled per vector in load_tile.
     auto vec_ok = [&](const void* ptr, long ld, long so, long si) {
         return ((reinterpret_cast<uintptr_t>(ptr) & 15) == 0) && (ld % V == 0) && (so % V == 0) && (si % V == 0);
@@ -300,7 +308,7 @@ int dpipe_gemm(int dtype, int transA, int transB, int M, int N, int K,
                const void* bias, int act, float alpha, int accumulate, int out_f32, int tile_hint, void* stream) {
     return dpipe_gemm_ex(dtype, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, batch_outer, batch_inner, strideA_outer, strideA_inner,
                          strideB_outer, strideB_inner, strideC_outer, strideC_inner, bias, act, alpha, accumulate, out_f32, tile_hint,
-                         nullptr, 0, stream);
+                         nullptr, 0, nullptr, 0, nullptr, 0, stream);
 }
 
 int dpipe_tr16_probe(const void* in256_i16, void* out256_i16, void* stream) {

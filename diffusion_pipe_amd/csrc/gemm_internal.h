@@ -18,6 +18,9 @@ struct GemmParams {
     // split-K (pipelined kernel only)
     int splitk, ksteps, ksteps_per_split;
     float* slabs; int* counters;
+    // fused epilogue extras
+    const void* residual; long ldr;       // C += residual[m, n] (C's dtype, row pitch ldr, batch strides of C)
+    void* colsum; int colsum_acc;          // pipelined TN kernel only: colsum[m] (+)= sum_k A[k][m]  (bias gradient of a wgrad GEMM), operand dtype
 };
 
 enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_SILU = 3, ACT_QUICK_GELU = 4 };

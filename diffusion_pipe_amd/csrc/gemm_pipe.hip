@@ -43,7 +43,7 @@ template <int BM_, int BN_, int WM_, int WN_, int STAGES_> struct Tile {
     static constexpr int IMG_A = BM * BK * 2, IMG_B = BN * BK * 2, STAGE_BYTES = IMG_A + IMG_B;
     static constexpr int PA = IMG_A / 1024 / NW, PB = IMG_B / 1024 / NW;   // 1 KiB DMA pieces per wave per operand
     static constexpr int NLOAD = PA + PB;
-    static constexpr int SLAB_F4 = BM * BN / 4;
+    static constexpr int SLAB_F4 = BM * BN / 4 + BM / 4;               // accumulators + one row of fused column sums
     static constexpr int ACC_F4 = TM * TN * 4;                        // float4 per thread in a slab
     static_assert(IMG_A % (1024 * NW) == 0 && IMG_B % (1024 * NW) == 0, "pieces must split evenly over the waves");
 };
@@ -99,6 +99,13 @@ __device__ __forceinline__ bf16x8_t read_frag(const char* img, int mn, int ks, i
         out[4] = hi[0]; out[5] = hi[1]; out[6] = hi[2]; out[7] = hi[3];
         return out;
     }
+}
+
+// sum of the 8 bf16 of an MFMA operand fragment (fp32)
+__device__ __forceinline__ float frag_sum(bf16x8_t f) {
+    const uint4 u = __builtin_bit_cast(uint4, f);
+    return (__uint_as_float(u.x << 16) + __uint_as_float(u.x & 0xffff0000u)) + (__uint_as_float(u.y << 16) + __uint_as_float(u.y & 0xffff0000u)) +
+           (__uint_as_float(u.z << 16) + __uint_as_float(u.z & 0xffff0000u)) + (__uint_as_float(u.w << 16) + __uint_as_float(u.w & 0xffff0000u));
 }
 
 // counted wait for this wave's LDS-DMA: `ahead` later K-steps (NLOAD DMA instructions each) may stay in flight
@@ -202,6 +209,13 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // fused bias gradient of a wgrad GEMM (A = dy stored [tokens][features]): colsum[m] = sum_k A[k][m], taken from the A
+    // fragments the MFMAs consume anyway -- by the waves of the tile column 0 workgroups that own distinct m rows
+    float csum[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) csum[i] = 0.f;
+    const bool do_colsum = A_MC && p.colsum != nullptr && tile_n == 0 && (wid % TL::WN) == 0;
+
     // ---- prologue: STAGES - 1 K-steps in flight
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
@@ -225,6 +239,12 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const GemmParams p) {
             for (int i = 0; i < TM; ++i) fa[ks][i] = read_frag<A_MC, BM>(imgA, wm0 + i * 32, ks, lane);
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[ks][j] = read_frag<B_MC, BN>(imgB, wn0 + j * 32, ks, lane);
+        }
+        if (do_colsum) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) csum[i] += frag_sum(fa[ks][i]);
         }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
@@ -251,6 +271,14 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const GemmParams p) {
                 for (int q = 0; q < 4; ++q)
                     mine[((i * TN + j) * 4 + q) * TL::NT + threadIdx.x] =
                         make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        if (do_colsum) {
+            float* crow = reinterpret_cast<float*>(mine + TL::SLAB_F4 - BM / 4);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float v = csum[i] + __shfl_xor(csum[i], 32, 64);
+                if (lane < 32) crow[wm0 + i * 32 + lane] = v;
+            }
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                       // all slab stores of this workgroup issued and waited for
         int* flag = reinterpret_cast<int*>(lds);               // the one LDS array doubles as the broadcast word
@@ -284,6 +312,33 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const GemmParams p) {
                         const float4 v = sl[((i * TN + j) * 4 + q) * TL::NT + threadIdx.x];
                         acc[i][j][4 * q] += v.x; acc[i][j][4 * q + 1] += v.y; acc[i][j][4 * q + 2] += v.z; acc[i][j][4 * q + 3] += v.w;
                     }
+        }
+    }
+
+    // ---- fused column sums: final value = this workgroup's (split-K: the slices' slab rows, in slice order)
+    if (A_MC && p.colsum != nullptr && tile_n == 0) {
+        if (p.splitk > 1) {
+            if (threadIdx.x < BM) {
+                const float* crow0 = reinterpret_cast<const float*>(reinterpret_cast<float4*>(p.slabs) + ((long)(z * nt + tile) * p.splitk) * TL::SLAB_F4 +
+                                                                    TL::SLAB_F4 - BM / 4);
+                float v = 0.f;
+                for (int s = 0; s < p.splitk; ++s) v += crow0[(long)s * TL::SLAB_F4 * 4 + threadIdx.x];
+                const int m = m0 + threadIdx.x;
+                if (m < p.M) {
+                    bf16_t* dst = reinterpret_cast<bf16_t*>(p.colsum) + (long)z * p.M + m;
+                    *dst = f32_to_bf16(p.colsum_acc ? bf16_to_f32(*dst) + v : v);
+                }
+            }
+        } else if (do_colsum) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float v = csum[i] + __shfl_xor(csum[i], 32, 64);
+                const int m = m0 + wm0 + i * 32 + lane;
+                if (lane < 32 && m < p.M) {
+                    bf16_t* dst = reinterpret_cast<bf16_t*>(p.colsum) + (long)z * p.M + m;
+                    *dst = f32_to_bf16(p.colsum_acc ? bf16_to_f32(*dst) + v : v);
+                }
+            }
         }
     }
 
@@ -321,6 +376,24 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const GemmParams p) {
                     for (int r = 0; r < 4; ++r) v[r] = epilogue_act(v[r], p.act);
                 }
                 const long idx = coff + (long)m * p.ldc + n;
+                if (p.residual) {
+                    const long ridx = coff + (long)m * p.ldr + n;
+                    if (p.out_f32) {
+                        const float* rp = reinterpret_cast<const float*>(p.residual) + ridx;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += rp[r];
+                    } else {
+                        const bf16_t* rp = reinterpret_cast<const bf16_t*>(p.residual) + ridx;
+                        if (full && p.vecA >= 3) {
+                            const uint2 rv = *reinterpret_cast<const uint2*>(rp);
+                            v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
+                            v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += bf16_to_f32(rp[r]);
+                        }
+                    }
+                }
                 if (p.out_f32) {
                     float* c = reinterpret_cast<float*>(p.C) + idx;
                     if (full && p.vecA >= 2) {
@@ -376,6 +449,7 @@ bool gemm_pipe_try(GemmParams& p, int transA, int transB, int batch, void* ws, l
     if (!al16(p.A) || !al16(p.B)) return false;
     if (p.lda % 8 || p.ldb % 8 || p.sAo % 8 || p.sAi % 8 || p.sBo % 8 || p.sBi % 8) return false;
     if ((!a_mc || !b_mc) && (p.K % BK) != 0) return false;
+    if (p.colsum && !a_mc) return false;                      // fused column sums read the K-major A image only
     const long kpad = (long)((p.K + BK - 1) / BK) * BK, mpad = (long)((p.M + 255) / 256) * 256, npad = (long)((p.N + 255) / 256) * 256;
     const long ext_a = a_mc ? kpad * p.lda + mpad : mpad * p.lda + kpad;
     const long ext_b = b_mc ? kpad * p.ldb + npad : npad * p.ldb + kpad;
@@ -391,7 +465,7 @@ bool gemm_pipe_try(GemmParams& p, int transA, int transB, int batch, void* ws, l
     const int bm = force_tile == 256 ? 256 : big ? 128 : 64, bn = force_tile == 256 ? 128 : bm;
     p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bn - 1) / bn;
     const long tiles = (long)p.tiles_m * p.tiles_n * batch;
-    const long slab_bytes = (long)bm * bn * 4;
+    const long slab_bytes = ((long)bm * bn + bm) * 4;
     int S = 1;
     if (ws && ws_bytes > COUNTER_BYTES) {
         if (force_splitk > 0) S = force_splitk;
@@ -413,6 +487,7 @@ bool gemm_pipe_try(GemmParams& p, int transA, int transB, int batch, void* ws, l
     const int celt = p.out_f32 ? 4 : 2;
     const bool c_ok = (reinterpret_cast<uintptr_t>(p.C) % (4 * celt) == 0) && p.ldc % 4 == 0 && p.sCo % 4 == 0 && p.sCi % 4 == 0;
     p.vecA = c_ok ? 2 : 0;
+    if (c_ok && p.residual && reinterpret_cast<uintptr_t>(p.residual) % 8 == 0 && p.ldr % 4 == 0) p.vecA = 3;   // 8-byte residual loads too
     p.vecB = (p.bias && reinterpret_cast<uintptr_t>(p.bias) % 8 == 0) ? 2 : 0;
     if (force_tile == 256) *rc_out = launch_pipe<T256>(p, a_mc, b_mc, batch, s);
     else if (force_tile == 129 || (force_tile == 0 && big && tiles128 >= 256 && (a_mc || b_mc || tiles128 >= 1024)))

@@ -50,7 +50,7 @@ _SIGNATURES = {
     'dpipe_softmax_bwd': (I, [P, P, P, L, I, L, F, I, P]),
     'dpipe_transpose': (I, [P, P, I, I, L, L, L, L, I, I, P]),
     'dpipe_gemm': (I, [I, I, I, I, I, I, P, L, P, L, P, L, I, I, L, L, L, L, L, L, P, I, F, I, I, I, P]),
-    'dpipe_gemm_ex': (I, [I, I, I, I, I, I, P, L, P, L, P, L, I, I, L, L, L, L, L, L, P, I, F, I, I, I, P, L, P]),
+    'dpipe_gemm_ex': (I, [I, I, I, I, I, I, P, L, P, L, P, L, I, I, L, L, L, L, L, L, P, I, F, I, I, I, P, L, P, L, P, I, P]),
     'dpipe_tr16_probe': (I, [P, P, P]),
     'dpipe_attn_fwd': (I, [P, P, P, P, P, P, I, I, I, I, I] + [L] * 12 + [F, I, P]),
     'dpipe_attn_bwd_partial_floats': (L, [I, I, I, I, I]),

@@ -27,8 +27,8 @@ class Linear(nn.Module):
             bound = 1 / math.sqrt(self.in_features)
             nn.init.uniform_(self.bias, -bound, bound)
 
-    def forward(self, x):
-        return ops.linear(x, self.weight, self.bias)
+    def forward(self, x, residual=None):
+        return ops.linear(x, self.weight, self.bias, residual)
 
     def extra_repr(self):
         return f'in_features={self.in_features}, out_features={self.out_features}, bias={self.bias is not None}'
@@ -99,10 +99,9 @@ class FeedForward(nn.Module):
         inner = dim * mult
         self.net = nn.ModuleList([GEGLU(dim, inner, device=device, dtype=dtype), Identity(), Linear(inner, dim, device=device, dtype=dtype)])
 
-    def forward(self, x):
-        for m in self.net:
-            x = m(x)
-        return x
+    def forward(self, x, residual=None):
+        x = self.net[0](x)
+        return self.net[2](x, residual)         # net[1] is the (identity) dropout slot; the block's residual add rides the epilogue
 
 
 class Attention(nn.Module):
@@ -121,7 +120,7 @@ class Attention(nn.Module):
         self.attn_impl = 'auto'
         self.fuse_projections = True      # fused QKV / KV GEMMs + packed flash attention in bf16 (fp32 parity mode: separate)
 
-    def forward(self, hidden_states, encoder_hidden_states=None):
+    def forward(self, hidden_states, encoder_hidden_states=None, residual=None):
         B, S, _ = hidden_states.shape
         H, D = self.heads, self.dim_head
         fused = self.fuse_projections and self.attn_impl == 'auto' and ops.flash_eligible(self.to_q.weight.dtype, D)
@@ -129,18 +128,18 @@ class Attention(nn.Module):
             qkv = ops.fused_linear(hidden_states, [self.to_q.weight, self.to_k.weight, self.to_v.weight],
                                    [self.to_q.bias, self.to_k.bias, self.to_v.bias])
             o = ops.attention_packed(qkv, None, H, D)
-            return self.to_out[0](o)
+            return self.to_out[0](o, residual)
         if fused:                                           # cross attention: Q GEMM + one KV GEMM on the context
             q = self.to_q(hidden_states)
             kv = ops.fused_linear(encoder_hidden_states, [self.to_k.weight, self.to_v.weight], [self.to_k.bias, self.to_v.bias])
             o = ops.attention_packed(q, kv, H, D)
-            return self.to_out[0](o)
+            return self.to_out[0](o, residual)
         ctx = hidden_states if encoder_hidden_states is None else encoder_hidden_states
         q = self.to_q(hidden_states).view(B, S, H, D)
         k = self.to_k(ctx).view(B, ctx.shape[1], H, D)
         v = self.to_v(ctx).view(B, ctx.shape[1], H, D)
         o = ops.attention(q, k, v, impl=self.attn_impl)
-        return self.to_out[0](o.reshape(B, S, H * D))
+        return self.to_out[0](o.reshape(B, S, H * D), residual)
 
 
 class Timesteps(nn.Module):

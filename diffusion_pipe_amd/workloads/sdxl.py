@@ -80,16 +80,16 @@ class CLIPAttention(nn.Module):
         self.q_proj, self.k_proj = dnn.Linear(c.hidden, c.hidden), dnn.Linear(c.hidden, c.hidden)
         self.v_proj, self.out_proj = dnn.Linear(c.hidden, c.hidden), dnn.Linear(c.hidden, c.hidden)
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
         B, S, C = x.shape
         if ops.flash_eligible(self.q_proj.weight.dtype, self.head_dim):      # fused QKV GEMM + packed causal attention
             qkv = ops.fused_linear(x, [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight],
                                    [self.q_proj.bias, self.k_proj.bias, self.v_proj.bias])
-            return self.out_proj(ops.attention_packed(qkv, None, self.heads, self.head_dim, causal=True))
+            return self.out_proj(ops.attention_packed(qkv, None, self.heads, self.head_dim, causal=True), residual)
         q = self.q_proj(x).view(B, S, self.heads, self.head_dim)
         k = self.k_proj(x).view(B, S, self.heads, self.head_dim)
         v = self.v_proj(x).view(B, S, self.heads, self.head_dim)
-        return self.out_proj(ops.attention(q, k, v, causal=True).reshape(B, S, C))
+        return self.out_proj(ops.attention(q, k, v, causal=True).reshape(B, S, C), residual)
 
 
 class CLIPMLP(nn.Module):
@@ -98,8 +98,8 @@ class CLIPMLP(nn.Module):
         self.fc1, self.fc2 = dnn.Linear(c.hidden, c.mlp), dnn.Linear(c.mlp, c.hidden)
         self.act = dnn.QuickGELU() if c.act == 'quick_gelu' else dnn.GELU()
 
-    def forward(self, x):
-        return self.fc2(self.act(self.fc1(x)))
+    def forward(self, x, residual=None):
+        return self.fc2(self.act(self.fc1(x)), residual)
 
 
 class CLIPEncoderLayer(nn.Module):
@@ -109,8 +109,8 @@ class CLIPEncoderLayer(nn.Module):
         self.layer_norm2, self.mlp = dnn.LayerNorm(c.hidden, eps=1e-5), CLIPMLP(c)
 
     def forward(self, x):
-        x = ops.gated_residual(x, self.self_attn(self.layer_norm1(x)))
-        return ops.gated_residual(x, self.mlp(self.layer_norm2(x)))
+        x = self.self_attn(self.layer_norm1(x), residual=x)
+        return self.mlp(self.layer_norm2(x), residual=x)
 
 
 class CLIPEmbeddings(nn.Module):
@@ -198,9 +198,10 @@ class BasicTransformerBlock(nn.Module):
         self.norm3, self.ff = dnn.LayerNorm(dim), dnn.FeedForward(dim)
 
     def forward(self, x, encoder_hidden_states):
-        x = ops.gated_residual(x, self.attn1(self.norm1(x)))
-        x = ops.gated_residual(x, self.attn2(self.norm2(x), encoder_hidden_states))
-        return ops.gated_residual(x, self.ff(self.norm3(x)))
+        # the three "x + f(norm(x))" adds ride the epilogue of f's output projection (GEMM `residual`)
+        x = self.attn1(self.norm1(x), residual=x)
+        x = self.attn2(self.norm2(x), encoder_hidden_states, residual=x)
+        return self.ff(self.norm3(x), residual=x)
 
 
 class Transformer2DModel(nn.Module):

@@ -141,13 +141,19 @@ int dpipe_gemm(int dtype, int transA, int transB, int M, int N, int K, const voi
  * kernel re-arms the counters itself); >= 4 KiB + 256 slabs makes every split decision available; NULL = never split.
  * tile_hint: 0 = auto, 64 / 128 = generic register-staged kernel with that tile, 1000 + S = pipelined kernel with S
  * K-slices forced (S = 0: its own choice), 2000 + S / 3000 + S = pipelined kernel with the 64 x 64 / 128 x 128 tile
- * forced; forced forms fail when the problem is not eligible: bf16, 16-byte aligned operands, leading dims multiples
- * of 8, K % 64 == 0 unless both operands are K-major. */
+ * forced (4000 / 5000 / 6000 + S: 128 x 128 with a 2-deep ring, 256 x 128, 64 x 64 with a 3-deep ring); forced forms
+ * fail when the problem is not eligible: bf16, 16-byte aligned operands, leading dims multiples of 8, K % 64 == 0 unless
+ * both operands are K-major.
+ * Fused epilogue extras: `residual` (C's dtype, row pitch ldr, C's batch strides; NULL = none): C = act(...) + residual
+ * -- the "x + attn(x)" / "x + ff(x)" adds of a transformer block folded into the output projection.  `colsum` (bf16 [M]
+ * per batch; NULL = none): colsum[m] (+)= sum_k A[k][m] for transA = 1 -- the bias gradient of nn.Linear computed inside
+ * its wgrad GEMM (dW = dy^T x, db = column sums of dy); returns DPIPE_ERR_UNSUPPORTED (-2) when the problem cannot take
+ * the pipelined kernel, the caller then uses dpipe_colsum. */
 int dpipe_gemm_ex(int dtype, int transA, int transB, int M, int N, int K, const void* A, long lda, const void* B,
                   long ldb, void* C, long ldc, int batch_outer, int batch_inner, long strideA_outer,
                   long strideA_inner, long strideB_outer, long strideB_inner, long strideC_outer, long strideC_inner,
                   const void* bias, int act, float alpha, int accumulate, int out_f32, int tile_hint, void* splitk_ws,
-                  long splitk_ws_bytes, void* stream);
+                  long splitk_ws_bytes, const void* residual, long ldr, void* colsum, int colsum_accumulate, void* stream);
 /* Test probe: runs ds_read_b64_tr_b16 over a 256-element i16 LDS image so the GPU tests can pin the lane mapping
  * the transposed-operand paths rely on. */
 int dpipe_tr16_probe(const void* in256_i16, void* out256_i16, void* stream);

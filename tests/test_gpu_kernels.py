@@ -545,3 +545,32 @@ def test_clip_attention_fused_causal_matches_reference(gpu):
     yr = F.linear(o, w['out_proj.weight'], w['out_proj.bias'])
     yr.square().mean().backward()
     assert _rel_err(y, yr) < 3e-2 and _rel_err(x.grad, xr.grad) < 4e-2
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('tokens', [150, 4096])
+def test_linear_residual_epilogue_and_fused_bias_gradient(gpu, dtype, tokens):
+    """y = x W^T + b + r in one GEMM; backward: db rides the wgrad GEMM (bf16: column sums of the A fragments, through the
+    split-K slabs when the token count makes the wgrad split), dr = dy.  Two micro-batches with in-kernel accumulation."""
+    from diffusion_pipe_amd import ops
+    g = torch.Generator().manual_seed(21 + tokens)
+    w = (torch.randn(320, 192, generator=g) / 14).to(gpu, dtype).requires_grad_(True)
+    b = torch.randn(320, generator=g).to(gpu, dtype).requires_grad_(True)
+    wr, br = (t.detach().float().requires_grad_(True) for t in (w, b))
+    ops.FUSE_GRAD_ACCUM = ops.FUSE_BIAS_GRAD = True
+    try:
+        for mb in range(2):
+            x = torch.randn(1, tokens, 192, generator=g).to(gpu, dtype).requires_grad_(True)
+            r = torch.randn(1, tokens, 320, generator=g).to(gpu, dtype).requires_grad_(True)
+            gy = (torch.randn(1, tokens, 320, generator=g) / 8).to(gpu, dtype)
+            y = ops.linear(x, w, b, r)
+            y.backward(gy)
+            xr, rr = (t.detach().float().requires_grad_(True) for t in (x, r))
+            yr = F.linear(xr, wr, br) + rr
+            yr.backward(gy.float())
+            tol = _tol(dtype)
+            assert _rel_err(y, yr) < tol and _rel_err(x.grad, xr.grad) < tol and _rel_err(r.grad, rr.grad) < 1e-6
+    finally:
+        ops.FUSE_GRAD_ACCUM = ops.FUSE_BIAS_GRAD = False
+    assert _rel_err(w.grad, wr.grad) < _tol(dtype) * 1.5
+    assert _rel_err(b.grad, br.grad) < _tol(dtype) * 1.5
