@@ -7,7 +7,9 @@
 A "step" is one optimizer step of the hot path (`engine.train_batch`): GAS micro-batches of one 1024x1024 image each
 (latents [1,4,128,128], 75-token prompts through both trained CLIP text encoders) through the SDXL UNet split over N
 pipeline stages, 1F1B schedule, fused loss, gradient clip, AdamW -- full fine-tune, bf16, synthetic data, random
-weights.  GAS = 4 * N so per-GPU work is constant as N grows ("weak").  Prints ONE JSON line on rank 0.
+weights.  GAS = 6 * N so per-GPU work is constant as N grows ("weak"); at N = 1 the six micro-batches of a step run on
+three concurrent hipGraph lanes (same-box sweep: GAS 4 / 2 lanes 11.65, GAS 6 / 2 lanes 12.08, GAS 6 / 3 lanes 13.63, GAS 8 / 4
+lanes 11.86 images/s).  Prints ONE JSON line on rank 0.
 
 Extra objects: `roofline` (dominant kernel = the hand-written MFMA GEMM, timed with HIP events around every launch of
 the last timed step) and `cpu_baseline` (the oracle's fp32 eager path on the host cores, bounded sample, N=1 only).
@@ -31,14 +33,14 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--gas', type=int, default=0, help='micro-batches per step (default 4 * gpus)')
+    ap.add_argument('--gas', type=int, default=0, help='micro-batches per step (default 6 * gpus)')
     ap.add_argument('--config', default='full', choices=['full', 'tiny'])
     ap.add_argument('--latent', type=int, default=128)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--activation-checkpointing', action='store_true')
     ap.add_argument('--partition', default='parameters')
     ap.add_argument('--no-graph', action='store_true', help='disable hipGraph capture of the micro-batch fwd+bwd')
-    ap.add_argument('--lanes', type=int, default=2, help='concurrent micro-batch lanes of the single-stage hipGraph path')
+    ap.add_argument('--lanes', type=int, default=3, help='concurrent micro-batch lanes of the single-stage hipGraph path')
     ap.add_argument('--test-single-device', action='store_true',
                     help='TEST ONLY: all ranks share cuda:0, collectives over gloo, stage payloads staged through the host')
     ap.add_argument('--parallel-wgrad', action='store_true', help='fork wgrad onto a side stream (A/B switch; measured slower)')
@@ -82,7 +84,7 @@ def main():
     cfg = sdxl.SDXLConfig() if args.config == 'full' else sdxl.tiny_config()
     latent = args.latent if args.config == 'full' else 32
     pp = world
-    gas = args.gas or 4 * world
+    gas = args.gas or 6 * world
     work = sdxl.SDXLWorkload(cfg, dtype=torch.bfloat16, seed=0, device=device)
     layers = work.to_layers()
     kwargs = {}

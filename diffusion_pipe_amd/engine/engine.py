@@ -92,12 +92,20 @@ class PipelineEngine:
         self.use_stage_graphs = want_graph and self.is_pipe_parallel
         self._graphs = {}
         self._stage_slots = {}
+        # stage-graph mode runs the forward half of the schedule (Load / RecvActivation / Forward / SendActivation) and the
+        # backward half (RecvGrad / Backward / SendGrad) on two HIP streams: in 1F1B steady state a stage's next forward and
+        # its pending backward belong to different micro-batches, so their graphs overlap on the GPU (same effect as the
+        # concurrent lanes of the single-stage path).  Per-slot events order a slot's forward before its backward and its
+        # backward before the slot is reused.
+        self._fwd_stream = torch.cuda.Stream(self.device) if self.use_stage_graphs else None
+        self._bwd_stream = torch.cuda.Stream(self.device) if self.use_stage_graphs else None
+        self._streams_forked = False
         self._g_total_loss = None
         # Concurrent micro-batch lanes (single-stage graph path): at micro-batch 1 most kernels of the step fill well under
         # half of the 256 CUs, so `graph_lanes` micro-batches replay at the same time on separate HIP streams, each lane
         # accumulating into its own gradient buffers (288 GB HBM: +5 GB per lane for SDXL); the lanes' gradients are summed
         # once before ReduceGrads / clip / optimizer.  Same math as sequential accumulation up to fp summation order.
-        self.graph_lanes = max(1, int(self._config.get('graph_lanes', 1))) if self.use_graph else 1
+        self.graph_lanes = max(1, int(self._config.get('graph_lanes', 1))) if self.use_graph else 1     # bench: 3 (best of 1..4 on MI355X)
         self._lanes = []
         if self.device.type == 'cuda' and self._config.get('fuse_grad_accumulation', True):
             from .. import ops as _ops
@@ -224,13 +232,38 @@ class PipelineEngine:
         self._eval_mode = False
         return out
 
+    _FWD_INSTR = (sched.LoadMicroBatch, sched.RecvActivation, sched.ForwardPass, sched.SendActivation)
+    _BWD_INSTR = (sched.RecvGrad, sched.BackwardPass, sched.SendGrad)
+
     def _exec_schedule(self, pipe_schedule):
+        two_streams = self.use_stage_graphs and not self._eval_mode
+        if two_streams:
+            main = torch.cuda.current_stream(self.device)
+            self._fwd_stream.wait_stream(main)          # previous optimizer step / data preparation
+            self._bwd_stream.wait_stream(main)
+            self._streams_forked = True
         for step_cmds in pipe_schedule:
             for cmd in step_cmds:
                 handler = self._INSTRUCTION_MAP.get(type(cmd))
                 if handler is None:
                     raise RuntimeError(f'{self.__class__.__name__} does not understand instruction {cmd!r}')
-                handler(self, **cmd.kwargs)
+                if two_streams and isinstance(cmd, self._FWD_INSTR):
+                    with torch.cuda.stream(self._fwd_stream):
+                        handler(self, **cmd.kwargs)
+                elif two_streams and isinstance(cmd, self._BWD_INSTR):
+                    with torch.cuda.stream(self._bwd_stream):
+                        handler(self, **cmd.kwargs)
+                else:
+                    self._join_streams()                # step end (reduce / clip / optimizer) sees both halves finished
+                    handler(self, **cmd.kwargs)
+        self._join_streams()
+
+    def _join_streams(self):
+        if self._streams_forked:
+            main = torch.cuda.current_stream(self.device)
+            main.wait_stream(self._fwd_stream)
+            main.wait_stream(self._bwd_stream)
+            self._streams_forked = False
 
     # ------------------------------------------------------------------------------------------- hipGraph path
     def _train_batch_graphed(self):
@@ -347,6 +380,7 @@ class PipelineEngine:
         outputs from static buffers, accumulates parameter gradients in place (fused into the wgrad / column-sum
         kernels) and leaves the input gradients in static tensors for SendGrad."""
         first, last = self.is_first_stage(), self.is_last_stage()
+        torch.cuda.synchronize(self.device)               # capture with both halves of the schedule idle
         params = [p for p in self.module.parameters() if p.requires_grad]
         saved_grads = {id(p): p.grad.clone() for p in params if p.grad is not None}     # micro-batches already accumulated
         saved_loss = self._g_total_loss.clone()
@@ -388,13 +422,17 @@ class PipelineEngine:
         cur.wait_stream(side)
         torch.cuda.synchronize(self.device)
 
+        from .. import ops as _ops
         static_in = make_inputs()
         fwd_graph, bwd_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(fwd_graph):
+        _ops.WS_LANE = 'stage-fwd'                  # forward and backward graphs replay on different streams at the same time:
+        with torch.cuda.graph(fwd_graph):           # they must not share split-K ticket counters / slabs
             out = forward(static_in)
         static_gout = None if last else grads_like(out)
+        _ops.WS_LANE = 'stage-bwd'
         with torch.cuda.graph(bwd_graph, pool=fwd_graph.pool()):
             backward(out, static_gout)
+        _ops.WS_LANE = None
         # undo the side effects of warm-up / capture on the accumulators
         for p in params:
             if p.grad is not None:
@@ -404,12 +442,15 @@ class PipelineEngine:
                     p.grad.zero_()
         self._g_total_loss.copy_(saved_loss)
         return {'fwd': fwd_graph, 'bwd': bwd_graph, 'inputs': static_in, 'labels': static_lab, 'out': out, 'gout': static_gout,
-                'single_in': single_in}
+                'single_in': single_in, 'fwd_done': None, 'bwd_done': None}
 
     def _exec_forward_pass_graphed(self, buffer_id):
         inputs = self.pipe_buffers['inputs'][buffer_id]
         labels = self.pipe_buffers['labels'][buffer_id] if self.is_last_stage() else None
         slot = self._stage_slot(buffer_id, inputs, labels)
+        cur = torch.cuda.current_stream(self.device)
+        if slot['bwd_done'] is not None:
+            cur.wait_event(slot['bwd_done'])            # the slot's previous micro-batch finished its backward
         with torch.no_grad():
             for dst, src in zip(slot['inputs'], _as_list(inputs)):
                 if src.numel() > 0:
@@ -419,12 +460,15 @@ class PipelineEngine:
                     if src.numel() > 0:
                         dst.copy_(src, non_blocking=True)
         slot['fwd'].replay()
+        slot['fwd_done'] = cur.record_event()
         self.pipe_buffers['inputs'][buffer_id] = slot['inputs'][0] if slot['single_in'] else slot['inputs']   # their .grad feeds SendGrad
         self.pipe_buffers['outputs'][buffer_id] = slot['out']
         self.pipe_buffers['slot'][buffer_id] = slot
 
     def _exec_backward_pass_graphed(self, buffer_id):
         slot = self.pipe_buffers['slot'][buffer_id]
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(slot['fwd_done'])                # this micro-batch's forward (other stream) has run
         if not self.is_last_stage():
             grads = self.pipe_buffers['grads'][buffer_id]
             assert len(grads) == len(slot['gout']), \
@@ -434,6 +478,7 @@ class PipelineEngine:
                     dst.copy_(src, non_blocking=True)
             self.pipe_buffers['grads'][buffer_id] = None
         slot['bwd'].replay()
+        slot['bwd_done'] = cur.record_event()
         self.pipe_buffers['outputs'][buffer_id] = None
 
     # ----------------------------------------------------------------------------------------- instructions
