@@ -188,7 +188,7 @@ def main():
                          'unit': 'TFLOP/s', 'frac': round(achieved / peak, 5), 'traffic': None,
                          'launches_per_step': int(launches), 'avg_launch_us': round(g_ms * 1e3 / max(launches, 1), 2),
                          'gemm_gpu_ms_per_step': round(g_ms / world, 2),
-                         'note': 'per-launch HIP-event times of one eager step (kernels run alone); graph replays overlap 2 micro-batches'},
+                         'note': 'per-launch HIP-event times of one eager step (kernels run alone); graph replays overlap the lanes'},
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle.cpu_baseline import sdxl_cpu_baseline
