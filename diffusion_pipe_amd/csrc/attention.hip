@@ -158,25 +158,36 @@ __global__ void __launch_bounds__(NW * 64, D == 64 ? 2 : 1) attn_fwd_kernel(cons
 #pragma unroll
             for (int ks = 0; ks < D / 16; ++ks) s = mfma16(frag_rows<KRS>(Kl, 32 * kb, 16 * ks, lane), qf[ks], s);
             float mx = -INFINITY;
+            // wave-uniform: every key of this 32-key block is valid for every query row of the wave -> no per-element masking
+            const bool full = key0 + 32 <= kvl && (!p.causal || key0 + 31 <= qrow - i);
+            if (full) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const bool ok = key < kvl && (!p.causal || key <= qrow);
-                const float v = ok ? s[e] * sl2 : -INFINITY;
-                s[e] = v; mx = fmaxf(mx, v);
+                for (int e = 0; e < 16; ++e) { const float v = s[e] * sl2; s[e] = v; mx = fmaxf(mx, v); }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const bool ok = key < kvl && (!p.causal || key <= qrow);
+                    const float v = ok ? s[e] * sl2 : -INFINITY;
+                    s[e] = v; mx = fmaxf(mx, v);
+                }
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m, mx);              // finite: key0 < kvl guarantees one valid key per row
-            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
             float rs = 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) { const float pe = __builtin_amdgcn_exp2f(s[e] - m_new); s[e] = pe; rs += pe; }
             rs += __shfl_xor(rs, 32, 64);
-            l = l * alpha + rs; m = m_new;
+            if (__all(m_new == m)) {                       // no row of the wave raised its maximum: alpha == 1 exactly, skip the rescale
+                l += rs;
+            } else {
+                const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+                l = l * alpha + rs; m = m_new;
 #pragma unroll
-            for (int db = 0; db < D / 32; ++db)
+                for (int db = 0; db < D / 32; ++db)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
+                    for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
+            }
             const bf16x8_t pf0 = pack_frag(s, 0), pf1 = pack_frag(s, 8);
 #pragma unroll
             for (int db = 0; db < D / 32; ++db) {
@@ -289,12 +300,17 @@ __global__ void __launch_bounds__(NW * 64, D == 64 ? 2 : 1) attn_bwd_dq_kernel(c
                 s = mfma16(frag_rows<KRS>(Kl, 32 * kb, 16 * ks, lane), qf[ks], s);
                 dp = mfma16(frag_rows<VRS>(Vl, 32 * kb, 16 * ks, lane), dof[ks], dp);
             }
+            if (key0 + 32 <= kvl && (!p.causal || key0 + 31 <= qrow - i)) {      // wave-uniform: block fully valid
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const bool ok = key < kvl && (!p.causal || key <= qrow);
-                const float pe = ok ? __builtin_amdgcn_exp2f(s[e] * sl2 - lse2) : 0.f;
-                s[e] = pe * (dp[e] - dl);
+                for (int e = 0; e < 16; ++e) s[e] = __builtin_amdgcn_exp2f(s[e] * sl2 - lse2) * (dp[e] - dl);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const bool ok = key < kvl && (!p.causal || key <= qrow);
+                    const float pe = ok ? __builtin_amdgcn_exp2f(s[e] * sl2 - lse2) : 0.f;
+                    s[e] = pe * (dp[e] - dl);
+                }
             }
             const bf16x8_t ds0 = pack_frag(s, 0), ds1 = pack_frag(s, 8);
 #pragma unroll
@@ -389,6 +405,8 @@ __global__ void __launch_bounds__(NW * 64, D == 64 ? 2 : 1) attn_bwd_dkv_kernel(
                 dp = mfma16(frag_rows<QRS>(DOl, 32 * qb, 16 * ks, lane), vf[ks], dp);
             }
             f32x16 pr;
+            // wave-uniform: all 32 keys of the wave are valid (padding queries carry lse = +inf -> p = 0) and nothing is causal
+            const bool full = !p.causal && (key - i) + 32 <= kvl;
 #pragma unroll
             for (int eg = 0; eg < 4; ++eg) {
                 const float4 l4 = *reinterpret_cast<const float4*>(&lse_l[32 * qb + 8 * eg + 4 * h]);
@@ -397,9 +415,14 @@ __global__ void __launch_bounds__(NW * 64, D == 64 ? 2 : 1) attn_bwd_dkv_kernel(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int e = 4 * eg + j;
-                    const int qq = qt * QT + 32 * qb + 8 * eg + 4 * h + j;
-                    const bool ok = klive && (!p.causal || key <= qq);
-                    const float pe = ok ? __builtin_amdgcn_exp2f(s[e] * sl2 - ll[j]) : 0.f;
+                    float pe;
+                    if (full) {
+                        pe = __builtin_amdgcn_exp2f(s[e] * sl2 - ll[j]);
+                    } else {
+                        const int qq = qt * QT + 32 * qb + 8 * eg + 4 * h + j;
+                        const bool ok = klive && (!p.causal || key <= qq);
+                        pe = ok ? __builtin_amdgcn_exp2f(s[e] * sl2 - ll[j]) : 0.f;
+                    }
                     pr[e] = pe; s[e] = pe * (dp[e] - dd[j]);
                 }
             }
