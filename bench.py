@@ -75,6 +75,8 @@ def main():
         else:
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
+    if os.environ.get('DPIPE_MIOPEN_BENCHMARK', '0') == '1':
+        torch.backends.cudnn.benchmark = True          # MIOpen exhaustive solver search per convolution shape (A/B switch)
     from diffusion_pipe_amd import hip, ops
     from diffusion_pipe_amd.data import split_batch
     from diffusion_pipe_amd.engine import ManualPipelineModule, initialize

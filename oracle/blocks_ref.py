@@ -93,3 +93,84 @@ def wan_head(p, x, e, eps):
     """models/wan/model.py:332-343.  e: [B, 1, C]."""
     e = (p['modulation'].unsqueeze(0) + e.unsqueeze(2)).chunk(2, dim=2)
     return F.linear(layer_norm(x, eps) * (1 + e[1].squeeze(2)) + e[0].squeeze(2), p['head.weight'], p['head.bias'])
+
+
+# ---- MMDiT blocks (Flux / HunyuanVideo / HunyuanImage).  PARITY UNPINNED: the dataflow follows the reference's in-tree
+# models/hunyuan_image_modeling.py:61-345, its helpers are restated from the un-vendored hyimage package. -----------------
+def modulate(x, shift, scale):
+    """[3P] hyimage modulate_layers.modulate: x * (1 + scale[:, None]) + shift[:, None]."""
+    return x * (1 + scale.unsqueeze(1)) + shift.unsqueeze(1)
+
+
+def apply_gate(x, gate):
+    """[3P] hyimage modulate_layers.apply_gate."""
+    return x * gate.unsqueeze(1)
+
+
+def apply_rotary_interleaved(x, cos, sin):
+    """[3P] hyimage posemb_layers.apply_rotary_emb(use_real=True): x * cos + rotate_half(x) * sin on interleaved pairs, with
+    the [S, d] tables given here as their distinct halves [S, d/2]."""
+    c = cos.repeat_interleave(2, dim=-1)[None, :, None, :]
+    s = sin.repeat_interleave(2, dim=-1)[None, :, None, :]
+    xr, xi = x.float().reshape(*x.shape[:-1], -1, 2).unbind(-1)
+    rot = torch.stack([-xi, xr], dim=-1).flatten(3)
+    return (x.float() * c + rot * s).to(x.dtype)
+
+
+def _mm_attention(q, k, v, kv_len):
+    """models/hunyuan_image_modeling.py:20-58 (flash_attn_no_pad with the padded text keys masked)."""
+    B, S = q.shape[0], k.shape[1]
+    mask = None
+    if kv_len is not None:
+        mask = (torch.arange(S)[None, :] < kv_len[:, None])[:, None, None, :]
+    o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), attn_mask=mask)
+    return o.transpose(1, 2).reshape(B, q.shape[1], -1)
+
+
+def _stream_qkv(p, s, x, shift, scale, heads, cos, sin):
+    h = modulate(layer_norm(x, 1e-6), shift, scale)
+    qkv = F.linear(h, p[f'{s}_attn_qkv.weight'], p.get(f'{s}_attn_qkv.bias'))
+    q, k, v = qkv.view(qkv.shape[0], qkv.shape[1], 3, heads, -1).unbind(2)
+    q, k = rms_norm(q, p[f'{s}_attn_q_norm.weight'], 1e-6), rms_norm(k, p[f'{s}_attn_k_norm.weight'], 1e-6)
+    if cos is not None:
+        q, k = apply_rotary_interleaved(q, cos, sin), apply_rotary_interleaved(k, cos, sin)
+    return q, k, v
+
+
+def _mlp(p, prefix, x):
+    return F.linear(F.gelu(F.linear(x, p[f'{prefix}.fc1.weight'], p[f'{prefix}.fc1.bias']), approximate='tanh'), p[f'{prefix}.fc2.weight'], p[f'{prefix}.fc2.bias'])
+
+
+def mm_double_block(p, img, txt, vec, heads, cos=None, sin=None, text_len=None):
+    """models/hunyuan_image_modeling.py:148-240."""
+    i = F.linear(F.silu(vec), p['img_mod.linear.weight'], p['img_mod.linear.bias']).chunk(6, dim=-1)
+    t = F.linear(F.silu(vec), p['txt_mod.linear.weight'], p['txt_mod.linear.bias']).chunk(6, dim=-1)
+    iq, ik, iv = _stream_qkv(p, 'img', img, i[0], i[1], heads, cos, sin)
+    tq, tk, tv = _stream_qkv(p, 'txt', txt, t[0], t[1], heads, None, None)
+    Si = img.shape[1]
+    kv_len = text_len + Si if text_len is not None else None
+    attn = _mm_attention(torch.cat([iq, tq], 1), torch.cat([ik, tk], 1), torch.cat([iv, tv], 1), kv_len)
+    img_attn, txt_attn = attn[:, :Si], attn[:, Si:]
+    img = img + apply_gate(F.linear(img_attn, p['img_attn_proj.weight'], p.get('img_attn_proj.bias')), i[2])
+    img = img + apply_gate(_mlp(p, 'img_mlp', modulate(layer_norm(img, 1e-6), i[3], i[4])), i[5])
+    txt = txt + apply_gate(F.linear(txt_attn, p['txt_attn_proj.weight'], p.get('txt_attn_proj.bias')), t[2])
+    txt = txt + apply_gate(_mlp(p, 'txt_mlp', modulate(layer_norm(txt, 1e-6), t[3], t[4])), t[5])
+    return img, txt
+
+
+def mm_single_block(p, x, vec, txt_len, heads, cos=None, sin=None, text_len=None):
+    """models/hunyuan_image_modeling.py:305-345."""
+    hidden = x.shape[-1]
+    shift, scale, gate = F.linear(F.silu(vec), p['modulation.linear.weight'], p['modulation.linear.bias']).chunk(3, dim=-1)
+    h = F.linear(modulate(layer_norm(x, 1e-6), shift, scale), p['linear1.weight'], p['linear1.bias'])
+    qkv, mlp = torch.split(h, [3 * hidden, h.shape[-1] - 3 * hidden], dim=-1)
+    q, k, v = qkv.reshape(qkv.shape[0], qkv.shape[1], 3, heads, -1).unbind(2)
+    q, k = rms_norm(q, p['q_norm.weight'], 1e-6), rms_norm(k, p['k_norm.weight'], 1e-6)
+    Si = x.shape[1] - txt_len
+    if cos is not None:
+        q = torch.cat([apply_rotary_interleaved(q[:, :Si], cos, sin), q[:, Si:]], 1)
+        k = torch.cat([apply_rotary_interleaved(k[:, :Si], cos, sin), k[:, Si:]], 1)
+    kv_len = text_len + Si if text_len is not None else None
+    attn = _mm_attention(q, k, v, kv_len)
+    out = F.linear(torch.cat([attn, F.gelu(mlp, approximate='tanh')], dim=2), p['linear2.weight'], p['linear2.bias'])
+    return x + apply_gate(out, gate)
