@@ -495,6 +495,12 @@ class PipelineEngine:
                 loaded = feats.clone().detach().to(self.device)
             else:
                 loaded = tuple(x.clone().detach().to(self.device) for x in feats)
+            if getattr(self.module, 'activation_checkpoint_interval', 0) > 0 and not self._eval_mode:
+                # like DeepSpeed's _exec_load_micro_batch under activation checkpointing: Function-style (reentrant) checkpoint
+                # wrappers -- unsloth_checkpoint / offloaded_checkpoint -- only build a backward node when an input needs one
+                for x in _as_list(loaded):
+                    if x.is_floating_point():
+                        x.requires_grad_(True)
             self.pipe_buffers['inputs'][buffer_id] = loaded
         if self.is_last_stage():
             labels = batch[1]

@@ -109,7 +109,7 @@ FUSE_GRAD_ACCUM = False
 
 
 def _accum_target(param):
-    if not FUSE_GRAD_ACCUM or param is None:
+    if not FUSE_GRAD_ACCUM or param is None or not param.is_leaf:
         return None
     g = param.grad
     if g is None or g.dtype != param.dtype or not g.is_contiguous() or g.shape != param.shape:

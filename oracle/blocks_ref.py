@@ -174,3 +174,31 @@ def mm_single_block(p, x, vec, txt_len, heads, cos=None, sin=None, text_len=None
     attn = _mm_attention(q, k, v, kv_len)
     out = F.linear(torch.cat([attn, F.gelu(mlp, approximate='tanh')], dim=2), p['linear2.weight'], p['linear2.bias'])
     return x + apply_gate(out, gate)
+
+
+# ---- whole Wan t2v model as the pipeline runs it (models/wan/wan.py:414-546, models/wan/model.py:449-518) -----------------
+def wan_forward(p, cfg, x_t, t, text_embeddings, seq_lens):
+    """p: dict of WanModel parameters (reference names); equal grids, cached text embeddings.  Returns [B, C, F, H, W]."""
+    B = x_t.shape[0]
+    x = F.conv3d(x_t, p['patch_embedding.weight'], p['patch_embedding.bias'], stride=cfg.patch_size)
+    grid = tuple(x.shape[2:])
+    x = x.flatten(2).transpose(1, 2)
+    e = sinusoidal_embedding_1d(cfg.freq_dim, t.flatten())
+    e = F.linear(F.silu(F.linear(e, p['time_embedding.0.weight'], p['time_embedding.0.bias'])), p['time_embedding.2.weight'], p['time_embedding.2.bias']).unsqueeze(1)
+    e0 = F.linear(F.silu(e), p['time_projection.1.weight'], p['time_projection.1.bias']).unflatten(2, (6, cfg.dim))
+    ctx = torch.stack([torch.cat([u[:n], u.new_zeros(cfg.text_len - n, u.shape[1])]) for u, n in zip(text_embeddings, seq_lens.tolist())])
+    ctx = F.linear(F.gelu(F.linear(ctx, p['text_embedding.0.weight'], p['text_embedding.0.bias']), approximate='tanh'),
+                   p['text_embedding.2.weight'], p['text_embedding.2.bias'])
+    d = cfg.dim // cfg.num_heads
+    theta = lambda n: torch.outer(torch.arange(1024, dtype=torch.float32), 1.0 / torch.pow(10000.0, torch.arange(0, n, 2, dtype=torch.float32) / n))  # noqa: E731
+    ang = torch.cat([theta(d - 4 * (d // 6)), theta(2 * (d // 6)), theta(2 * (d // 6))], dim=1)          # models/wan/model.py:29-37,478-483
+    cos, sin = rope_tables(torch.cos(ang), torch.sin(ang), grid)
+    for i in range(cfg.num_layers):
+        bp = {k[len(f'blocks.{i}.'):]: v for k, v in p.items() if k.startswith(f'blocks.{i}.')}
+        x = wan_block(bp, x, e0, ctx, cfg.num_heads, cos, sin, cfg.eps)
+    hp = {k[len('head.'):]: v for k, v in p.items() if k.startswith('head.')}
+    x = wan_head(hp, x, e.squeeze(1).unsqueeze(1), cfg.eps)
+    f, h, w = grid
+    pt, ph, pw = cfg.patch_size
+    u = x.view(B, f, h, w, pt, ph, pw, cfg.out_dim)
+    return torch.einsum('bfhwpqrc->bcfphqwr', u).reshape(B, cfg.out_dim, f * pt, h * ph, w * pw)

@@ -230,3 +230,33 @@ def test_microbatch_loader_epoch_tracking():
     assert seen == [0, 0, 1, 1, 2, 2]
     assert loader.epoch == 2                         # epoch advances as soon as the final micro-batch is returned
     assert next(loader)[0][0][0, 0].item() == 0
+
+
+def test_offloaded_checkpoint_recomputes_like_plain_autograd():
+    """activation_checkpoint_func = offloaded_checkpoint (the reference's unsloth_checkpoint contract, utils/unsloth_utils.py:
+    24-79): same outputs and gradients as running the function directly; `no_backward` arguments come back as None."""
+    from diffusion_pipe_amd.engine import offloaded_checkpoint
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(8, 8)
+    seen = []
+
+    def fn(x, aux, flag):
+        seen.append(flag is None)
+        y = torch.tanh(lin(x)) * (aux if aux is not None else 1.0)
+        return y, aux
+
+    x = torch.randn(4, 8, requires_grad=True)
+    aux = torch.full((4, 8), 2.0, requires_grad=True)
+    flag = torch.ones(1)
+    flag.no_backward = True
+    y, _ = offloaded_checkpoint(fn, x, aux, flag)
+    y.square().sum().backward()
+    got = (x.grad.clone(), aux.grad.clone(), lin.weight.grad.clone())
+    x.grad = aux.grad = None
+    lin.weight.grad = None
+    y2, _ = fn(x, aux, flag)
+    y2.square().sum().backward()
+    assert torch.allclose(y, y2)
+    for a, b in zip(got, (x.grad, aux.grad, lin.weight.grad)):
+        assert torch.allclose(a, b, atol=1e-6)
+    assert seen[:2] == [False, True]        # forward saw the flag, the recomputation got None in its place

@@ -100,6 +100,16 @@ def test_sdxl_eval_batch_and_activation_checkpointing(gpu):
     eng2._configure_optimizer(lambda ps: torch.optim.SGD(ps, lr=0.0), [p for p in module.parameters()])
     assert abs(eng2.train_batch(iter(micro)).item() - base) / abs(base) < 1e-5
     assert abs(eng2.get_global_grad_norm().item() - engine.get_global_grad_norm().item()) / engine.get_global_grad_norm().item() < 1e-4
+    # checkpoint inputs parked in pinned host memory (the reference's activation_checkpointing = 'unsloth'); threshold lowered
+    # so that the tiny model's stage inputs actually travel over PCIe
+    from diffusion_pipe_amd.engine import offloaded_checkpoint
+    module = ManualPipelineModule(layers=work.to_layers(), num_stages=1, partition_method='uniform', loss_fn=work.get_loss_fn(),
+                                  activation_checkpoint_interval=1, checkpointable_layers=work.checkpointable_layers,
+                                  activation_checkpoint_func=partial(offloaded_checkpoint, threshold=1000))
+    eng3, _, _, _ = initialize(model=module, config={'gradient_accumulation_steps': len(micro), 'gradient_clipping': 1.0}, device=gpu)
+    eng3._configure_optimizer(lambda ps: torch.optim.SGD(ps, lr=0.0), [p for p in module.parameters()])
+    assert abs(eng3.train_batch(iter(micro)).item() - base) / abs(base) < 1e-5
+    assert abs(eng3.get_global_grad_norm().item() - engine.get_global_grad_norm().item()) / engine.get_global_grad_norm().item() < 1e-4
 
 
 def test_concurrent_micro_batch_lanes_match_sequential_graph_path(gpu):
