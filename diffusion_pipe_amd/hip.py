@@ -45,6 +45,9 @@ _SIGNATURES = {
     'dpipe_lnmod_fwd': (I, [P, P, P, P, P, P, P, P, L, I, L, F, I, I, I, P]),
     'dpipe_lnmod_workspace_floats': (I, [L, I, L]),
     'dpipe_lnmod_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, L, I, I, I, I, P]),
+    'dpipe_groupnorm_workspace_floats': (L, [L, I, L, I]),
+    'dpipe_groupnorm_fwd': (I, [P, P, P, P, P, P, P, L, I, L, I, F, I, I, I, P]),
+    'dpipe_groupnorm_bwd': (I, [P, P, P, P, P, P, P, P, P, P, L, I, L, I, I, I, I, I, P]),
     'dpipe_rope': (I, [P, P, P, P, L, L, L, I, I, I, I, P]),
     'dpipe_softmax_fwd': (I, [P, P, L, I, L, F, I, I, P]),
     'dpipe_softmax_bwd': (I, [P, P, P, L, I, L, F, I, P]),

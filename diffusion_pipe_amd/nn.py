@@ -12,6 +12,9 @@ from torch import nn
 
 from . import ops
 
+import os as _os
+_ATEN_GROUPNORM = _os.environ.get('DPIPE_ATEN_GROUPNORM', '0') == '1'
+
 
 class Linear(nn.Module):
     def __init__(self, in_features, out_features, bias=True, device=None, dtype=None):
@@ -44,6 +47,22 @@ class LayerNorm(nn.Module):
     def forward(self, x, scale=None, shift=None):
         """Optionally fused AdaLN modulation: LN(x) * (1 + scale) + shift."""
         return ops.layer_norm_modulate(x, self.weight, self.bias, scale, shift, self.eps)
+
+
+class GroupNorm(nn.Module):
+    """nn.GroupNorm (same parameter names) on the HIP kernels, optionally fused with the SiLU that follows it."""
+
+    def __init__(self, num_groups, num_channels, eps=1e-5, affine=True, device=None, dtype=None):
+        super().__init__()
+        self.num_groups, self.num_channels, self.eps = num_groups, num_channels, eps
+        self.weight = nn.Parameter(torch.ones(num_channels, device=device, dtype=dtype)) if affine else None
+        self.bias = nn.Parameter(torch.zeros(num_channels, device=device, dtype=dtype)) if affine else None
+
+    def forward(self, x, act=None):
+        if _ATEN_GROUPNORM:     # A/B switch (DPIPE_ATEN_GROUPNORM=1): ATen's GroupNorm + the separate SiLU kernel
+            y = torch.nn.functional.group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
+            return ops.silu(y) if act == 'silu' else y
+        return ops.group_norm(x, self.num_groups, self.weight, self.bias, self.eps, act)
 
 
 class RMSNorm(nn.Module):

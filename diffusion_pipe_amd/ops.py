@@ -564,6 +564,56 @@ def layer_norm_modulate(x, gamma=None, beta=None, scale=None, shift=None, eps=1e
     return _LNModFn.apply(x, gamma, beta, scale, shift, eps)
 
 
+class _GroupNormFn(Function):
+    """nn.GroupNorm(G, C) on NCHW (+ fused SiLU): diffusers ResnetBlock2D / Transformer2DModel norms behind models/sdxl.py:797-865."""
+
+    @staticmethod
+    def forward(ctx, x, num_groups, weight, bias, eps, act):
+        require_cuda(x, weight, bias)
+        xc = _contig(x)
+        N, C = xc.shape[0], xc.shape[1]
+        HW = xc.numel() // (N * C)
+        y = torch.empty_like(xc)
+        mean = torch.empty(N * num_groups, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        ws = torch.empty(lib().dpipe_groupnorm_workspace_floats(N, C, HW, num_groups), device=x.device, dtype=torch.float32)
+        wdt = dtype_code(weight.dtype) if weight is not None else dtype_code(x.dtype)
+        check(lib().dpipe_groupnorm_fwd(ptr(xc), ptr(weight), ptr(bias), ptr(y), ptr(mean), ptr(rstd), ptr(ws), N, C, HW, num_groups, float(eps),
+                                        ACT[act], dtype_code(x.dtype), wdt, stream()), 'groupnorm_fwd')
+        ctx.save_for_backward(xc, weight, bias, mean, rstd)
+        ctx.meta = (num_groups, act, wdt)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xc, weight, bias, mean, rstd = ctx.saved_tensors
+        G, act, wdt = ctx.meta
+        N, C = xc.shape[0], xc.shape[1]
+        HW = xc.numel() // (N * C)
+        gy = _contig(gy)
+        gx = torch.empty_like(xc)
+        fused = False
+        dgamma = dbeta = None
+        if weight is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]):
+            tg, tb = _accum_target(weight), _accum_target(bias)
+            if tg is not None and (bias is None or tb is not None):
+                dgamma, dbeta, fused = tg, tb, True
+            else:
+                dgamma = torch.empty_like(weight)
+                dbeta = torch.empty_like(bias) if bias is not None else None
+        ws = torch.empty(lib().dpipe_groupnorm_workspace_floats(N, C, HW, G), device=xc.device, dtype=torch.float32)
+        check(lib().dpipe_groupnorm_bwd(ptr(xc), ptr(gy), ptr(weight), ptr(bias), ptr(mean), ptr(rstd), ptr(gx), ptr(dgamma), ptr(dbeta), ptr(ws),
+                                        N, C, HW, G, ACT[act], dtype_code(xc.dtype), wdt, int(fused), stream()), 'groupnorm_bwd')
+        if fused:
+            dgamma = dbeta = None
+        return gx, None, dgamma, dbeta, None, None
+
+
+def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, act=None):
+    """x: [N, C, *spatial] contiguous; act: None or 'silu' (applied to the normalised, affine-transformed value)."""
+    return _GroupNormFn.apply(x, num_groups, weight, bias, eps, act)
+
+
 # ------------------------------------------------------------------------------------------------- RoPE (K3)
 class _RopeFn(Function):
     """Rotary embedding on [B, S, H, D] with fp32 cos/sin tables [S, D/2] (models/wan/model.py:40-67)."""

@@ -172,19 +172,19 @@ class CLIPTextModel(nn.Module):
 class ResnetBlock2D(nn.Module):
     def __init__(self, in_ch, out_ch, temb_ch, groups=32, eps=1e-5):
         super().__init__()
-        self.norm1 = nn.GroupNorm(groups, in_ch, eps=eps)
+        self.norm1 = dnn.GroupNorm(groups, in_ch, eps=eps)
         self.conv1 = nn.Conv2d(in_ch, out_ch, 3, padding=1)
         self.time_emb_proj = dnn.Linear(temb_ch, out_ch)
-        self.norm2 = nn.GroupNorm(groups, out_ch, eps=eps)
+        self.norm2 = dnn.GroupNorm(groups, out_ch, eps=eps)
         self.conv2 = nn.Conv2d(out_ch, out_ch, 3, padding=1)
         self.nonlinearity = dnn.SiLU()
         self.conv_shortcut = nn.Conv2d(in_ch, out_ch, 1) if in_ch != out_ch else None
 
     def forward(self, x, temb):
-        h = self.conv1(self.nonlinearity(self.norm1(x)))
+        h = self.conv1(self.norm1(x, act='silu'))                     # GroupNorm + SiLU in one pass
         t = self.time_emb_proj(self.nonlinearity(temb))[:, :, None, None]
         h = h + t.to(h.dtype)
-        h = self.conv2(self.nonlinearity(self.norm2(h)))
+        h = self.conv2(self.norm2(h, act='silu'))
         if self.conv_shortcut is not None:
             x = self.conv_shortcut(x)
         return x + h
@@ -210,7 +210,7 @@ class Transformer2DModel(nn.Module):
     def __init__(self, heads, head_dim, in_ch, num_layers, cross_dim, groups=32):
         super().__init__()
         inner = heads * head_dim
-        self.norm = nn.GroupNorm(groups, in_ch, eps=1e-6)
+        self.norm = dnn.GroupNorm(groups, in_ch, eps=1e-6)
         self.proj_in = dnn.Linear(in_ch, inner)
         self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, heads, head_dim, cross_dim) for _ in range(num_layers)])
         self.proj_out = dnn.Linear(inner, in_ch)
@@ -307,7 +307,7 @@ class UNet2DConditionModel(nn.Module):
         self.up_blocks = nn.ModuleList(up)
         self.num_upsamplers = len(ch) - 1
 
-        self.conv_norm_out = nn.GroupNorm(g, ch[0], eps=1e-5)
+        self.conv_norm_out = dnn.GroupNorm(g, ch[0], eps=1e-5)
         self.conv_act = dnn.SiLU()
         self.conv_out = nn.Conv2d(ch[0], c.in_channels, 3, padding=1)
 
@@ -447,7 +447,7 @@ class FinalLayer(nn.Module):
 
     def forward(self, inputs):
         h, ts, emb, ctx, skips, fus = _unpack(inputs)
-        return self.conv_out(self.conv_act(self.conv_norm_out(h))), ts
+        return self.conv_out(self.conv_norm_out(h, act='silu')), ts
 
 
 # -------------------------------------------------------------------------------------------------- the adapter

@@ -111,6 +111,19 @@ int dpipe_lnmod_bwd(const void* x, const void* gy, const void* gamma, const void
                     void* dshift, float* workspace, long rows, int cols, long rows_per_mod, int dtype, int wdtype,
                     int mdtype, int accumulate_params, void* stream);   /* accumulate_params: dgamma / dbeta += */
 
+/* ---- GroupNorm (+ fused SiLU) on NCHW activations: nn.GroupNorm(G, C) of the diffusers ResnetBlock2D / Transformer2DModel
+ * behind models/sdxl.py:797-865 (and the SiLU that follows it in the resnets).  x, y, dy, dx: [N, C, HW] contiguous, HW a
+ * multiple of the 16-byte vector; gamma / beta [C] (NULL = no affine); mean / rstd [N * G] fp32 saved for backward;
+ * act: DPIPE_ACT_NONE or DPIPE_ACT_SILU; workspace: dpipe_groupnorm_workspace_floats() floats.
+ * bwd: dgamma / dbeta may be NULL; accumulate_params != 0 adds into them (fused gradient accumulation). */
+long dpipe_groupnorm_workspace_floats(long N, int C, long HW, int G);
+int dpipe_groupnorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
+                        float* workspace, long N, int C, long HW, int G, float eps, int act, int dtype, int wdtype,
+                        void* stream);
+int dpipe_groupnorm_bwd(const void* x, const void* dy, const void* gamma, const void* beta, const float* mean,
+                        const float* rstd, void* dx, void* dgamma, void* dbeta, float* workspace, long N, int C, long HW,
+                        int G, int act, int dtype, int wdtype, int accumulate_params, void* stream);
+
 /* ---- K3 RoPE (models/wan/model.py:40-67 rope_apply; Flux/HunyuanVideo cos/sin tables) -------------------------
  * x, y: [B, S, H, D] contiguous; cos/sin: [S, D/2] fp32.  interleaved=1 rotates pairs (2i, 2i+1) (view_as_complex),
  * interleaved=0 rotates (i, i + D/2).  conj=1 applies the inverse rotation (the backward pass). */

@@ -574,3 +574,34 @@ def test_linear_residual_epilogue_and_fused_bias_gradient(gpu, dtype, tokens):
         ops.FUSE_GRAD_ACCUM = ops.FUSE_BIAS_GRAD = False
     assert _rel_err(w.grad, wr.grad) < _tol(dtype) * 1.5
     assert _rel_err(b.grad, br.grad) < _tol(dtype) * 1.5
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('act', [None, 'silu'])
+@pytest.mark.parametrize('shape', [(2, 64, 16, 16), (1, 320, 32, 32), (1, 1280, 32, 32), (1, 960, 64, 64), (3, 32, 8, 8)])
+def test_group_norm_fused_silu(gpu, dtype, act, shape):
+    """nn.GroupNorm(32, C) (+ SiLU) forward / backward on NCHW vs PyTorch fp32, incl. in-kernel parameter-gradient accumulation."""
+    from diffusion_pipe_amd import ops
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(C + H)
+    x = (torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3).to(gpu, dtype).requires_grad_(True)
+    w = (torch.rand(C, generator=g) + 0.5).to(gpu, dtype).requires_grad_(True)
+    b = (torch.randn(C, generator=g) * 0.3).to(gpu, dtype).requires_grad_(True)
+    gy = torch.randn(N, C, H, W, generator=g).to(gpu, dtype)
+    y = ops.group_norm(x, 32, w, b, 1e-5, act)
+    y.backward(gy)
+    xr, wr, br = (t.detach().float().requires_grad_(True) for t in (x, w, b))
+    yr = F.group_norm(xr, 32, wr, br, 1e-5)
+    if act == 'silu':
+        yr = F.silu(yr)
+    yr.backward(gy.float())
+    tol = _tol(dtype)
+    assert _rel_err(y, yr) < tol and _rel_err(x.grad, xr.grad) < tol * 1.5
+    assert _rel_err(w.grad, wr.grad) < tol * 1.5 and _rel_err(b.grad, br.grad) < tol * 1.5
+    # second micro-batch accumulates into the existing .grad inside the kernel
+    ops.FUSE_GRAD_ACCUM = True
+    try:
+        ops.group_norm(x, 32, w, b, 1e-5, act).backward(gy)
+    finally:
+        ops.FUSE_GRAD_ACCUM = False
+    assert _rel_err(w.grad, 2 * wr.grad) < tol * 2 and _rel_err(b.grad, 2 * br.grad) < tol * 2
