@@ -23,6 +23,12 @@ from .module import PipelineModule
 from .p2p import HostStagedLink, StageLink
 
 
+def _capture_mode():
+    """hipGraph capture error mode: with a process group alive, RCCL's watchdog thread issues (harmless) event queries while
+    this thread captures -- only calls of the capturing thread may invalidate the capture then."""
+    return 'thread_local' if (dist.is_available() and dist.is_initialized()) else 'global'
+
+
 def _is_float(t):
     return torch.is_tensor(t) and t.is_floating_point()
 
@@ -347,7 +353,7 @@ class PipelineEngine:
         cur.wait_stream(side)
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode=_capture_mode()):
             body()
         # undo the warm-up's side effects: gradient buffers stay allocated (persistent, addresses baked into the
         # graph); parameters that receive no gradient keep grad = None like the eager path.
@@ -426,11 +432,11 @@ class PipelineEngine:
         static_in = make_inputs()
         fwd_graph, bwd_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         _ops.WS_LANE = 'stage-fwd'                  # forward and backward graphs replay on different streams at the same time:
-        with torch.cuda.graph(fwd_graph):           # they must not share split-K ticket counters / slabs
+        with torch.cuda.graph(fwd_graph, capture_error_mode=_capture_mode()):   # they must not share split-K ticket counters / slabs
             out = forward(static_in)
         static_gout = None if last else grads_like(out)
         _ops.WS_LANE = 'stage-bwd'
-        with torch.cuda.graph(bwd_graph, pool=fwd_graph.pool()):
+        with torch.cuda.graph(bwd_graph, pool=fwd_graph.pool(), capture_error_mode=_capture_mode()):
             backward(out, static_gout)
         _ops.WS_LANE = None
         # undo the side effects of warm-up / capture on the accumulators
