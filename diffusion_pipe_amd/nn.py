@@ -37,6 +37,79 @@ class Linear(nn.Module):
         return f'in_features={self.in_features}, out_features={self.out_features}, bias={self.bias is not None}'
 
 
+class LoRALinear(nn.Module):
+    """LoRA-wrapped Linear, the restatement of peft's `lora.Linear` the reference trains adapters with
+    (models/base.py:272-297, models/sdxl.py:431-459; peft is an un-vendored dependency, requirements.txt:9):
+
+        y = base_layer(x) + lora_B(lora_A(dropout(x))) * (alpha / r)
+
+    Module / parameter names follow peft (`base_layer`, `lora_A.<adapter>`, `lora_B.<adapter>`), so a peft state dict
+    loads unchanged.  lora_A uses nn.Linear's default init, lora_B starts at zero.  The base weight is frozen, so its wgrad
+    GEMM disappears from the backward pass; the up-projection adds into the base output inside its GEMM epilogue."""
+
+    def __init__(self, base_layer, rank, alpha, dropout=0.0, dtype=None, adapter_name='default'):
+        super().__init__()
+        dev = base_layer.weight.device
+        dtype = dtype or base_layer.weight.dtype
+        self.base_layer = base_layer
+        self.in_features, self.out_features = base_layer.in_features, base_layer.out_features
+        self.r, self.lora_alpha, self.scaling, self.adapter_name = rank, alpha, alpha / rank, adapter_name
+        self.dropout_p = float(dropout)
+        self.lora_A = nn.ModuleDict({adapter_name: Linear(self.in_features, rank, bias=False, device=dev, dtype=dtype)})
+        self.lora_B = nn.ModuleDict({adapter_name: Linear(rank, self.out_features, bias=False, device=dev, dtype=dtype)})
+        nn.init.zeros_(self.lora_B[adapter_name].weight)
+        for p in base_layer.parameters():
+            p.requires_grad_(False)
+
+    @property
+    def weight(self):
+        return self.base_layer.weight
+
+    @property
+    def bias(self):
+        return self.base_layer.bias
+
+    def forward(self, x, residual=None):
+        y = self.base_layer(x, residual)
+        A, B = self.lora_A[self.adapter_name], self.lora_B[self.adapter_name]
+        h = x
+        if self.dropout_p > 0.0 and self.training:
+            h = torch.nn.functional.dropout(h, self.dropout_p)
+        h = A(h)
+        if self.scaling != 1.0:
+            h = h * self.scaling
+        if B.weight.dtype == y.dtype:
+            return B(h, y)                    # y + h B^T: the add rides the up-projection's epilogue
+        return y + B(h).to(y.dtype)
+
+    def extra_repr(self):
+        return f'r={self.r}, alpha={self.lora_alpha}, dropout={self.dropout_p}'
+
+
+def apply_lora(root, rank, alpha, dropout=0.0, dtype=None, target=None, adapter_name='default'):
+    """Wrap Linear layers under `root` with LoRALinear and freeze everything else (what `peft.get_peft_model` /
+    diffusers' `add_adapter` do for the reference).  `target(name, module) -> bool` restricts the wrapped layers (the
+    reference targets every nn.Linear inside the adapter's `adapter_target_modules` classes, models/base.py:262-270).
+    Returns the names of the wrapped layers."""
+    sites = []
+    for name, module in root.named_modules():
+        for child_name, child in module.named_children():
+            full = f'{name}.{child_name}' if name else child_name
+            if type(child) is Linear and (target is None or target(full, child)):
+                sites.append((module, child_name, child, full))
+    for p in root.parameters():
+        p.requires_grad_(False)
+    for parent, child_name, child, _ in sites:
+        parent._modules[child_name] = LoRALinear(child, rank, alpha, dropout, dtype, adapter_name)
+    return [full for *_, full in sites]
+
+
+def lora_state_dict(root, adapter_name='default'):
+    """The adapter's tensors keyed like peft's `get_peft_model_state_dict` (adapter name stripped)."""
+    tag = f'.{adapter_name}.'
+    return {k.replace(tag, '.'): v for k, v in root.state_dict().items() if '.lora_A.' in k or '.lora_B.' in k}
+
+
 class LayerNorm(nn.Module):
     def __init__(self, dim, eps=1e-5, elementwise_affine=True, bias=True, device=None, dtype=None):
         super().__init__()
@@ -142,7 +215,8 @@ class Attention(nn.Module):
     def forward(self, hidden_states, encoder_hidden_states=None, residual=None):
         B, S, _ = hidden_states.shape
         H, D = self.heads, self.dim_head
-        fused = self.fuse_projections and self.attn_impl == 'auto' and ops.flash_eligible(self.to_q.weight.dtype, D)
+        plain = type(self.to_q) is Linear and type(self.to_k) is Linear and type(self.to_v) is Linear     # no adapter wrapped around them
+        fused = plain and self.fuse_projections and self.attn_impl == 'auto' and ops.flash_eligible(self.to_q.weight.dtype, D)
         if fused and encoder_hidden_states is None:         # self attention: one QKV GEMM, packed attention
             qkv = ops.fused_linear(hidden_states, [self.to_q.weight, self.to_k.weight, self.to_v.weight],
                                    [self.to_q.bias, self.to_k.bias, self.to_v.bias])

@@ -1,0 +1,132 @@
+"""Optimizer / LR-schedule factory of the training step.
+
+Mirrors what the reference's `train.py` builds around `model_engine._configure_optimizer`:
+  * `get_optimizer(model_parameters)` (train.py:650-815): stages without trainable parameters get a no-op optimizer
+    (`DummyOptimizer`, train.py:61-76); `beta2_half_life` -> beta2 = 0.5 ** (global_batch / half_life); the adapter's
+    `get_param_groups()` decides per-component learning rates (models/sdxl.py:604-630); every group is then split into a
+    weight-decay group and a no-weight-decay group (1-D parameters and `llm_adapter.embed*`, train.py:791-813).
+  * LR schedule (train.py:849-862): constant / linear / cosine, optional linear warm-up chained with SequentialLR.
+The update itself stays a PyTorch optimizer on the raw bf16 parameters, as in the reference (no fp32 master weights:
+the reference's ds_config has no fp16 / bf16 / ZeRO section, train.py:423-429).  On ROCm the `fused=True` multi-tensor
+AdamW is the fast path; optimizers that only exist as CUDA extensions in the reference (bitsandbytes 8-bit, optimi) are
+reported as unavailable instead of being silently replaced.
+"""
+from collections import defaultdict
+
+import torch
+
+_TORCH_OPTIMIZERS = {
+    'adamw': torch.optim.AdamW,
+    'sgd': torch.optim.SGD,
+    'adam': torch.optim.Adam,
+}
+_NEEDS_EXTERNAL = {
+    'adamw8bit': 'bitsandbytes', 'adamw_optimi': 'optimi', 'stableadamw': 'optimi', 'adamw8bitkahan': 'bitsandbytes',
+    'offload': 'torchao', 'automagic': None, 'genericoptim': None,
+}
+
+
+class DummyOptimizer(torch.optim.Optimizer):
+    """Optimizer of a pipeline stage that owns no trainable parameter (e.g. a stage of frozen layers under LoRA)."""
+
+    def __init__(self):
+        self.state = defaultdict(dict)
+        self.param_groups = []
+
+    def step(self, closure=None):
+        pass
+
+    def zero_grad(self, set_to_none=True):
+        pass
+
+    def state_dict(self):
+        return {}
+
+    def load_state_dict(self, state_dict):
+        pass
+
+
+def computed_beta2(global_batch_size, beta2_half_life):
+    """beta2 such that the second-moment EMA halves every `beta2_half_life` examples (train.py:658-663)."""
+    return 0.5 ** (global_batch_size / beta2_half_life)
+
+
+def split_weight_decay(param_groups):
+    """Each group -> [group with >= 2-D params, group with 1-D params and weight_decay = 0]; empty halves are dropped and
+    the with-decay half comes first (train.py:791-813)."""
+    out = []
+    for pg in param_groups:
+        pg = dict(pg)
+        params = pg.pop('params')
+        no_wd = [p for p in params if p.ndim == 1 or getattr(p, 'original_name', '').startswith('llm_adapter.embed')]
+        no_wd_ids = {id(p) for p in no_wd}
+        wd = [p for p in params if id(p) not in no_wd_ids]
+        if wd:
+            out.append(dict(pg, params=wd))
+        if no_wd:
+            out.append(dict(pg, params=no_wd, weight_decay=0))
+    return out
+
+
+def _optimizer_class(optim_type):
+    key = optim_type.lower()
+    if key in _TORCH_OPTIMIZERS:
+        return _TORCH_OPTIMIZERS[key]
+    if key in _NEEDS_EXTERNAL:
+        dep = _NEEDS_EXTERNAL[key]
+        raise NotImplementedError(f"optimizer type '{optim_type}' is not available in this ROCm build"
+                                  + (f" (the reference takes it from '{dep}', a CUDA-only extension)" if dep else ''))
+    if hasattr(torch.optim, optim_type):
+        return getattr(torch.optim, optim_type)
+    raise NotImplementedError(f'unknown optimizer type: {optim_type}')
+
+
+def make_optimizer_factory(config, workload, global_batch_size, device_is_gpu=True):
+    """-> get_optimizer(model_parameters), the callable handed to `engine._configure_optimizer` (train.py:817).
+
+    `config['optimizer']` is the reference's TOML table ({type, lr, betas, weight_decay, eps, beta2_half_life?, ...});
+    `workload.get_param_groups(params)` supplies the per-component groups (parameters carry `.original_name`)."""
+    optim_config = dict(config['optimizer'])
+
+    def get_optimizer(model_parameters):
+        model_parameters = list(model_parameters)
+        if len(model_parameters) == 0:
+            return DummyOptimizer()
+        cfg = dict(optim_config)
+        optim_type = cfg.pop('type')
+        if cfg.pop('gradient_release', False):
+            raise NotImplementedError('gradient_release (one optimizer step per micro-batch) is outside the train_batch hot path')
+        half_life = cfg.pop('beta2_half_life', None)
+        if half_life:
+            betas = list(cfg['betas'])
+            assert len(betas) == 2
+            betas[1] = computed_beta2(global_batch_size, half_life)
+            cfg['betas'] = betas
+        if 'betas' in cfg:
+            cfg['betas'] = tuple(cfg['betas'])
+        klass = _optimizer_class(optim_type)
+        if klass in (torch.optim.AdamW, torch.optim.Adam) and 'fused' not in cfg and 'foreach' not in cfg:
+            cfg['fused' if device_is_gpu else 'foreach'] = True       # one multi-tensor launch chain per step
+        groups = split_weight_decay(workload.get_param_groups(model_parameters))
+        return klass(groups, **cfg)
+
+    return get_optimizer
+
+
+def make_lr_scheduler(optimizer, config, steps_per_epoch):
+    """constant | linear | cosine (+ linear warm-up), train.py:849-862."""
+    kind = config.get('lr_scheduler', 'constant')
+    sched = torch.optim.lr_scheduler
+    if kind == 'constant':
+        main = sched.ConstantLR(optimizer, factor=1.0)
+    elif kind == 'linear':
+        main = sched.LinearLR(optimizer, start_factor=1.0, end_factor=0.0, total_iters=config['epochs'] * steps_per_epoch)
+    elif kind == 'cosine':
+        main = sched.CosineAnnealingLR(optimizer, T_max=config['epochs'] * steps_per_epoch, eta_min=1e-6)
+    else:
+        raise NotImplementedError(f'Unknown lr_scheduler: {kind}')
+    warmup = config.get('warmup_steps', 0)
+    if warmup > 0:
+        ramp = sched.LinearLR(optimizer, start_factor=1 / warmup, total_iters=warmup)
+        main = sched.SequentialLR(optimizer, schedulers=[ramp, main], milestones=[warmup])
+    return main

@@ -82,7 +82,8 @@ class CLIPAttention(nn.Module):
 
     def forward(self, x, residual=None):
         B, S, C = x.shape
-        if ops.flash_eligible(self.q_proj.weight.dtype, self.head_dim):      # fused QKV GEMM + packed causal attention
+        plain = all(type(m) is dnn.Linear for m in (self.q_proj, self.k_proj, self.v_proj))    # False once an adapter wraps them
+        if plain and ops.flash_eligible(self.q_proj.weight.dtype, self.head_dim):      # fused QKV GEMM + packed causal attention
             qkv = ops.fused_linear(x, [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight],
                                    [self.q_proj.bias, self.k_proj.bias, self.v_proj.bias])
             return self.out_proj(ops.attention_packed(qkv, None, self.heads, self.head_dim, causal=True), residual)
@@ -460,6 +461,7 @@ class SDXLWorkload:
     def __init__(self, config: Optional[SDXLConfig] = None, model_config=None, dtype=torch.bfloat16, seed=0, device='cpu'):
         self.cfg = config or SDXLConfig()
         self.model_config = model_config or {}
+        self.train_config = {}            # the run's TOML dict (`config['optimizer']['lr']` is the base LR of get_param_groups)
         self.v_pred = self.model_config.get('v_pred', False)
         self.min_snr_gamma = self.model_config.get('min_snr_gamma', None)
         self.debiased_estimation_loss = self.model_config.get('debiased_estimation_loss', None)
@@ -481,6 +483,22 @@ class SDXLWorkload:
 
     def modules(self):
         return {'unet': self.unet, 'text_encoder': self.text_encoder, 'text_encoder_2': self.text_encoder_2}
+
+    def configure_adapter(self, adapter_config):
+        """LoRA on every Linear of the UNet's down / mid / up blocks and of both text encoders (models/sdxl.py:431-459);
+        everything else is frozen, adapter tensors take `adapter_config['dtype']`.  -> {component: wrapped layer names}."""
+        if adapter_config.get('type', 'lora') != 'lora':
+            raise NotImplementedError(f"Adapter type {adapter_config['type']} is not implemented")
+        kw = dict(rank=adapter_config['rank'], alpha=adapter_config['alpha'], dropout=adapter_config.get('dropout', 0.0),
+                  dtype=adapter_config.get('dtype'))
+        in_blocks = lambda name, module: name.split('.')[0] in ('down_blocks', 'mid_block', 'up_blocks')
+        wrapped = {}
+        for prefix, top, target in (('unet', self.unet, in_blocks), ('text_encoder', self.text_encoder, None),
+                                    ('text_encoder_2', self.text_encoder_2, None)):
+            wrapped[prefix] = dnn.apply_lora(top, target=target, **kw)
+            for n, p in top.named_parameters():
+                p.original_name = f'{prefix}.{n}'
+        return wrapped
 
     def to_layers(self):
         unet = self.unet
@@ -553,7 +571,7 @@ class SDXLWorkload:
                     break
             else:
                 raise RuntimeError(f'Unexpected parameter: {p.original_name}')
-        base_lr = self.model_config.get('lr')
+        base_lr = self.train_config.get('optimizer', {}).get('lr', self.model_config.get('lr'))
         out = []
         for prefix, key in (('unet.', 'unet_lr'), ('text_encoder.', 'text_encoder_1_lr'), ('text_encoder_2.', 'text_encoder_2_lr')):
             g = {'params': groups[prefix]}

@@ -252,6 +252,23 @@ class WanWorkload:
         self.t_dist = get_t_distribution(self.model_config)
         self._grid = None
 
+    adapter_target_modules = ['WanAttentionBlock']
+
+    def configure_adapter(self, adapter_config):
+        """LoRA on every Linear inside the `adapter_target_modules` blocks (models/base.py:262-297, models/wan/wan.py:70)."""
+        if adapter_config.get('type', 'lora') != 'lora':
+            raise NotImplementedError(f"Adapter type {adapter_config['type']} is not implemented")
+        inside = set()
+        for name, module in self.transformer.named_modules():
+            if module.__class__.__name__ in self.adapter_target_modules:
+                inside.update(f'{name}.{n}' for n, sub in module.named_modules() if n)
+        wrapped = dnn.apply_lora(self.transformer, rank=adapter_config['rank'], alpha=adapter_config['alpha'],
+                                 dropout=adapter_config.get('dropout', 0.0), dtype=adapter_config.get('dtype'),
+                                 target=lambda name, module: name in inside)
+        for n, p in self.transformer.named_parameters():
+            p.original_name = n
+        return wrapped
+
     def to_layers(self):
         m = self.transformer
         return [InitialLayer(m)] + [TransformerLayer(b) for b in m.blocks] + [FinalLayer(m, lambda L: self._grid)]

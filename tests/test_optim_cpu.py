@@ -1,0 +1,101 @@
+"""Optimizer / LR-schedule factory and the LoRA wrapping structure -- host logic only (no kernels run)."""
+import math
+
+import pytest
+import torch
+
+from diffusion_pipe_amd import nn as dnn
+from diffusion_pipe_amd import optim
+from diffusion_pipe_amd.workloads import sdxl
+
+
+def _workload():
+    work = sdxl.SDXLWorkload(sdxl.tiny_config(), model_config={'unet_lr': 4e-5, 'text_encoder_2_lr': 1e-6}, dtype=torch.float32)
+    work.train_config = {'optimizer': {'type': 'adamw', 'lr': 2e-5, 'betas': [0.9, 0.99], 'weight_decay': 0.01, 'eps': 1e-8}}
+    return work
+
+
+def test_stage_without_trainable_parameters_gets_noop_optimizer():
+    work = _workload()
+    opt = optim.make_optimizer_factory(work.train_config, work, global_batch_size=4, device_is_gpu=False)([])
+    assert isinstance(opt, optim.DummyOptimizer) and opt.param_groups == [] and opt.state_dict() == {}
+    opt.step()
+    opt.zero_grad()
+
+
+def test_param_groups_component_lrs_and_weight_decay_split():
+    work = _workload()
+    params = [p for m in work.modules().values() for p in m.parameters()]
+    opt = optim.make_optimizer_factory(work.train_config, work, global_batch_size=4, device_is_gpu=False)(params)
+    assert isinstance(opt, torch.optim.AdamW)
+    # 3 components x (decay, no-decay), decay half first; component order unet, text_encoder, text_encoder_2
+    got = [(g['lr'], g['weight_decay'], {p.original_name.split('.')[0] for p in g['params']}, {p.ndim == 1 for p in g['params']})
+           for g in opt.param_groups]
+    assert got == [(4e-5, 0.01, {'unet'}, {False}), (4e-5, 0, {'unet'}, {True}),
+                   (2e-5, 0.01, {'text_encoder'}, {False}), (2e-5, 0, {'text_encoder'}, {True}),
+                   (1e-6, 0.01, {'text_encoder_2'}, {False}), (1e-6, 0, {'text_encoder_2'}, {True})]
+    assert sum(len(g['params']) for g in opt.param_groups) == len(params)
+    assert all(g['betas'] == (0.9, 0.99) for g in opt.param_groups)
+    with pytest.raises(RuntimeError, match='Unexpected parameter'):
+        stray = torch.nn.Parameter(torch.zeros(2, 2))
+        stray.original_name = 'vae.x'
+        work.get_param_groups([stray])
+
+
+def test_beta2_half_life_and_unavailable_optimizers():
+    work = _workload()
+    cfg = {'optimizer': dict(work.train_config['optimizer'], beta2_half_life=2000)}
+    params = list(work.unet.parameters())
+    opt = optim.make_optimizer_factory(cfg, work, global_batch_size=16, device_is_gpu=False)(params)
+    assert math.isclose(opt.param_groups[0]['betas'][1], 0.5 ** (16 / 2000))
+    assert cfg['optimizer']['betas'] == [0.9, 0.99]          # the caller's config is not mutated between stages
+    for kind in ('AdamW8bit', 'adamw_optimi', 'StableAdamW'):
+        with pytest.raises(NotImplementedError, match='not available'):
+            optim.make_optimizer_factory({'optimizer': {'type': kind, 'lr': 1e-4}}, work, 4)(params)
+    sgd = optim.make_optimizer_factory({'optimizer': {'type': 'SGD', 'lr': 1e-3, 'momentum': 0.9}}, work, 4)(params)
+    assert isinstance(sgd, torch.optim.SGD)
+
+
+def test_lr_schedules():
+    p = torch.nn.Parameter(torch.zeros(3))
+
+    def lrs(config, steps):
+        opt = torch.optim.SGD([p], lr=1.0)
+        sched = optim.make_lr_scheduler(opt, config, steps_per_epoch=10)
+        out = []
+        for _ in range(steps):
+            out.append(opt.param_groups[0]['lr'])
+            opt.step()
+            sched.step()
+        return out
+    assert lrs({'warmup_steps': 0}, 3) == [1.0, 1.0, 1.0]
+    # LinearLR(start_factor=1/w, total_iters=w): factor_k = 1/w + (1 - 1/w) k / w -- the reference's warm-up, as torch defines it
+    assert lrs({'warmup_steps': 4}, 6) == pytest.approx([0.25, 0.4375, 0.625, 0.8125, 1.0, 1.0])
+    lin = lrs({'lr_scheduler': 'linear', 'epochs': 1, 'warmup_steps': 0}, 11)
+    assert lin[0] == 1.0 and lin[5] == pytest.approx(0.5) and lin[10] == pytest.approx(0.0)
+    cos = lrs({'lr_scheduler': 'cosine', 'epochs': 2, 'warmup_steps': 0}, 21)
+    assert cos[10] == pytest.approx(0.5 + 0.5e-6, rel=1e-4) and cos[20] == pytest.approx(1e-6)
+    with pytest.raises(NotImplementedError):
+        optim.make_lr_scheduler(torch.optim.SGD([p], lr=1.0), {'lr_scheduler': 'exotic'}, 10)
+
+
+def test_lora_wrapping_structure_follows_the_reference_targets():
+    work = sdxl.SDXLWorkload(sdxl.tiny_config(), dtype=torch.bfloat16)
+    n_linear = {k: sum(type(m) is dnn.Linear for m in mod.modules()) for k, mod in work.modules().items()}
+    wrapped = work.configure_adapter({'type': 'lora', 'rank': 4, 'alpha': 8, 'dropout': 0.0, 'dtype': torch.float32})
+    # text encoders: every Linear; UNet: only inside down / mid / up blocks (time / add embeddings stay plain)
+    assert len(wrapped['text_encoder']) == n_linear['text_encoder'] and len(wrapped['text_encoder_2']) == n_linear['text_encoder_2']
+    assert 0 < len(wrapped['unet']) < n_linear['unet']
+    assert all(n.split('.')[0] in ('down_blocks', 'mid_block', 'up_blocks') for n in wrapped['unet'])
+    assert type(work.unet.time_embedding.linear_1) is dnn.Linear
+    trainable = {p.original_name: p for m in work.modules().values() for p in m.parameters() if p.requires_grad}
+    assert len(trainable) == 2 * sum(len(v) for v in wrapped.values())
+    assert all(('.lora_A.default.' in n or '.lora_B.default.' in n) and p.dtype == torch.float32 for n, p in trainable.items())
+    name = 'unet.' + wrapped['unet'][0]
+    lora = work.unet.get_submodule(wrapped['unet'][0])
+    assert lora.base_layer.weight.dtype == torch.bfloat16 and not lora.base_layer.weight.requires_grad
+    assert torch.count_nonzero(lora.lora_B['default'].weight) == 0 and lora.scaling == 2.0
+    sd = dnn.lora_state_dict(work.unet)
+    assert f"{wrapped['unet'][0]}.lora_A.weight" in sd and len(sd) == 2 * len(wrapped['unet'])
+    with pytest.raises(NotImplementedError):
+        work.configure_adapter({'type': 'lokr', 'rank': 4, 'alpha': 4})
