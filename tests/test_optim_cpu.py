@@ -99,3 +99,35 @@ def test_lora_wrapping_structure_follows_the_reference_targets():
     assert f"{wrapped['unet'][0]}.lora_A.weight" in sd and len(sd) == 2 * len(wrapped['unet'])
     with pytest.raises(NotImplementedError):
         work.configure_adapter({'type': 'lokr', 'rank': 4, 'alpha': 4})
+
+
+def test_flux_prepare_inputs_host_logic_matches_oracle():
+    """models/flux.py:323-394: patchify, position ids, timestep transforms, tuple layout (host tensors only)."""
+    from diffusion_pipe_amd.workloads import flux
+    from oracle import flux_ref
+    cfg = flux.tiny_flux_config()
+    batch = flux.synthetic_flux_batch(cfg, batch_size=3, latent_hw=(8, 12), text_tokens=10, seed=3)
+    assert torch.equal(flux.patchify(batch['latents']), flux_ref.patchify(batch['latents']))
+    assert torch.equal(flux.prepare_latent_image_ids(4, 6), flux_ref.latent_image_ids(4, 6))
+    for mc in ({}, {'shift': 3.0}, {'flux_shift': True}, {'timestep_sample_method': 'uniform'}, {'sigmoid_scale': 1.3, 'guidance': 3.5}):
+        work = flux.FluxWorkload(cfg, model_config=mc, dtype=torch.float32)
+        torch.manual_seed(11)
+        feats, (target, mask) = work.prepare_inputs(batch)
+        x_t, t5, clip, t, img_ids, txt_ids, guidance, img_seq_len = feats
+        # replay the RNG stream: t draw first, then the noise
+        torch.manual_seed(11)
+        method = mc.get('timestep_sample_method', 'logit_normal')
+        z = torch.distributions.normal.Normal(0, 1).sample((3,)) if method == 'logit_normal' else torch.distributions.uniform.Uniform(0, 1).sample((3,))
+        want_t = flux_ref.timestep_transform(z, method, mc.get('sigmoid_scale', 1.0), mc.get('shift'), mc.get('flux_shift', False), image_tokens=24)
+        x0 = torch.randn_like(batch['latents'])
+        te = want_t.view(-1, 1, 1, 1)
+        assert torch.allclose(t, want_t, atol=1e-7)
+        assert torch.allclose(x_t, flux_ref.patchify((1 - te) * batch['latents'] + te * x0), atol=1e-6)
+        assert torch.allclose(target, flux_ref.patchify(x0 - batch['latents']), atol=1e-6)
+        assert x_t.shape == (3, 24, 16) and img_ids.shape == (3, 24, 3) and txt_ids.shape == (3, 10, 3) and not txt_ids.any()
+        assert guidance.tolist() == [float(mc.get('guidance', 1.0))] * 3 and img_seq_len.tolist() == [24] * 3 and mask is None
+    # eval quantile: deterministic t = sigmoid(icdf(q))
+    work = flux.FluxWorkload(cfg, dtype=torch.float32)
+    t = work.prepare_inputs(batch, timestep_quantile=0.5)[0][3]
+    assert torch.allclose(t, torch.full((3,), 0.5))
+    assert len(work.to_layers()) == 1 + cfg.num_layers + cfg.num_single_layers + 1
