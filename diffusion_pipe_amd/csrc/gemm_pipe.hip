@@ -54,6 +54,8 @@ using T128R2 = Tile<128, 128, 2, 4, 2>;     // 2-deep ring, 64 KiB -> 2 workgrou
                                             // MN-contiguous operand (dgrad / wgrad), 1.2x at 8192^3; slower with few tiles (no second workgroup).
 using T64S3 = Tile<64, 64, 2, 2, 3>;         // selectable, not chosen automatically: 3-deep ring (3 workgroups per CU)
 using T256 = Tile<256, 128, 4, 2, 3>;       // selectable, not chosen automatically: 256 x 128, 8 waves of 64 x 64, 144 KiB (T128R2 beats it)
+using T256S = Tile<256, 256, 2, 4, 2>;      // 256 x 256, 8 waves of 128 x 64 (128 accumulator VGPRs), 2 x 64 KiB: twice the MFMA work per DMA'd
+                                            // byte of the 128^2 tile -- the large-GEMM configuration (DiT-sized linears: Flux / Wan / HunyuanVideo)
 
 // Byte offset (from the operand base of this batch) of the 16 bytes lane `lane` fetches for DMA piece q of an image of
 // ROWS mn-rows at K-step 0.  The DMA writes lane L of piece q to LDS byte (q * 1024 + 16 L); the logical chunk fetched
@@ -80,9 +82,13 @@ __device__ __forceinline__ unsigned dma_voffset(int q, int lane, int mn0, long l
 template <bool MC, int ROWS>
 __device__ __forceinline__ bf16x8_t read_frag(const char* img, int mn, int ks, int lane) {
     if (!MC) {
-        const int row = mn + (lane & 31);
-        const int pc = (2 * ks + (lane >> 5)) ^ ((row >> 1) & 7);
-        return *reinterpret_cast<const bf16x8_t*>(img + row * 128 + pc * 16);
+        // mn is a multiple of 32, so the swizzle term (row >> 1) & 7 depends on the lane only and 2 ks + h == (2 ks) ^ h:
+        // the lane part of the address is one of 4 values (per ks) shared by every fragment of both operands; mn * 128
+        // is wave-uniform / an immediate offset
+        const int l31 = lane & 31;
+        const int x = (lane >> 5) ^ ((l31 >> 1) & 7);
+        const int lane_off = l31 * 128 + ((x ^ (2 * ks)) << 4);
+        return *reinterpret_cast<const bf16x8_t*>(img + mn * 128 + lane_off);
     } else {
         // ds_read_b64_tr_b16: in a 16-lane group lane t supplies the address of 4 contiguous bf16 of k-row (t >> 2) at
         // columns 4 (t & 3) of a [4][16] block and receives column t of it (the 4 k values of one mn index).
@@ -110,7 +116,16 @@ __device__ __forceinline__ float frag_sum(bf16x8_t f) {
 
 // counted wait for this wave's LDS-DMA: `ahead` later K-steps (NLOAD DMA instructions each) may stay in flight
 template <int NLOAD> __device__ __forceinline__ void wait_dma_ahead(int ahead) {
-    static_assert(NLOAD == 4 || NLOAD == 6, "DMA pieces per wave per K-step");
+    static_assert(NLOAD == 4 || NLOAD == 6 || NLOAD == 8, "DMA pieces per wave per K-step");
+    if constexpr (NLOAD == 8) {
+        switch (ahead) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        }
+        return;
+    }
     if constexpr (NLOAD == 4) {
         switch (ahead) {
         case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -186,20 +201,22 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const GemmParams p) {
     for (int j = 0; j < TL::PB; ++j) voB[j] = dma_voffset<B_MC, BN>(j * TL::NW + wid, lane, n0, p.ldb) + (unsigned)kbeg * stepB;
     // One K-step of this wave's DMA pieces into ring buffer `buf` (piece j of an operand lands at LDS byte
     // (j * NW + wid) * 1024 of its image); advances the per-lane source offsets by one K-step.
-#define ISSUE_STAGE(buf)                                                                                                      \
+#define ISSUE_RANGE(buf, J0, J1)                                                                                              \
     do {                                                                                                                      \
         char* base_ = lds + (buf) * TL::STAGE_BYTES + wid * 1024;                                                             \
-        _Pragma("unroll") for (int j = 0; j < TL::PA; ++j) {                                                                  \
-            char* dst_ = base_ + j * TL::NW * 1024; const unsigned off_ = voA[j];   /* non-dependent builtin operands */      \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)dst_, 16, off_, 0, 0, 0);                              \
-            voA[j] += stepA;                                                                                                  \
-        }                                                                                                                     \
-        _Pragma("unroll") for (int j = 0; j < TL::PB; ++j) {                                                                  \
-            char* dst_ = base_ + TL::IMG_A + j * TL::NW * 1024; const unsigned off_ = voB[j];                                 \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)dst_, 16, off_, 0, 0, 0);                              \
-            voB[j] += stepB;                                                                                                  \
+        _Pragma("unroll") for (int j = (J0); j < (J1); ++j) {                                                                 \
+            if (j < TL::PA) {                                                                                                 \
+                char* dst_ = base_ + j * TL::NW * 1024; const unsigned off_ = voA[j];   /* non-dependent builtin operands */  \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)dst_, 16, off_, 0, 0, 0);                          \
+                voA[j] += stepA;                                                                                              \
+            } else {                                                                                                          \
+                char* dst_ = base_ + TL::IMG_A + (j - TL::PA) * TL::NW * 1024; const unsigned off_ = voB[j - TL::PA];         \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)dst_, 16, off_, 0, 0, 0);                          \
+                voB[j - TL::PA] += stepB;                                                                                     \
+            }                                                                                                                 \
         }                                                                                                                     \
     } while (0)
+#define ISSUE_STAGE(buf) ISSUE_RANGE(buf, 0, NLOAD)
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -227,38 +244,73 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const GemmParams p) {
         // step `it` has landed AND every wave has finished reading buffer `nxt` (it computed step it-1 from it).
         wait_dma_ahead<NLOAD>(min(nk - it - 1, STAGES - 2));
         __builtin_amdgcn_s_barrier();
-        if (it + STAGES - 1 < nk) ISSUE_STAGE(nxt);
+        const bool refill = it + STAGES - 1 < nk;
+        if (TM * TN < 8 && refill) ISSUE_STAGE(nxt);
         const char* imgA = lds + cur * TL::STAGE_BYTES;
         const char* imgB = imgA + TL::IMG_A;
-        // all fragment reads of the K-step are issued up front: the MFMAs of k-slice ks start as soon as their
-        // fragments land while the later slices are still in flight (counted lgkmcnt by the compiler)
-        bf16x8_t fa[4][TM], fb[4][TN];
+        if constexpr (TM * TN < 8) {
+            // all fragment reads of the K-step are issued up front: the MFMAs of k-slice ks start as soon as their
+            // fragments land while the later slices are still in flight (counted lgkmcnt by the compiler)
+            bf16x8_t fa[4][TM], fb[4][TN];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+            for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[ks][i] = read_frag<A_MC, BM>(imgA, wm0 + i * 32, ks, lane);
+                for (int i = 0; i < TM; ++i) fa[ks][i] = read_frag<A_MC, BM>(imgA, wm0 + i * 32, ks, lane);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[ks][j] = read_frag<B_MC, BN>(imgB, wn0 + j * 32, ks, lane);
-        }
-        if (do_colsum) {
+                for (int j = 0; j < TN; ++j) fb[ks][j] = read_frag<B_MC, BN>(imgB, wn0 + j * 32, ks, lane);
+            }
+            if (do_colsum) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) csum[i] += frag_sum(fa[ks][i]);
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) csum[i] += frag_sum(fa[ks][i]);
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)   // operands swapped: D[row = n][col = m]
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8_mfma, fb[ks][j]), __builtin_bit_cast(bf16x8_mfma, fa[ks][i]), acc[i][j], 0, 0, 0);
+        } else {
+            // 8 MFMA tiles per wave (256^2 configuration, 128 accumulator VGPRs): fragments are double-buffered per k-slice --
+            // slice ks + 1 is read while the 8 MFMAs of slice ks run
+            bf16x8_t fa[2][TM], fb[2][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[0][i] = read_frag<A_MC, BM>(imgA, wm0 + i * 32, 0, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[0][j] = read_frag<B_MC, BN>(imgB, wn0 + j * 32, 0, lane);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                // this wave's share of the next K-step's DMA is spread over the first two k-slices: a piece costs the issuing wave
+                // 60 .. 180 cycles (MI355X_MICROARCH.md), which now falls into the shadow of the other wave's MFMAs instead of
+                // both waves of a SIMD issuing all their pieces right after the barrier
+                if (refill && ks < 2) ISSUE_RANGE(nxt, ks * NLOAD / 2, (ks + 1) * NLOAD / 2);   // first half of the K-step: the second half is the landing window
+                if (ks + 1 < 4) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa[(ks + 1) & 1][i] = read_frag<A_MC, BM>(imgA, wm0 + i * 32, ks + 1, lane);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb[(ks + 1) & 1][j] = read_frag<B_MC, BN>(imgB, wn0 + j * 32, ks + 1, lane);
+                }
+                if (do_colsum) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) csum[i] += frag_sum(fa[ks & 1][i]);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8_mfma, fb[ks & 1][j]), __builtin_bit_cast(bf16x8_mfma, fa[ks & 1][i]), acc[i][j], 0, 0, 0);
+            }
         }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)   // operands swapped: D[row = n][col = m]
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        __builtin_bit_cast(bf16x8_mfma, fb[ks][j]), __builtin_bit_cast(bf16x8_mfma, fa[ks][i]), acc[i][j], 0, 0, 0);
         cur = (cur + 1 == STAGES) ? 0 : cur + 1;
         nxt = (nxt + 1 == STAGES) ? 0 : nxt + 1;
     }
 
 #undef ISSUE_STAGE
+#undef ISSUE_RANGE
     // ---- split-K: publish this slice's slab; the last arriver of the tile reduces all slabs in slice order
     if (p.splitk > 1) {
         float4* slab0 = reinterpret_cast<float4*>(p.slabs) + ((long)(z * nt + tile) * p.splitk) * TL::SLAB_F4;
@@ -462,7 +514,13 @@ bool gemm_pipe_try(GemmParams& p, int transA, int transB, int batch, void* ws, l
     // long K can be split three ways over few tiles; else 64 x 64 (4 x the workgroups, 2 resident per CU)
     const bool long_k = p.ksteps >= 48;
     const bool big = force_tile ? force_tile >= 128 : (tiles128 >= 128 || (long_k && tiles128 >= 48));
-    const int bm = force_tile == 256 ? 256 : big ? 128 : 64, bn = force_tile == 256 ? 128 : bm;
+    // 256 x 256 (T256S) for DiT-sized forward / dgrad GEMMs: K-contiguous or mixed operands, >= 64 K-steps to amortise the
+    // un-overlapped prologue / epilogue of the one resident workgroup, >= half a wave of 256^2 tiles.  Measured
+    // (tools/kernel_timing.py large): +9 .. +21 % over T128R2 there (8192^3: 1.27 vs 1.08 PFLOP/s), -2 .. -6 % at K = 3072, and
+    // wgrad (both operands MN-contiguous) stays faster on T128R2
+    const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * batch;
+    if (force_tile == 0 && !a_mc && p.ksteps >= 64 && tiles256 >= 128) force_tile = 257;
+    const int bm = (force_tile == 256 || force_tile == 257) ? 256 : big ? 128 : 64, bn = force_tile == 256 ? 128 : bm;
     p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bn - 1) / bn;
     const long tiles = (long)p.tiles_m * p.tiles_n * batch;
     const long slab_bytes = ((long)bm * bn + bm) * 4;
@@ -489,7 +547,8 @@ bool gemm_pipe_try(GemmParams& p, int transA, int transB, int batch, void* ws, l
     p.vecA = c_ok ? 2 : 0;
     if (c_ok && p.residual && reinterpret_cast<uintptr_t>(p.residual) % 8 == 0 && p.ldr % 4 == 0) p.vecA = 3;   // 8-byte residual loads too
     p.vecB = (p.bias && reinterpret_cast<uintptr_t>(p.bias) % 8 == 0) ? 2 : 0;
-    if (force_tile == 256) *rc_out = launch_pipe<T256>(p, a_mc, b_mc, batch, s);
+    if (force_tile == 257) *rc_out = launch_pipe<T256S>(p, a_mc, b_mc, batch, s);
+    else if (force_tile == 256) *rc_out = launch_pipe<T256>(p, a_mc, b_mc, batch, s);
     else if (force_tile == 129 || (force_tile == 0 && big && tiles128 >= 256 && (a_mc || b_mc || tiles128 >= 1024)))
         *rc_out = launch_pipe<T128R2>(p, a_mc, b_mc, batch, s);
     else if (force_tile == 63) *rc_out = launch_pipe<T64S3>(p, a_mc, b_mc, batch, s);

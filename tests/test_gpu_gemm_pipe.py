@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 
 PIPE = 1000          # tile_hint: pipelined kernel, its own tile / split choice; PIPE + S forces S slices
 T64, T128 = 2000, 3000   # ... with the 64 x 64 / 128 x 128 tile forced (+ S)
-T128S2, T256, T64S3 = 4000, 5000, 6000  # further configurations: 128 x 128 with a 2-deep ring, 256 x 128, 64 x 64 with a 3-deep ring
+T128S2, T256, T64S3, T256S = 4000, 5000, 6000, 7000  # further configurations: 128 x 128 with a 2-deep ring, 256 x 128, 64 x 64 with a 3-deep ring,
+                                                      # 256 x 256 (the DiT-sized configuration: double-buffered fragments, DMA spread over the K-step)
 
 
 def _rel_err(a, b):
@@ -34,7 +35,7 @@ SHAPES = [(128, 128, 64), (256, 384, 192), (77, 1280, 1280), (100, 72, 128), (10
 @pytest.mark.parametrize('trans', [(False, True), (False, False), (True, False), (True, True)])
 @pytest.mark.parametrize('shape', SHAPES)
 @pytest.mark.parametrize('split', [0, 1, 2, 5])
-@pytest.mark.parametrize('tile', [T64, T128, T128S2, T256, T64S3])
+@pytest.mark.parametrize('tile', [T64, T128, T128S2, T256, T64S3, T256S])
 def test_pipe_gemm_matches_fp32_matmul(gpu, trans, shape, split, tile):
     from diffusion_pipe_amd import ops
     from diffusion_pipe_amd.hip import DpipeHipError
@@ -165,3 +166,26 @@ def test_pipe_agrees_with_generic_kernel_on_sdxl_shapes(gpu):
         generic = ops.mm(a, b, bool(ta), bool(tb), tile_hint=128)
         assert _rel_err(auto, ref) < 1.6e-2
         assert _rel_err(auto, generic) < 1.6e-2
+
+
+@pytest.mark.parametrize('trans', [(False, True), (False, False), (True, False)])
+@pytest.mark.parametrize('hint', [0, T256S, T256S + 2])
+def test_pipe_dit_sized_gemm_256_tile(gpu, trans, hint):
+    """DiT-sized problem (>= 128 tiles of 256 x 256, 64 K-steps): the automatic choice for NT / NN is the 256 x 256 configuration;
+    ragged M / N against the 256-tile, fused bias + GELU + residual epilogue, accumulate and fp32 output."""
+    from diffusion_pipe_amd import ops
+    ta, tb = trans
+    M, N, K = 3000, 2936, 4096
+    a, b, ref = _operands(gpu, ta, tb, M, N, K, 41)
+    out = ops.mm(a, b, ta, tb, tile_hint=hint)
+    assert _rel_err(out, ref) < 1.6e-2
+    g = torch.Generator(device='cpu').manual_seed(5)
+    bias = torch.randn(N, generator=g).to(gpu, torch.bfloat16)
+    res = torch.randn(M, N, generator=g).to(gpu, torch.bfloat16)
+    got = ops.mm(a, b, ta, tb, bias=bias, act='gelu_tanh', residual=res, tile_hint=hint)
+    want = F.gelu(ref + bias.float(), approximate="tanh") + res.float()
+    assert _rel_err(got, want) < 1.6e-2
+    acc = torch.randn(M, N, generator=g).to(gpu)
+    base = acc.clone()
+    ops.mm(a, b, ta, tb, out=acc, accumulate=True, tile_hint=hint)
+    assert _rel_err(acc, base + ref) < 2e-3

@@ -144,7 +144,35 @@ def cold_main():
         print(json.dumps(rec), flush=True)
 
 
-if 'cold' in sys.argv[1:]:
+def large_main():
+    """DiT-sized linears (Flux D=3072 / S=4608, Wan-14B D=5120 / S=9216) and 8192^3: tile configurations vs hipBLASLt, with a
+    correctness check of each configuration against the fp32 product of the same bf16 operands."""
+    dev = torch.device('cuda:0')
+    cases = [(0, 1, 8192, 8192, 8192), (0, 1, 4608, 9216, 3072), (0, 0, 4608, 3072, 9216), (1, 0, 9216, 3072, 4608),
+             (0, 1, 4608, 12288, 3072), (0, 1, 4608, 3072, 12288), (0, 1, 9216, 5120, 5120), (0, 0, 9216, 5120, 13824),
+             (1, 0, 13824, 5120, 9216), (0, 1, 9216, 13824, 5120), (0, 1, 4096, 4096, 4096), (0, 1, 2048, 2048, 2048)]
+    for (ta, tb, M, N, K) in cases:
+        a = torch.randn((K, M) if ta else (M, K), device=dev, dtype=torch.bfloat16)
+        b = torch.randn((N, K) if tb else (K, N), device=dev, dtype=torch.bfloat16)
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        aa, bb = (a.t() if ta else a), (b.t() if tb else b)
+        want = (aa[:256].float() @ bb.float())
+        fl = 2.0 * M * N * K
+        rec = {'op': 'gemm_large', 'ta': ta, 'tb': tb, 'M': M, 'N': N, 'K': K}
+        for name, hint in (('auto', 0), ('t128', 3001), ('t128r2', 4001), ('t256x128', 5001), ('t256', 7001)):
+            out.zero_()
+            ops.mm(a, b, bool(ta), bool(tb), out=out, tile_hint=hint)
+            err = ((out[:256].float() - want).abs().max() / want.abs().max()).item()
+            us = graph_time(lambda: ops.mm(a, b, bool(ta), bool(tb), out=out, tile_hint=hint), n=5, reps=3)
+            rec[name] = [round(us, 1), round(fl / us / 1e6), round(err, 4)]
+        us = graph_time(lambda: torch.matmul(aa, bb, out=out), n=5, reps=3)
+        rec['torch'] = [round(us, 1), round(fl / us / 1e6)]
+        print(json.dumps(rec), flush=True)
+
+
+if 'large' in sys.argv[1:]:
+    large_main()
+elif 'cold' in sys.argv[1:]:
     cold_main()
 elif 'attn' in sys.argv[1:]:
     attn_main()
