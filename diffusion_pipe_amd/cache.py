@@ -1,0 +1,279 @@
+"""Latent / text-embedding cache of the data feed, on-disk compatible with the reference's
+`utils/cache.py:10-133`:
+
+    <dir>/metadata.db   sqlite: fingerprint(value) | items(shard, shard_index) | shard_<N>(offset, size)
+    <dir>/shard_<N>.bin concatenated `torch.save` blobs, one per item (item = dict of tensors / python values)
+
+`Cache` keeps the reference's API (`Cache(path, fingerprint, shard_size_gb)`, `len`, `cache[i]`, `add`,
+`finalize_current_shard`, `clear`; a changed fingerprint wipes the directory; re-opening appends into a NEW shard) so
+`utils/dataset.py:85-161` can use it unchanged.  What is different is the read side, which at MI355X step rates is what
+feeds the engine: shards are mmap'd once (no seek + read + copy per item), and `CachePrefetcher` reads ahead on worker
+threads into PINNED host memory and issues the host-to-device copies on a side HIP stream, so `train_batch` never waits on
+unpickling or on a pageable-memory copy.  (The reference reads with one DataLoader worker and pageable tensors,
+utils/dataset.py:1303,1367.)
+"""
+import io
+import mmap
+import os
+import sqlite3
+import threading
+from collections import defaultdict
+from pathlib import Path
+
+import torch
+
+
+class _View(io.RawIOBase):
+    """Read-only file object over a slice of an mmap (torch.load reads storages straight out of the mapping)."""
+
+    def __init__(self, buf, offset, size):
+        self._mv = memoryview(buf)[offset:offset + size]
+        self._pos = 0
+
+    def readable(self):
+        return True
+
+    def seekable(self):
+        return True
+
+    def tell(self):
+        return self._pos
+
+    def seek(self, pos, whence=os.SEEK_SET):
+        base = {os.SEEK_SET: 0, os.SEEK_CUR: self._pos, os.SEEK_END: len(self._mv)}[whence]
+        self._pos = max(0, min(len(self._mv), base + pos))
+        return self._pos
+
+    def readinto(self, b):
+        n = min(len(b), len(self._mv) - self._pos)
+        b[:n] = self._mv[self._pos:self._pos + n]
+        self._pos += n
+        return n
+
+    def close(self):
+        self._mv.release()
+        super().close()
+
+
+class Cache:
+    def __init__(self, path, fingerprint, shard_size_gb=1, verbose=False):
+        self.path = Path(path)
+        self.fingerprint = fingerprint
+        self.metadata_db = self.path / 'metadata.db'
+        self.shard_size_gb = shard_size_gb
+        self.verbose = verbose
+        os.makedirs(self.path, exist_ok=True)
+        self._lock = threading.Lock()
+        self.init()
+
+    def _log(self, msg):
+        if self.verbose:
+            print(f'[CACHE] {msg}')
+
+    def __len__(self):
+        return len(self.items)
+
+    # ------------------------------------------------------------------------------------------------------ reading
+    def _shard_map(self, shard_id):
+        m = self._maps.get(shard_id)
+        if m is None:
+            with self._lock:
+                m = self._maps.get(shard_id)
+                if m is None:
+                    f = open(self.path / f'shard_{shard_id}.bin', 'rb')
+                    m = (mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ), f)
+                    self._maps[shard_id] = m
+        return m[0]
+
+    def locate(self, idx):
+        """-> (shard id, byte offset, byte size) of item idx."""
+        shard_id, shard_index = self.items[idx]
+        offset, size = self.shard_metadata[shard_id][shard_index]
+        return shard_id, offset, size
+
+    def __getitem__(self, idx):
+        assert isinstance(idx, int)
+        shard_id, offset, size = self.locate(idx)
+        if shard_id == self.shard and self.shard_file is not None:
+            self.shard_file.flush()                       # reading back an item of the shard being written
+            with open(self.path / f'shard_{shard_id}.bin', 'rb') as f:
+                f.seek(offset)
+                return torch.load(io.BytesIO(f.read(size)), map_location='cpu')
+        view = _View(self._shard_map(shard_id), offset, size)
+        try:
+            return torch.load(view, map_location='cpu')
+        finally:
+            view.close()
+
+    # ------------------------------------------------------------------------------------------------- open / reset
+    def init(self):
+        self.con = sqlite3.connect(self.metadata_db, check_same_thread=False)
+        self.con.execute('CREATE TABLE IF NOT EXISTS fingerprint(value)')
+        row = self.con.execute('SELECT value FROM fingerprint').fetchone()
+        if row is not None:
+            self._log(f'Existing cache has fingerprint {row[0]}')
+            if self.fingerprint != row[0]:
+                self._log('Fingerprint changed, deleting existing cache files')
+                self.clear()
+                return
+        else:
+            self.con.execute('INSERT INTO fingerprint VALUES(?)', (self.fingerprint,))
+        self.con.execute('CREATE TABLE IF NOT EXISTS items(shard, shard_index)')
+        self.items = self.con.execute('SELECT shard, shard_index FROM items').fetchall() or []
+        self.shard = max((s for s, _ in self.items), default=-1) + 1        # appends go to a new shard
+        self.shard_file = None
+        self.shard_metadata = defaultdict(list)
+        for (table,) in self.con.execute('SELECT name FROM sqlite_master').fetchall():
+            if table.startswith('shard_'):
+                self.shard_metadata[int(table.split('_')[-1])] = self.con.execute(f'SELECT offset, size FROM {table}').fetchall()
+        self._maps = {}
+        self.con.commit()
+        self._log(f'Existing cache length: {len(self)}')
+
+    def _close_maps(self):
+        for m, f in getattr(self, '_maps', {}).values():
+            m.close()
+            f.close()
+        self._maps = {}
+
+    def clear(self):
+        """Delete every cache file, start empty under the current fingerprint."""
+        self._close_maps()
+        if getattr(self, 'shard_file', None) is not None:
+            self.shard_file.close()
+            self.shard_file = None
+        self.con.close()
+        os.remove(self.metadata_db)
+        for bin_path in self.path.glob('*.bin'):
+            os.remove(bin_path)
+        self.init()
+
+    def close(self):
+        self.finalize_current_shard()
+        self._close_maps()
+        self.con.close()
+
+    # ------------------------------------------------------------------------------------------------------ writing
+    def create_new_shard(self):
+        self.shard_file = open(self.path / f'shard_{self.shard}.bin', 'wb')
+        self.shard_table = f'shard_{self.shard}'
+        self.con.execute(f'CREATE TABLE {self.shard_table}(offset, size)')
+        self.shard_index = 0
+        self.offset = 0
+
+    def finalize_current_shard(self):
+        if self.shard_file is None:
+            return
+        self.shard_file.close()
+        self.shard_file = None
+        self.shard += 1
+        self.con.commit()
+
+    def add(self, item):
+        if self.shard_file is None:
+            self.create_new_shard()
+        buffer = io.BytesIO()
+        torch.save(item, buffer)
+        blob = buffer.getbuffer()
+        self.shard_file.write(blob)
+        entry = (self.shard, self.shard_index)
+        self.items.append(entry)
+        self.con.execute('INSERT INTO items VALUES(?, ?)', entry)
+        self.shard_index += 1
+        size = len(blob)
+        self.shard_metadata[self.shard].append((self.offset, size))
+        self.con.execute(f'INSERT INTO {self.shard_table} VALUES (?, ?)', (self.offset, size))
+        self.offset += size
+        if self.shard_file.tell() / 1_000_000_000 >= self.shard_size_gb:
+            self.finalize_current_shard()
+
+
+def _map_tensors(obj, fn):
+    if torch.is_tensor(obj):
+        return fn(obj)
+    if isinstance(obj, dict):
+        return {k: _map_tensors(v, fn) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_map_tensors(v, fn) for v in obj)
+    return obj
+
+
+class CachePrefetcher:
+    """Ordered read-ahead over `cache[i] for i in indices`: `workers` threads unpickle up to `depth` items ahead (torch.load
+    releases the GIL while copying storages), stage tensors in pinned host memory and -- with `device` -- enqueue the
+    host-to-device copies on a side HIP stream; the consumer's stream waits on the copy event only when it takes the item.
+    Iteration order is exactly `indices` (the reference's batch order, utils/dataset.py:347-390, is computed upstream)."""
+
+    def __init__(self, cache, indices, depth=8, workers=2, device=None, pin=None):
+        self.cache, self.indices = cache, list(indices)
+        self.device = torch.device(device) if device is not None else None
+        self.pin = (torch.cuda.is_available() if pin is None else pin)
+        self.depth, self.workers = max(1, depth), max(1, workers)
+        self._copy_stream = torch.cuda.Stream(self.device) if (self.device is not None and self.device.type == 'cuda') else None
+        self._slots = {}
+        self._cv = threading.Condition()
+        self._next_fetch = 0
+        self._next_take = 0
+        self._stop = False
+        self._threads = [threading.Thread(target=self._work, daemon=True) for _ in range(self.workers)]
+        for t in self._threads:
+            t.start()
+
+    def _stage(self, item):
+        if self.pin:
+            item = _map_tensors(item, lambda t: t.pin_memory() if not t.is_pinned() else t)
+        event = None
+        if self._copy_stream is not None:
+            with torch.cuda.stream(self._copy_stream):
+                item = _map_tensors(item, lambda t: t.to(self.device, non_blocking=True))
+                event = self._copy_stream.record_event()
+        return item, event
+
+    def _work(self):
+        while True:
+            with self._cv:
+                while not self._stop and (self._next_fetch >= len(self.indices) or self._next_fetch - self._next_take >= self.depth):
+                    if self._next_fetch >= len(self.indices):
+                        return
+                    self._cv.wait()
+                if self._stop:
+                    return
+                pos = self._next_fetch
+                self._next_fetch += 1
+            try:
+                staged = self._stage(self.cache[self.indices[pos]])
+            except BaseException as e:          # surfaced on the consumer thread when it reaches this position
+                staged = (e, None)
+            with self._cv:
+                self._slots[pos] = staged
+                self._cv.notify_all()
+
+    def __iter__(self):
+        return self
+
+    def __len__(self):
+        return len(self.indices)
+
+    def __next__(self):
+        with self._cv:
+            if self._next_take >= len(self.indices):
+                raise StopIteration
+            pos = self._next_take
+            while pos not in self._slots:
+                self._cv.wait()
+            item, event = self._slots.pop(pos)
+            self._next_take += 1
+            self._cv.notify_all()
+        if isinstance(item, BaseException):
+            raise item
+        if event is not None:
+            torch.cuda.current_stream(self.device).wait_event(event)
+            _map_tensors(item, lambda t: t.record_stream(torch.cuda.current_stream(self.device)) or t)
+        return item
+
+    def close(self):
+        with self._cv:
+            self._stop = True
+            self._cv.notify_all()
+        for t in self._threads:
+            t.join(timeout=5)
