@@ -43,6 +43,7 @@ def parse():
     ap.add_argument('--lanes', type=int, default=3, help='concurrent micro-batch lanes of the single-stage hipGraph path')
     ap.add_argument('--test-single-device', action='store_true',
                     help='TEST ONLY: all ranks share cuda:0, collectives over gloo, stage payloads staged through the host')
+    ap.add_argument('--torch-adamw', action='store_true', help='A/B switch: torch.optim.AdamW(fused=True) + separate lane-sum / clip / zero passes')
     ap.add_argument('--parallel-wgrad', action='store_true', help='fork wgrad onto a side stream (A/B switch; measured slower)')
     return ap.parse_args()
 
@@ -101,14 +102,11 @@ def main():
                                                          'parallel_wgrad': args.parallel_wgrad, 'p2p_via_host': args.test_single_device, 'graph_lanes': args.lanes}, device=device)
     params = [p for p in module.parameters() if p.requires_grad]
 
-    def make_opt(ps):
-        if len(ps) == 0:
-            return None
-        groups = work.get_param_groups(ps)
-        try:
-            return torch.optim.AdamW(groups, lr=1e-5, betas=(0.9, 0.99), weight_decay=0.01, fused=True)
-        except Exception:
-            return torch.optim.AdamW(groups, lr=1e-5, betas=(0.9, 0.99), weight_decay=0.01, foreach=True)
+    # the reference's optimizer construction (train.py:650-815): AdamW on the raw bf16 parameters, per-component groups split into
+    # weight-decay / no-weight-decay halves; on the GPU the step end (lane sum + clip + update + zero) runs as the fused HIP passes
+    from diffusion_pipe_amd import optim
+    work.train_config = {'optimizer': {'type': 'adamw', 'lr': 1e-5, 'betas': [0.9, 0.99], 'weight_decay': 0.01, 'eps': 1e-8}}
+    make_opt = optim.make_optimizer_factory(work.train_config, work, global_batch_size=gas, use_hip_adamw=not args.torch_adamw)
     engine._configure_optimizer(make_opt, params)
 
     # synthetic data: a pool of distinct pre-pulled steps (the reference pre-pulls every step's micro-batches, train.py:164-173)

@@ -306,8 +306,19 @@ class PipelineEngine:
                 entry['graph'].replay()
         for lane in lanes:
             main.wait_stream(lane['stream'])
-        # lane 0 owns the step's gradients; add the other lanes' accumulators and losses into it
         base = lanes[0]
+        _ops.WS_LANE = None
+        if self._fused_step_end() and not self.is_data_parallel:
+            # the lanes' accumulators go straight into the fused step end: summed, clipped, applied and zeroed in one pass
+            for lane in lanes[1:]:
+                base['loss'].add_(lane['loss'])
+            for p in params:
+                p.grad = base['grads'].get(id(p))
+            self.total_loss = base['loss']
+            self._exec_reduce_tied_grads()
+            self._exec_optimizer_step(lane_grads=[lane['grads'] for lane in lanes])
+            return
+        # lane 0 owns the step's gradients; add the other lanes' accumulators and losses into it
         for lane in lanes[1:]:
             dst = [base['grads'][k] for k in lane['grads'] if k in base['grads']]
             src = [lane['grads'][k] for k in lane['grads'] if k in base['grads']]
@@ -317,7 +328,6 @@ class PipelineEngine:
         for p in params:
             p.grad = base['grads'].get(id(p))
         self.total_loss = base['loss']
-        _ops.WS_LANE = None
         self._exec_reduce_tied_grads()
         self._exec_reduce_grads()
         self._exec_optimizer_step()                              # zeroes lane 0's buffers (p.grad)
@@ -631,7 +641,41 @@ class PipelineEngine:
             ops.grads_clip_scale_(grads, sumsq, self._gradient_clipping)
         self._last_grad_norm = sumsq.sqrt()
 
-    def _exec_optimizer_step(self, lr_kwargs=None):
+    def _fused_step_end(self):
+        """True when the optimizer brings the fused HIP step end (optim.FusedAdamW) and nothing overrides the clip."""
+        return (self.optimizer is not None and hasattr(self.optimizer, 'fused_update') and self.clip_grad_fn is None
+                and self.grad_kernels is None and self.device.type == 'cuda')
+
+    def _fused_optimizer_step(self, lane_grads):
+        """Norm of the (lane-summed) gradients -> the reference's cross-stage / DP composition of the scalar
+        (utils/patches.py:222-239) -> one pass: clip, AdamW, zero."""
+        opt = self.optimizer
+        persistent = self.use_graph or self.use_stage_graphs
+        sumsq = None
+        if self._gradient_clipping > 0.0:
+            counted = not (self.is_pipe_parallel and self.clip_norm_scope == 'deepspeed' and self.stage_id != 0)
+            sumsq = opt.grads_sumsq(lane_grads) if counted else None
+            if sumsq is None:
+                sumsq = torch.zeros((), device=self.device, dtype=torch.float32)
+            if self.is_pipe_parallel:
+                dist.all_reduce(sumsq, op=dist.ReduceOp.SUM, group=self.grid.get_model_parallel_group())
+            if self.is_data_parallel:
+                norm = sumsq.sqrt() / float(self.dp_world_size)
+                dist.all_reduce(norm, group=self.grid.get_data_parallel_group())
+                sumsq = norm * norm
+            self._last_grad_norm = sumsq.sqrt()
+        opt.fused_update(lane_grads, sumsq, self._gradient_clipping, zero_grads=persistent)
+
+    def _exec_optimizer_step(self, lr_kwargs=None, lane_grads=None):
+        if self._fused_step_end():
+            self._fused_optimizer_step(lane_grads)
+            if not (self.use_graph or self.use_stage_graphs):
+                for p in self.module.parameters():
+                    p.grad = None
+            if self.lr_scheduler is not None:
+                self.lr_scheduler.step(**(lr_kwargs or {}))
+            self.global_steps += 1
+            return
         if self._gradient_clipping > 0.0:
             self.clip_fp32_gradients()
         if self.optimizer is not None:

@@ -928,6 +928,71 @@ def grads_clip_scale_(grads, total_sumsq, max_norm):
                                            float(max_norm), stream()), 'multi_clip_scale')
 
 
+# ------------------------------------------------------------------------ fused step end (lane sum + clip + AdamW + zero)
+_adam_tables = {}
+
+
+def _adam_table(params, exp_avgs, exp_avg_sqs, lane_grads):
+    """Device pointer / chunk tables of one (dtype, param group); cached on the buffer addresses (persistent in the graph path)."""
+    L = len(lane_grads)
+    key = tuple(t.data_ptr() for t in params) + tuple(t.data_ptr() for t in exp_avgs) + tuple(g.data_ptr() for lane in lane_grads for g in lane)
+    hit = _adam_tables.get(key)
+    if hit is not None:
+        return hit
+    dev = params[0].device
+    ctens, coff, clen = [], [], []
+    for i, t in enumerate(params):
+        n = t.numel()
+        for off in range(0, n, _CHUNK):
+            ctens.append(i); coff.append(off); clen.append(min(_CHUNK, n - off))
+    i64 = lambda xs: torch.tensor(xs, dtype=torch.int64, device=dev)
+    table = {'p': i64([t.data_ptr() for t in params]), 'm': i64([t.data_ptr() for t in exp_avgs]), 'v': i64([t.data_ptr() for t in exp_avg_sqs]),
+             'g': i64([lane_grads[l][i].data_ptr() for i in range(len(params)) for l in range(L)]),
+             'ctens': torch.tensor(ctens, dtype=torch.int32, device=dev), 'coff': i64(coff),
+             'clen': torch.tensor(clen, dtype=torch.int32, device=dev), 'n': len(ctens),
+             'partials': torch.empty(max(len(ctens), 1), device=dev, dtype=torch.float32), 'keep': (params, exp_avgs, exp_avg_sqs, lane_grads)}
+    if len(_adam_tables) > 64:
+        _adam_tables.clear()
+    _adam_tables[key] = table
+    return table
+
+
+def _adam_check(params, exp_avgs, exp_avg_sqs, lane_grads):
+    require_cuda(*params)
+    dt = params[0].dtype
+    if dt not in (torch.bfloat16, torch.float32):
+        raise DpipeHipError(f'fused AdamW: unsupported dtype {dt}')
+    if not 1 <= len(lane_grads) <= 8:
+        raise DpipeHipError('fused AdamW: 1..8 gradient lanes')
+    for group in (params, exp_avgs, exp_avg_sqs, *lane_grads):
+        if len(group) != len(params):
+            raise DpipeHipError('fused AdamW: ragged tensor lists')
+        for t, p in zip(group, params):
+            if t.dtype != dt or t.shape != p.shape or not t.is_contiguous():
+                raise DpipeHipError('fused AdamW: parameters, states and gradients must be contiguous tensors of one dtype and shape')
+    return dt
+
+
+def adamw_grads_sumsq(params, exp_avgs, exp_avg_sqs, lane_grads, out, accumulate=False):
+    """out (+)= sum over elements of (sum over lanes g)^2 for one same-dtype tensor group (fp32 device scalar)."""
+    dt = _adam_check(params, exp_avgs, exp_avg_sqs, lane_grads)
+    t = _adam_table(params, exp_avgs, exp_avg_sqs, lane_grads)
+    check(lib().dpipe_adamw_sumsq(ptr(t['g']), len(lane_grads), ptr(t['ctens']), ptr(t['coff']), ptr(t['clen']), t['n'], dtype_code(dt),
+                                  ptr(t['partials']), ptr(out), int(accumulate), stream()), 'adamw_sumsq')
+    return out
+
+
+def adamw_step(params, exp_avgs, exp_avg_sqs, lane_grads, *, lr, beta1, beta2, eps, weight_decay, step, total_sumsq=None, max_norm=0.0,
+               zero_grads=True):
+    """One fused pass over a same-dtype group: g = clip * sum_lanes g; AdamW update in fp32; lanes zeroed."""
+    dt = _adam_check(params, exp_avgs, exp_avg_sqs, lane_grads)
+    t = _adam_table(params, exp_avgs, exp_avg_sqs, lane_grads)
+    check(lib().dpipe_adamw_step(ptr(t['p']), ptr(t['m']), ptr(t['v']), ptr(t['g']), len(lane_grads), ptr(t['ctens']), ptr(t['coff']), ptr(t['clen']),
+                                 t['n'], dtype_code(dt), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                 float(1.0 - beta1 ** step), float(1.0 - beta2 ** step), ptr(total_sumsq), float(max_norm), int(zero_grads),
+                                 stream()), 'adamw_step')
+
+
 # ----------------------------------------------------------------------------------------- small helpers (K7/K8)
 def sinusoidal_embedding(t, dim, max_period=10000.0, sin_first=False, downscale_shift=0.0, scale=1.0):
     """[cos | sin] (Wan, models/wan/model.py:15-25) or [sin | cos] (sin_first) timestep embedding, fp32."""

@@ -16,7 +16,7 @@ from collections import defaultdict
 import torch
 
 _TORCH_OPTIMIZERS = {
-    'adamw': torch.optim.AdamW,
+    'adamw': torch.optim.AdamW,        # replaced by FusedAdamW on a GPU stage (make_optimizer_factory)
     'sgd': torch.optim.SGD,
     'adam': torch.optim.Adam,
 }
@@ -44,6 +44,108 @@ class DummyOptimizer(torch.optim.Optimizer):
 
     def load_state_dict(self, state_dict):
         pass
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW (decoupled weight decay, bias correction, no amsgrad) whose whole step end runs in two HIP
+    multi-tensor passes (csrc/optim.hip): the gradient norm of the lane-summed gradients, then ONE pass that sums the engine's
+    concurrent micro-batch gradient accumulators, applies the clip coefficient, updates (p, exp_avg, exp_avg_sq) in fp32
+    arithmetic and zeroes the accumulators.  State keys / dtypes are torch.optim.AdamW's (`step`, `exp_avg`, `exp_avg_sq` in
+    the parameter dtype -- raw bf16 parameters, no fp32 master copy, as the reference trains: train.py:423-429), so
+    optimizer checkpoints interchange with the reference's.
+
+    `step()` is the plain torch contract (reads p.grad, leaves it alone).  The engine uses the split form instead:
+    `grads_sumsq(lanes)` -> (cross-stage / DP reduction of the scalar by the engine) -> `fused_update(lanes, total, max_norm)`."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
+            raise ValueError('invalid AdamW hyper-parameter')
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+
+    def _buckets(self, lane_grads_of):
+        """[(group, dtype, params, exp_avgs, exp_avg_sqs, lanes)] over parameters that have a gradient."""
+        out = []
+        for group in self.param_groups:
+            by_dtype = {}
+            for p in group['params']:
+                lanes = lane_grads_of(p)
+                if lanes is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st['step'] = 0.0
+                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                b = by_dtype.setdefault(p.dtype, ([], [], [], [[] for _ in lanes]))
+                b[0].append(p.data if p.is_contiguous() else None)
+                if b[0][-1] is None:
+                    raise RuntimeError('FusedAdamW needs contiguous parameters')
+                b[1].append(st['exp_avg'])
+                b[2].append(st['exp_avg_sq'])
+                for lane_list, g in zip(b[3], lanes):
+                    lane_list.append(g)
+            out += [(group, dt, *b) for dt, b in by_dtype.items()]
+        return out
+
+    @staticmethod
+    def _lanes_from(lane_grads):
+        if lane_grads is None:
+            return lambda p: None if p.grad is None else [p.grad]
+
+        def of(p):
+            gs = [lane.get(id(p)) for lane in lane_grads]
+            if all(g is None for g in gs):
+                return None
+            if any(g is None for g in gs):
+                raise RuntimeError('FusedAdamW: a parameter has a gradient accumulator in some lanes only')
+            return gs
+        return of
+
+    @torch.no_grad()
+    def grads_sumsq(self, lane_grads=None, only=None):
+        """fp32 device scalar: sum over parameters of ||sum over lanes of g||^2.  lane_grads: list of {id(p): grad} dicts (one per
+        lane) or None = [p.grad].  `only(p) -> bool` restricts the counted parameters."""
+        from . import ops
+        of = self._lanes_from(lane_grads)
+        if only is not None:
+            inner = of
+            of = lambda p: inner(p) if only(p) else None
+        total = None
+        for _, _, ps, ms, vs, lanes in self._buckets(of):
+            if total is None:
+                total = torch.empty((), device=ps[0].device, dtype=torch.float32)
+                ops.adamw_grads_sumsq(ps, ms, vs, lanes, total, accumulate=False)
+            else:
+                ops.adamw_grads_sumsq(ps, ms, vs, lanes, total, accumulate=True)
+        return total
+
+    @torch.no_grad()
+    def fused_update(self, lane_grads=None, total_sumsq=None, max_norm=0.0, zero_grads=True):
+        from . import ops
+        for group, _, ps, ms, vs, lanes in self._buckets(self._lanes_from(lane_grads)):
+            step = None
+            beta1, beta2 = group['betas']
+            for p in group['params']:
+                st = self.state.get(p)
+                if st and 'step' in st:
+                    step = float(st['step']) + 1.0 if step is None else step
+                    break
+            ops.adamw_step(ps, ms, vs, lanes, lr=group['lr'], beta1=beta1, beta2=beta2, eps=group['eps'], weight_decay=group['weight_decay'],
+                           step=step, total_sumsq=total_sumsq, max_norm=max_norm, zero_grads=zero_grads)
+        of = self._lanes_from(lane_grads)
+        for group in self.param_groups:
+            for p in group['params']:
+                if of(p) is not None:
+                    self.state[p]['step'] = float(self.state[p]['step']) + 1.0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self.fused_update(None, None, 0.0, zero_grads=False)
+        return loss
 
 
 def computed_beta2(global_batch_size, beta2_half_life):
@@ -81,7 +183,7 @@ def _optimizer_class(optim_type):
     raise NotImplementedError(f'unknown optimizer type: {optim_type}')
 
 
-def make_optimizer_factory(config, workload, global_batch_size, device_is_gpu=True):
+def make_optimizer_factory(config, workload, global_batch_size, device_is_gpu=True, use_hip_adamw=True):
     """-> get_optimizer(model_parameters), the callable handed to `engine._configure_optimizer` (train.py:817).
 
     `config['optimizer']` is the reference's TOML table ({type, lr, betas, weight_decay, eps, beta2_half_life?, ...});
@@ -105,7 +207,10 @@ def make_optimizer_factory(config, workload, global_batch_size, device_is_gpu=Tr
         if 'betas' in cfg:
             cfg['betas'] = tuple(cfg['betas'])
         klass = _optimizer_class(optim_type)
-        if klass in (torch.optim.AdamW, torch.optim.Adam) and 'fused' not in cfg and 'foreach' not in cfg:
+        plain_adamw = klass is torch.optim.AdamW and not set(cfg) - {'lr', 'betas', 'eps', 'weight_decay'}
+        if plain_adamw and device_is_gpu and use_hip_adamw:
+            klass = FusedAdamW                                        # lane sum + clip + update + zero in two HIP passes
+        elif klass in (torch.optim.AdamW, torch.optim.Adam) and 'fused' not in cfg and 'foreach' not in cfg:
             cfg['fused' if device_is_gpu else 'foreach'] = True       # one multi-tensor launch chain per step
         groups = split_weight_decay(workload.get_param_groups(model_parameters))
         return klass(groups, **cfg)

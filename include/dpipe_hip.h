@@ -85,6 +85,23 @@ int dpipe_multi_sumsq(const void* const* ptrs, const int* chunk_tensor, const lo
 int dpipe_multi_clip_scale(void* const* ptrs, const int* chunk_tensor, const long* chunk_off, const int* chunk_len,
                            int nchunks, int dtype, const float* total_sumsq, float max_norm, void* stream);
 
+/* ---- step end: lane sum + clip + AdamW + zero in two passes (replaces the reference's separate clip_grad_norm_
+ * utils/patches.py:175-246 and torch.optim.AdamW step train.py:672-678) ----------------------
+ * Same chunk table; g_ptrs holds `lanes` gradient pointers per tensor, laid out [tensor][lane] (lanes = the engine's
+ * concurrent micro-batch accumulators, 1..8); all tensors of one call share `dtype` (bf16 or fp32; p, m, v, g alike).
+ * sumsq: out_sumsq[0] (+)= sum over elements of (sum over lanes g)^2, fp32, deterministic two-stage.
+ * step:  g = min(1, max_norm / (sqrt(total_sumsq[0]) + 1e-6)) * sum_lanes g   (total_sumsq NULL or max_norm <= 0: no clip)
+ *        p *= 1 - lr wd; m = lerp(m, g, 1 - beta1); v = beta2 v + (1 - beta2) g^2;
+ *        p -= lr / bias_correction1 * m / (sqrt(v) / sqrt(bias_correction2) + eps)      (fp32 arithmetic, torch's fused AdamW)
+ *        zero_grads != 0: every lane's gradient is overwritten with 0 in the same pass. */
+int dpipe_adamw_sumsq(const void* const* g_ptrs, int lanes, const int* chunk_tensor, const long* chunk_off,
+                      const int* chunk_len, int nchunks, int dtype, float* partials, float* out_sumsq, int accumulate,
+                      void* stream);
+int dpipe_adamw_step(void* const* p_ptrs, void* const* m_ptrs, void* const* v_ptrs, void* const* g_ptrs, int lanes,
+                     const int* chunk_tensor, const long* chunk_off, const int* chunk_len, int nchunks, int dtype, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, float bias_correction1,
+                     float bias_correction2, const float* total_sumsq, float max_norm, int zero_grads, void* stream);
+
 /* ---- K2 RMSNorm (models/wan/model.py:70-86; per-head form models/hunyuan_image_modeling.py:98-103) ------------
  * y = cast(x * rsqrt(mean(x^2) + eps)) * w ; w may be NULL; rstd [rows] saved for backward (may be NULL). */
 int dpipe_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, long rows, int cols, float eps, int dtype,

@@ -1,0 +1,112 @@
+"""GPU: the fused step end (csrc/optim.hip through dpipe_adamw_sumsq / dpipe_adamw_step, optim.FusedAdamW) against
+torch.optim.AdamW -- the optimizer the reference constructs (train.py:672-678) -- and the reference's clip composition
+(utils/patches.py:175-246).  fp32 parameters: 1e-6 relative after 5 steps.  bf16 parameters: each step is compared with the
+fp32 update of the same bf16 state rounded once to bf16 (the kernel computes in fp32 and rounds once: <= 1 bf16 ulp)."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(7,), (1000, 33), (64, 64), (3, 5, 7), (65537,), (1,)]          # ragged / unaligned tails, a chunk boundary (65536)
+
+
+def _params(dtype, gpu, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.nn.Parameter(torch.randn(s, generator=g).to(gpu, dtype)) for s in SHAPES]
+
+
+def test_fused_adamw_fp32_matches_torch_adamw(gpu):
+    from diffusion_pipe_amd.optim import FusedAdamW
+    mine = _params(torch.float32, gpu)
+    ref = [torch.nn.Parameter(p.detach().cpu().clone()) for p in mine]
+    kw = dict(lr=3e-3, betas=(0.9, 0.95), eps=1e-8)
+    groups = lambda ps: [{'params': ps[:3], 'weight_decay': 0.1}, {'params': ps[3:], 'weight_decay': 0.0, 'lr': 1e-3}]
+    opt, ropt = FusedAdamW(groups(mine), **kw), torch.optim.AdamW(groups(ref), foreach=False, **kw)
+    g = torch.Generator().manual_seed(1)
+    for _ in range(5):
+        for p, r in zip(mine, ref):
+            r.grad = torch.randn(r.shape, generator=g)
+            p.grad = r.grad.to(gpu)
+        opt.step()
+        ropt.step()
+    for p, r in zip(mine, ref):
+        assert torch.allclose(p.detach().cpu(), r.detach(), rtol=2e-6, atol=1e-7)
+        assert torch.allclose(opt.state[p]['exp_avg_sq'].cpu(), ropt.state[r]['exp_avg_sq'], rtol=2e-6, atol=1e-12)
+        assert opt.state[p]['step'] == 5.0 and p.grad is not None           # step() leaves the gradients alone
+    # optimizer checkpoints interchange with torch.optim.AdamW's
+    ropt2 = torch.optim.AdamW(groups([torch.nn.Parameter(p.detach().clone()) for p in mine]), **kw)
+    ropt2.load_state_dict(copy.deepcopy(opt.state_dict()))
+    assert float(ropt2.state[ropt2.param_groups[0]['params'][0]]['step']) == 5.0
+
+
+@pytest.mark.parametrize('lanes', [1, 3])
+def test_fused_step_end_lanes_clip_zero_bf16(gpu, lanes):
+    from diffusion_pipe_amd.optim import FusedAdamW
+    ps = _params(torch.bfloat16, gpu, seed=3)
+    opt = FusedAdamW([{'params': ps[:2], 'weight_decay': 0.05}, {'params': ps[2:], 'weight_decay': 0.0}], lr=1e-2, betas=(0.9, 0.99), eps=1e-8)
+    g = torch.Generator().manual_seed(5)
+    max_norm = 1.0
+    for step in range(1, 4):
+        lane_grads = [{id(p): (torch.randn(p.shape, generator=g) * 0.05).to(gpu, torch.bfloat16) for p in ps} for _ in range(lanes)]
+        # fp32 reference from the current bf16 state
+        before = [(p.detach().float().cpu(), opt.state[p]['exp_avg'].float().cpu() if opt.state[p] else torch.zeros(p.shape),
+                   opt.state[p]['exp_avg_sq'].float().cpu() if opt.state[p] else torch.zeros(p.shape)) for p in ps]
+        gsum = [sum(lane[id(p)].float().cpu() for lane in lane_grads) for p in ps]
+        want_sumsq = sum((x.double() ** 2).sum() for x in gsum)
+        coef = min(1.0, max_norm / (want_sumsq.sqrt().item() + 1e-6))
+        total = opt.grads_sumsq(lane_grads)
+        assert abs(total.item() - want_sumsq.item()) / want_sumsq.item() < 1e-5
+        opt.fused_update(lane_grads, total, max_norm, zero_grads=True)
+        torch.cuda.synchronize()
+        for i, p in enumerate(ps):
+            wd = 0.05 if i < 2 else 0.0
+            p0, m0, v0 = before[i]
+            gr = gsum[i] * coef
+            pw = p0 * (1 - 1e-2 * wd)
+            m1 = m0 + (1 - 0.9) * (gr - m0)
+            v1 = 0.99 * v0 + (1 - 0.99) * gr * gr
+            pw = pw - (1e-2 / (1 - 0.9 ** step)) * m1 / (v1.sqrt() / (1 - 0.99 ** step) ** 0.5 + 1e-8)
+            # one bf16 ulp (8 significant bits) at the scale of the operands: the clip coefficient comes from an fp32 device
+            # reduction (1e-6 relative to the host's), which can flip a rounding, and m / p are differences of nearby terms
+            scales = (p0.abs(), torch.maximum(m0.abs(), gr.abs()), torch.maximum(v0, gr * gr))
+            for (got, want), scale in zip(((p.detach(), pw), (opt.state[p]['exp_avg'], m1), (opt.state[p]['exp_avg_sq'], v1)), scales):
+                got, want_bf = got.float().cpu(), want.to(torch.bfloat16).float()
+                ulp = torch.maximum(want.abs(), scale).clamp_min(1e-30) * 2.0 ** -7
+                assert ((got - want_bf).abs() <= ulp).all()
+                assert (got == want_bf).float().mean() > 0.98                       # fp32 arithmetic, one rounding: almost always identical
+            assert all(not lane[id(p)].any() for lane in lane_grads)                 # every lane zeroed in the same pass
+
+
+def test_engine_lanes_with_fused_step_end_match_torch_adamw_path(gpu):
+    """SDXL (tiny) on the hipGraph path with 2 lanes: FusedAdamW (lanes summed / clipped / applied / zeroed by the fused passes) vs
+    torch.optim.AdamW (foreach lane sum, clip kernels, torch step): same loss trajectory and gradient norms over 3 steps."""
+    from diffusion_pipe_amd import optim
+    from diffusion_pipe_amd.data import split_batch
+    from diffusion_pipe_amd.engine import ManualPipelineModule, initialize
+    from diffusion_pipe_amd.workloads import sdxl
+    cfg = sdxl.tiny_config()
+    gas = 4
+    out = {}
+    for use_hip in (True, False):
+        work = sdxl.SDXLWorkload(cfg, model_config={'min_snr_gamma': 5.0}, dtype=torch.bfloat16, seed=2)
+        work.train_config = {'optimizer': {'type': 'adamw', 'lr': 2e-4, 'betas': [0.9, 0.99], 'weight_decay': 0.01, 'eps': 1e-8}}
+        module = ManualPipelineModule(layers=work.to_layers(), num_stages=1, partition_method='parameters', loss_fn=work.get_loss_fn(), dynamic_shape=True)
+        engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 1, 'gradient_accumulation_steps': gas,
+                                                             'gradient_clipping': 0.5, 'hip_graph': True, 'graph_lanes': 2}, device=gpu)
+        params = [p for p in module.parameters() if p.requires_grad]
+        engine._configure_optimizer(optim.make_optimizer_factory(work.train_config, work, gas, use_hip_adamw=use_hip), params)
+        assert isinstance(engine.optimizer, optim.FusedAdamW) == use_hip
+        torch.manual_seed(7)
+        micro = split_batch(work.prepare_inputs(sdxl.synthetic_batch(cfg, batch_size=gas, latent_hw=32, seed=3, ids_len=75)), gas)
+        losses, norms = [], []
+        for _ in range(3):
+            losses.append(engine.train_batch(iter(copy.deepcopy(micro))).item())
+            norms.append(engine.get_global_grad_norm().item())
+        out[use_hip] = (losses, norms)
+    (l1, n1), (l0, n0) = out[True], out[False]
+    assert l1[0] == pytest.approx(l0[0], rel=1e-3) and n1[0] == pytest.approx(n0[0], rel=5e-3)      # step 1: identical weights (bf16 run-to-run noise only)
+    assert l1[2] < l1[0] and l0[2] < l0[0]                                                         # both trajectories descend
+    for a, b in zip(l1 + n1, l0 + n0):
+        assert a == pytest.approx(b, rel=3e-2)
