@@ -35,7 +35,13 @@ module = ManualPipelineModule(layers=work.to_layers(), num_stages=world, partiti
 engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 1, 'gradient_accumulation_steps': gas, 'gradient_clipping': 1.0,
                                                      'hip_graph': mode != 'eager', 'p2p_via_host': True, 'clip_norm_scope': 'global'}, device=dev)
 params = [p for p in module.parameters() if p.requires_grad]
-engine._configure_optimizer(lambda ps: torch.optim.SGD(ps, lr=1e-3) if len(ps) else None, params)
+if len(sys.argv) > 3 and sys.argv[3] == 'fused_adamw':     # the fused HIP step end: norm of the local grads -> cross-stage all-reduce -> clip + AdamW + zero
+    from diffusion_pipe_amd import optim
+    work.train_config = {'optimizer': {'type': 'adamw', 'lr': 2e-4, 'betas': [0.9, 0.99], 'weight_decay': 0.01, 'eps': 1e-8}}
+    engine._configure_optimizer(optim.make_optimizer_factory(work.train_config, work, gas), params)
+    assert isinstance(engine.optimizer, optim.FusedAdamW) or len(params) == 0
+else:
+    engine._configure_optimizer(lambda ps: torch.optim.SGD(ps, lr=1e-3) if len(ps) else None, params)
 res = []
 for step in range(3):
     torch.manual_seed(100 + step)
@@ -59,17 +65,17 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(tmp_path, mode, world):
+def _run(tmp_path, mode, world, opt='sgd'):
     script = tmp_path / 'worker.py'
     script.write_text(WORKER)
-    out = tmp_path / f'{mode}_{world}.json'
+    out = tmp_path / f'{mode}_{world}_{opt}.json'
     env = dict(os.environ, DPIPE_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0')
     if world == 1:
         env.update(RANK='0', WORLD_SIZE='1')
-        cmd = [sys.executable, str(script), mode, str(out)]
+        cmd = [sys.executable, str(script), mode, str(out), opt]
     else:
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}', '--master-addr', '127.0.0.1',
-               '--master-port', str(_free_port()), str(script), mode, str(out)]
+               '--master-port', str(_free_port()), str(script), mode, str(out), opt]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return json.loads(out.read_text())
@@ -88,3 +94,15 @@ def test_pp2_stage_graphs_match_single_stage_engine(gpu, tmp_path):
     # the two pp=2 modes replay the same kernels on the same data: first step agrees tightly
     assert abs(graph2['res'][0][0] - eager2['res'][0][0]) / abs(eager2['res'][0][0]) < 2e-3
     assert abs(graph2['res'][0][1] - eager2['res'][0][1]) / eager2['res'][0][1] < 2e-3
+
+
+def test_pp2_fused_step_end_matches_single_stage_engine(gpu, tmp_path):
+    """FusedAdamW under pipeline parallelism: each stage contributes its local squared norm, the scalar is all-reduced over the
+    pipe group, every stage applies the same clip coefficient inside its fused update (utils/patches.py:222-245 composition)."""
+    base = _run(tmp_path, 'graph', 1, 'fused_adamw')
+    eager2 = _run(tmp_path, 'eager', 2, 'fused_adamw')
+    graph2 = _run(tmp_path, 'graph', 2, 'fused_adamw')
+    assert graph2['stage_graphs']
+    for (l0, n0), (l1, n1), (l2, n2) in zip(base['res'], eager2['res'], graph2['res']):
+        assert abs(l1 - l0) / abs(l0) < 2e-2 and abs(l2 - l0) / abs(l0) < 2e-2, (l0, l1, l2)
+        assert abs(n1 - n0) / n0 < 3e-2 and abs(n2 - n0) / n0 < 3e-2, (n0, n1, n2)
