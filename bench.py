@@ -59,6 +59,11 @@ def gemm_roofline(trace):
 
 def main():
     args = parse()
+    # watchdog: a run that stops making progress (a wedged collective, a kernel that never retires) dumps every thread's Python
+    # stack and exits instead of holding the GPU until the caller's clock runs out
+    import faulthandler
+    faulthandler.enable()
+    faulthandler.dump_traceback_later(int(os.environ.get('DPIPE_BENCH_WATCHDOG_S', '1500')), exit=True)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -198,6 +203,7 @@ def main():
             cb['unit'] = 'images/s'
             out['cpu_baseline'] = cb
         print(json.dumps(out), flush=True)
+    faulthandler.cancel_dump_traceback_later()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
