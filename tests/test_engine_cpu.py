@@ -126,6 +126,9 @@ def _worker(rank, world, port, mode, outdir):
         elif mode == 'pp2_dsclip':
             batches = [make_batches(gas, 2, 100)]
             losses, params, engine = engine_run(1, gas, 0.05, batches, num_stages=2, partition_method='uniform', scope='deepspeed')
+        elif mode == 'pp2_loader':
+            _loader_worker(rank, outdir)
+            return
         else:  # dp2: each replica sees its own micro-batches
             batches = [make_batches(2 * gas, 2, 100 + s)[rank * gas:(rank + 1) * gas] for s in range(steps)]
             losses, params, engine = engine_run(steps, gas, 0.5, batches, num_stages=1)
@@ -133,6 +136,38 @@ def _worker(rank, world, port, mode, outdir):
         torch.save({'losses': losses, 'range': (start, stop), 'params': [p.detach() for p in params]}, os.path.join(outdir, f'r{rank}.pt'))
     finally:
         dist.destroy_process_group()
+
+
+def _loader_worker(rank, outdir):
+    """The reference's data feed under pp = 2 (train.py:164-173, utils/dataset.py:1341-1405): both end stages pull the SAME dataset
+    batches but draw their own noise; the first stage's noise-dependent target is handed to the last stage (`broadcast_target`), the
+    iterator for a step is pre-pulled on the end stages only, epochs advance when the dataset wraps."""
+    steps, gas = 3, 2
+    g = torch.Generator().manual_seed(5)
+    dataset = [{'x': torch.randn(2 * gas, D, generator=g), 'ids': torch.randint(0, 10, (2 * gas, 3), generator=g)} for _ in range(2)]
+    noise_gen = torch.Generator().manual_seed(1000 + rank)              # each process draws different noise, like the reference
+
+    def prepare_inputs(batch, timestep_quantile=None):
+        noise = torch.randn(batch['x'].shape, generator=noise_gen)
+        return (batch['x'] + 0.1 * noise, batch['ids']), (noise - batch['x'], None)        # (features), (target, mask)
+
+    layers = make_layers()
+    module = ManualPipelineModule(layers=layers, num_stages=2, partition_method='uniform', loss_fn=oracle.default_loss_fn(), dynamic_shape=True)
+    engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 2, 'gradient_accumulation_steps': gas,
+                                                         'gradient_clipping': 0.5, 'clip_norm_scope': 'global'}, device='cpu')
+    engine.grad_kernels = oracle.TorchGradKernels
+    engine._configure_optimizer(lambda ps: torch.optim.AdamW(ps, lr=1e-2), [p for p in module.parameters()])
+    loader = dpdata.MicroBatchLoader(dataset, engine, gas, prepare_inputs)
+    seen, losses, epochs = [], [], []
+    for _ in range(steps):
+        it = dpdata.get_data_iterator_for_step(loader, engine)
+        micro = list(it)
+        seen.append(micro)
+        engine.reset_activation_shape()
+        losses.append(engine.train_batch(iter(micro)).item())
+        loader.sync_epoch()
+        epochs.append(loader.epoch)
+    torch.save({'losses': losses, 'seen': seen, 'epochs': epochs}, os.path.join(outdir, f'r{rank}.pt'))
 
 
 def _spawn(mode):
@@ -260,3 +295,20 @@ def test_offloaded_checkpoint_recomputes_like_plain_autograd():
     for a, b in zip(got, (x.grad, aux.grad, lin.weight.grad)):
         assert torch.allclose(a, b, atol=1e-6)
     assert seen[:2] == [False, True]        # forward saw the flag, the recomputation got None in its place
+
+
+def test_pp2_data_feed_hands_first_stage_targets_to_the_last_stage():
+    first, last = _spawn('pp2_loader')
+    # the last stage trains against the FIRST stage's noise-dependent targets, its own draws are discarded
+    for mb_first, mb_last in zip(sum(first['seen'], []), sum(last['seen'], [])):
+        assert torch.equal(mb_first[1][0], mb_last[1][0]) and mb_last[1][1].numel() == 0          # None mask -> empty tensor
+        assert not torch.equal(mb_first[0][0], mb_last[0][0])                                      # features: independent noise
+    # oracle: sequential steps on the first stage's features and targets
+    layers = make_layers()
+    params = [p for l in layers for p in l.parameters()]
+    opt = torch.optim.AdamW(params, lr=1e-2)
+    want = [oracle.eager_train_step(layers, oracle.default_loss_fn(), micro, opt, gradient_clipping=0.5, params=params)[0].item()
+            for micro in first['seen']]
+    assert first['losses'] == pytest.approx(want, rel=1e-6) and last['losses'] == pytest.approx(want, rel=1e-6)
+    # 2 dataset batches x gas = 2 micro-batches each: step 3 starts epoch 2 on both end stages (one micro-batch is always pre-pulled)
+    assert first['epochs'] == last['epochs'] and first['epochs'][0] == 1 and first['epochs'][-1] == 2
