@@ -6,7 +6,10 @@ pairs (K3), flash / unfused attention (K4), LayerNorm fused with the AdaLN scale
 GELU(tanh) (K6), sinusoidal timestep features (K7).  Parity: tests/test_gpu_wan.py against vectors minted from the
 reference's own code (oracle/make_golden.py).
 """
+import math
+
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from .. import nn as dnn
@@ -279,9 +282,15 @@ class WanWorkload:
         bs, _, frames, h, w = latents.shape
         pt, ph, pw = self.cfg.patch_size
         self._grid = (frames // pt, h // ph, w // pw)
+        if mask is not None:
+            mask = F.interpolate(mask.unsqueeze(1), size=(h, w), mode='nearest-exact').unsqueeze(2)     # [B, 1, 1, h, w] on the latent grid
         t = self.t_dist
         if shift := self.model_config.get('shift', None):
             t = (t * shift) / (1 + (shift - 1) * t)
+        elif self.model_config.get('flux_shift', False):                # resolution-dependent shift (utils/common.py:114-121)
+            slope = (1.15 - 0.5) / (4096 - 256)
+            mu = slope * ((h // 2) * (w // 2)) + (0.5 - slope * 256)
+            t = math.exp(mu) / (math.exp(mu) + (1 / t - 1) ** 1.0)
         t = slice_t_distribution(t, min_t=self.model_config.get('min_t', 0.0), max_t=self.model_config.get('max_t', 1.0))
         t = sample_t(t, bs, quantile=timestep_quantile)
         x_1 = latents
