@@ -72,3 +72,65 @@ def test_oracle_wan_forward_matches_reference_whole_model_step():
     feats, (target, mask) = work.prepare_inputs({'latents': g['in.latents'], 'mask': None, 'text_embeddings': g['in.text_embeddings'],
                                                  'seq_lens': g['in.seq_lens']})
     assert torch.equal(feats[0], g['prep.x_t']) and torch.equal(feats[2], g['prep.t']) and torch.equal(target, g['prep.target']) and mask is None
+
+
+def test_oracle_sdxl_layers_match_the_reference_wrapper_classes():
+    """oracle/sdxl_ref.py's 23 pipeline layers against the reference's OWN wrapper classes (models/sdxl.py:654-995, lifted and run over
+    the same restated blocks by oracle/make_golden_sdxl_layers.py): every stage-boundary tuple layout (skip stack push / pop,
+    forward_upsample_size), the conditioning (timestep + text-time embedding, chunked prompt encoding) and the final output."""
+    import json
+    from safetensors.torch import load_file
+    from diffusion_pipe_amd.workloads import sdxl
+    from oracle import sdxl_ref
+    from oracle.make_golden_sdxl_layers import weight_checksum
+    base = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'sdxl_layers')
+    meta, g = json.load(open(base + '.json')), load_file(base + '.safetensors')
+    cfg = sdxl.tiny_config()
+    ref = sdxl_ref.SDXLRef(cfg, seed=meta['seed'])
+    assert abs(weight_checksum(ref) - meta['weight_checksum']) <= 1e-9 * meta['weight_checksum']          # same seeded weights as the generator
+    layers = ref.to_layers()
+    assert [type(l).__name__ for l in layers] == meta['layer_names']
+    assert [type(l).__name__ for l in sdxl.SDXLWorkload(cfg, dtype=torch.float32).to_layers()] == meta['layer_names']    # product: same 23 layers
+    for tag, rec in meta['cases'].items():
+        x = (g[f'{tag}.latents'].clone(), g[f'{tag}.timesteps'], g[f'{tag}.ids1'], g[f'{tag}.ids2'], g[f'{tag}.add_time_ids'])
+        for i, layer in enumerate(layers):
+            x = layer(x)
+            got = [list(t.shape) for t in x] if isinstance(x, tuple) else list(x.shape)
+            assert got == rec['layouts'][i], (tag, i, type(layer).__name__)
+            if i == 0:
+                assert torch.allclose(x[2], g[f'{tag}.emb'], rtol=1e-5, atol=1e-6) and torch.allclose(x[3], g[f'{tag}.encoder_hidden_states'], rtol=1e-5, atol=1e-6)
+                assert bool(x[-1]) == rec['forward_upsample_size']
+        out, ts = x
+        assert torch.allclose(out, g[f'{tag}.out'], rtol=1e-4, atol=1e-5) and torch.equal(ts, g[f'{tag}.out_ts'])
+
+
+def test_oracle_flux_layers_match_the_reference_wrapper_classes():
+    """oracle/flux_ref.py's pipeline layers against the reference's OWN Flux wrapper classes and prepare_inputs (models/flux.py:323-404,
+    456-548, lifted and run over the same restated blocks by oracle/make_golden_flux_layers.py); the product's prepare_inputs / layer list too."""
+    import json
+    from safetensors.torch import load_file
+    from diffusion_pipe_amd.workloads import flux
+    from oracle import flux_ref
+    from oracle.make_golden_flux_layers import weight_checksum
+    base = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'flux_layers')
+    meta, g = json.load(open(base + '.json')), load_file(base + '.safetensors')
+    cfg = flux.tiny_flux_config()
+    ref = flux_ref.FluxRef(cfg, seed=meta['seed'])
+    assert abs(weight_checksum(ref) - meta['weight_checksum']) <= 1e-9 * meta['weight_checksum']
+    work = flux.FluxWorkload(cfg, model_config={'guidance': 3.5}, dtype=torch.float32)
+    want_names = meta['layer_names']
+    assert [type(l).__name__ for l in work.to_layers()] == want_names and len(ref.to_layers()) == len(want_names)
+    torch.manual_seed(meta['seed_prepare_inputs'])
+    feats, (target, mask) = work.prepare_inputs({'latents': g['latents'], 'mask': None, 't5_embed': g['t5_embed'], 'clip_embed': g['clip_embed']})
+    for i, f in enumerate(feats):
+        assert torch.allclose(f.float(), g[f'feature.{i}'].float(), rtol=1e-6, atol=1e-6), i
+    assert torch.allclose(target, g['target'], rtol=1e-6, atol=1e-6) and mask is None
+    x = tuple(g[f'feature.{i}'].clone() for i in range(8))
+    for i, layer in enumerate(ref.to_layers()):
+        x = layer(x)
+        got = [list(v.shape) for v in x] if isinstance(x, tuple) else list(x.shape)
+        assert got == meta['layouts'][i], (i, type(layer).__name__)
+        if i == 0:
+            assert torch.allclose(x[2], g['temb'], rtol=1e-5, atol=1e-6) and torch.equal(x[3], g['freqs_cos']) and torch.equal(x[4], g['freqs_sin'])
+    assert torch.allclose(x, g['out'], rtol=1e-4, atol=1e-5)
+    assert abs(((x - g['target']) ** 2).mean().item() - meta['loss']) / meta['loss'] < 1e-5
