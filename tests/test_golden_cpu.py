@@ -134,3 +134,46 @@ def test_oracle_flux_layers_match_the_reference_wrapper_classes():
             assert torch.allclose(x[2], g['temb'], rtol=1e-5, atol=1e-6) and torch.equal(x[3], g['freqs_cos']) and torch.equal(x[4], g['freqs_sin'])
     assert torch.allclose(x, g['out'], rtol=1e-4, atol=1e-5)
     assert abs(((x - g['target']) ** 2).mean().item() - meta['loss']) / meta['loss'] < 1e-5
+
+
+def test_oracle_mmdit_blocks_match_the_in_tree_reference_blocks():
+    """oracle/blocks_ref.mm_double_block / mm_single_block against the reference's in-tree models/hunyuan_image_modeling.py blocks
+    (imported unmodified, hyimage leaf helpers stubbed: oracle/make_golden_mmdit.py): outputs on the valid rows, loss, input and
+    parameter gradients, with 5 of 12 text tokens of one sample padded."""
+    import json
+    from safetensors.torch import load_file
+    base = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'mmdit_blocks_fp32')
+    meta, g = json.load(open(base + '.json')), load_file(base + '.safetensors')
+    heads, Si, St = meta['heads'], meta['img_tokens'], meta['txt_tokens']
+    text_len = g['in.text_len']
+    valid = (torch.arange(St)[None, :] < text_len[:, None])[:, :, None].float()
+    cos, sin = g['in.cos_half'], g['in.sin_half']
+
+    def close(a, b, tol=1e-4):
+        return (a - b).abs().max() <= tol * b.abs().max() + 1e-7
+
+    # double-stream block
+    p = {k[len('double.param.'):]: v.clone().requires_grad_(True) for k, v in g.items() if k.startswith('double.param.')}
+    img, txt, vec = (g[f'in.{n}'].clone().requires_grad_(True) for n in ('img', 'txt', 'vec'))
+    o_img, o_txt = br.mm_double_block(p, img, txt, vec, heads, cos, sin, text_len)
+    assert close(o_img, g['double.out_img']) and close(o_txt * valid, g['double.out_txt'] * valid)
+    loss = (o_img * g['in.w_img']).sum() + (o_txt * g['in.w_txt'] * valid).sum()
+    assert abs(loss.item() - meta['double_loss']) / abs(meta['double_loss']) < 1e-5
+    loss.backward()
+    assert close(img.grad, g['double.grad.img']) and close(vec.grad, g['double.grad.vec'])
+    assert close(txt.grad * valid, g['double.grad.txt'] * valid)                       # padded text rows: don't-care (masked out of the loss)
+    for k, v in p.items():
+        assert close(v.grad, g[f'double.pgrad.{k}'], 2e-4), k
+    # single-stream block
+    p = {k[len('single.param.'):]: v.clone().requires_grad_(True) for k, v in g.items() if k.startswith('single.param.')}
+    x = torch.cat([g['in.img'], g['in.txt']], dim=1).requires_grad_(True)
+    vec = g['in.vec'].clone().requires_grad_(True)
+    rows = torch.cat([torch.ones(2, Si, 1), valid], dim=1)
+    out = br.mm_single_block(p, x, vec, St, heads, cos, sin, text_len)
+    assert close(out * rows, g['single.out'] * rows)
+    loss = (out * torch.cat([g['in.w_img'], g['in.w_txt'] * valid], dim=1)).sum()
+    assert abs(loss.item() - meta['single_loss']) / abs(meta['single_loss']) < 1e-5
+    loss.backward()
+    assert close(x.grad * rows, g['single.grad.x'] * rows) and close(vec.grad, g['single.grad.vec'])
+    for k, v in p.items():
+        assert close(v.grad, g[f'single.pgrad.{k}'], 2e-4), k
