@@ -40,6 +40,20 @@ def lift(path, name, cls=None, namespace=None):
     return ns[name], f'{path}:{node.lineno}-{node.end_lineno}'
 
 
+def lift_classes(path, names, namespace):
+    """Compile the named top-level classes of a reference file (autocast decorators dropped: CPU fp32 run)."""
+    full = os.path.join(REF, path)
+    tree = ast.parse(open(full).read(), filename=full)
+    nodes = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name in names]
+    for cls in nodes:
+        for fn in cls.body:
+            if isinstance(fn, ast.FunctionDef):
+                fn.decorator_list = [d for d in fn.decorator_list if 'autocast' not in ast.unparse(d)]
+    ns = dict(namespace)
+    exec(compile(ast.Module(body=nodes, type_ignores=[]), full, 'exec'), ns)
+    return ns
+
+
 # ------------------------------------------------------------------------------------------------ [3P] stubs
 class _Instr:
     def __init__(self, *args):
@@ -81,6 +95,35 @@ class TrainScheduleStub:
         if even_step and not even_stage:
             return step_id // 2 - self.stages + (self.stage_id + 1) // 2, False
         return (step_id - 1) // 2 - self.stages + 1 + self.stage_id // 2, False
+
+
+def loader_trace(make_loader):
+    """The scenario both loaders are put through: 3 dataset batches x GAS 2; 8 micro-batches, a state dict after the 3rd, a fresh loader
+    resumed from it, 7 more micro-batches.  Records (payload id, epoch, num_batches_pulled) after every next()."""
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 3
+
+        def __getitem__(self, i):
+            return {'x': torch.full((4, 2), float(i)), 'mask': None}
+    model = type('M', (), {'prepare_inputs': staticmethod(lambda batch, timestep_quantile=None: ((batch['x'],), (batch['x'] + 100, batch['mask'])))})
+    engine = type('E', (), {'is_pipe_parallel': False})()
+
+    def run(loader, n):
+        it = iter(loader)
+        out = []
+        for _ in range(n):
+            f, l = next(it)
+            out.append([float(f[0][0, 0]), int(f[0].shape[0]), float(l[0][0, 0]), int(l[1].numel()), loader.epoch, loader.num_batches_pulled])
+        return out
+    a = make_loader(DS(), engine, 2, model)
+    first = run(a, 3)
+    state = a.state_dict()
+    more = run(a, 5)
+    b = make_loader(DS(), engine, 2, model)
+    b.load_state_dict(dict(state))
+    resumed = run(b, 7)
+    return {'len': len(a), 'first': first, 'state': state, 'more': more, 'resumed': resumed, 'resumed_state': b.state_dict()}
 
 
 def main():
@@ -344,6 +387,11 @@ def main():
         torch.manual_seed(79)
         feats, label = flux_prep(st, {'latents': lat16, 'clip_embed': clip, 't5_embed': t5, 'mask': mskf if use_mask else None}, timestep_quantile=q)
         record(tag, feats, label)
+
+    # ---- a3: PipelineDataLoader (utils/dataset.py:1302-1435): micro-batch stream, epoch roll-over, resume from a state dict ------------
+    ld_ns = lift_classes('utils/dataset.py', {'PipelineDataLoader', 'SkipFirstNSampler'}, {'torch': torch, 'split_batch': split_b, 'dist': None})
+    gold['loader_trace'] = loader_trace(lambda ds, eng, gas, model: ld_ns['PipelineDataLoader'](ds, eng, gas, model, num_dataloader_workers=0))
+    meta['PipelineDataLoader'] = 'utils/dataset.py:1302-1435'
 
     os.makedirs(OUT, exist_ok=True)
     with open(os.path.join(OUT, 'reflogic.json'), 'w') as fh:

@@ -20,25 +20,11 @@ from safetensors.torch import save_file
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 from oracle.make_golden import REF, import_reference_wan          # noqa: E402
-from oracle.make_golden_reflogic import lift                       # noqa: E402
+from oracle.make_golden_reflogic import lift, lift_classes         # noqa: E402, F401
 
 OUT = os.path.join(HERE, '..', 'tests', 'golden')
 CFG = dict(model_type='t2v', patch_size=(1, 2, 2), text_len=24, in_dim=16, dim=128, ffn_dim=256, freq_dim=256, text_dim=64, out_dim=16,
            num_heads=2, num_layers=2, window_size=(-1, -1), qk_norm=True, cross_attn_norm=True, eps=1e-6)
-
-
-def lift_classes(path, names, namespace):
-    """Compile the named top-level classes of a reference file (autocast decorators dropped: CPU fp32 run)."""
-    full = os.path.join(REF, path)
-    tree = ast.parse(open(full).read(), filename=full)
-    nodes = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name in names]
-    for cls in nodes:
-        for fn in cls.body:
-            if isinstance(fn, ast.FunctionDef):
-                fn.decorator_list = [d for d in fn.decorator_list if 'autocast' not in ast.unparse(d)]
-    ns = dict(namespace)
-    exec(compile(ast.Module(body=nodes, type_ignores=[]), full, 'exec'), ns)
-    return ns
 
 
 def main():

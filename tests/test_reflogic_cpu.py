@@ -214,3 +214,25 @@ def test_flux_prepare_inputs_matches_reference_body():
         torch.manual_seed(79)
         feats, label = work.prepare_inputs({'latents': lat, 'clip_embed': clip, 't5_embed': t5, 'mask': msk if use_mask else None}, timestep_quantile=q)
         _check_prepared(tag, feats, label, exact=False)
+
+
+def test_micro_batch_loader_follows_the_reference_dataloader_trace():
+    """data.MicroBatchLoader put through the scenario the reference's own PipelineDataLoader class (utils/dataset.py:1302-1435, lifted)
+    was recorded on: micro-batch order, None mask -> empty tensor, epoch roll-over as soon as the last micro-batch is handed out,
+    num_batches_pulled bookkeeping, and resuming from a state dict (restarts at the batch boundary, as the reference does)."""
+    from oracle.make_golden_reflogic import loader_trace
+
+    class Adapter:                                    # MicroBatchLoader takes the dataset and the prepare_inputs hook directly
+        def __init__(self, ds, engine, gas, model):
+            self.inner = data.MicroBatchLoader(ds, engine, gas, model.prepare_inputs)
+
+        def __getattr__(self, name):
+            return getattr(self.inner, name)
+
+        def __iter__(self):
+            return iter(self.inner)
+
+        def __len__(self):
+            return len(self.inner)
+    got = loader_trace(Adapter)
+    assert got == G['loader_trace']
