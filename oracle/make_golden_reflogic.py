@@ -393,6 +393,48 @@ def main():
     gold['loader_trace'] = loader_trace(lambda ds, eng, gas, model: ld_ns['PipelineDataLoader'](ds, eng, gas, model, num_dataloader_workers=0))
     meta['PipelineDataLoader'] = 'utils/dataset.py:1302-1435'
 
+    # ---- a10: get_optimizer (train.py:650-815, nested in the main block) over SDXLPipeline.get_param_groups (models/sdxl.py:604-630) -------
+    import inspect
+    full = os.path.join(REF, 'train.py')
+    tree = ast.parse(open(full).read(), filename=full)
+    node = next(n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == 'get_optimizer')
+    dummy_cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == 'DummyOptimizer')
+    meta['get_optimizer'] = f'train.py:{node.lineno}-{node.end_lineno}'
+    gpg, meta['sdxl.get_param_groups'] = lift('models/sdxl.py', 'get_param_groups', cls='SDXLPipeline', namespace={'is_main_process': lambda: False})
+    from collections import defaultdict
+
+    def make_params():
+        specs = [('unet.conv_in.weight', (8, 4, 3, 3)), ('unet.conv_in.bias', (8,)), ('unet.mid.attn.to_q.weight', (8, 8)), ('unet.norm.weight', (8,)),
+                 ('text_encoder.layers.0.q_proj.weight', (4, 4)), ('text_encoder.layers.0.q_proj.bias', (4,)), ('text_encoder.final_layer_norm.weight', (4,)),
+                 ('text_encoder_2.text_projection.weight', (6, 4)), ('text_encoder_2.embeddings.position_embedding.weight', (7, 4)), ('text_encoder_2.ln.bias', (4,))]
+        out = []
+        for name, shape in specs:
+            prm = torch.nn.Parameter(torch.zeros(shape))
+            prm.original_name = name
+            out.append(prm)
+        return out
+    gold['get_optimizer'] = []
+    for case, (optim_cfg, model_cfg, gbs) in enumerate([
+            ({'type': 'adamw', 'lr': 2e-5, 'betas': [0.9, 0.99], 'weight_decay': 0.01, 'eps': 1e-8}, {}, 4),
+            ({'type': 'AdamW', 'lr': 2e-5, 'betas': [0.9, 0.99], 'weight_decay': 0.01, 'eps': 1e-8, 'beta2_half_life': 2000},
+             {'unet_lr': 4e-5, 'text_encoder_2_lr': 1e-6}, 16),
+            ({'type': 'sgd', 'lr': 1e-3, 'momentum': 0.9, 'weight_decay': 0.1}, {'text_encoder_1_lr': 5e-4}, 8)]):
+        config = {'optimizer': json.loads(json.dumps(optim_cfg))}
+        model_stub = type('M', (), {})()
+        model_stub.config, model_stub.model_config = config, model_cfg
+        model_stub.get_param_groups = lambda params, m=model_stub: gpg(m, params)
+        ns = {'torch': torch, 'inspect': inspect, 'config': config, 'global_batch_size': gbs, 'model': model_stub, 'pipeline_model': None,
+              'ds_config': {'gradient_accumulation_steps': 1}, 'defaultdict': defaultdict, 'print': lambda *a, **k: None}
+        exec(compile(ast.Module(body=[dummy_cls, node], type_ignores=[]), full, 'exec'), ns)
+        params = make_params()
+        opt = ns['get_optimizer'](params)
+        groups = [{'params': [q.original_name for q in gr['params']], **{k: (list(v) if isinstance(v, tuple) else v) for k, v in gr.items()
+                                                                          if k in ('lr', 'weight_decay', 'betas', 'eps', 'momentum')}} for gr in opt.param_groups]
+        empty = ns['get_optimizer']([])
+        gold['get_optimizer'].append({'optimizer': optim_cfg, 'model_config': model_cfg, 'global_batch_size': gbs, 'class': type(opt).__name__,
+                                      'groups': groups, 'empty_class': type(empty).__name__, 'empty_groups': empty.param_groups,
+                                      'empty_state_dict': empty.state_dict()})
+
     os.makedirs(OUT, exist_ok=True)
     with open(os.path.join(OUT, 'reflogic.json'), 'w') as fh:
         json.dump({'generated_from': meta, 'torch': torch.__version__, 'golden': gold}, fh, indent=0)

@@ -236,3 +236,39 @@ def test_micro_batch_loader_follows_the_reference_dataloader_trace():
             return len(self.inner)
     got = loader_trace(Adapter)
     assert got == G['loader_trace']
+
+
+def test_optimizer_factory_matches_the_reference_get_optimizer():
+    """optim.make_optimizer_factory over SDXLWorkload.get_param_groups against the reference's own get_optimizer body (train.py:650-815,
+    lifted out of the main block) over its own SDXLPipeline.get_param_groups (models/sdxl.py:604-630): optimizer class, group order,
+    per-component learning rates, weight-decay split, beta2 from beta2_half_life, the no-op optimizer of a parameterless stage."""
+    from diffusion_pipe_amd import optim
+    from diffusion_pipe_amd.workloads import sdxl
+    for rec in G['get_optimizer']:
+        names = [n for gr in rec['groups'] for n in gr['params']]
+        shapes = {'unet.conv_in.weight': (8, 4, 3, 3), 'unet.mid.attn.to_q.weight': (8, 8), 'text_encoder.layers.0.q_proj.weight': (4, 4),
+                  'text_encoder_2.text_projection.weight': (6, 4), 'text_encoder_2.embeddings.position_embedding.weight': (7, 4)}
+        order = ['unet.conv_in.weight', 'unet.conv_in.bias', 'unet.mid.attn.to_q.weight', 'unet.norm.weight', 'text_encoder.layers.0.q_proj.weight',
+                 'text_encoder.layers.0.q_proj.bias', 'text_encoder.final_layer_norm.weight', 'text_encoder_2.text_projection.weight',
+                 'text_encoder_2.embeddings.position_embedding.weight', 'text_encoder_2.ln.bias']
+        assert sorted(order) == sorted(names)
+        params = []
+        for n in order:
+            p = torch.nn.Parameter(torch.zeros(shapes.get(n, (4,))))
+            p.original_name = n
+            params.append(p)
+        work = sdxl.SDXLWorkload.__new__(sdxl.SDXLWorkload)                 # only get_param_groups is exercised: no model is built
+        work.model_config, work.train_config = rec['model_config'], {'optimizer': dict(rec['optimizer'])}
+        factory = optim.make_optimizer_factory(work.train_config, work, rec['global_batch_size'], device_is_gpu=False)
+        opt = factory(params)
+        assert type(opt).__name__ == rec['class']
+        got = [{'params': [q.original_name for q in gr['params']], **{k: (list(v) if isinstance(v, tuple) else v) for k, v in gr.items()
+                                                                       if k in ('lr', 'weight_decay', 'betas', 'eps', 'momentum')}} for gr in opt.param_groups]
+        assert len(got) == len(rec['groups'])
+        for a, b in zip(got, rec['groups']):
+            assert a['params'] == b['params'] and a['lr'] == b['lr'] and a['weight_decay'] == b['weight_decay']
+            for k in ('betas', 'eps', 'momentum'):
+                if k in b:
+                    assert a[k] == pytest.approx(b[k], rel=1e-12), k
+        empty = factory([])
+        assert type(empty).__name__ == rec['empty_class'] and empty.param_groups == rec['empty_groups'] and empty.state_dict() == rec['empty_state_dict']
