@@ -177,3 +177,39 @@ def test_oracle_mmdit_blocks_match_the_in_tree_reference_blocks():
     assert close(x.grad * rows, g['single.grad.x'] * rows) and close(vec.grad, g['single.grad.vec'])
     for k, v in p.items():
         assert close(v.grad, g[f'single.pgrad.{k}'], 2e-4), k
+
+
+def test_oracle_clip_text_encoders_match_hf_transformers():
+    """oracle/sdxl_ref.CLIPTextModel (both SDXL encoder geometries) against the real HF transformers CLIPTextModel /
+    CLIPTextModelWithProjection (oracle/make_golden_clip.py): penultimate hidden state, first output (projected pooled embedding for
+    encoder 2; for encoder 1 the reference never reads it), loss and every parameter gradient."""
+    import json
+    from safetensors.torch import load_file
+    from diffusion_pipe_amd.workloads import sdxl
+    from oracle import sdxl_ref
+    base = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'clip_encoders_fp32')
+    meta, g = json.load(open(base + '.json')), load_file(base + '.safetensors')
+    cfg = sdxl.tiny_config()
+    for tag, c in (('te1', cfg.te1), ('te2', cfg.te2)):
+        model = sdxl_ref.CLIPTextModel(c)
+        sd = {k[len(f'{tag}.param.'):]: v for k, v in g.items() if k.startswith(f'{tag}.param.')}
+        if c.proj_dim is None:
+            sd = {k: v for k, v in sd.items() if not k.startswith('text_projection.')}
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        assert not missing and not unexpected, (tag, missing, unexpected)
+        hidden_states, pooled = model(g[f'{tag}.ids'])
+        assert len(hidden_states) == meta['encoders'][tag]['hidden_states']
+        penult = hidden_states[-2]
+        assert torch.allclose(penult, g[f'{tag}.penultimate'], rtol=1e-4, atol=1e-5)
+        loss = (penult * g[f'{tag}.w1']).sum()
+        if tag == 'te2':
+            assert torch.allclose(pooled, g[f'{tag}.first'], rtol=1e-4, atol=1e-5)
+            loss = loss + (pooled * g[f'{tag}.w2']).sum()
+        assert abs(loss.item() - g[f'{tag}.loss'].item()) <= 1e-5 * abs(g[f'{tag}.loss'].item())
+        loss.backward()
+        scale = max(g[f'{tag}.grad.{k}'].abs().max().item() for k, _ in model.named_parameters())
+        for k, p in model.named_parameters():
+            want = g[f'{tag}.grad.{k}']
+            got = p.grad if p.grad is not None else torch.zeros_like(p)          # layers past the penultimate state get no gradient in encoder 1
+            # (analytically-zero gradients such as k_proj.bias are pure rounding noise: absolute floor at 1e-5 of the largest gradient)
+            assert (got - want).abs().max() <= 2e-4 * want.abs().max() + 1e-5 * scale, (tag, k)

@@ -142,3 +142,39 @@ def test_concurrent_micro_batch_lanes_match_sequential_graph_path(gpu):
         for (l0, n0), (l1, n1) in zip(base, got):
             assert abs(l1 - l0) / abs(l0) < 5e-3, (lanes, base, got)
             assert abs(n1 - n0) / n0 < 1e-2, (lanes, base, got)
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-3), (torch.bfloat16, 4e-2)])
+def test_clip_text_encoders_match_hf_transformers_vectors(gpu, dtype, tol):
+    """The HIP-kernel CLIP text encoders (both SDXL geometries: quick_gelu / gelu + projection, causal attention) against vectors from
+    the real HF transformers CLIPTextModel / CLIPTextModelWithProjection (oracle/make_golden_clip.py): penultimate hidden state,
+    projected pooled embedding, loss, all parameter gradients as one vector."""
+    import os
+    from safetensors.torch import load_file
+    from diffusion_pipe_amd.workloads import sdxl
+    g = load_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'clip_encoders_fp32.safetensors'))
+    cfg = sdxl.tiny_config()
+    for tag, c in (('te1', cfg.te1), ('te2', cfg.te2)):
+        model = sdxl.CLIPTextModel(c)
+        sd = {k[len(f'{tag}.param.'):]: v for k, v in g.items() if k.startswith(f'{tag}.param.')}
+        if c.proj_dim is None:
+            sd = {k: v for k, v in sd.items() if not k.startswith('text_projection.')}
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        assert not missing and not unexpected, (tag, missing, unexpected)
+        model.to(gpu, dtype)
+        penult, pooled = model(g[f'{tag}.ids'].to(gpu), want_pooled=(tag == 'te2'))
+        want_p = g[f'{tag}.penultimate']
+        assert ((penult.float().cpu() - want_p).abs().max() / want_p.abs().max()).item() < tol
+        loss = (penult.float() * g[f'{tag}.w1'].to(gpu)).sum()
+        if tag == 'te2':
+            want_e = g[f'{tag}.first']
+            assert ((pooled.float().cpu() - want_e).abs().max() / want_e.abs().max()).item() < tol
+            loss = loss + (pooled.float() * g[f'{tag}.w2'].to(gpu)).sum()
+        assert abs(loss.item() - g[f'{tag}.loss'].item()) / abs(g[f'{tag}.loss'].item()) < tol
+        loss.backward()
+        err2 = ref2 = 0.0
+        for k, p in model.named_parameters():
+            want = g[f'{tag}.grad.{k}']
+            got = p.grad.float().cpu() if p.grad is not None else torch.zeros_like(want)
+            err2, ref2 = err2 + (got - want).double().pow(2).sum().item(), ref2 + want.double().pow(2).sum().item()
+        assert (err2 / ref2) ** 0.5 < tol, tag
