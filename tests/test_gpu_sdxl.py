@@ -144,7 +144,7 @@ def test_concurrent_micro_batch_lanes_match_sequential_graph_path(gpu):
             assert abs(n1 - n0) / n0 < 1e-2, (lanes, base, got)
 
 
-@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-3), (torch.bfloat16, 4e-2)])
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
 def test_clip_text_encoders_match_hf_transformers_vectors(gpu, dtype, tol):
     """The HIP-kernel CLIP text encoders (both SDXL geometries: quick_gelu / gelu + projection, causal attention) against vectors from
     the real HF transformers CLIPTextModel / CLIPTextModelWithProjection (oracle/make_golden_clip.py): penultimate hidden state,

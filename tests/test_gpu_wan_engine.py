@@ -43,7 +43,7 @@ def test_wan_train_batch_matches_oracle(gpu, dtype, tol):
     assert abs(norm - want_norm) / want_norm < tol * 1.5, (norm, want_norm)
 
 
-@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-3), (torch.bfloat16, 4e-2)])
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
 def test_wan_model_matches_reference_whole_model_vectors(gpu, dtype, tol):
     """The HIP-kernel Wan model (to_layers() = Initial + blocks + Final, default loss) against vectors from the reference's own
     WanModel driven through the reference's own pipeline layers, prepare_inputs and loss (oracle/make_golden_wan_model.py):
