@@ -9,8 +9,9 @@ Per double block: two AdaLN-Zero modulations (SiLU -> Linear -> 6 chunks), Layer
 QKV GEMM per stream (K1), per-head RMSNorm of q / k (K2), RoPE over the joint [text ; image] sequence (K3), flash attention
 (K4), output projections, gated residuals (K5), GELU-tanh feed-forward (K6).  Single block: the same on the concatenated
 sequence with the parallel MLP branch and one output GEMM over [attention | mlp].
-The diffusers package is absent from the image: restated from its published definition, PARITY UNPINNED (oracle side:
-oracle/flux_ref.py).
+The diffusers package is absent from the image: the block arithmetic is restated from its published definition (parity unpinned);
+the wrappers, to_layers and prepare_inputs are pinned by the reference's own code (oracle/make_golden_flux_layers.py,
+oracle/make_golden_reflogic.py; oracle side: oracle/flux_ref.py).
 """
 import math
 from dataclasses import dataclass

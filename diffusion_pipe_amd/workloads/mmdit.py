@@ -1,8 +1,9 @@
 """MMDiT double-stream / single-stream blocks (Flux, HunyuanVideo, HunyuanImage: BASELINE configs 3 and 5) on the MI355X
 kernels.  Dataflow and parameter names follow the reference's in-tree restatement with fused QKV,
 models/hunyuan_image_modeling.py:61-345 (its helpers ModulateDiT / MLP / RMSNorm / modulate / apply_gate / apply_rotary_emb
-live in the un-vendored hyimage package: restated from their published definitions, PARITY UNPINNED -- the oracle side is
-oracle/blocks_ref.py:mm_double_block / mm_single_block).
+live in the un-vendored hyimage package and are restated from their published definitions; the block dataflow itself is pinned:
+the oracle side, oracle/blocks_ref.py:mm_double_block / mm_single_block, is tested against vectors from the reference file imported
+unmodified -- oracle/make_golden_mmdit.py).
 
 Per block: AdaLN modulation from `vec` (SiLU -> Linear), LayerNorm fused with scale/shift (K5), ONE fused QKV GEMM per stream
 (K1), per-head RMSNorm of q and k (K2), RoPE on the image tokens (K3), joint attention over [image ; text] tokens with the
