@@ -50,9 +50,9 @@ class Last(nn.Module):
         return self.lin(x + skip) * (1 + ids.float().mean() * 0)
 
 
-def make_layers(seed=0):
+def make_layers(seed=0, n_mid=4):
     torch.manual_seed(seed)
-    return [First(), Mid(), Mid(), Mid(), Mid(), Last()]
+    return [First()] + [Mid() for _ in range(n_mid)] + [Last()]
 
 
 def make_batches(n, bs, seed):
@@ -66,8 +66,8 @@ def make_batches(n, bs, seed):
     return out
 
 
-def oracle_run(steps, gas, clip, batches_per_step):
-    layers = make_layers()
+def oracle_run(steps, gas, clip, batches_per_step, n_mid=4):
+    layers = make_layers(n_mid=n_mid)
     params = [p for l in layers for p in l.parameters()]
     opt = torch.optim.AdamW(params, lr=1e-2)
     losses = []
@@ -77,8 +77,8 @@ def oracle_run(steps, gas, clip, batches_per_step):
     return losses, [p.detach().clone() for p in params]
 
 
-def engine_run(steps, gas, clip, batches_for_rank, num_stages, partition_method='uniform', split=None, scope='global'):
-    layers = make_layers()
+def engine_run(steps, gas, clip, batches_for_rank, num_stages, partition_method='uniform', split=None, scope='global', n_mid=4):
+    layers = make_layers(n_mid=n_mid)
     all_params = [p for l in layers for p in l.parameters()]
     module = ManualPipelineModule(layers=layers, num_stages=num_stages, partition_method=partition_method,
                                   manual_partition_split=split, loss_fn=oracle.default_loss_fn(), dynamic_shape=True)
@@ -126,6 +126,18 @@ def _worker(rank, world, port, mode, outdir):
         elif mode == 'pp2_dsclip':
             batches = [make_batches(gas, 2, 100)]
             losses, params, engine = engine_run(1, gas, 0.05, batches, num_stages=2, partition_method='uniform', scope='deepspeed')
+        elif mode == 'pp4':          # 4 stages x 1 replica: fill / steady state / drain of the 1F1B order over three stage boundaries
+            batches = [make_batches(gas + 2, 2, 100 + s) for s in range(steps)]
+            losses, params, engine = engine_run(steps, gas + 2, 0.5, batches, num_stages=4, partition_method='uniform', scope='global')
+            assert engine.module.parts == [0, 2, 4, 5, 6]
+        elif mode == 'pp8':          # the BASELINE pp = 8 depth: 10 layers over 8 stages, 16 micro-batches
+            batches = [make_batches(16, 2, 100 + s) for s in range(steps)]
+            losses, params, engine = engine_run(steps, 16, 0.5, batches, num_stages=8, partition_method='uniform', scope='global', n_mid=8)
+        elif mode == 'pp2dp2':       # 2 stages x 2 replicas: replica d sees its own micro-batches, gradients averaged over the DP group
+            d = engine_dp_rank(rank)
+            batches = [make_batches(2 * gas, 2, 100 + s)[d * gas:(d + 1) * gas] for s in range(steps)]
+            losses, params, engine = engine_run(steps, gas, 0.5, batches, num_stages=2, partition_method='manual', split=[3], scope='global')
+            assert engine.grid.get_data_parallel_rank() == d and engine.dp_world_size == 2
         elif mode == 'pp2_loader':
             _loader_worker(rank, outdir)
             return
@@ -170,10 +182,15 @@ def _loader_worker(rank, outdir):
     torch.save({'losses': losses, 'seen': seen, 'epochs': epochs}, os.path.join(outdir, f'r{rank}.pt'))
 
 
-def _spawn(mode):
+def engine_dp_rank(rank):
+    """[3P] PipeDataParallelTopology(axes = pipe, data): rank = stage * num_dp + dp_rank (2 x 2 grid here)."""
+    return rank % 2
+
+
+def _spawn(mode, world=2):
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(2, _free_port(), mode, d), nprocs=2, join=True)
-        return [torch.load(os.path.join(d, f'r{r}.pt')) for r in range(2)]
+        mp.spawn(_worker, args=(world, _free_port(), mode, d), nprocs=world, join=True)
+        return [torch.load(os.path.join(d, f'r{r}.pt')) for r in range(world)]
 
 
 def _stage_params(res, layer_param_counts):
@@ -312,3 +329,41 @@ def test_pp2_data_feed_hands_first_stage_targets_to_the_last_stage():
     assert first['losses'] == pytest.approx(want, rel=1e-6) and last['losses'] == pytest.approx(want, rel=1e-6)
     # 2 dataset batches x gas = 2 micro-batches each: step 3 starts epoch 2 on both end stages (one micro-batch is always pre-pulled)
     assert first['epochs'] == last['epochs'] and first['epochs'][0] == 1 and first['epochs'][-1] == 2
+
+
+def test_engine_pp4_gloo_matches_oracle():
+    steps, gas = 2, 6
+    batches = [make_batches(gas, 2, 100 + s) for s in range(steps)]
+    want_l, want_p = oracle_run(steps, gas, 0.5, batches)
+    res = _spawn('pp4', world=4)
+    for r in res:
+        assert r['losses'] == pytest.approx(want_l, rel=1e-6)
+    got = _stage_params(res, [2] * 6)
+    for a, b in zip(got, want_p):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+
+
+def test_engine_pp2_dp2_gloo_matches_oracle():
+    """The 2 x 2 grid the reference runs on 4 GPUs with pipeline_stages = 2: equals one process over all 2 * gas micro-batches."""
+    steps, gas = 2, 4
+    batches = [make_batches(2 * gas, 2, 100 + s) for s in range(steps)]
+    want_l, want_p = oracle_run(steps, 2 * gas, 0.5, batches)
+    res = _spawn('pp2dp2', world=4)
+    for r in res:
+        assert r['losses'] == pytest.approx(want_l, rel=1e-5)
+    for replica in (0, 1):                                   # ranks {0, 2} hold replica 0's stages, {1, 3} replica 1's
+        got = _stage_params([res[replica], res[2 + replica]], [2] * 6)
+        for a, b in zip(got, want_p):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+def test_engine_pp8_gloo_matches_oracle():
+    steps, gas = 2, 16
+    batches = [make_batches(gas, 2, 100 + s) for s in range(steps)]
+    want_l, want_p = oracle_run(steps, gas, 0.5, batches, n_mid=8)
+    res = _spawn('pp8', world=8)
+    for r in res:
+        assert r['losses'] == pytest.approx(want_l, rel=1e-6)
+    got = _stage_params(res, [2] * 10)
+    for a, b in zip(got, want_p):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
