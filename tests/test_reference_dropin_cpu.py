@@ -1,0 +1,130 @@
+"""Drop-in check of the engine boundary: functions and classes of the REFERENCE'S training loop, lifted out of
+/root/reference at test time with `ast` and executed unmodified, drive THIS repository's engine, loader and module -- the reference's
+own `evaluate_single` / `get_data_iterator_for_step` (train.py:167-195) and its `Saver` (utils/saver.py:47-128: save_full_model,
+save_adapter, save_checkpoint).  Skipped where the reference tree is absent (the GPU box); CPU only."""
+import os
+
+import pytest
+import torch
+from torch import nn
+
+REF = '/root/reference'
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason='reference tree not present')
+
+from diffusion_pipe_amd import data as dpdata                          # noqa: E402
+from diffusion_pipe_amd import evaluate as dpeval                      # noqa: E402
+from diffusion_pipe_amd.engine import ManualPipelineModule, initialize  # noqa: E402
+from oracle import eager_step as oracle                                # noqa: E402
+
+D = 8
+
+
+class Toy(nn.Module):
+    def __init__(self, first=False):
+        super().__init__()
+        self.lin, self.first = nn.Linear(D, D), first
+
+    def forward(self, x):
+        if self.first:
+            x = x[0] if isinstance(x, tuple) else x
+        return torch.tanh(self.lin(x))
+
+
+def _engine(trainable_only_last=False):
+    torch.manual_seed(0)
+    layers = [Toy(first=True), Toy(), Toy()]
+    for i, layer in enumerate(layers):
+        for n, p in layer.named_parameters():
+            p.original_name = f'blocks.{i}.{n}'
+            if trainable_only_last and i < 2:
+                p.requires_grad_(False)
+    module = ManualPipelineModule(layers=layers, num_stages=1, partition_method='uniform', loss_fn=oracle.default_loss_fn(), dynamic_shape=True)
+    engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 2, 'gradient_accumulation_steps': 2, 'gradient_clipping': 1.0},
+                                 device='cpu')
+    engine.grad_kernels = oracle.TorchGradKernels
+    engine._configure_optimizer(lambda ps: torch.optim.AdamW(ps, lr=1e-2), [p for p in module.parameters() if p.requires_grad])
+    return engine, module, layers
+
+
+def _dataset():
+    g = torch.Generator().manual_seed(4)
+    return [{'x': torch.randn(4, D, generator=g)} for _ in range(3)]
+
+
+def _prepare_inputs(batch, timestep_quantile=None):
+    q = 0.5 if timestep_quantile is None else timestep_quantile
+    noise = torch.randn(batch['x'].shape) if timestep_quantile is None else torch.full_like(batch['x'], q)
+    return (batch['x'] * (1 - q) + noise * q,), (noise - batch['x'], None)
+
+
+def test_reference_evaluate_single_drives_this_engine():
+    from oracle.make_golden_reflogic import lift
+    get_it, _ = lift('train.py', 'get_data_iterator_for_step')
+    ref_eval, where = lift('train.py', 'evaluate_single', namespace={'get_data_iterator_for_step': get_it})
+    assert where.startswith('train.py:')
+    engine, module, layers = _engine()
+    loader = dpdata.MicroBatchLoader(_dataset(), engine, 2, _prepare_inputs)
+    for q in (0.1, 0.5, 0.9):
+        want = ref_eval(engine, loader, 2, q)                          # the reference's own loop over this engine / loader
+        got = dpeval.evaluate_single(engine, loader, 2, q)
+        assert got == pytest.approx(want, rel=1e-7)
+        # and both equal the oracle's mean loss over the same micro-batches
+        loader.set_eval_quantile(q)
+        micro = [next(iter(loader)) for _ in range(6)]
+        loader.reset()
+        per_step = [oracle.eager_eval(layers, oracle.default_loss_fn(), micro[i:i + 2]).item() for i in (0, 2, 4)]
+        assert got == pytest.approx(sum(per_step) / 3, rel=1e-6)
+    torch.manual_seed(123)
+    before = torch.random.get_rng_state()
+    out = dpeval.evaluate(engine, {'eval0': loader}, 2)
+    assert torch.equal(torch.random.get_rng_state(), before)          # training RNG stream untouched
+    assert len(out) == 10 and out['eval0/loss'] == pytest.approx(sum(out[f'eval0/loss_quantile_{q:.2f}'] for q in dpeval.TIMESTEP_QUANTILES_FOR_EVAL) / 9)
+
+
+def test_reference_saver_drives_this_engine(tmp_path):
+    from oracle.make_golden_reflogic import lift, lift_classes
+    conv, _ = lift('utils/saver.py', 'convert_state_dict_dtype')
+    dist_stub = type('dist', (), {'barrier': staticmethod(lambda: None)})
+    logger = type('L', (), {'warning': staticmethod(lambda *a: None)})
+    ns = lift_classes('utils/saver.py', {'Saver'}, {'Path': __import__('pathlib').Path, 'os': os, 'shutil': __import__('shutil'), 'torch': torch,
+                                                   'dist': dist_stub, 'logger': logger, 'convert_state_dict_dtype': conv, 'is_main_process': lambda: True,
+                                                   'print': lambda *a, **k: None})
+    Saver = ns['Saver']
+    saved = {}
+
+    class Model:                                                          # the adapter hooks the Saver calls
+        def save_model(self, save_dir, state_dict):
+            saved['model'] = dict(state_dict)
+
+        def save_adapter(self, save_dir, state_dict):
+            saved['adapter'] = dict(state_dict)
+    cfg_file = tmp_path / 'run.toml'
+    cfg_file.write_text('x = 1\n')
+    args = type('A', (), {'config': str(cfg_file)})
+
+    # full fine-tune: every parameter, keyed by original_name, cast to save_dtype
+    engine, module, layers = _engine()
+    loader = dpdata.MicroBatchLoader(_dataset(), engine, 2, _prepare_inputs)
+    s = Saver(args, {'save_dtype': torch.bfloat16}, False, tmp_path / 'out', Model(), loader, engine, module)
+    s.save_model('step1')
+    want = {p.original_name: p for p in module.parameters()}
+    assert saved['model'].keys() == want.keys() and all(v.dtype == torch.bfloat16 for v in saved['model'].values())
+    assert all(torch.equal(saved['model'][k], want[k].detach().to(torch.bfloat16)) for k in want)
+    assert (tmp_path / 'out' / 'step1' / 'run.toml').exists() and not (tmp_path / 'out' / 'step1' / 'tmp').exists()
+
+    # adapter: only trainable parameters
+    engine2, module2, _ = _engine(trainable_only_last=True)
+    s2 = Saver(args, {}, True, tmp_path / 'out2', Model(), loader, engine2, module2)
+    s2.save_model('epoch1')
+    assert set(saved['adapter']) == {'blocks.2.lin.weight', 'blocks.2.lin.bias'}
+
+    # training-state checkpoint through the reference's call (save_latest, exclude_frozen_parameters, client_state with the loader state)
+    it = iter(loader)
+    engine.train_batch(iter([next(it), next(it)]))
+    s.save_checkpoint(step=7, examples=28)
+    engine3, module3, _ = _engine()
+    path, client = engine3.load_checkpoint(str(tmp_path / 'out'))
+    assert client['step'] == 7 and client['examples'] == 28 and client['custom_loader'] == loader.state_dict()
+    for a, b in zip(module3.parameters(), module.parameters()):
+        assert torch.equal(a, b)
+    assert engine3.optimizer.state_dict()['state'].keys() == engine.optimizer.state_dict()['state'].keys()
