@@ -128,3 +128,31 @@ def test_reference_saver_drives_this_engine(tmp_path):
     for a, b in zip(module3.parameters(), module.parameters()):
         assert torch.equal(a, b)
     assert engine3.optimizer.state_dict()['state'].keys() == engine.optimizer.state_dict()['state'].keys()
+
+
+def test_reference_clip_grad_norm_as_the_engine_clip_override():
+    """`engine.clip_grad_fn` (the hook the reference fills with its patched clip_grad_norm_, utils/patches.py:175-246,429): the lifted
+    reference function, given this engine's grid as `mpu`, produces the same step as the engine's own kernels-based clip."""
+    import math
+    from oracle.make_golden_reflogic import lift
+    acc = type('Acc', (), {'current_device_name': staticmethod(lambda: 'cpu'), 'FloatTensor': staticmethod(lambda v: torch.tensor(v, dtype=torch.float32))})
+    dist_stub = type('dist', (), {'all_reduce': staticmethod(lambda t, op=None, group=None: None), 'get_world_size': staticmethod(lambda group=None: 1),
+                                  'ReduceOp': type('R', (), {'MAX': 0, 'SUM': 1})})
+    groups_stub = type('groups', (), {'_get_data_parallel_group': staticmethod(lambda: None)})
+    ds_stub = type('deepspeed', (), {'runtime': type('rt', (), {'utils': type('u', (), {'is_model_parallel_parameter': staticmethod(lambda p: False)})})})
+    ref_clip, _ = lift('utils/patches.py', 'clip_grad_norm_', namespace={'torch': torch, 'inf': math.inf, 'get_accelerator': lambda: acc, 'dist': dist_stub,
+                                                                        'groups': groups_stub, 'deepspeed': ds_stub})
+    results = []
+    for use_reference in (False, True):
+        engine, module, layers = _engine()
+        engine._gradient_clipping = 0.05
+        if use_reference:
+            engine.clip_grad_fn = ref_clip
+        loader = dpdata.MicroBatchLoader(_dataset(), engine, 2, lambda b, timestep_quantile=None: _prepare_inputs(b, 0.3))
+        it = iter(loader)
+        loss = engine.train_batch(iter([next(it), next(it)])).item()
+        results.append((loss, float(engine.get_global_grad_norm()), [p.detach().clone() for p in module.parameters()]))
+    (l0, n0, p0), (l1, n1, p1) = results
+    assert l0 == pytest.approx(l1, rel=1e-7) and n0 == pytest.approx(n1, rel=1e-6) and n0 > 0.05
+    for a, b in zip(p0, p1):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-8)
