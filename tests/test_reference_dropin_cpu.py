@@ -156,3 +156,18 @@ def test_reference_clip_grad_norm_as_the_engine_clip_override():
     assert l0 == pytest.approx(l1, rel=1e-7) and n0 == pytest.approx(n1, rel=1e-6) and n0 > 0.05
     for a, b in zip(p0, p1):
         assert torch.allclose(a, b, rtol=1e-6, atol=1e-8)
+
+
+def test_reference_patched_schedule_runs_on_this_train_schedule_class():
+    """utils/patches.py:419 assigns `TrainSchedule.steps = train_schedule_steps`: the lifted function, bound to THIS repository's
+    TrainSchedule (its index helpers and instruction classes), yields exactly the engine's native instruction stream."""
+    from diffusion_pipe_amd.engine import schedule as ps
+    from oracle.make_golden_reflogic import lift
+    names = ('LoadMicroBatch', 'ForwardPass', 'BackwardPass', 'SendActivation', 'RecvActivation', 'SendGrad', 'RecvGrad', 'ReduceTiedGrads', 'ReduceGrads',
+             'OptimizerStep')
+    fn, _ = lift('utils/patches.py', 'train_schedule_steps', namespace={n: getattr(ps, n) for n in names})
+    for stages, mbs in ((1, 3), (2, 4), (4, 8), (8, 16), (3, 2)):
+        for stage in range(stages):
+            native = [list(step) for step in ps.TrainSchedule(mbs, stages, stage).steps()]
+            patched = [list(step) for step in fn(ps.TrainSchedule(mbs, stages, stage))]
+            assert patched == native, (stages, mbs, stage)
