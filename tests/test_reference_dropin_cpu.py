@@ -171,3 +171,40 @@ def test_reference_patched_schedule_runs_on_this_train_schedule_class():
             native = [list(step) for step in ps.TrainSchedule(mbs, stages, stage).steps()]
             patched = [list(step) for step in fn(ps.TrainSchedule(mbs, stages, stage))]
             assert patched == native, (stages, mbs, stage)
+
+
+def test_reference_wan_adapter_layers_train_through_this_engine():
+    """The reference's own WanModel (imported) and pipeline layers (lifted) as the `layers=` of this repository's ManualPipelineModule:
+    one train_batch on CPU reproduces the golden loss and gradient norm of the reference's plain eager step (tests/golden/wan_model_fp32).
+    Layers that stay PyTorch modules run unchanged -- the engine only needs nn.Modules / callables (SURVEY.md 8(b) B1 conventions)."""
+    import json
+    from safetensors.torch import load_file
+    from oracle.make_golden import import_reference_wan
+    from oracle.make_golden_reflogic import lift, lift_classes
+    from oracle.make_golden_wan_model import CFG
+    base = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'wan_model_fp32')
+    g, meta = load_file(base + '.safetensors'), json.load(open(base + '.json'))
+    m = import_reference_wan()
+    model = m.WanModel(**CFG).float()
+    model.load_state_dict({k[len('param.'):]: v for k, v in g.items() if k.startswith('param.')}, strict=False)
+    make_contiguous, _ = lift('models/base.py', 'make_contiguous', namespace={'torch': torch})
+    ns = lift_classes('models/wan/wan.py', {'InitialLayer', 'TransformerLayer', 'FinalLayer'},
+                      {'nn': nn, 'torch': torch, 'make_contiguous': make_contiguous, 'sinusoidal_embedding_1d': m.sinusoidal_embedding_1d})
+    to_layers, _ = lift('models/wan/wan.py', 'to_layers', cls='WanPipeline', namespace=ns)
+    pipe = type('Pipe', (), {})()
+    pipe.transformer, pipe.cache_text_embeddings = model, True
+    pipe.offloader = type('Off', (), {'wait_for_block': staticmethod(lambda i: None), 'submit_move_blocks_forward': staticmethod(lambda i: None)})
+    layers = to_layers(pipe)
+    loss_fn, _ = lift('models/base.py', 'get_loss_fn', cls='BasePipeline', namespace={'torch': torch, 'F': torch.nn.functional})
+    module = ManualPipelineModule(layers=layers, num_stages=1, partition_method='parameters', loss_fn=loss_fn(type('S', (), {'config': {}})()),
+                                  dynamic_shape=True)
+    engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 2, 'gradient_accumulation_steps': 1, 'gradient_clipping': 1e9},
+                                 device='cpu')
+    engine.grad_kernels = oracle.TorchGradKernels
+    engine._configure_optimizer(lambda ps: torch.optim.SGD(ps, lr=0.0), [p for p in module.parameters()])
+    empty = torch.tensor([])
+    micro = ((g['prep.x_t'], empty, g['prep.t'], g['in.text_embeddings'], g['in.seq_lens'], empty), (g['prep.target'], empty))
+    loss = engine.train_batch(iter([micro])).item()
+    assert loss == pytest.approx(meta['loss'], rel=1e-6)
+    want_norm = sum(v.double().pow(2).sum().item() for k, v in g.items() if k.startswith('grad.')) ** 0.5
+    assert float(engine.get_global_grad_norm()) == pytest.approx(want_norm, rel=1e-5)
