@@ -408,6 +408,12 @@ class FluxWorkload:
     def get_param_groups(self, parameters):
         return [{'params': list(parameters)}]
 
+    # ---- saved files (models/flux.py:231-290)
+    def save_model(self, save_dir, diffusers_sd):
+        """Full fine-tune -> one BFL-layout model.safetensors."""
+        from ..formats import save_flux_bfl
+        save_flux_bfl(save_dir, diffusers_sd)
+
 
 def synthetic_flux_batch(cfg: FluxConfig, batch_size=1, latent_hw=(16, 16), text_tokens=24, seed=0):
     """SURVEY 8(d) config 3 shapes: latents randn[B, C/4, h, w], t5_embed randn[B, T, 4096], clip_embed randn[B, 768]."""

@@ -309,6 +309,19 @@ class WanWorkload:
     def get_param_groups(self, parameters):
         return [{'params': list(parameters)}]
 
+    # ---- saved files (models/wan/wan.py:258-265, models/base.py:367-386)
+    def save_adapter(self, save_dir, peft_state_dict, adapter_config=None):
+        from ..formats import save_comfyui_adapter
+        save_comfyui_adapter(save_dir, peft_state_dict, adapter_config)
+
+    def save_model(self, save_dir, state_dict):
+        from ..formats import save_plain_model
+        save_plain_model(save_dir, state_dict)
+
+    def load_adapter_weights(self, adapter_path):
+        from ..formats import load_comfyui_adapter
+        return load_comfyui_adapter(self.transformer, adapter_path)
+
 
 def synthetic_wan_batch(cfg: WanConfig, batch_size=1, frames=2, latent_hw=(12, 16), text_tokens=20, seed=0):
     g = torch.Generator().manual_seed(seed)

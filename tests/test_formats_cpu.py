@@ -1,0 +1,73 @@
+"""Saved-file formats: diffusion_pipe_amd.formats against files written by the reference's own save functions
+(oracle/make_golden_formats.py lifts FluxPipeline.save_model + its BFL mapping, WanPipeline.save_adapter / save_model and
+BasePipeline.load_adapter_weights) -- byte-identical safetensors files (SHA-256) for the same seeded state dicts."""
+import hashlib
+import json
+import os
+
+import pytest
+import safetensors
+import torch
+from safetensors.torch import load_file
+
+from diffusion_pipe_amd import formats
+from oracle.make_golden_formats import flux_state_dict, wan_lora_state_dict
+
+G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'formats.json')))
+same_build = torch.__version__ == G['torch'] and safetensors.__version__ == G['safetensors']
+
+
+def _sha(path):
+    return hashlib.sha256(open(path, 'rb').read()).hexdigest()
+
+
+def test_flux_full_model_is_written_in_the_bfl_layout(tmp_path):
+    sd = flux_state_dict()
+    from diffusion_pipe_amd.workloads import flux
+    work = flux.FluxWorkload(flux.tiny_flux_config(), dtype=torch.float32)
+    work.save_model(tmp_path, sd)
+    got = load_file(tmp_path / 'model.safetensors')
+    assert {k: list(v.shape) for k, v in sorted(got.items())} == G['flux_bfl']['keys']
+    # fused projections are concatenated in q, k, v (, mlp) order; the final adaLN halves are swapped to (shift, scale)
+    assert torch.equal(got['double_blocks.1.img_attn.qkv.weight'], torch.cat([sd[f'transformer_blocks.1.attn.to_{x}.weight'] for x in 'qkv']))
+    assert torch.equal(got['single_blocks.2.linear1.bias'], torch.cat([sd[f'single_transformer_blocks.2.{x}.bias'] for x in ('attn.to_q', 'attn.to_k', 'attn.to_v', 'proj_mlp')]))
+    scale, shift = sd['norm_out.linear.weight'].chunk(2, dim=0)
+    assert torch.equal(got['final_layer.adaLN_modulation.1.weight'], torch.cat([shift, scale]))
+    if same_build:
+        assert _sha(tmp_path / 'model.safetensors') == G['flux_bfl']['sha256']
+    with pytest.raises(KeyError):
+        formats.flux_diffusers_to_bfl(dict(sd, **{'transformer_blocks.0.unknown.weight': torch.zeros(1)}))
+
+
+def test_wan_adapter_and_model_files(tmp_path):
+    from diffusion_pipe_amd.workloads import wan
+    lora = wan_lora_state_dict()
+    work = wan.WanWorkload(wan.tiny_wan_config(), dtype=torch.float32, seed=12)
+    names = work.configure_adapter({'type': 'lora', 'rank': 4, 'alpha': 4})
+    work.save_adapter(tmp_path / 'a', lora, {'rank': 4, 'alpha': 4, 'target_modules': names})
+    saved = load_file(tmp_path / 'a' / 'adapter_model.safetensors')
+    assert len(saved) == G['wan_adapter']['count'] and sorted(saved)[:4] == G['wan_adapter']['keys']
+    assert all(k.startswith('diffusion_model.') and '.default' not in k for k in saved)
+    cfg = json.load(open(tmp_path / 'a' / 'adapter_config.json'))
+    assert cfg['r'] == 4 and cfg['lora_alpha'] == 4 and cfg['peft_type'] == 'LORA' and len(cfg['target_modules']) == len(names)
+    if same_build:
+        assert _sha(tmp_path / 'a' / 'adapter_model.safetensors') == G['wan_adapter']['sha256']
+    # loading maps the file back onto the adapter parameters (strip prefix, re-insert the adapter name)
+    os.remove(tmp_path / 'a' / 'adapter_config.json')
+    loaded = work.load_adapter_weights(tmp_path / 'a')
+    assert len(loaded) == G['wan_adapter']['loader']['count'] and loaded[:4] == G['wan_adapter']['loader']['keys']
+    params = dict(work.transformer.named_parameters())
+    assert all(torch.equal(params[k], lora[k.replace('.default', '')]) for k in loaded)
+    # full fine-tune: the parameters' own names
+    work2 = wan.WanWorkload(wan.tiny_wan_config(), dtype=torch.float32, seed=12)
+    full = {n: p.detach().clone() for n, p in work2.transformer.named_parameters()}
+    work2.save_model(tmp_path / 'm', full)
+    assert len(load_file(tmp_path / 'm' / 'model.safetensors')) == G['wan_model']['count']
+    if same_build:
+        assert _sha(tmp_path / 'm' / 'model.safetensors') == G['wan_model']['sha256']
+    with pytest.raises(RuntimeError, match='not in the model parameters'):
+        from safetensors.torch import save_file
+        save_file({'diffusion_model.blocks.9.nope.lora_A.weight': torch.zeros(1)}, str(tmp_path / 'bad.safetensors'))
+        (tmp_path / 'b').mkdir()
+        os.replace(tmp_path / 'bad.safetensors', tmp_path / 'b' / 'bad.safetensors')
+        work.load_adapter_weights(tmp_path / 'b')
