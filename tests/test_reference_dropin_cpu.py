@@ -208,3 +208,42 @@ def test_reference_wan_adapter_layers_train_through_this_engine():
     assert loss == pytest.approx(meta['loss'], rel=1e-6)
     want_norm = sum(v.double().pow(2).sum().item() for k, v in g.items() if k.startswith('grad.')) ** 0.5
     assert float(engine.get_global_grad_norm()) == pytest.approx(want_norm, rel=1e-5)
+
+
+def test_product_saver_writes_what_the_reference_saver_writes(tmp_path):
+    """diffusion_pipe_amd.saver.Saver next to the reference's own Saver (lifted) over the same engine: identical merged state dicts handed
+    to the adapter hooks, the same files on disk, the same epoch / step bookkeeping."""
+    from diffusion_pipe_amd.saver import Saver as Mine
+    from oracle.make_golden_reflogic import lift, lift_classes
+    conv, _ = lift('utils/saver.py', 'convert_state_dict_dtype')
+    ns = lift_classes('utils/saver.py', {'Saver'}, {'Path': __import__('pathlib').Path, 'os': os, 'shutil': __import__('shutil'), 'torch': torch, 'sys': __import__('sys'),
+                                                   'dist': type('dist', (), {'barrier': staticmethod(lambda: None)}), 'logger': type('L', (), {'warning': staticmethod(lambda *a: None)}),
+                                                   'convert_state_dict_dtype': conv, 'is_main_process': lambda: True, 'print': lambda *a, **k: None,
+                                                   'need_to_checkpoint': lambda config, epoch=None: epoch is not None and epoch % config.get('checkpoint_every_n_epochs', 10 ** 9) == 0})
+    cfg_file = tmp_path / 'run.toml'
+    cfg_file.write_text('x = 1\n')
+    args = type('A', (), {'config': str(cfg_file)})
+    config = {'save_dtype': torch.bfloat16, 'save_every_n_epochs': 1, 'checkpoint_every_n_epochs': 2, 'epochs': 3, 'save_every_n_steps': 5}
+    outs = {}
+    for tag, klass in (('ref', ns['Saver']), ('mine', Mine)):
+        got = {}
+        model = type('M', (), {'save_model': lambda self, d, sd, got=got: got.update(model=dict(sd)), 'save_adapter': lambda self, d, sd, got=got: got.update(adapter=dict(sd))})()
+        engine, module, _ = _engine(trainable_only_last=True)
+        loader = dpdata.MicroBatchLoader(_dataset(), engine, 2, _prepare_inputs)
+        for is_adapter in (False, True):
+            s = klass(args, config, is_adapter, tmp_path / f'{tag}{int(is_adapter)}', model, loader, engine, module)
+            s.save_model('final')
+            it = iter(loader)
+            for _ in range(6):                                  # one full pass: the loader rolls over to epoch 2
+                next(it)
+            got[f'epoch{int(is_adapter)}'] = s.process_epoch(1, 4, 16)
+            got[f'step{int(is_adapter)}'] = s.process_step(5, 20)
+            loader.reset()
+        got['files'] = sorted(str(p.relative_to(tmp_path)).replace(tag, 'X', 1) for p in tmp_path.rglob('*') if p.is_file() and str(p.relative_to(tmp_path)).startswith(tag))
+        outs[tag] = got
+    ref, mine = outs['ref'], outs['mine']
+    assert ref['model'].keys() == mine['model'].keys() and all(torch.equal(ref['model'][k], mine['model'][k]) for k in ref['model'])
+    assert ref['adapter'].keys() == mine['adapter'].keys() == {'blocks.2.lin.weight', 'blocks.2.lin.bias'}
+    for k in ('epoch0', 'epoch1', 'step0', 'step1'):
+        assert ref[k] == mine[k], k
+    assert ref['files'] == mine['files'] and len(mine['files']) >= 4          # config copies of the saved models, no tmp/ left behind
