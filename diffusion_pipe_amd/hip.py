@@ -5,7 +5,6 @@ and every wrapper checks the return code of the C call (`check`).  PyTorch is us
 current HIP stream.
 """
 import ctypes
-import os
 from ctypes import c_char_p, c_float, c_int, c_long, c_void_p, POINTER
 from pathlib import Path
 

@@ -4,7 +4,6 @@ Wan DiT block arithmetic, one function per reference routine, each citing the li
 PINNED: tests/test_golden_cpu.py checks every function here against vectors minted from the reference's own
 models/wan/model.py (oracle/make_golden.py -> tests/golden/wan_block_fp32.safetensors).
 """
-import math
 
 import torch
 import torch.nn.functional as F

@@ -13,7 +13,6 @@ frozen.  Module names: `<layer>.base_layer`, `<layer>.lora_A.<adapter>`, `<layer
 """
 import math
 
-import torch
 from torch import nn
 
 

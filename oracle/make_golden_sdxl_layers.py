@@ -16,7 +16,6 @@ import os
 import sys
 
 import torch
-import torch.nn.functional as F
 from safetensors.torch import save_file
 from torch import nn
 

@@ -8,7 +8,6 @@ parameter gradient.  Pins oracle/blocks_ref.py:wan_forward on CPU and (next) the
 
     python oracle/make_golden_wan_model.py
 """
-import ast
 import json
 import os
 import sys

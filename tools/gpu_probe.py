@@ -2,7 +2,6 @@
 Writes JSON lines to stdout; used to steer kernel work, not part of the product path."""
 import json
 import sys
-import time
 
 import torch
 
