@@ -143,3 +143,35 @@ def test_split_batch_edge_cases():
     assert torch.equal(f0[0], feats[0][:2]) and torch.equal(f1[2], feats[2][2:])
     assert f0[1].numel() == 0 and l1[1].numel() == 0        # None -> empty tensor
     assert all(torch.is_tensor(t) for t in f0 + l0)
+
+
+def test_partition_methods_on_real_layer_lists():
+    """PipelineModule._partition_layers on the SDXL (23 layers) and Flux layer lists (single process; the 4-stage topology is swapped in
+    after construction): 'parameters' = the balanced DP over ALL parameters of each layer (train.py:81-90), 'type:<regex>' balances the
+    matching layers, 'uniform' splits by count, the reference's 'manual' honours explicit boundaries."""
+    import torch
+    from diffusion_pipe_amd.engine import ManualPipelineModule, PipelineModule
+    from diffusion_pipe_amd.workloads import flux, sdxl
+
+    def parts(module, method, stages, rank=0):
+        module._topo, module.global_rank = PipeDataParallelTopology(num_pp=stages, num_dp=1), rank
+        module._partition_layers(method)
+        return module.parts, (module._local_start, module._local_stop)
+    work = sdxl.SDXLWorkload(sdxl.tiny_config(), dtype=torch.float32)
+    layers = work.to_layers()
+    counts = [sum(p.numel() for p in l.parameters()) for l in layers]
+    m = PipelineModule(layers=layers, num_stages=1, partition_method='uniform', loss_fn=work.get_loss_fn())
+    assert m.parts == [0, 23]
+    got, bounds = parts(m, 'parameters', 4, rank=2)
+    assert got == ol.partition_balanced(counts, 4) and got[0] == 0 and got[-1] == 23 and bounds == (got[2], got[3])
+    assert parts(m, 'uniform', 4)[0] == ol.partition_uniform(23, 4)
+    marks = [1 if type(l).__name__ == 'UpBlockInnerLayer' else 0 for l in layers]
+    assert parts(m, 'type:UpBlockInner', 4)[0] == ol.partition_balanced(marks, 4) and sum(marks) == 9
+    manual = ManualPipelineModule(layers=layers, num_stages=1, partition_method='uniform')
+    manual.manual_partition_split = [3, 9, 17]
+    assert parts(manual, 'manual', 4, rank=3) == ([0, 3, 9, 17, 23], (17, 23)) and ol.manual_partition(23, 4, [3, 9, 17]) == [0, 3, 9, 17, 23]
+    fl = flux.FluxWorkload(flux.tiny_flux_config(), dtype=torch.float32).to_layers()
+    fm = PipelineModule(layers=fl, num_stages=1, partition_method='uniform')
+    assert parts(fm, 'type:transformerwrapper', 2)[0] == ol.partition_balanced([1 if 'TransformerWrapper' in type(l).__name__ else 0 for l in fl], 2)
+    with pytest.raises(NotImplementedError):
+        parts(m, 'profile', 4)
