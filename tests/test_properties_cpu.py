@@ -104,3 +104,34 @@ def test_cache_round_trip(tmp_path_factory, sizes, shard_kb):
         got = again[i]
         assert torch.equal(got['x'], items[i]['x']) and got['caption'] == items[i]['caption'] and got['mask'] is None
     again.close()
+
+
+def _comm_ops(cls, mbs, stages, stage):
+    kinds = {'SendActivation': ('send', +1, 'act'), 'RecvActivation': ('recv', -1, 'act'), 'SendGrad': ('send', -1, 'grad'), 'RecvGrad': ('recv', +1, 'grad')}
+    return [(kinds[c.name][0], stage + kinds[c.name][1], kinds[c.name][2]) for step in cls(mbs, stages, stage).steps() for c in step if c.name in kinds]
+
+
+def test_instruction_order_is_deadlock_free_under_blocking_rendezvous():
+    """RCCL point-to-point semantics on ONE in-order communication stream per rank: a send / recv at the head of a rank's queue completes
+    only when the peer's queue head is the matching recv / send.  Every stage's transfer sequence (train and eval schedules) must drain
+    for every pipeline depth the metric names (1..8) and any micro-batch count -- gloo's non-blocking isend would hide an ordering bug."""
+    for stages in range(1, 9):
+        for mbs in list(range(1, 20)) + [24, 32, 48]:
+            for cls in (ps.TrainSchedule, ps.InferenceSchedule):
+                queues = [_comm_ops(cls, mbs, stages, s) for s in range(stages)]
+                heads = [0] * stages
+                progress = True
+                while progress:
+                    progress = False
+                    for a in range(stages):
+                        if heads[a] >= len(queues[a]):
+                            continue
+                        kind, b, what = queues[a][heads[a]]
+                        assert 0 <= b < stages
+                        if heads[b] < len(queues[b]):
+                            kb, pb, wb = queues[b][heads[b]]
+                            if pb == a and wb == what and {kind, kb} == {'send', 'recv'}:
+                                heads[a] += 1
+                                heads[b] += 1
+                                progress = True
+                assert all(h == len(q) for h, q in zip(heads, queues)), (cls.__name__, stages, mbs)
