@@ -123,7 +123,16 @@ def loader_trace(make_loader):
     b = make_loader(DS(), engine, 2, model)
     b.load_state_dict(dict(state))
     resumed = run(b, 7)
-    return {'len': len(a), 'first': first, 'state': state, 'more': more, 'resumed': resumed, 'resumed_state': b.state_dict()}
+    # a state dict taken exactly at an epoch boundary (what save_checkpoint stores when process_epoch fires): the loader has just rolled
+    # over, num_batches_pulled == 0, and load_state_dict turns that into skip = -1 -- the sampler then starts at index -1
+    c = make_loader(DS(), engine, 2, model)
+    run(c, 6)
+    boundary_state = c.state_dict()
+    d = make_loader(DS(), engine, 2, model)
+    d.load_state_dict(dict(boundary_state))
+    boundary_resumed = run(d, 9)
+    return {'len': len(a), 'first': first, 'state': state, 'more': more, 'resumed': resumed, 'resumed_state': b.state_dict(),
+            'boundary_state': boundary_state, 'boundary_resumed': boundary_resumed}
 
 
 def main():
