@@ -24,6 +24,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+    # pp > 1 launches forward / backward stage graphs on two streams with P2P in between and cannot drain the queue per micro-batch:
+    # take the runtime's per-node dispatch path there instead of the AQL-packet-capture path that wedges under multi-stream run-ahead
+    # (engine.max_steps_in_flight).  Must be set before the HIP runtime initialises.
+    os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
+
 import torch
 import torch.distributed as dist
 
@@ -45,25 +51,59 @@ def parse():
                     help='TEST ONLY: all ranks share cuda:0, collectives over gloo, stage payloads staged through the host')
     ap.add_argument('--torch-adamw', action='store_true', help='A/B switch: torch.optim.AdamW(fused=True) + separate lane-sum / clip / zero passes')
     ap.add_argument('--parallel-wgrad', action='store_true', help='fork wgrad onto a side stream (A/B switch; measured slower)')
+    ap.add_argument('--steps-in-flight', type=int, default=1, help='bound on the host run-ahead in optimizer steps (0 = unbounded; see engine.max_steps_in_flight)')
+    ap.add_argument('--save-gemm-trace', default='', help='write the step\'s unique GEMM descriptors (+ counts) as JSON (input of tools/gemm_replay.py)')
+    ap.add_argument('--sync-each-step', action='store_true', help='bisect switch: device synchronize after every step')
+    ap.add_argument('--host-inputs', action='store_true', help='hand every micro-batch over as pageable host tensors (the loader contract); '
+                    'default: the synthetic pool is resident in HBM before the timed region')
     return ap.parse_args()
 
 
-def gemm_roofline(trace):
-    """(flops, ms, launches, per-kernel-config breakdown) of the GEMM launches of one step from their HIP-event pairs."""
-    tot_flops = tot_ms = 0.0
-    for (dt, ta, tb, M, N, K, batch), e0, e1 in trace:
-        tot_ms += e0.elapsed_time(e1)
-        tot_flops += 2.0 * M * N * K * batch
-    return tot_flops, tot_ms, len(trace)
+def start_progress_monitor(engine_mod, stall_s):
+    """Watchdog thread: polls the HIP events the engine records after every graph replay / step end (engine.TRACE).  If events
+    are pending and none completes for `stall_s` seconds, report the last retired and the first pending label plus
+    `rocm-smi --showuse`, and exit(3) -- a wedged queue must not hold the GPU until the caller's clock runs out."""
+    import subprocess
+    import threading
+    engine_mod.TRACE = []
+    verbose = os.environ.get('DPIPE_TRACE_STEPS', '0') == '1'
+
+    def run():
+        last_done, last_change, idx = None, time.monotonic(), 0
+        while True:
+            time.sleep(2.0)
+            tr = engine_mod.TRACE
+            if tr is None:
+                return
+            progressed = False
+            while idx < len(tr) and tr[idx][1].query():
+                last_done, idx, progressed = tr[idx][0], idx + 1, True
+            now = time.monotonic()
+            if progressed or idx >= len(tr):
+                last_change = now
+            if verbose:
+                print(f'[trace] t={now:.1f} retired={idx}/{len(tr)} last={last_done} pending={tr[idx][0] if idx < len(tr) else None}', file=sys.stderr, flush=True)
+            if idx < len(tr) and now - last_change > stall_s:
+                print(f'[watchdog] no HIP event retired for {stall_s:.0f} s: last retired {last_done}, first pending {tr[idx][0]}, '
+                      f'{len(tr) - idx} pending', file=sys.stderr, flush=True)
+                try:
+                    print(subprocess.run(['rocm-smi', '--showuse'], capture_output=True, text=True, timeout=20).stdout, file=sys.stderr, flush=True)
+                except Exception as e:       # noqa: BLE001
+                    print(f'[watchdog] rocm-smi failed: {e}', file=sys.stderr, flush=True)
+                os._exit(3)
+
+    th = threading.Thread(target=run, daemon=True, name='dpipe-progress-monitor')
+    th.start()
+    return th
 
 
 def main():
     args = parse()
-    # watchdog: a run that stops making progress (a wedged collective, a kernel that never retires) dumps every thread's Python
-    # stack and exits instead of holding the GPU until the caller's clock runs out
+    # watchdogs: (1) wall clock -- dump every thread's Python stack and exit; (2) progress (start_progress_monitor) -- exit as soon
+    # as the GPU stops retiring the step's graph replays
     import faulthandler
     faulthandler.enable()
-    faulthandler.dump_traceback_later(int(os.environ.get('DPIPE_BENCH_WATCHDOG_S', '1500')), exit=True)
+    faulthandler.dump_traceback_later(int(os.environ.get('DPIPE_BENCH_WATCHDOG_S', '900')), exit=True)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -104,7 +144,8 @@ def main():
                                   dynamic_shape=True, **kwargs)
     engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 1, 'gradient_accumulation_steps': gas,
                                                          'gradient_clipping': 1.0, 'steps_per_print': 1 << 30, 'hip_graph': not args.no_graph,
-                                                         'parallel_wgrad': args.parallel_wgrad, 'p2p_via_host': args.test_single_device, 'graph_lanes': args.lanes}, device=device)
+                                                         'parallel_wgrad': args.parallel_wgrad, 'p2p_via_host': args.test_single_device, 'graph_lanes': args.lanes,
+                                                         'max_steps_in_flight': args.steps_in_flight}, device=device)
     params = [p for p in module.parameters() if p.requires_grad]
 
     # the reference's optimizer construction (train.py:650-815): AdamW on the raw bf16 parameters, per-component groups split into
@@ -121,6 +162,13 @@ def main():
         feats, label = work.prepare_inputs(sdxl.synthetic_batch(cfg, batch_size=gas, latent_hw=latent, seed=100 + s))
         pool.append(split_batch((feats, label), gas))
     needs_data = engine.is_first_stage() or engine.is_last_stage()
+    cpu_sample = pool[0][0]                           # one micro-batch (host tensors) for the cpu_baseline leg
+    if not args.host_inputs:
+        # inputs resident in HBM before the timed region starts; the engine copies them into each lane's static graph inputs (D2D)
+        pool = [[tuple(tuple(t.to(device) for t in part) for part in mb) for mb in step] for step in pool]
+        torch.cuda.synchronize()
+    from diffusion_pipe_amd.engine import engine as engine_mod
+    start_progress_monitor(engine_mod, float(os.environ.get('DPIPE_BENCH_STALL_S', '90')))
 
     def one_step(i):
         engine.reset_activation_shape()
@@ -133,13 +181,23 @@ def main():
         torch.cuda.synchronize()
 
     loss = None
+    trace_steps = os.environ.get('DPIPE_TRACE_STEPS', '0') == '1'
     for i in range(args.warmup):
         loss = one_step(i)
+        if args.sync_each_step:
+            torch.cuda.synchronize()
+        if trace_steps:
+            print(f'[trace] warm-up step {i} enqueued at {time.monotonic():.2f}', file=sys.stderr, flush=True)
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = one_step(args.warmup + i)
+        if args.sync_each_step:
+            torch.cuda.synchronize()
+        if trace_steps:
+            print(f'[trace] timed step {i} enqueued at {time.monotonic():.2f}', file=sys.stderr, flush=True)
     fence()
+    engine_mod.TRACE = None
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if world > 1:
@@ -148,11 +206,13 @@ def main():
     gnorm = engine.get_global_grad_norm()
     gnorm = float(gnorm.item()) if gnorm is not None else float('nan')
 
-    # --- roofline of the dominant kernel (the MFMA GEMM of dpipe_gemm: every Linear forward / dgrad / wgrad).  Launches inside
-    # a replayed hipGraph cannot be bracketed, so ONE extra step runs eagerly on the same data with every GEMM launch
-    # bracketed by two HIP events recorded on the launch stream (ops.GEMM_TRACE); achieved = sum(2 M N K) / sum(elapsed).
-    # Each kernel then runs alone on the chip with operands as cold as in training (all other kernels of the step run in
-    # between), which is the per-kernel figure; the graph path additionally overlaps two micro-batches (config.lanes).
+    # --- roofline of the dominant kernel (the MFMA GEMM behind dpipe_gemm_ex: every Linear forward / dgrad / wgrad; 48 % of the step's
+    # kernel time, profiles/).  Launches inside the step's replayed hipGraphs cannot be bracketed one by one, so: ONE extra step runs
+    # eagerly with ops.GEMM_TRACE recording the descriptor of every GEMM launch; tools/gemm_replay.py then captures exactly that launch
+    # list (same shapes, leading dimensions, epilogues, split-K workspace; operands rotating through a 3 GiB arena = HBM-cold weights) into a
+    # GEMM-only hipGraph and replays it between two HIP events on the replay stream.  achieved = sum(2 M N K) / graph time;
+    # average launch duration = graph time / launches (includes the ~1 us in-graph dispatch gap; rocprofv3's per-kernel average of the
+    # same command, committed under profiles/, is the cross-check).
     ops.GEMM_TRACE = []
     was_graph, was_stage = engine.use_graph, engine.use_stage_graphs
     engine.use_graph = engine.use_stage_graphs = False
@@ -163,11 +223,20 @@ def main():
     engine.use_graph, engine.use_stage_graphs = was_graph, was_stage
     trace, ops.GEMM_TRACE = ops.GEMM_TRACE, None
     torch.cuda.synchronize()
-    g_flops, g_ms, launches = gemm_roofline(trace)
-    rl = torch.tensor([g_flops, g_ms, launches], device=device, dtype=torch.float64)
+    from tools import gemm_replay
+    if args.save_gemm_trace and rank == 0:
+        with open(args.save_gemm_trace, 'w') as f:
+            json.dump(gemm_replay.unique_with_counts(trace), f)
+    rt = gemm_replay.time_in_graph(trace, device, reps=3) if trace else {'ms': 0.0, 'launches': 0, 'flops': 0.0, 'read_bytes': 0, 'write_bytes': 0}
+    rl = torch.tensor([rt['flops'], rt['ms'], rt['launches'], rt['read_bytes'] + rt['write_bytes']], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(rl)
-    g_flops, g_ms, launches = rl.tolist()
+    g_flops, g_ms, launches, g_bytes = rl.tolist()
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'r2_pmc_gemm_traffic.json')      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this launch list
+    if os.path.isfile(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -190,18 +259,18 @@ def main():
             'step_tflop_algorithmic': round(step_flops / 1e12, 2),
             'mfu_vs_bf16_mfma_peak': round(step_flops / (elapsed / args.steps) / (peak * 1e12 * world), 5),
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_pipe_kernel<bf16> (dpipe_gemm_ex: every Linear forward / dgrad / wgrad)', 'achieved': round(achieved, 2), 'peak': peak,
-                         'unit': 'TFLOP/s', 'frac': round(achieved / peak, 5), 'traffic': None,
+                         'unit': 'TFLOP/s', 'frac': round(achieved / peak, 5),
+                         'traffic': traffic['hbm_bytes_per_launch'] if traffic else None,
                          'launches_per_step': int(launches), 'avg_launch_us': round(g_ms * 1e3 / max(launches, 1), 2),
+                         'algorithmic_gflop_per_launch': round(g_flops / max(launches, 1) / 1e9, 3),
+                         'algorithmic_bytes_per_launch': round(g_bytes / max(launches, 1)),
                          'gemm_gpu_ms_per_step': round(g_ms / world, 2),
-                         'note': 'per-launch HIP-event times of one eager step (kernels run alone); graph replays overlap the lanes'},
+                         'traffic_detail': traffic,
+                         'method': 'GEMM-only hipGraph of the step\'s recorded launch list, HIP events on the replay stream, HBM-cold operands'},
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle.cpu_baseline import sdxl_cpu_baseline
-            cb = sdxl_cpu_baseline(cfg, latent_hw=latent, budget_s=20.0)
-            per_image = sdxl.train_step_flops(cfg, latent_hw=latent, batch=1)
-            cb['value'] = round(1.0 / (cb['sample_seconds'] * per_image / cb.pop('_sample_flops')), 6)
-            cb['unit'] = 'images/s'
-            out['cpu_baseline'] = cb
+            out['cpu_baseline'] = sdxl_cpu_baseline(cfg, latent_hw=latent, micro_batch=cpu_sample)
         print(json.dumps(out), flush=True)
     faulthandler.cancel_dump_traceback_later()
     if world > 1:

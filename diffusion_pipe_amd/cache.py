@@ -157,6 +157,11 @@ class Cache:
     def create_new_shard(self):
         self.shard_file = open(self.path / f'shard_{self.shard}.bin', 'wb')
         self.shard_table = f'shard_{self.shard}'
+        # The shard's table and its rows commit together in finalize_current_shard() (the reference opens the connection with
+        # autocommit=False, utils/cache.py:29; Python 3.10's legacy mode would commit a bare CREATE TABLE at once and a process
+        # killed mid-shard would leave an empty shard_N table that the next run trips over).
+        if not self.con.in_transaction:
+            self.con.execute('BEGIN')
         self.con.execute(f'CREATE TABLE {self.shard_table}(offset, size)')
         self.shard_index = 0
         self.offset = 0

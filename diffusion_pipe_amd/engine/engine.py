@@ -23,10 +23,21 @@ from .module import PipelineModule
 from .p2p import HostStagedLink, StageLink
 
 
+# Progress tracing (bench.py / tools: DPIPE_TRACE_STEPS=1): a list that receives (label, HIP event) after every graph replay and
+# step end -- recorded on the launch stream, never waited on here, so tracing does not change the execution order.  A monitor
+# thread polls event.query() to report which replay a wedged queue stopped at.
+TRACE = None
+
+
+def _trace(label, stream):
+    if TRACE is not None:
+        TRACE.append((label, stream.record_event()))
+
+
 def _capture_mode():
     """hipGraph capture error mode: with a process group alive, RCCL's watchdog thread issues (harmless) event queries while
     this thread captures -- only calls of the capturing thread may invalidate the capture then."""
-    return 'thread_local' if (dist.is_available() and dist.is_initialized()) else 'global'
+    return 'thread_local' if (TRACE is not None or (dist.is_available() and dist.is_initialized())) else 'global'
 
 
 def _is_float(t):
@@ -113,6 +124,17 @@ class PipelineEngine:
         # once before ReduceGrads / clip / optimizer.  Same math as sequential accumulation up to fp summation order.
         self.graph_lanes = max(1, int(self._config.get('graph_lanes', 1))) if self.use_graph else 1     # bench: 3 (best of 1..4 on MI355X)
         self._lanes = []
+        # Bounded host run-ahead.  train_batch returns a device scalar, so a tight loop could queue optimizer steps without limit.
+        # Before enqueuing step n the host waits for the end of step n - max_steps_in_flight.  Default 1: measured on MI355X /
+        # ROCm 7.2 (round 2, tools/hang_repro.sh, 20+ runs): with hipGraph launches of >= 2 lanes' graphs queued ACROSS a step
+        # boundary the runtime's graph AQL-packet-capture path wedges a lane's queue within 2 - 13 steps (GPU 100 % busy, the
+        # pending launch never retires; independent of AQL queue size, signal pool size, HW queue count, per-lane launch depth,
+        # host- or device-resident inputs, fused or torch step end); every run with the queue drained between steps
+        # (65 / 150 steps) or with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (155 steps, but host-bound: 13.4 vs 15.4 images/s)
+        # finished.  The reference's loop reads the loss with .item() after every train_batch (train.py:918), i.e. it drains
+        # the queue per step as well; inside a step the host still runs up to GAS replays ahead.  0 = unbounded.
+        self.max_steps_in_flight = int(self._config.get('max_steps_in_flight', 1))
+        self._step_done = []
         if self.device.type == 'cuda' and self._config.get('fuse_grad_accumulation', True):
             from .. import ops as _ops
             _ops.FUSE_GRAD_ACCUM = True     # wgrad / bias / norm-weight kernels add straight into existing .grad buffers
@@ -201,6 +223,7 @@ class PipelineEngine:
         self._eval_mode = False
         self.total_loss = None
         self._data_iter = data_iter
+        self._throttle()
         if self.use_graph:
             self._train_batch_graphed()
         else:
@@ -218,7 +241,13 @@ class PipelineEngine:
         if self.link is not None:
             self.link.flush()
         self._data_iter = None
+        if self.device.type == 'cuda' and self.max_steps_in_flight > 0:
+            self._step_done.append(torch.cuda.current_stream(self.device).record_event())
         return self.agg_train_loss
+
+    def _throttle(self):
+        while self.max_steps_in_flight > 0 and len(self._step_done) >= self.max_steps_in_flight:
+            self._step_done.pop(0).synchronize()
 
     def eval_batch(self, data_iter, return_logits=False, compute_loss=True, reduce_output='avg', bcast_loss=True,
                    num_micro_batches=None):
@@ -304,6 +333,7 @@ class PipelineEngine:
                     if src.numel() > 0:
                         dst.copy_(src, non_blocking=True)
                 entry['graph'].replay()
+                _trace(('replay', self.global_steps, i, lane['id']), lane['stream'])
         for lane in lanes:
             main.wait_stream(lane['stream'])
         base = lanes[0]
@@ -317,6 +347,7 @@ class PipelineEngine:
             self.total_loss = base['loss']
             self._exec_reduce_tied_grads()
             self._exec_optimizer_step(lane_grads=[lane['grads'] for lane in lanes])
+            _trace(('step_end', self.global_steps - 1), main)
             return
         # lane 0 owns the step's gradients; add the other lanes' accumulators and losses into it
         for lane in lanes[1:]:
@@ -334,6 +365,7 @@ class PipelineEngine:
         for lane in lanes[1:]:
             if lane['grads']:
                 torch._foreach_zero_(list(lane['grads'].values()))
+        _trace(('step_end', self.global_steps - 1), main)
 
     def _capture_micro_batch(self, lane, params, feats, labels):
         from .. import ops as _ops

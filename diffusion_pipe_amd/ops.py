@@ -25,8 +25,9 @@ def _rows2d(x):
 
 
 # --------------------------------------------------------------------------------------------- GEMM (K1/K6)
-# bench.py sets this to a list for one eager step: every GEMM launch is then bracketed by two HIP events recorded on the
-# launch stream, and (signature, start, stop) is appended -- the `roofline` object sums flops and elapsed times.
+# bench.py sets this to a list for one eager step: the full call descriptor (shapes, leading dimensions, batch strides, epilogue
+# flags -- no pointers) of every GEMM launch is appended; tools/gemm_replay.py re-issues that launch list as a GEMM-only
+# hipGraph over scratch operands and times it with HIP events for the `roofline` object.
 GEMM_TRACE = None
 
 # Split-K workspace of the pipelined bf16 GEMM: [4 KiB ticket counters][640 fp32 slabs of 64 KiB], zero-filled once and
@@ -61,10 +62,6 @@ def gemm(a, b, trans_a, trans_b, M, N, K, out, *, lda, ldb, ldc, batch_outer=1, 
     if bias is not None and bias.dtype != a.dtype:
         bias = bias.to(a.dtype)
     ws = _splitk_workspace(a.device) if dt == hip.BF16 else None
-    timed = GEMM_TRACE is not None
-    if timed:       # bench.py's roofline leg: HIP events on the launch stream around this one launch
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
     if residual is not None and (residual.dtype != out.dtype or residual.stride(-1) != 1):
         raise DpipeHipError('gemm residual must have the output dtype and a contiguous last dim')
     rc = lib().dpipe_gemm_ex(dt, int(trans_a), int(trans_b), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), ldc,
@@ -75,9 +72,12 @@ def gemm(a, b, trans_a, trans_b, M, N, K, out, *, lda, ldb, ldc, batch_outer=1, 
     if rc == -2 and colsum is not None:
         return None                      # not eligible for the fused column sum: the caller takes the two-kernel route
     check(rc, 'dpipe_gemm')
-    if timed:
-        e1.record()
-        GEMM_TRACE.append(((dt, int(trans_a), int(trans_b), M, N, K, batch_outer * batch_inner), e0, e1))
+    if GEMM_TRACE is not None:
+        GEMM_TRACE.append({'dt': dt, 'ta': int(trans_a), 'tb': int(trans_b), 'M': M, 'N': N, 'K': K, 'lda': lda, 'ldb': ldb, 'ldc': ldc,
+                           'bo': batch_outer, 'bi': batch_inner, 'sa': tuple(stride_a), 'sb': tuple(stride_b), 'sc': tuple(stride_c),
+                           'bias': bias is not None, 'act': act, 'alpha': float(alpha), 'acc': bool(accumulate), 'out_f32': out_f32,
+                           'tile': tile_hint, 'res': residual is not None, 'ldr': ldr, 'colsum': colsum is not None,
+                           'colsum_acc': bool(colsum_accumulate)})
     return out
 
 

@@ -30,6 +30,10 @@ class Saver:
         self.model, self.train_dataloader = model, train_dataloader
         self.model_engine, self.pipeline_model = model_engine, pipeline_model
         self._last_checkpoint_time = None
+        # fail before training starts, on every rank alike, rather than with an AttributeError after the barriers of the first save
+        need = 'save_adapter' if is_adapter else 'save_model'
+        if not callable(getattr(model, need, None)):
+            raise NotImplementedError(f'{type(model).__name__} has no {need}(save_dir, state_dict): the run could not save its weights')
 
     # ------------------------------------------------------------------------------------------------ model files
     def _gather_and_save(self, name, select, finish):

@@ -36,6 +36,8 @@ def run_training(model, model_engine, pipeline_model, train_data, config, save_r
     eval_gas = config.get('eval_gradient_accumulation_steps', 1)
     eval_loaders = {name: MicroBatchLoader(ds, model_engine, eval_gas, model.prepare_inputs) for name, ds in (eval_data or {}).items()}
     saver = Saver(args, config, is_adapter, save_root, model, loader, model_engine, pipeline_model)
+    if max_steps is None and 'max_steps' in config:
+        max_steps = config['max_steps']
     out = {'losses': [], 'evals': {}}
 
     def run_eval(at):
@@ -53,7 +55,7 @@ def run_training(model, model_engine, pipeline_model, train_data, config, save_r
         out['losses'].append(loss)
         epoch_loss, num_steps = epoch_loss + loss, num_steps + 1
         loader.sync_epoch()
-        new_epoch, _, _ = saver.process_epoch(epoch, step, examples)
+        new_epoch, checkpointed, saved = saver.process_epoch(epoch, step, examples)
         finished_epoch = new_epoch != epoch
         log('train/loss', loss, step)
         every_steps, every_epochs = config.get('eval_every_n_steps'), config.get('eval_every_n_epochs')
@@ -63,12 +65,19 @@ def run_training(model, model_engine, pipeline_model, train_data, config, save_r
             log('train/epoch_loss', epoch_loss / num_steps, epoch)
             epoch_loss, num_steps = 0.0, 0
             if new_epoch is None:
+                final_model_name = f'epoch{epoch}'
                 break
             epoch = new_epoch
-        saver.process_step(step, examples)
+        checkpointed, saved = saver.process_step(step, examples)
         if max_steps is not None and step >= max_steps:
+            final_model_name = f'step{step}'
             break
         step += 1
         examples += global_batch
-    out.update(step=step, epoch=epoch)
+    # final training-state checkpoint and model, unless the last iteration just wrote them (train.py:969-973)
+    if not checkpointed:
+        saver.save_checkpoint(step, examples)
+    if not saved:
+        saver.save_model(final_model_name)
+    out.update(step=step, epoch=epoch, final_model_name=final_model_name)
     return out

@@ -1,0 +1,59 @@
+"""BASELINE config 2 at FULL size on the MI355X: SDXL 1024x1024 (latent 128), the full `SDXLConfig()`, micro-batch 1, GAS 6, AdamW, clip 1.0 --
+the configuration `bench.py` times.  Regression test for the round-1 driver-bench hang (hipGraph replays of 3 concurrent lanes queued
+across step boundaries wedged the queue): >= 12 optimizer steps are enqueued back to back with NO host synchronisation by the caller,
+the 3-lane graph path must finish, stay finite and follow the 1-lane path's trajectory (same math up to the summation order of the
+lanes' bf16 gradient accumulators)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+STEPS = 12
+GAS = 6
+
+
+def _engine(gpu, lanes, pool_seed=100):
+    from diffusion_pipe_amd import optim
+    from diffusion_pipe_amd.data import split_batch
+    from diffusion_pipe_amd.engine import ManualPipelineModule, initialize
+    from diffusion_pipe_amd.workloads import sdxl
+    cfg = sdxl.SDXLConfig()
+    work = sdxl.SDXLWorkload(cfg, dtype=torch.bfloat16, seed=0, device=gpu)
+    module = ManualPipelineModule(layers=work.to_layers(), num_stages=1, partition_method='parameters', loss_fn=work.get_loss_fn(), dynamic_shape=True)
+    engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 1, 'gradient_accumulation_steps': GAS, 'gradient_clipping': 1.0,
+                                                         'hip_graph': True, 'graph_lanes': lanes}, device=gpu)
+    work.train_config = {'optimizer': {'type': 'adamw', 'lr': 1e-5, 'betas': [0.9, 0.99], 'weight_decay': 0.01, 'eps': 1e-8}}
+    engine._configure_optimizer(optim.make_optimizer_factory(work.train_config, work, global_batch_size=GAS), [p for p in module.parameters() if p.requires_grad])
+    torch.manual_seed(1234)
+    pool = []
+    for s in range(3):
+        feats, label = work.prepare_inputs(sdxl.synthetic_batch(cfg, batch_size=GAS, latent_hw=128, seed=pool_seed + s))
+        pool.append(split_batch((feats, label), GAS))
+    return engine, pool
+
+
+def _trajectory(gpu, lanes):
+    engine, pool = _engine(gpu, lanes)
+    losses, norms = [], []
+    for i in range(STEPS):                                   # no .item(), no synchronize: device scalars only
+        engine.reset_activation_shape()
+        losses.append(engine.train_batch(iter(pool[i % len(pool)])))
+        norms.append(engine.get_global_grad_norm())
+    torch.cuda.synchronize()
+    out = [float(l.item()) for l in losses], [float(n.item()) for n in norms]
+    del engine, pool
+    torch.cuda.empty_cache()
+    return out
+
+
+def test_full_size_sdxl_three_lanes_twelve_unsynchronised_steps_match_one_lane(gpu):
+    loss3, norm3 = _trajectory(gpu, 3)
+    assert all(math.isfinite(v) for v in loss3 + norm3), (loss3, norm3)
+    loss1, norm1 = _trajectory(gpu, 1)
+    assert all(math.isfinite(v) for v in loss1 + norm1), (loss1, norm1)
+    for i, (a, b) in enumerate(zip(loss3, loss1)):
+        assert abs(a - b) <= 2e-2 * abs(b) + 1e-4, f'step {i}: loss {a} (3 lanes) vs {b} (1 lane)'
+    for i, (a, b) in enumerate(zip(norm3, norm1)):
+        assert abs(a - b) <= 5e-2 * abs(b) + 1e-4, f'step {i}: grad norm {a} (3 lanes) vs {b} (1 lane)'

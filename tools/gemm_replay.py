@@ -1,0 +1,138 @@
+"""Re-issue a recorded GEMM launch list (ops.GEMM_TRACE descriptors: shapes, leading dimensions, batch strides, epilogue flags) over scratch
+operands -- as ONE hipGraph timed with HIP events (bench.py's `roofline`: in-graph, back-to-back launches exactly as the training step replays
+them, average launch duration = graph time / launches) or eagerly (`python tools/gemm_replay.py <trace.json>`: a rocprofv3 `--pmc FETCH_SIZE` /
+`--pmc WRITE_SIZE` target; the counter collector cannot attribute launches inside a replayed hipGraph).
+
+Operands rotate through a scratch arena much larger than the 8 x 4 MiB L2s + the 256 MiB Infinity Cache, so every launch finds its weights
+HBM-cold as in training (each weight is read once per micro-batch pass); element values are small random bf16."""
+import json
+import sys
+from collections import OrderedDict
+
+import torch
+
+ESZ = {0: 2, 1: 4}      # hip.BF16, hip.F32
+
+
+def _extent(rows, cols, ld, d, s):
+    return (rows - 1) * ld + cols + (d['bo'] - 1) * s[0] + (d['bi'] - 1) * s[1]
+
+
+def operand_elems(d):
+    """elements spanned by A, B, C of one descriptor (the bytes a launch must at least touch are algorithmic_bytes())."""
+    ra, ca = (d['K'], d['M']) if d['ta'] else (d['M'], d['K'])
+    rb, cb = (d['N'], d['K']) if d['tb'] else (d['K'], d['N'])
+    return (_extent(ra, ca, d['lda'], d, d['sa']), _extent(rb, cb, d['ldb'], d, d['sb']), _extent(d['M'], d['N'], d['ldc'], d, d['sc']))
+
+
+def flops(d):
+    return 2.0 * d['M'] * d['N'] * d['K'] * d['bo'] * d['bi']
+
+
+def algorithmic_bytes(d):
+    """every operand read once, the result written once (+ read once when accumulating / adding a residual)"""
+    batch = d['bo'] * d['bi']
+    e = ESZ[d['dt']]
+    oe = 4 if d['out_f32'] else e
+    rd = (d['M'] * d['K'] + d['N'] * d['K']) * e * batch + (d['N'] * e if d['bias'] else 0)
+    rd += d['M'] * d['N'] * oe * batch * (int(d['acc']) + int(d['res']))
+    wr = d['M'] * d['N'] * oe * batch + (d['M'] * e * batch if d['colsum'] else 0)
+    return rd, wr
+
+
+class Arena:
+    def __init__(self, device, nbytes):
+        n = nbytes // 2
+        self.buf = (torch.randn(n, device=device, dtype=torch.float32) * 0.05).to(torch.bfloat16) if n <= (1 << 28) else \
+            torch.cat([(torch.randn(1 << 28, device=device, dtype=torch.float32) * 0.05).to(torch.bfloat16) for _ in range((n + (1 << 28) - 1) >> 28)])[:n]
+        self.bytes = self.buf.view(torch.uint8)
+        self.off = 0
+
+    def take(self, nbytes, dtype):
+        nbytes = (nbytes + 255) & ~255
+        if self.off + nbytes > self.bytes.numel():
+            self.off = 0
+        v = self.bytes[self.off:self.off + nbytes].view(dtype)
+        self.off += nbytes
+        return v
+
+
+def issue(trace, arena, ops):
+    """launch every descriptor once on the current stream over fresh arena slices"""
+    from diffusion_pipe_amd import hip
+    for d in trace:
+        dt = torch.bfloat16 if d['dt'] == hip.BF16 else torch.float32
+        odt = torch.float32 if d['out_f32'] else dt
+        ea, eb, ec = operand_elems(d)
+        a = arena.take(ea * ESZ[d['dt']], dt)[:ea]
+        b = arena.take(eb * ESZ[d['dt']], dt)[:eb]
+        osz = 4 if d['out_f32'] else ESZ[d['dt']]
+        c = arena.take(ec * osz, odt)[:ec]
+        bias = arena.take(d['N'] * ESZ[d['dt']], dt)[:d['N']] if d['bias'] else None
+        er = (d['M'] - 1) * d['ldr'] + d['N'] + (d['bo'] - 1) * d['sc'][0] + (d['bi'] - 1) * d['sc'][1] if d['res'] else 0
+        res = arena.take(er * osz, odt)[:er] if d['res'] else None
+        cs = arena.take(d['M'] * d['bo'] * d['bi'] * ESZ[d['dt']], dt)[:d['M'] * d['bo'] * d['bi']] if d['colsum'] else None
+        ops.gemm(a, b, d['ta'], d['tb'], d['M'], d['N'], d['K'], c, lda=d['lda'], ldb=d['ldb'], ldc=d['ldc'], batch_outer=d['bo'], batch_inner=d['bi'],
+                 stride_a=d['sa'], stride_b=d['sb'], stride_c=d['sc'], bias=bias, act=d['act'], alpha=d['alpha'], accumulate=d['acc'], tile_hint=d['tile'],
+                 residual=res, ldr=d['ldr'], colsum=cs, colsum_accumulate=d['colsum_acc'])
+
+
+def time_in_graph(trace, device, reps=3, arena_bytes=3 << 30):
+    """-> dict(ms per replay of the launch list, launches, flops, algorithmic read / write bytes).  One hipGraph of every launch, replayed
+    `reps` times on the current stream between two HIP events recorded on that same stream."""
+    from diffusion_pipe_amd import ops
+    trace = [d for d in trace]
+    arena = Arena(device, arena_bytes)
+    ops.WS_LANE = 'roofline'
+    side = torch.cuda.Stream(device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(side):
+        issue(trace[:64], arena, ops)                      # warm-up (workspace allocation, module load)
+    torch.cuda.current_stream(device).wait_stream(side)
+    torch.cuda.synchronize(device)
+    arena.off = 0
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+        issue(trace, arena, ops)
+    ops.WS_LANE = None
+    graph.replay()
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        graph.replay()
+    e1.record()
+    torch.cuda.synchronize(device)
+    rd = sum(algorithmic_bytes(d)[0] for d in trace)
+    wr = sum(algorithmic_bytes(d)[1] for d in trace)
+    return {'ms': e0.elapsed_time(e1) / reps, 'launches': len(trace), 'flops': sum(flops(d) for d in trace), 'read_bytes': rd, 'write_bytes': wr}
+
+
+def unique_with_counts(trace):
+    u = OrderedDict()
+    for d in trace:
+        k = json.dumps(d, sort_keys=True)
+        u[k] = u.get(k, 0) + 1
+    return [dict(json.loads(k), count=n) for k, n in u.items()]
+
+
+def main():
+    """eager replay of a saved unique-descriptor list (bench.py --save-gemm-trace): each descriptor `reps` times over rotating operands"""
+    sys.path.insert(0, '.')
+    from diffusion_pipe_amd import ops
+    path, div = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    uniq = json.load(open(path))
+    dev = torch.device('cuda:0')
+    arena = Arena(dev, 3 << 30)
+    total = 0
+    for d in uniq:
+        n = max(1, d['count'] // div)            # the step's own launch mix: every descriptor as often as the step issues it (/ div)
+        d = {k: (tuple(v) if isinstance(v, list) else v) for k, v in d.items() if k != 'count'}
+        issue([d] * n, arena, ops)
+        total += n
+    torch.cuda.synchronize()
+    print(f'{len(uniq)} unique GEMM descriptors, {total} eager launches')
+
+
+if __name__ == '__main__':
+    main()
