@@ -1,0 +1,109 @@
+// conv_pipe.hip -- 2-D convolution of the SDXL UNet (models/sdxl.py:797-865 call sites -> diffusers ResnetBlock2D / Downsample2D /
+// Upsample2D convs) as implicit GEMM on the LDS-DMA pipelined MFMA kernel (gemm_pipe_kernel.h, CONV modes).  NHWC bf16 activations,
+// weights [Cout][kh][kw][Cin] (= torch channels_last storage of a [Cout, Cin, kh, kw] parameter), fp32 accumulation.
+//   forward : y[b, oy, ox, co]  = act(sum_{ky, kx, ci} x[b, oy s + ky - p, ox s + kx - p, ci] w[co, ky, kx, ci] + bias[co]) (+ residual)
+//             GEMM  M = B Ho Wo, N = Cout, K = kh kw Cin; A rows gathered (optionally through a fused nearest 2x up-sampling of x)
+//   dgrad   : dx[b, y, x, ci]   = sum_{ky, kx, co} dy[b, (y + p - ky) / s, (x + p - kx) / s, co] w[co, ky, kx, ci]   (divisible positions only)
+//             GEMM  M = B H W, N = Cin, K = kh kw Cout; A rows gathered from dy, B = the same weight buffer read MN-contiguous
+//   wgrad   : dw[co, ky, kx, ci] (+)= sum_{b, oy, ox} dy[b, oy, ox, co] x[b, oy s + ky - p, ox s + kx - p, ci];  dbias[co] (+)= sum dy
+//             one GEMM per tap (grid.y): M = Cout, N = Cin, K = B Ho Wo; B k-rows gathered, bias gradient from the A fragments
+// Padding never materialises: an out-of-image pixel gets a DMA source offset beyond the buffer extent and the hardware bounds check
+// returns zeros.  Bound: MFMA (same tile machinery and split-K as dpipe_gemm_ex); algorithmic work 2 M N K.
+#include "gemm_pipe_kernel.h"
+#include "../../include/dpipe_hip.h"
+
+using namespace dpipe_pipe;
+
+namespace {
+
+int ilog2_exact(int v) { return v == 1 ? 0 : v == 2 ? 1 : -1; }
+
+template <int CONV>
+int launch_conv(GemmParams& p, bool b_mc, int batch, void* ws, long ws_bytes, int tile_hint, hipStream_t s) {
+    const int force_tile = tile_hint >= 7000 ? 257 : tile_hint >= 4000 && tile_hint < 5000 ? 129 : tile_hint >= 3000 && tile_hint < 4000 ? 128
+                         : tile_hint >= 2000 && tile_hint < 3000 ? 64 : 0;
+    const int force_s = tile_hint >= 1000 ? tile_hint % 1000 : 0;
+    const bool a_mc = CONV == 2;
+    int tile = gemm_pipe_plan(p, a_mc, b_mc, batch, ws, ws_bytes, force_s, force_tile);
+    if (tile == 256 || tile == 63) tile = 128;
+    switch (tile) {
+    case 257: return launch_pipe<T256S, CONV>(p, a_mc, b_mc, batch, s);
+    case 129: return launch_pipe<T128R2, CONV>(p, a_mc, b_mc, batch, s);
+    case 128: return launch_pipe<T128, CONV>(p, a_mc, b_mc, batch, s);
+    default: return launch_pipe<T64, CONV>(p, a_mc, b_mc, batch, s);
+    }
+}
+
+void base_params(GemmParams& p) {
+    p.bias = nullptr; p.sAo = p.sAi = p.sBo = p.sBi = p.sCo = p.sCi = 0; p.batch_inner = 1; p.alpha = 1.f; p.act = ACT_NONE; p.accumulate = 0; p.out_f32 = 0;
+    p.splitk = 1; p.ksteps = p.ksteps_per_split = 0; p.slabs = nullptr; p.counters = nullptr; p.residual = nullptr; p.ldr = 0; p.colsum = nullptr; p.colsum_acc = 0;
+    p.vecA = p.vecB = 0; p.tiles_m = p.tiles_n = 0;
+}
+
+bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+#define BAD(msg) do { set_last_error(msg); return DPIPE_ERR_ARG; } while (0)
+#define UNSUP(msg) do { set_last_error(msg); return DPIPE_ERR_UNSUPPORTED; } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int dpipe_conv2d_fwd(const void* x, long ldx, const void* w, const void* bias, const void* residual, long ldr, void* y, long ldy,
+                     int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int upsample, int act,
+                     void* ws, long ws_bytes, int tile_hint, void* stream) {
+    if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || pad < 0) BAD("dpipe_conv2d_fwd: bad argument");
+    const int sl = ilog2_exact(stride), ul = ilog2_exact(upsample);
+    if (sl < 0 || ul < 0) UNSUP("dpipe_conv2d_fwd: stride and upsample must be 1 or 2");
+    if (Cin % 64 || ldx % 8 || ldy % 4 || !al16(x) || !al16(w)) UNSUP("dpipe_conv2d_fwd: needs Cin % 64 == 0, 16-byte aligned operands, ldx % 8 == 0");
+    const int Hi = H << ul, Wi = W << ul;
+    const int Ho = (Hi + 2 * pad - kh) / stride + 1, Wo = (Wi + 2 * pad - kw) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) BAD("dpipe_conv2d_fwd: empty output");
+    GemmParams p; base_params(p);
+    p.A = x; p.lda = ldx; p.B = w; p.ldb = (long)kh * kw * Cin; p.C = y; p.ldc = ldy;
+    p.M = B * Ho * Wo; p.N = Cout; p.K = kh * kw * Cin;
+    p.bias = bias; p.act = act; p.residual = residual; p.ldr = ldr;
+    p.cg = ConvGeom{Ho, Wo, H, W, kw, kh * kw, Cin / 64, sl, ul, pad, 0, 0, 0, ((long)B * H * W - 1) * ldx + Cin, 0};
+    if (p.cg.a_ext * 2 >= (1L << 31) || (long)Cout * p.ldb * 2 >= (1L << 31)) UNSUP("dpipe_conv2d_fwd: operand beyond 2 GiB");
+    return launch_conv<1>(p, false, 1, ws, ws_bytes, tile_hint, reinterpret_cast<hipStream_t>(stream));
+}
+
+int dpipe_conv2d_dgrad(const void* dy, long lddy, const void* w, void* dx, long lddx,
+                       int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
+                       void* ws, long ws_bytes, int tile_hint, void* stream) {
+    if (!dy || !w || !dx || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || pad < 0) BAD("dpipe_conv2d_dgrad: bad argument");
+    const int sl = ilog2_exact(stride);
+    if (sl < 0) UNSUP("dpipe_conv2d_dgrad: stride must be 1 or 2");
+    if (Cout % 64 || Cin % 8 || lddy % 8 || lddx % 4 || !al16(dy) || !al16(w)) UNSUP("dpipe_conv2d_dgrad: needs Cout % 64 == 0, Cin % 8 == 0, aligned operands");
+    const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) BAD("dpipe_conv2d_dgrad: empty output");
+    GemmParams p; base_params(p);
+    p.A = dy; p.lda = lddy; p.B = w; p.ldb = (long)kh * kw * Cin; p.C = dx; p.ldc = lddx;
+    p.M = B * H * W; p.N = Cin; p.K = kh * kw * Cout;
+    p.cg = ConvGeom{H, W, Ho, Wo, kw, kh * kw, Cout / 64, sl, 0, pad, 1, 0, (long)Cin, ((long)B * Ho * Wo - 1) * lddy + Cout, (long)Cout * kh * kw * Cin};
+    if (p.cg.a_ext * 2 >= (1L << 31) || p.cg.b_ext * 2 >= (1L << 31)) UNSUP("dpipe_conv2d_dgrad: operand beyond 2 GiB");
+    return launch_conv<1>(p, true, 1, ws, ws_bytes, tile_hint, reinterpret_cast<hipStream_t>(stream));
+}
+
+int dpipe_conv2d_wgrad(const void* dy, long lddy, const void* x, long ldx, void* dw, void* dbias,
+                       int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int upsample,
+                       int accumulate, int bias_accumulate, void* ws, long ws_bytes, int tile_hint, void* stream) {
+    if (!dy || !x || !dw || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || pad < 0) BAD("dpipe_conv2d_wgrad: bad argument");
+    const int sl = ilog2_exact(stride), ul = ilog2_exact(upsample);
+    if (sl < 0 || ul < 0) UNSUP("dpipe_conv2d_wgrad: stride and upsample must be 1 or 2");
+    if (Cin % 8 || Cout % 8 || lddy % 8 || ldx % 8 || !al16(dy) || !al16(x)) UNSUP("dpipe_conv2d_wgrad: needs Cin % 8 == 0, Cout % 8 == 0, aligned operands");
+    const int Hi = H << ul, Wi = W << ul;
+    const int Ho = (Hi + 2 * pad - kh) / stride + 1, Wo = (Wi + 2 * pad - kw) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) BAD("dpipe_conv2d_wgrad: empty output");
+    const int taps = kh * kw;
+    GemmParams p; base_params(p);
+    p.A = dy; p.lda = lddy; p.B = x; p.ldb = ldx; p.C = dw; p.ldc = (long)taps * Cin;
+    p.M = Cout; p.N = Cin; p.K = B * Ho * Wo;
+    p.batch_inner = taps; p.sCi = Cin;
+    p.accumulate = accumulate; p.colsum = dbias; p.colsum_acc = bias_accumulate;
+    p.cg = ConvGeom{Ho, Wo, H, W, kw, taps, 0, sl, ul, pad, 0, 0, 0, 0, ((long)B * H * W - 1) * ldx + Cin};
+    if (((long)(p.K + 63) * lddy + Cout + 256) * 2 >= (1L << 31) || p.cg.b_ext * 2 >= (1L << 31)) UNSUP("dpipe_conv2d_wgrad: operand beyond 2 GiB");
+    return launch_conv<2>(p, true, taps, ws, ws_bytes, tile_hint, reinterpret_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -5,6 +5,21 @@
 
 namespace dpipe {
 
+// Implicit-GEMM convolution geometry (gemm_pipe_kernel.h CONV modes; NHWC bf16 tensors).  "rows" = the pixel grid the GEMM enumerates
+// (CONV 1: the M rows; CONV 2: the K rows); "src" = the tensor whose pixels are gathered.
+struct ConvGeom {
+    int rows_h, rows_w;          // pixel grid enumerated: row r -> (b, y, x) = (r / (rows_h * rows_w), ...)
+    int src_h, src_w;            // spatial size of the gathered tensor (before a fused nearest up-sampling)
+    int kw, taps;                // kernel width, kh * kw
+    int cchunks;                 // CONV 1: channels of the gathered tensor / 64 (k-steps per tap)
+    int stride_log2, ups_log2;   // conv stride 1 / 2; fused nearest up-sampling of the source 1x / 2x
+    int pad;
+    int flip;                    // CONV 1 dgrad: source = (y + pad - ky) / stride when divisible, else zero
+    int tap0;                    // CONV 2: first tap of this launch (grid.y indexes taps)
+    long b_tap_stride;           // CONV 1 dgrad: element offset of tap t inside a weight row (= Cin); B k-row pitch = ldb
+    long a_ext, b_ext;           // element extents of the gathered / irregularly addressed operands (buffer bounds)
+};
+
 struct GemmParams {
     const void* A; const void* B; void* C; const void* bias;
     int M, N, K;
@@ -21,6 +36,7 @@ struct GemmParams {
     // fused epilogue extras
     const void* residual; long ldr;       // C += residual[m, n] (C's dtype, row pitch ldr, batch strides of C)
     void* colsum; int colsum_acc;          // pipelined TN kernel only: colsum[m] (+)= sum_k A[k][m]  (bias gradient of a wgrad GEMM), operand dtype
+    ConvGeom cg;                           // CONV modes only
 };
 
 enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_SILU = 3, ACT_QUICK_GELU = 4 };
@@ -39,5 +55,8 @@ __device__ __forceinline__ float epilogue_act(float x, int act) {
 // once by the host and private to one stream; NULL disables split-K.
 bool gemm_pipe_try(GemmParams& p, int transA, int transB, int batch, void* ws, long ws_bytes, int force_splitk, int force_tile,
                    hipStream_t s, int* rc_out);
+// Tile / split-K choice shared by the GEMM and the convolution front ends: fills p.tiles_*, p.ksteps*, p.splitk, p.counters, p.slabs,
+// p.vecA / p.vecB (epilogue vector flags) and returns the tile code (64, 128, 129 = 128^2 2-deep ring, 256 = 256 x 128, 257 = 256^2, 63).
+int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, long ws_bytes, int force_splitk, int force_tile);
 
 }  // namespace dpipe

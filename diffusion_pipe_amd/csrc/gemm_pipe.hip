@@ -1,493 +1,7 @@
-// gemm_pipe.hip -- the bf16 hot-path GEMM of the training step: LDS-DMA pipelined MFMA kernel with in-launch split-K.
-//
-//   C[z] = act(alpha * op(A[z]) . op(B[z]) + bias) (+ C[z])        (same contract as dpipe_gemm, bf16 operands)
-//
-// Why a second kernel: at micro-batch 1 the SDXL / DiT linears are small (M = 77 .. 4096 tokens, N, K = 640 .. 10240):
-// a 128 x 128 tiling yields 10 .. 100 workgroups for 256 CUs and every workgroup walks K serially, so the generic
-// register-staged kernel (gemm.hip) is bound by one global-load latency per K-step, not by MFMA or HBM.  This kernel
-//   * streams operand tiles global -> LDS with `buffer_load_dwordx4 ... lds` (no staging VGPRs, no ds_write pass) into
-//     a ring of STAGES x 32 KiB buffers, keeps STAGES-1 K-steps in flight across ONE raw s_barrier per K-step and
-//     drains them with counted `s_waitcnt vmcnt(N)` (never 0 in steady state);
-//   * lays the LDS images out bank-conflict-free by permuting the per-lane SOURCE address (the DMA destination is
-//     lane-linear): K-contiguous operands as [128 rows][8 x 16 B] with chunk ^= (row >> 1) & 7 for ds_read_b128,
-//     MN-contiguous operands (dgrad's W, wgrad's dy and x) as [64 k-rows][4 x 64 B] with granule ^= krow & 3 for
-//     ds_read_b64_tr_b16 -- so no transposed copy of any operand is ever materialised;
-//   * uses the buffer descriptor's bounds check for ragged tiles (out-of-range rows read as zero);
-//   * splits K over up to 16 workgroups per tile when the tile count alone cannot fill the chip: each slice stores an
-//     fp32 slab in MFMA-native order (coalesced 16-B stores), publishes it with an agent-scope release + ticket counter,
-//     and the last arriver acquires, sums the slabs in slice order (deterministic) and runs the epilogue;
-//   * computes C^T tiles (operands swapped in the MFMA) so each lane owns 4 consecutive N elements of one row:
-//     8-byte bf16 / 16-byte fp32 stores and vector bias loads instead of 2-byte scatter.
-// Workgroup = 256 threads = 4 waves (2 x 2), 64 x 64 per wave, v_mfma_f32_32x32x16_bf16, fp32 accumulate.
-#include "gemm_internal.h"
+// gemm_pipe.hip -- dispatch of the plain bf16 GEMM onto the LDS-DMA pipelined kernel (gemm_pipe_kernel.h): eligibility, tile / split-K choice.
+#include "gemm_pipe_kernel.h"
 #include "../../include/dpipe_hip.h"
 
-using namespace dpipe;
-
-namespace dpipe_pipe {   // named: a kernel template argument may not have internal linkage (its host stub would be dropped)
-
-constexpr int BK = 64;
-constexpr int COUNTER_BYTES = 4096;
-
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(3))) bf16x4_t lds_bf16x4_t;
-
-// Tile geometry.  T64: 64 x 64 tile, 4 waves (2 x 2, 32 x 32 each), 4-deep ring of 16 KiB stages -> 2 workgroups per CU;
-// the small-problem configuration (4 x the workgroups of T128: aggregate L1/L2 bandwidth of more CUs is what bounds a
-// GEMM whose whole operand set is a few MB).  T128: 128 x 128 tile, 8 waves (2 x 4, 64 x 32 each) = 2 waves per SIMD so
-// one wave's DMA issue (60..180 cycles per 1 KiB piece, MI355X_MICROARCH.md) hides under the other's MFMAs; 3 x 32 KiB.
-template <int BM_, int BN_, int WM_, int WN_, int STAGES_> struct Tile {
-    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, STAGES = STAGES_;
-    static constexpr int NW = WM * WN, NT = NW * 64;
-    static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;       // 32x32 MFMA tiles per wave
-    static constexpr int IMG_A = BM * BK * 2, IMG_B = BN * BK * 2, STAGE_BYTES = IMG_A + IMG_B;
-    static constexpr int PA = IMG_A / 1024 / NW, PB = IMG_B / 1024 / NW;   // 1 KiB DMA pieces per wave per operand
-    static constexpr int NLOAD = PA + PB;
-    static constexpr int SLAB_F4 = BM * BN / 4 + BM / 4;               // accumulators + one row of fused column sums
-    static constexpr int ACC_F4 = TM * TN * 4;                        // float4 per thread in a slab
-    static_assert(IMG_A % (1024 * NW) == 0 && IMG_B % (1024 * NW) == 0, "pieces must split evenly over the waves");
-};
-using T64 = Tile<64, 64, 2, 2, 4>;
-using T128 = Tile<128, 128, 2, 4, 3>;
-using T128R2 = Tile<128, 128, 2, 4, 2>;     // 2-deep ring, 64 KiB -> 2 workgroups per CU: one tile's epilogue / prologue overlaps the other's K-loop.
-                                            // Measured (tools/kernel_timing.py cold): 1.3-1.7x over T128 once there are >= 256 tiles and an
-                                            // MN-contiguous operand (dgrad / wgrad), 1.2x at 8192^3; slower with few tiles (no second workgroup).
-using T64S3 = Tile<64, 64, 2, 2, 3>;         // selectable, not chosen automatically: 3-deep ring (3 workgroups per CU)
-using T256 = Tile<256, 128, 4, 2, 3>;       // selectable, not chosen automatically: 256 x 128, 8 waves of 64 x 64, 144 KiB (T128R2 beats it)
-using T256S = Tile<256, 256, 2, 4, 2>;      // 256 x 256, 8 waves of 128 x 64 (128 accumulator VGPRs), 2 x 64 KiB: twice the MFMA work per DMA'd
-                                            // byte of the 128^2 tile -- the large-GEMM configuration (DiT-sized linears: Flux / Wan / HunyuanVideo)
-
-// Byte offset (from the operand base of this batch) of the 16 bytes lane `lane` fetches for DMA piece q of an image of
-// ROWS mn-rows at K-step 0.  The DMA writes lane L of piece q to LDS byte (q * 1024 + 16 L); the logical chunk fetched
-// is the inverse of the read-side swizzle.
-template <bool MC, int ROWS>
-__device__ __forceinline__ unsigned dma_voffset(int q, int lane, int mn0, long ld) {
-    if (!MC) {   // image [ROWS mn-rows][128 B]: physical 16-B chunk pc of row holds logical chunk pc ^ ((row >> 1) & 7)
-        const int row = 8 * q + (lane >> 3);
-        const int pc = lane & 7;
-        const int lc = pc ^ ((row >> 1) & 7);
-        return (unsigned)(((long)(mn0 + row) * ld + lc * 8) * 2);
-    } else {     // image [64 k-rows][ROWS * 2 B]: physical 64-B granule pg of a k-row holds logical granule pg ^ f(krow)
-        constexpr int CPR = ROWS / 8;            // 16-B chunks per k-row (16 or 8)
-        constexpr int G = ROWS / 32;             // 64-B granules per k-row (4 or 2)
-        const int krow = q * (64 / CPR) + lane / CPR;
-        const int pc = lane % CPR;
-        const int f = G >= 4 ? (krow & 3) : ((krow >> 1) & 1);
-        const int lc = (((pc >> 2) ^ f) << 2) | (pc & 3);
-        return (unsigned)(((long)krow * ld + mn0 + lc * 8) * 2);
-    }
-}
-
-// MFMA operand fragment (32 mn-rows x 16 k): lane (i = lane & 31, h = lane >> 5) gets k = 16 ks + 8 h .. + 8 of row mn + i.
-template <bool MC, int ROWS>
-__device__ __forceinline__ bf16x8_t read_frag(const char* img, int mn, int ks, int lane) {
-    if (!MC) {
-        // mn is a multiple of 32, so the swizzle term (row >> 1) & 7 depends on the lane only and 2 ks + h == (2 ks) ^ h:
-        // the lane part of the address is one of 4 values (per ks) shared by every fragment of both operands; mn * 128
-        // is wave-uniform / an immediate offset
-        const int l31 = lane & 31;
-        const int x = (lane >> 5) ^ ((l31 >> 1) & 7);
-        const int lane_off = l31 * 128 + ((x ^ (2 * ks)) << 4);
-        return *reinterpret_cast<const bf16x8_t*>(img + mn * 128 + lane_off);
-    } else {
-        // ds_read_b64_tr_b16: in a 16-lane group lane t supplies the address of 4 contiguous bf16 of k-row (t >> 2) at
-        // columns 4 (t & 3) of a [4][16] block and receives column t of it (the 4 k values of one mn index).
-        constexpr int RB = ROWS * 2, G = ROWS / 32;
-        const int t = lane & 15, g = lane >> 4;
-        const int krow = 16 * ks + 8 * (g >> 1) + (t >> 2);
-        const int col_b = (16 * (g & 1) + 4 * (t & 3)) * 2;          // byte column inside the 64-B granule
-        const int f = G >= 4 ? (krow & 3) : ((krow >> 1) & 1);       // identical for krow + 4
-        const char* p = img + krow * RB + ((mn >> 5) ^ f) * 64 + col_b;
-        const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(p));
-        const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(p + 4 * RB));
-        bf16x8_t out;
-        out[0] = lo[0]; out[1] = lo[1]; out[2] = lo[2]; out[3] = lo[3];
-        out[4] = hi[0]; out[5] = hi[1]; out[6] = hi[2]; out[7] = hi[3];
-        return out;
-    }
-}
-
-// sum of the 8 bf16 of an MFMA operand fragment (fp32)
-__device__ __forceinline__ float frag_sum(bf16x8_t f) {
-    const uint4 u = __builtin_bit_cast(uint4, f);
-    return (__uint_as_float(u.x << 16) + __uint_as_float(u.x & 0xffff0000u)) + (__uint_as_float(u.y << 16) + __uint_as_float(u.y & 0xffff0000u)) +
-           (__uint_as_float(u.z << 16) + __uint_as_float(u.z & 0xffff0000u)) + (__uint_as_float(u.w << 16) + __uint_as_float(u.w & 0xffff0000u));
-}
-
-// counted wait for this wave's LDS-DMA: `ahead` later K-steps (NLOAD DMA instructions each) may stay in flight
-template <int NLOAD> __device__ __forceinline__ void wait_dma_ahead(int ahead) {
-    static_assert(NLOAD == 4 || NLOAD == 6 || NLOAD == 8, "DMA pieces per wave per K-step");
-    if constexpr (NLOAD == 8) {
-        switch (ahead) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-        }
-        return;
-    }
-    if constexpr (NLOAD == 4) {
-        switch (ahead) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-        }
-    } else {
-        switch (ahead) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
-        }
-    }
-}
-
-template <int BM_, int BN_, int WM_, int WN_, int STAGES_, bool A_MC, bool B_MC>
-__global__ void __launch_bounds__(512) gemm_pipe_kernel(const GemmParams p) {
-    using TL = Tile<BM_, BN_, WM_, WN_, STAGES_>;
-    constexpr int BM = TL::BM, BN = TL::BN, STAGES = TL::STAGES, TM = TL::TM, TN = TL::TN, NLOAD = TL::NLOAD;
-    static_assert(STAGES >= 2 && STAGES <= 5, "ring depth (the vmcnt ladder covers <= 3 K-steps ahead)");
-    __shared__ __attribute__((aligned(1024))) char lds[STAGES * TL::STAGE_BYTES];
-
-    // XCD-aware bijective remap (consecutive ids round-robin over the 8 XCDs): each XCD owns a contiguous run of
-    // (tile, slice) pairs; slices of one tile are adjacent, so a tile's slabs stay in one L2.
-    const int nt = p.tiles_m * p.tiles_n;
-    const int nwg = nt * p.splitk;
-    const int orig = blockIdx.x;
-    const int xq = nwg / 8, xr = nwg % 8, xcd = orig % 8;
-    const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + orig / 8;
-    const int split = wg % p.splitk, tile = wg / p.splitk;
-    // grouped rasterisation: consecutive tiles walk 8 tile-rows before moving one tile-column over, so the ~32 tiles an
-    // XCD works on at any moment form an 8 x 4 block sharing 8 + 4 operand panels (instead of 32 + 1): ~2.7x less
-    // L2 miss traffic once the operands outgrow the 4 MiB L2.
-    constexpr int GR = 8;
-    const int gsz = GR * p.tiles_n;
-    const int grp = tile / gsz, first_m = grp * GR;
-    const int rows_in = min(p.tiles_m - first_m, GR);
-    const int tile_m = first_m + (tile - grp * gsz) % rows_in, tile_n = (tile - grp * gsz) / rows_in;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    const int z = blockIdx.y;
-    const long zo = z / p.batch_inner, zi = z % p.batch_inner;
-    const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + zo * p.sAo + zi * p.sAi;
-    const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B) + zo * p.sBo + zi * p.sBi;
-    // Buffer extents for the bounds check (out-of-range dwords read as zero).  An MN-contiguous operand's last row is
-    // rounded up to whole 16-byte pieces: the check is per dword, and an odd MN count would otherwise zero the last
-    // element of the last K-row (its row pitch is a multiple of 8 elements, so those bytes exist; they only feed
-    // output indices >= M / N, which are never stored).
-    const unsigned a_bytes = (unsigned)((A_MC ? (long)(p.K - 1) * p.lda + ((p.M + 7) & ~7) : (long)(p.M - 1) * p.lda + p.K) * 2);
-    const unsigned b_bytes = (unsigned)((B_MC ? (long)(p.K - 1) * p.ldb + ((p.N + 7) & ~7) : (long)(p.N - 1) * p.ldb + p.K) * 2);
-    // (hipcc's host pass drops a kernel's launch stub -- silently -- when a target builtin is called with type-dependent
-    // operands: the DMA builtin below only ever sees non-dependent locals, hence the ISSUE_STAGE macro)
-    const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), (short)0, (int)a_bytes, 0x00020000);
-    const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), (short)0, (int)b_bytes, 0x00020000);
-
-    const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm0 = (wid / TL::WN) * (BM / TL::WM), wn0 = (wid % TL::WN) * (BN / TL::WN);
-
-    const int kbeg = split * p.ksteps_per_split;
-    const int kend = min(p.ksteps, kbeg + p.ksteps_per_split);
-    const int nk = kend - kbeg;
-
-    // per-lane source offsets of this wave's DMA pieces (piece q = j * NW + wid), advanced by one K-step per issue
-    const unsigned stepA = A_MC ? (unsigned)(BK * p.lda * 2) : (unsigned)(BK * 2);
-    const unsigned stepB = B_MC ? (unsigned)(BK * p.ldb * 2) : (unsigned)(BK * 2);
-    unsigned voA[TL::PA], voB[TL::PB];
-#pragma unroll
-    for (int j = 0; j < TL::PA; ++j) voA[j] = dma_voffset<A_MC, BM>(j * TL::NW + wid, lane, m0, p.lda) + (unsigned)kbeg * stepA;
-#pragma unroll
-    for (int j = 0; j < TL::PB; ++j) voB[j] = dma_voffset<B_MC, BN>(j * TL::NW + wid, lane, n0, p.ldb) + (unsigned)kbeg * stepB;
-    // One K-step of this wave's DMA pieces into ring buffer `buf` (piece j of an operand lands at LDS byte
-    // (j * NW + wid) * 1024 of its image); advances the per-lane source offsets by one K-step.
-#define ISSUE_RANGE(buf, J0, J1)                                                                                              \
-    do {                                                                                                                      \
-        char* base_ = lds + (buf) * TL::STAGE_BYTES + wid * 1024;                                                             \
-        _Pragma("unroll") for (int j = (J0); j < (J1); ++j) {                                                                 \
-            if (j < TL::PA) {                                                                                                 \
-                char* dst_ = base_ + j * TL::NW * 1024; const unsigned off_ = voA[j];   /* non-dependent builtin operands */  \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)dst_, 16, off_, 0, 0, 0);                          \
-                voA[j] += stepA;                                                                                              \
-            } else {                                                                                                          \
-                char* dst_ = base_ + TL::IMG_A + (j - TL::PA) * TL::NW * 1024; const unsigned off_ = voB[j - TL::PA];         \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)dst_, 16, off_, 0, 0, 0);                          \
-                voB[j - TL::PA] += stepB;                                                                                     \
-            }                                                                                                                 \
-        }                                                                                                                     \
-    } while (0)
-#define ISSUE_STAGE(buf) ISSUE_RANGE(buf, 0, NLOAD)
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    // fused bias gradient of a wgrad GEMM (A = dy stored [tokens][features]): colsum[m] = sum_k A[k][m], taken from the A
-    // fragments the MFMAs consume anyway -- by the waves of the tile column 0 workgroups that own distinct m rows
-    float csum[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) csum[i] = 0.f;
-    const bool do_colsum = A_MC && p.colsum != nullptr && tile_n == 0 && (wid % TL::WN) == 0;
-
-    // ---- prologue: STAGES - 1 K-steps in flight
-#pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s)
-        if (s < nk) ISSUE_STAGE(s);
-
-    int cur = 0, nxt = STAGES - 1;
-    for (int it = 0; it < nk; ++it) {
-        // retire this wave's DMA of K-step `it` (later steps stay in flight), then one barrier: every wave's share of
-        // step `it` has landed AND every wave has finished reading buffer `nxt` (it computed step it-1 from it).
-        wait_dma_ahead<NLOAD>(min(nk - it - 1, STAGES - 2));
-        __builtin_amdgcn_s_barrier();
-        const bool refill = it + STAGES - 1 < nk;
-        if (TM * TN < 8 && refill) ISSUE_STAGE(nxt);
-        const char* imgA = lds + cur * TL::STAGE_BYTES;
-        const char* imgB = imgA + TL::IMG_A;
-        if constexpr (TM * TN < 8) {
-            // all fragment reads of the K-step are issued up front: the MFMAs of k-slice ks start as soon as their
-            // fragments land while the later slices are still in flight (counted lgkmcnt by the compiler)
-            bf16x8_t fa[4][TM], fb[4][TN];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) fa[ks][i] = read_frag<A_MC, BM>(imgA, wm0 + i * 32, ks, lane);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) fb[ks][j] = read_frag<B_MC, BN>(imgB, wn0 + j * 32, ks, lane);
-            }
-            if (do_colsum) {
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) csum[i] += frag_sum(fa[ks][i]);
-            }
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)   // operands swapped: D[row = n][col = m]
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8_mfma, fb[ks][j]), __builtin_bit_cast(bf16x8_mfma, fa[ks][i]), acc[i][j], 0, 0, 0);
-        } else {
-            // 8 MFMA tiles per wave (256^2 configuration, 128 accumulator VGPRs): fragments are double-buffered per k-slice --
-            // slice ks + 1 is read while the 8 MFMAs of slice ks run
-            bf16x8_t fa[2][TM], fb[2][TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[0][i] = read_frag<A_MC, BM>(imgA, wm0 + i * 32, 0, lane);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[0][j] = read_frag<B_MC, BN>(imgB, wn0 + j * 32, 0, lane);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                // this wave's share of the next K-step's DMA is spread over the first two k-slices: a piece costs the issuing wave
-                // 60 .. 180 cycles (MI355X_MICROARCH.md), which now falls into the shadow of the other wave's MFMAs instead of
-                // both waves of a SIMD issuing all their pieces right after the barrier
-                if (refill && ks < 2) ISSUE_RANGE(nxt, ks * NLOAD / 2, (ks + 1) * NLOAD / 2);   // first half of the K-step: the second half is the landing window
-                if (ks + 1 < 4) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) fa[(ks + 1) & 1][i] = read_frag<A_MC, BM>(imgA, wm0 + i * 32, ks + 1, lane);
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) fb[(ks + 1) & 1][j] = read_frag<B_MC, BN>(imgB, wn0 + j * 32, ks + 1, lane);
-                }
-                if (do_colsum) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) csum[i] += frag_sum(fa[ks & 1][i]);
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8_mfma, fb[ks & 1][j]), __builtin_bit_cast(bf16x8_mfma, fa[ks & 1][i]), acc[i][j], 0, 0, 0);
-            }
-        }
-        cur = (cur + 1 == STAGES) ? 0 : cur + 1;
-        nxt = (nxt + 1 == STAGES) ? 0 : nxt + 1;
-    }
-
-#undef ISSUE_STAGE
-#undef ISSUE_RANGE
-    // ---- split-K: publish this slice's slab; the last arriver of the tile reduces all slabs in slice order
-    if (p.splitk > 1) {
-        float4* slab0 = reinterpret_cast<float4*>(p.slabs) + ((long)(z * nt + tile) * p.splitk) * TL::SLAB_F4;
-        float4* mine = slab0 + (long)split * TL::SLAB_F4;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    mine[((i * TN + j) * 4 + q) * TL::NT + threadIdx.x] =
-                        make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-        if (do_colsum) {
-            float* crow = reinterpret_cast<float*>(mine + TL::SLAB_F4 - BM / 4);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const float v = csum[i] + __shfl_xor(csum[i], 32, 64);
-                if (lane < 32) crow[wm0 + i * 32 + lane] = v;
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                       // all slab stores of this workgroup issued and waited for
-        int* flag = reinterpret_cast<int*>(lds);               // the one LDS array doubles as the broadcast word
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int ticket = __hip_atomic_fetch_add(&p.counters[z * nt + tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *flag = (ticket == p.splitk - 1);
-        }
-        __syncthreads();
-        if (!*flag) return;
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(&p.counters[z * nt + tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        for (int s = 0; s < p.splitk; ++s) {
-            const float4* sl = slab0 + (long)s * TL::SLAB_F4;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 v = sl[((i * TN + j) * 4 + q) * TL::NT + threadIdx.x];
-                        acc[i][j][4 * q] += v.x; acc[i][j][4 * q + 1] += v.y; acc[i][j][4 * q + 2] += v.z; acc[i][j][4 * q + 3] += v.w;
-                    }
-        }
-    }
-
-    // ---- fused column sums: final value = this workgroup's (split-K: the slices' slab rows, in slice order)
-    if (A_MC && p.colsum != nullptr && tile_n == 0) {
-        if (p.splitk > 1) {
-            if (threadIdx.x < BM) {
-                const float* crow0 = reinterpret_cast<const float*>(reinterpret_cast<float4*>(p.slabs) + ((long)(z * nt + tile) * p.splitk) * TL::SLAB_F4 +
-                                                                    TL::SLAB_F4 - BM / 4);
-                float v = 0.f;
-                for (int s = 0; s < p.splitk; ++s) v += crow0[(long)s * TL::SLAB_F4 * 4 + threadIdx.x];
-                const int m = m0 + threadIdx.x;
-                if (m < p.M) {
-                    bf16_t* dst = reinterpret_cast<bf16_t*>(p.colsum) + (long)z * p.M + m;
-                    *dst = f32_to_bf16(p.colsum_acc ? bf16_to_f32(*dst) + v : v);
-                }
-            }
-        } else if (do_colsum) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const float v = csum[i] + __shfl_xor(csum[i], 32, 64);
-                const int m = m0 + wm0 + i * 32 + lane;
-                if (lane < 32 && m < p.M) {
-                    bf16_t* dst = reinterpret_cast<bf16_t*>(p.colsum) + (long)z * p.M + m;
-                    *dst = f32_to_bf16(p.colsum_acc ? bf16_to_f32(*dst) + v : v);
-                }
-            }
-        }
-    }
-
-    // ---- epilogue.  D layout of the swapped 32x32 MFMA: m = lane & 31, n = (e & 3) + 8 (e >> 2) + 4 (lane >> 5):
-    // for each q = e >> 2 the lane holds 4 consecutive n of one output row.
-    const long coff = zo * p.sCo + zi * p.sCi;
-    const int h = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm0 + i * 32 + (lane & 31);
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn0 + j * 32 + 8 * q + 4 * h;
-                if (n >= p.N) continue;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = p.alpha * acc[i][j][4 * q + r];
-                const bool full = n + 3 < p.N;
-                if (p.bias) {
-                    const bf16_t* bp = reinterpret_cast<const bf16_t*>(p.bias) + n;
-                    if (full && p.vecB >= 2) {
-                        const uint2 bv = *reinterpret_cast<const uint2*>(bp);
-                        v[0] += __uint_as_float(bv.x << 16); v[1] += __uint_as_float(bv.x & 0xffff0000u);
-                        v[2] += __uint_as_float(bv.y << 16); v[3] += __uint_as_float(bv.y & 0xffff0000u);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += bf16_to_f32(bp[r]);
-                    }
-                }
-                if (p.act != ACT_NONE) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = epilogue_act(v[r], p.act);
-                }
-                const long idx = coff + (long)m * p.ldc + n;
-                if (p.residual) {
-                    const long ridx = coff + (long)m * p.ldr + n;
-                    if (p.out_f32) {
-                        const float* rp = reinterpret_cast<const float*>(p.residual) + ridx;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += rp[r];
-                    } else {
-                        const bf16_t* rp = reinterpret_cast<const bf16_t*>(p.residual) + ridx;
-                        if (full && p.vecA >= 3) {
-                            const uint2 rv = *reinterpret_cast<const uint2*>(rp);
-                            v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
-                            v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += bf16_to_f32(rp[r]);
-                        }
-                    }
-                }
-                if (p.out_f32) {
-                    float* c = reinterpret_cast<float*>(p.C) + idx;
-                    if (full && p.vecA >= 2) {
-                        float4 o = make_float4(v[0], v[1], v[2], v[3]);
-                        if (p.accumulate) { const float4 old = *reinterpret_cast<const float4*>(c); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
-                        *reinterpret_cast<float4*>(c) = o;
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) if (n + r < p.N) c[r] = p.accumulate ? c[r] + v[r] : v[r];
-                    }
-                } else {
-                    bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + idx;
-                    if (full && p.vecA >= 2) {
-                        if (p.accumulate) {
-                            const uint2 old = *reinterpret_cast<const uint2*>(c);
-                            v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
-                            v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
-                        }
-                        *reinterpret_cast<uint2*>(c) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (n + r < p.N) c[r] = f32_to_bf16(p.accumulate ? bf16_to_f32(c[r]) + v[r] : v[r]);
-                    }
-                }
-            }
-    }
-}
-
-template <typename TL>
-int launch_pipe(const GemmParams& p, bool a_mc, bool b_mc, int batch, hipStream_t s) {
-    dim3 grid((unsigned)(p.tiles_m * p.tiles_n * p.splitk), (unsigned)batch);
-#define DPIPE_PIPE_LAUNCH(AM, BMC) gemm_pipe_kernel<TL::BM, TL::BN, TL::WM, TL::WN, TL::STAGES, AM, BMC><<<grid, TL::NT, 0, s>>>(p)
-    if (!a_mc && !b_mc) DPIPE_PIPE_LAUNCH(false, false);
-    else if (!a_mc && b_mc) DPIPE_PIPE_LAUNCH(false, true);
-    else if (a_mc && b_mc) DPIPE_PIPE_LAUNCH(true, true);
-    else DPIPE_PIPE_LAUNCH(true, false);
-#undef DPIPE_PIPE_LAUNCH
-    return check_launch("dpipe_gemm(pipe)");
-}
-
-}  // namespace dpipe_pipe
 
 using namespace dpipe_pipe;
 
@@ -507,6 +21,19 @@ bool gemm_pipe_try(GemmParams& p, int transA, int transB, int batch, void* ws, l
     const long ext_b = b_mc ? kpad * p.ldb + npad : npad * p.ldb + kpad;
     if (ext_a * 2 >= (1L << 31) || ext_b * 2 >= (1L << 31)) return false;
 
+    const int tile = gemm_pipe_plan(p, a_mc, b_mc, batch, ws, ws_bytes, force_splitk, force_tile);
+    switch (tile) {
+    case 257: *rc_out = launch_pipe<T256S>(p, a_mc, b_mc, batch, s); break;
+    case 256: *rc_out = launch_pipe<T256>(p, a_mc, b_mc, batch, s); break;
+    case 129: *rc_out = launch_pipe<T128R2>(p, a_mc, b_mc, batch, s); break;
+    case 63: *rc_out = launch_pipe<T64S3>(p, a_mc, b_mc, batch, s); break;
+    case 128: *rc_out = launch_pipe<T128>(p, a_mc, b_mc, batch, s); break;
+    default: *rc_out = launch_pipe<T64>(p, a_mc, b_mc, batch, s); break;
+    }
+    return true;
+}
+
+int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, long ws_bytes, int force_splitk, int force_tile) {
     p.ksteps = (p.K + BK - 1) / BK;
     const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
     const long tiles64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64) * batch;
@@ -547,13 +74,9 @@ bool gemm_pipe_try(GemmParams& p, int transA, int transB, int batch, void* ws, l
     p.vecA = c_ok ? 2 : 0;
     if (c_ok && p.residual && reinterpret_cast<uintptr_t>(p.residual) % 8 == 0 && p.ldr % 4 == 0) p.vecA = 3;   // 8-byte residual loads too
     p.vecB = (p.bias && reinterpret_cast<uintptr_t>(p.bias) % 8 == 0) ? 2 : 0;
-    if (force_tile == 257) *rc_out = launch_pipe<T256S>(p, a_mc, b_mc, batch, s);
-    else if (force_tile == 256) *rc_out = launch_pipe<T256>(p, a_mc, b_mc, batch, s);
-    else if (force_tile == 129 || (force_tile == 0 && big && tiles128 >= 256 && (a_mc || b_mc || tiles128 >= 1024)))
-        *rc_out = launch_pipe<T128R2>(p, a_mc, b_mc, batch, s);
-    else if (force_tile == 63) *rc_out = launch_pipe<T64S3>(p, a_mc, b_mc, batch, s);
-    else *rc_out = big ? launch_pipe<T128>(p, a_mc, b_mc, batch, s) : launch_pipe<T64>(p, a_mc, b_mc, batch, s);
-    return true;
+    if (force_tile == 257 || force_tile == 256 || force_tile == 63) return force_tile;
+    if (force_tile == 129 || (force_tile == 0 && big && tiles128 >= 256 && (a_mc || b_mc || tiles128 >= 1024))) return 129;
+    return big ? 128 : 64;
 }
 
 }  // namespace dpipe

@@ -135,7 +135,40 @@ class GroupNorm(nn.Module):
         if _ATEN_GROUPNORM:     # A/B switch (DPIPE_ATEN_GROUPNORM=1): ATen's GroupNorm + the separate SiLU kernel
             y = torch.nn.functional.group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
             return ops.silu(y) if act == 'silu' else y
+        if x.dim() == 4 and not x.is_contiguous() and ops.is_channels_last(x):
+            return ops.group_norm_nhwc(x, self.num_groups, self.weight, self.bias, self.eps, act)      # channels-last UNet (csrc/groupnorm_nhwc.hip)
         return ops.group_norm(x, self.num_groups, self.weight, self.bias, self.eps, act)
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d (same parameter names / logical shapes, so checkpoints map 1:1) whose weight is STORED channels-last and whose bf16
+    forward / backward run as implicit GEMM on the MFMA tile kernel (csrc/conv_pipe.hip) over channels-last activations.  Returns a
+    channels-last [B, Cout, Ho, Wo] tensor.  `upsample=2` folds diffusers' nearest 2x Upsample2D into the convolution's gather;
+    `residual` / `extra_bias` ride the epilogue.  Shapes the kernel does not take (the UNet's 4-channel conv_in / conv_out, fp32
+    exact-parity mode) go through torch's convolution on the same channels-last tensors."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        if self.weight.dim() == 4 and not self.weight.permute(0, 2, 3, 1).is_contiguous():
+            self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
+        return out
+
+    def forward(self, x, upsample=1, residual=None, extra_bias=None):
+        bias = self.bias
+        if extra_bias is not None:                      # per-channel addend folded into the bias vector (time embedding of a resnet, batch 1)
+            bias = extra_bias if bias is None else bias + extra_bias
+        if x.is_cuda and ops.conv2d_eligible(x.dtype, self.weight, self.stride, self.padding, self.dilation, self.groups) \
+                and self.padding_mode == 'zeros' and not isinstance(self.padding, str):
+            return ops.conv2d_nhwc(x, self.weight, bias, self.stride[0], self.padding[0], upsample, residual)
+        if upsample > 1:
+            x = torch.nn.functional.interpolate(x, scale_factor=float(upsample), mode='nearest')
+        y = self._conv_forward(x.contiguous(memory_format=torch.channels_last), self.weight, bias)
+        y = y.contiguous(memory_format=torch.channels_last)
+        return y if residual is None else y + residual
 
 
 class RMSNorm(nn.Module):

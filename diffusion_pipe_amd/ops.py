@@ -614,6 +614,155 @@ def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, act=None):
     return _GroupNormFn.apply(x, num_groups, weight, bias, eps, act)
 
 
+# ------------------------------------------------------------------------- channels-last (NHWC) UNet ops: GroupNorm, Conv2d
+def is_channels_last(x):
+    """4-D tensor with logical shape [N, C, H, W] whose memory is dense [N, H, W, C]."""
+    return x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous()
+
+
+def nhwc_view(x):
+    """[N, C, H, W] (any layout) -> contiguous [N, H, W, C] tensor; zero-copy for channels-last inputs."""
+    v = x.permute(0, 2, 3, 1)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+class _GroupNormNHWCFn(Function):
+    """nn.GroupNorm(G, C) (+ fused SiLU) on a channels-last [N, C, H, W] tensor = [N, HW, C] memory (csrc/groupnorm_nhwc.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, num_groups, weight, bias, eps, act):
+        require_cuda(x, weight, bias)
+        xv = nhwc_view(x)
+        N, H, W, C = xv.shape
+        HW = H * W
+        y = torch.empty_like(xv)
+        mean = torch.empty(N * num_groups, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        ws = torch.empty(lib().dpipe_groupnorm_nhwc_workspace_floats(N, C, HW, num_groups), device=x.device, dtype=torch.float32)
+        wdt = dtype_code(weight.dtype) if weight is not None else dtype_code(x.dtype)
+        check(lib().dpipe_groupnorm_nhwc_fwd(ptr(xv), ptr(weight), ptr(bias), ptr(y), ptr(mean), ptr(rstd), ptr(ws), N, C, HW, num_groups, float(eps),
+                                             ACT[act], dtype_code(x.dtype), wdt, stream()), 'groupnorm_nhwc_fwd')
+        ctx.save_for_backward(xv, weight, bias, mean, rstd)
+        ctx.meta = (num_groups, act, wdt)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xv, weight, bias, mean, rstd = ctx.saved_tensors
+        G, act, wdt = ctx.meta
+        N, H, W, C = xv.shape
+        gyv = nhwc_view(gy)
+        gx = torch.empty_like(xv)
+        fused = False
+        dgamma = dbeta = None
+        if weight is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]):
+            tg, tb = _accum_target(weight), _accum_target(bias)
+            if tg is not None and (bias is None or tb is not None):
+                dgamma, dbeta, fused = tg, tb, True
+            else:
+                dgamma = torch.empty_like(weight)
+                dbeta = torch.empty_like(bias) if bias is not None else None
+        ws = torch.empty(lib().dpipe_groupnorm_nhwc_workspace_floats(N, C, H * W, G), device=xv.device, dtype=torch.float32)
+        check(lib().dpipe_groupnorm_nhwc_bwd(ptr(xv), ptr(gyv), ptr(weight), ptr(bias), ptr(mean), ptr(rstd), ptr(gx), ptr(dgamma), ptr(dbeta), ptr(ws),
+                                             N, C, H * W, G, ACT[act], dtype_code(xv.dtype), wdt, int(fused), stream()), 'groupnorm_nhwc_bwd')
+        if fused:
+            dgamma = dbeta = None
+        return gx.permute(0, 3, 1, 2), None, dgamma, dbeta, None, None
+
+
+def group_norm_nhwc(x, num_groups, weight=None, bias=None, eps=1e-5, act=None):
+    """x: [N, C, H, W] channels-last; returns a channels-last tensor of the same logical shape."""
+    return _GroupNormNHWCFn.apply(x, num_groups, weight, bias, eps, act)
+
+
+def conv2d_eligible(x_dtype, weight, stride, padding, dilation=(1, 1), groups=1):
+    """The implicit-GEMM convolution (csrc/conv_pipe.hip) takes bf16, stride 1 / 2, square padding, Cin % 64 == 0 and Cout % 64 == 0."""
+    Cout, Cin, kh, kw = weight.shape
+    return (x_dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and groups == 1 and tuple(dilation) == (1, 1)
+            and stride[0] == stride[1] and stride[0] in (1, 2) and padding[0] == padding[1] and Cin % 64 == 0 and Cout % 64 == 0)
+
+
+def _dense_like(t, ref):
+    return t is not None and t.dtype == ref.dtype and t.shape == ref.shape and t.stride() == ref.stride()
+
+
+class _Conv2dNHWCFn(Function):
+    """nn.Conv2d on channels-last activations as implicit GEMM (forward, dgrad, wgrad + fused bias gradient); `upsample` = 2 folds the
+    nearest-neighbour 2x up-sampling of diffusers' Upsample2D into the gather; `residual` rides the epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, stride, pad, upsample):
+        require_cuda(x, weight, bias, residual)
+        xv = nhwc_view(x)
+        B, H, W, Cin = xv.shape
+        Cout, Cin_w, kh, kw = weight.shape
+        if Cin_w != Cin:
+            raise DpipeHipError(f'conv2d: input has {Cin} channels, weight expects {Cin_w}')
+        if not weight.permute(0, 2, 3, 1).is_contiguous():
+            raise DpipeHipError('conv2d: weight must be stored channels-last ([Cout, kh, kw, Cin] memory); use nn.Conv2d of diffusion_pipe_amd.nn')
+        Ho = (H * upsample + 2 * pad - kh) // stride + 1
+        Wo = (W * upsample + 2 * pad - kw) // stride + 1
+        y = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=x.dtype)
+        rv = None
+        if residual is not None:
+            rv = nhwc_view(residual)
+            if rv.shape != y.shape or rv.dtype != y.dtype:
+                raise DpipeHipError('conv2d: residual must have the output shape and dtype')
+        if bias is not None and bias.dtype != x.dtype:
+            bias = bias.to(x.dtype)
+        ws = _splitk_workspace(x.device)
+        check(lib().dpipe_conv2d_fwd(ptr(xv), Cin, ptr(weight), ptr(bias), ptr(rv), Cout, ptr(y), Cout, B, H, W, Cin, Cout, kh, kw, stride, pad, upsample,
+                                     0, ptr(ws), ws.numel(), 0, stream()), 'conv2d_fwd')
+        ctx.save_for_backward(xv, weight, bias)
+        ctx.geom = (stride, pad, upsample, residual is not None)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xv, weight, bias = ctx.saved_tensors
+        stride, pad, upsample, has_res = ctx.geom
+        B, H, W, Cin = xv.shape
+        Cout, _, kh, kw = weight.shape
+        gyv = nhwc_view(gy)
+        if gyv.dtype != xv.dtype:
+            gyv = gyv.to(xv.dtype)
+        ws = _splitk_workspace(xv.device)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            Hi, Wi = H * upsample, W * upsample
+            dxu = torch.empty((B, Hi, Wi, Cin), device=xv.device, dtype=xv.dtype)
+            check(lib().dpipe_conv2d_dgrad(ptr(gyv), Cout, ptr(weight), ptr(dxu), Cin, B, Hi, Wi, Cin, Cout, kh, kw, stride, pad,
+                                           ptr(ws), ws.numel(), 0, stream()), 'conv2d_dgrad')
+            if upsample > 1:       # adjoint of the nearest up-sampling: sum over each 2 x 2 block
+                dxu = dxu.view(B, H, upsample, W, upsample, Cin).sum(dim=(2, 4))
+            gx = dxu.permute(0, 3, 1, 2)
+        need_w, need_b = ctx.needs_input_grad[1], bias is not None and ctx.needs_input_grad[2]
+        if need_w or need_b:
+            tw = _accum_target_dense(weight)
+            tb = _accum_target(bias) if need_b else None
+            w_out = tw if tw is not None else torch.empty_like(weight)           # preserve_format: channels-last like the weight
+            b_out = (tb if tb is not None else torch.empty_like(bias)) if need_b else None
+            check(lib().dpipe_conv2d_wgrad(ptr(gyv), Cout, ptr(xv), Cin, ptr(w_out), ptr(b_out), B, H, W, Cin, Cout, kh, kw, stride, pad, upsample,
+                                           int(tw is not None), int(tb is not None), ptr(ws), ws.numel(), 0, stream()), 'conv2d_wgrad')
+            gw = None if tw is not None else w_out
+            gb = None if (tb is not None or not need_b) else b_out
+        gres = gy if (has_res and ctx.needs_input_grad[3]) else None
+        return gx, gw, gb, gres, None, None, None
+
+
+def _accum_target_dense(param):
+    """like _accum_target for parameters that are dense but not row-major (channels-last conv weights): .grad must share the strides"""
+    if not FUSE_GRAD_ACCUM or param is None or not param.is_leaf:
+        return None
+    g = param.grad
+    return g if _dense_like(g, param) else None
+
+
+def conv2d_nhwc(x, weight, bias=None, stride=1, padding=0, upsample=1, residual=None):
+    """x: [B, Cin, H, W] channels-last bf16, weight: [Cout, Cin, kh, kw] channels-last -> [B, Cout, Ho, Wo] channels-last."""
+    return _Conv2dNHWCFn.apply(x, weight, bias, residual, int(stride), int(padding), int(upsample))
+
+
 # ------------------------------------------------------------------------------------------------- RoPE (K3)
 class _RopeFn(Function):
     """Rotary embedding on [B, S, H, D] with fp32 cos/sin tables [S, D/2] (models/wan/model.py:40-67)."""
@@ -904,8 +1053,8 @@ def grads_sumsq(grads):
         if not group:
             continue
         for g in group:
-            if not g.is_contiguous():
-                raise DpipeHipError('gradients must be contiguous')
+            if not (g.is_contiguous() or (g.dim() == 4 and g.is_contiguous(memory_format=torch.channels_last))):
+                raise DpipeHipError('gradients must be dense (row-major or channels-last)')
         ptrs, ctens, coff, clen, n = _chunk_table(group)
         partials = torch.empty(max(n, 1), device=dev, dtype=torch.float32)
         out = torch.empty((), device=dev, dtype=torch.float32)
@@ -968,8 +1117,9 @@ def _adam_check(params, exp_avgs, exp_avg_sqs, lane_grads):
         if len(group) != len(params):
             raise DpipeHipError('fused AdamW: ragged tensor lists')
         for t, p in zip(group, params):
-            if t.dtype != dt or t.shape != p.shape or not t.is_contiguous():
-                raise DpipeHipError('fused AdamW: parameters, states and gradients must be contiguous tensors of one dtype and shape')
+            dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+            if t.dtype != dt or t.shape != p.shape or not dense or t.stride() != p.stride():
+                raise DpipeHipError('fused AdamW: parameters, states and gradients must be dense tensors of one dtype, shape and memory layout')
     return dt
 
 

@@ -74,12 +74,13 @@ class FusedAdamW(torch.optim.Optimizer):
                 st = self.state[p]
                 if not st:
                     st['step'] = 0.0
-                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)      # channels-last conv weights keep their layout
+                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 b = by_dtype.setdefault(p.dtype, ([], [], [], [[] for _ in lanes]))
-                b[0].append(p.data if p.is_contiguous() else None)
-                if b[0][-1] is None:
-                    raise RuntimeError('FusedAdamW needs contiguous parameters')
+                dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+                if not dense:
+                    raise RuntimeError('FusedAdamW needs dense (row-major or channels-last) parameters')
+                b[0].append(p.data)
                 b[1].append(st['exp_avg'])
                 b[2].append(st['exp_avg_sq'])
                 for lane_list, g in zip(b[3], lanes):

@@ -21,7 +21,15 @@ from .. import ops
 
 
 def make_contiguous(*values):
-    return tuple(x.contiguous() if torch.is_tensor(x) else x for x in values)
+    """Dense tensors for the stage boundary; feature maps ([B, C, H, W] logical shape, as in the reference's tuples) stay channels-last
+    in memory: the UNet below runs NHWC (implicit-GEMM convolutions and token-major transformer blocks share one layout)."""
+    def dense(x):
+        if not torch.is_tensor(x):
+            return x
+        if x.dim() == 4 and x.is_floating_point():
+            return x.contiguous(memory_format=torch.channels_last)
+        return x.contiguous()
+    return tuple(dense(x) for x in values)
 
 
 # ----------------------------------------------------------------------------------------------------- configs
@@ -174,21 +182,23 @@ class ResnetBlock2D(nn.Module):
     def __init__(self, in_ch, out_ch, temb_ch, groups=32, eps=1e-5):
         super().__init__()
         self.norm1 = dnn.GroupNorm(groups, in_ch, eps=eps)
-        self.conv1 = nn.Conv2d(in_ch, out_ch, 3, padding=1)
+        self.conv1 = dnn.Conv2d(in_ch, out_ch, 3, padding=1)
         self.time_emb_proj = dnn.Linear(temb_ch, out_ch)
         self.norm2 = dnn.GroupNorm(groups, out_ch, eps=eps)
-        self.conv2 = nn.Conv2d(out_ch, out_ch, 3, padding=1)
+        self.conv2 = dnn.Conv2d(out_ch, out_ch, 3, padding=1)
         self.nonlinearity = dnn.SiLU()
-        self.conv_shortcut = nn.Conv2d(in_ch, out_ch, 1) if in_ch != out_ch else None
+        self.conv_shortcut = dnn.Conv2d(in_ch, out_ch, 1) if in_ch != out_ch else None
 
     def forward(self, x, temb):
-        h = self.conv1(self.norm1(x, act='silu'))                     # GroupNorm + SiLU in one pass
-        t = self.time_emb_proj(self.nonlinearity(temb))[:, :, None, None]
-        h = h + t.to(h.dtype)
-        h = self.conv2(self.norm2(h, act='silu'))
+        x = x.contiguous(memory_format=torch.channels_last)
+        t = self.time_emb_proj(self.nonlinearity(temb))
+        if x.shape[0] == 1:        # batch 1: the time-embedding addend is one value per channel -> it joins conv1's bias vector in the epilogue
+            h = self.conv1(self.norm1(x, act='silu'), extra_bias=t.reshape(-1).to(x.dtype))     # GroupNorm + SiLU in one pass
+        else:
+            h = self.conv1(self.norm1(x, act='silu')) + t[:, :, None, None].to(x.dtype)
         if self.conv_shortcut is not None:
             x = self.conv_shortcut(x)
-        return x + h
+        return self.conv2(self.norm2(h, act='silu'), residual=x)       # the block's "x + h" rides conv2's epilogue
 
 
 class BasicTransformerBlock(nn.Module):
@@ -218,35 +228,36 @@ class Transformer2DModel(nn.Module):
 
     def forward(self, x, encoder_hidden_states):
         B, C, H, W = x.shape
-        residual = x
+        x = x.contiguous(memory_format=torch.channels_last)          # [B, HW, C] memory: the token-major view below is free
+        residual = x.permute(0, 2, 3, 1).reshape(B, H * W, C)
         h = self.norm(x).permute(0, 2, 3, 1).reshape(B, H * W, C)
         h = self.proj_in(h)
         ctx = encoder_hidden_states.to(h.dtype)
         for blk in self.transformer_blocks:
             h = blk(h, ctx)
-        h = self.proj_out(h).reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
-        return h + residual
+        h = self.proj_out(h, residual)                               # "+ residual" in the projection's epilogue
+        return h.reshape(B, H, W, C).permute(0, 3, 1, 2)
 
 
 class Downsample2D(nn.Module):
     def __init__(self, ch):
         super().__init__()
-        self.conv = nn.Conv2d(ch, ch, 3, stride=2, padding=1)
+        self.conv = dnn.Conv2d(ch, ch, 3, stride=2, padding=1)
 
     def forward(self, x):
-        return self.conv(x)
+        return self.conv(x.contiguous(memory_format=torch.channels_last))
 
 
 class Upsample2D(nn.Module):
     def __init__(self, ch):
         super().__init__()
-        self.conv = nn.Conv2d(ch, ch, 3, padding=1)
+        self.conv = dnn.Conv2d(ch, ch, 3, padding=1)
 
     def forward(self, x, output_size=None):
-        if output_size is None:
-            x = F.interpolate(x, scale_factor=2.0, mode='nearest')
-        else:
-            x = F.interpolate(x, size=output_size, mode='nearest')
+        x = x.contiguous(memory_format=torch.channels_last)
+        if output_size is None or tuple(output_size) == (2 * x.shape[2], 2 * x.shape[3]):
+            return self.conv(x, upsample=2)              # nearest 2x up-sampling folded into the convolution's gather
+        x = F.interpolate(x, size=output_size, mode='nearest')
         return self.conv(x)
 
 
@@ -267,7 +278,7 @@ class UNet2DConditionModel(nn.Module):
         super().__init__()
         self.config = c
         ch, temb, g, head_dim = c.block_out_channels, c.time_embed_dim, c.norm_groups, 64
-        self.conv_in = nn.Conv2d(c.in_channels, ch[0], 3, padding=1)
+        self.conv_in = dnn.Conv2d(c.in_channels, ch[0], 3, padding=1)
         self.time_proj = dnn.Timesteps(ch[0], flip_sin_to_cos=True, downscale_freq_shift=0)
         self.time_embedding = dnn.TimestepEmbedding(ch[0], temb)
         self.add_time_proj = dnn.Timesteps(c.addition_time_embed_dim, flip_sin_to_cos=True, downscale_freq_shift=0)
@@ -310,7 +321,7 @@ class UNet2DConditionModel(nn.Module):
 
         self.conv_norm_out = dnn.GroupNorm(g, ch[0], eps=1e-5)
         self.conv_act = dnn.SiLU()
-        self.conv_out = nn.Conv2d(ch[0], c.in_channels, 3, padding=1)
+        self.conv_out = dnn.Conv2d(ch[0], c.in_channels, 3, padding=1)
 
 
 # -------------------------------------------------------------------------------------- pipeline layer wrappers

@@ -128,6 +128,36 @@ int dpipe_lnmod_bwd(const void* x, const void* gy, const void* gamma, const void
                     void* dshift, float* workspace, long rows, int cols, long rows_per_mod, int dtype, int wdtype,
                     int mdtype, int accumulate_params, void* stream);   /* accumulate_params: dgamma / dbeta += */
 
+/* ---- 2-D convolution as implicit GEMM (NHWC bf16): the nn.Conv2d of diffusers' ResnetBlock2D / Downsample2D / Upsample2D
+ * behind the UNet call sites models/sdxl.py:797-865 (the reference reaches MIOpen / cuDNN through torch.nn.functional.conv2d).
+ * x: [B, H, W, Cin] with pixel pitch ldx elements; w: [Cout, kh, kw, Cin] contiguous (the channels_last storage of a
+ * [Cout, Cin, kh, kw] parameter); y / dy: [B, Ho, Wo, Cout]; stride, upsample in {1, 2}; `upsample` = nearest 2x up-sampling of x
+ * fused into the gather (Upsample2D), H / W are then the size BEFORE up-sampling; Ho = ((H * upsample) + 2 pad - kh) / stride + 1.
+ * Zero padding never materialises (out-of-image taps read through the buffer bounds check).  Same LDS-DMA MFMA tile machinery,
+ * split-K workspace (`splitk_ws`, see dpipe_gemm_ex) and `tile_hint` as dpipe_gemm_ex.
+ *   fwd  : y = act(conv(x, w) + bias) (+ residual [B, Ho, Wo, Cout] with pitch ldr);            needs Cin % 64 == 0
+ *   dgrad: dx [B, H, W, Cin] = conv_transpose(dy, w)  (no fused up-sampling: H, W = the conv's input size);  needs Cout % 64 == 0, Cin % 8 == 0
+ *   wgrad: dw [Cout, kh, kw, Cin] (+)= dy^T * gathered x, dbias [Cout] (+)= column sums of dy (NULL = skip); needs Cin % 8 == 0, Cout % 8 == 0 */
+int dpipe_conv2d_fwd(const void* x, long ldx, const void* w, const void* bias, const void* residual, long ldr, void* y, long ldy,
+                     int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int upsample, int act,
+                     void* splitk_ws, long splitk_ws_bytes, int tile_hint, void* stream);
+int dpipe_conv2d_dgrad(const void* dy, long lddy, const void* w, void* dx, long lddx,
+                       int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
+                       void* splitk_ws, long splitk_ws_bytes, int tile_hint, void* stream);
+int dpipe_conv2d_wgrad(const void* dy, long lddy, const void* x, long ldx, void* dw, void* dbias,
+                       int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int upsample,
+                       int accumulate, int bias_accumulate, void* splitk_ws, long splitk_ws_bytes, int tile_hint, void* stream);
+
+/* ---- GroupNorm (+ fused SiLU) on NHWC activations: the same nn.GroupNorm(G, C) call sites as below for the channels-last UNet.
+ * x, y, dy, dx: [N, HW, C] contiguous, C a multiple of the 16-byte vector and <= 8192; other arguments as dpipe_groupnorm_fwd / _bwd;
+ * workspace: dpipe_groupnorm_nhwc_workspace_floats() floats. */
+long dpipe_groupnorm_nhwc_workspace_floats(long N, int C, long HW, int G);
+int dpipe_groupnorm_nhwc_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd, float* workspace,
+                             long N, int C, long HW, int G, float eps, int act, int dtype, int wdtype, void* stream);
+int dpipe_groupnorm_nhwc_bwd(const void* x, const void* dy, const void* gamma, const void* beta, const float* mean, const float* rstd,
+                             void* dx, void* dgamma, void* dbeta, float* workspace, long N, int C, long HW, int G, int act, int dtype,
+                             int wdtype, int accumulate_params, void* stream);
+
 /* ---- GroupNorm (+ fused SiLU) on NCHW activations: nn.GroupNorm(G, C) of the diffusers ResnetBlock2D / Transformer2DModel
  * behind models/sdxl.py:797-865 (and the SiLU that follows it in the resnets).  x, y, dy, dx: [N, C, HW] contiguous, HW a
  * multiple of the 16-byte vector; gamma / beta [C] (NULL = no affine); mean / rstd [N * G] fp32 saved for backward;

@@ -1,0 +1,117 @@
+"""Implicit-GEMM convolution (csrc/conv_pipe.hip) and channels-last GroupNorm (csrc/groupnorm_nhwc.hip) through the C ABI vs plain PyTorch
+fp32 references of the same ops on the same bf16-rounded operands (the nn.Conv2d / nn.GroupNorm call sites of the SDXL UNet,
+models/sdxl.py:797-865).  Tolerance: per element |got - want| <= atol + rtol * |want| with bf16 output rounding (2^-8) as rtol and an
+atol of 2^-8 times the output's RMS (fp32 accumulation inside; only the stored result is rounded)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, want, what, rtol=2 ** -7, atol_rms=2 ** -7):
+    got, want = got.float(), want.float()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    tol = atol_rms * want.pow(2).mean().sqrt().clamp_min(1e-6) + rtol * want.abs()
+    bad = (got - want).abs() > tol
+    assert not bad.any(), f'{what}: {int(bad.sum())} / {bad.numel()} elements off, worst {(got - want).abs().max().item():.4g} (rms {want.pow(2).mean().sqrt().item():.4g})'
+
+
+CASES = [  # B, H, W, Cin, Cout, k, stride, pad, upsample
+    (1, 32, 32, 128, 128, 3, 1, 1, 1),        # 64-pixel-row tiles, one tap per two K-steps
+    (1, 32, 32, 320, 640, 3, 1, 1, 1),        # resnet conv at SDXL channel counts (5 / 10 K-chunks per tap)
+    (2, 20, 12, 64, 192, 3, 1, 1, 1),         # batch 2, ragged pixel count (240 rows per image), ragged N tile
+    (1, 64, 64, 64, 64, 3, 2, 1, 1),          # Downsample2D: stride 2
+    (1, 17, 23, 128, 64, 3, 2, 1, 1),         # odd sizes, stride 2
+    (1, 16, 16, 128, 128, 3, 1, 1, 2),        # Upsample2D: nearest 2x folded into the gather
+    (2, 9, 7, 64, 128, 3, 1, 1, 2),
+    (1, 32, 32, 960, 320, 1, 1, 0, 1),        # conv_shortcut 1x1
+    (1, 64, 64, 1920, 640, 3, 1, 1, 1),       # long K (270 K-steps): split-K path
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_conv2d_forward_backward_vs_fp32(gpu, case):
+    from diffusion_pipe_amd import nn as dnn
+    B, H, W, Cin, Cout, k, stride, pad, ups = case
+    torch.manual_seed(sum(case))
+    conv = dnn.Conv2d(Cin, Cout, k, stride=stride, padding=pad).to(gpu, torch.bfloat16)
+    x = torch.randn(B, Cin, H, W, device=gpu).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = conv(x, upsample=ups)
+    assert y.permute(0, 2, 3, 1).is_contiguous()
+    # fp32 reference of the same op on the same bf16 operands
+    xr = x.detach().float().requires_grad_(True)
+    wr = conv.weight.detach().float().contiguous().requires_grad_(True)
+    br = conv.bias.detach().float().requires_grad_(True)
+    xin = F.interpolate(xr, scale_factor=float(ups), mode='nearest') if ups > 1 else xr
+    want = F.conv2d(xin, wr, br, stride=stride, padding=pad)
+    _close(y, want, 'forward')
+    gy = torch.randn_like(want).to(torch.bfloat16)
+    y.backward(gy.contiguous(memory_format=torch.channels_last))
+    want.backward(gy.float())
+    _close(x.grad, xr.grad, 'dgrad')
+    _close(conv.weight.grad, wr.grad, 'wgrad')
+    _close(conv.bias.grad, br.grad, 'bias grad')
+    assert conv.weight.grad.stride() == conv.weight.stride()        # gradient keeps the channels-last layout of the parameter
+
+
+def test_conv2d_residual_extra_bias_and_fused_accumulation(gpu):
+    from diffusion_pipe_amd import nn as dnn, ops
+    torch.manual_seed(3)
+    conv = dnn.Conv2d(128, 128, 3, padding=1).to(gpu, torch.bfloat16)
+    x = torch.randn(1, 128, 24, 24, device=gpu).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    res = torch.randn(1, 128, 24, 24, device=gpu).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    t = torch.randn(128, device=gpu).to(torch.bfloat16).requires_grad_(True)
+    gy = torch.randn(1, 128, 24, 24, device=gpu).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    xr, rr, tr = (v.detach().float().requires_grad_(True) for v in (x, res, t))
+    wr, br = conv.weight.detach().float().contiguous().requires_grad_(True), conv.bias.detach().float().requires_grad_(True)
+    want = F.conv2d(xr, wr, br + tr, padding=1) + rr
+    want.backward(gy.float())
+    old = ops.FUSE_GRAD_ACCUM
+    try:
+        ops.FUSE_GRAD_ACCUM = True
+        for rep in range(2):            # second pass accumulates into the existing .grad buffers inside the wgrad epilogue
+            y = conv(x, residual=res, extra_bias=t)
+            if rep == 0:
+                _close(y, want, 'forward with residual + extra bias')
+            y.backward(gy)
+    finally:
+        ops.FUSE_GRAD_ACCUM = old
+    _close(conv.weight.grad, 2 * wr.grad, 'accumulated wgrad')
+    _close(conv.bias.grad, 2 * br.grad, 'accumulated bias grad')
+    _close(t.grad, 2 * tr.grad, 'extra-bias grad')
+    _close(res.grad, 2 * rr.grad, 'residual grad')
+    _close(x.grad, 2 * xr.grad, 'dgrad')
+
+
+GN_CASES = [(1, 320, 32, 32, 32), (2, 64, 9, 7, 32), (1, 1280, 16, 16, 32), (1, 2560, 8, 8, 32), (3, 96, 5, 5, 4), (1, 960, 64, 64, 32)]
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32], ids=['bf16', 'fp32'])
+@pytest.mark.parametrize('act', [None, 'silu'])
+@pytest.mark.parametrize('case', GN_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_group_norm_nhwc_vs_fp32(gpu, case, act, dtype):
+    from diffusion_pipe_amd import nn as dnn
+    N, C, H, W, G = case
+    torch.manual_seed(N * C + H)
+    gn = dnn.GroupNorm(G, C, eps=1e-5).to(gpu, dtype)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(C) * 0.5 + 1.0)
+        gn.bias.copy_(torch.randn(C) * 0.3)
+    x = (torch.randn(N, C, H, W, device=gpu) * 1.5 + 0.3).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = gn(x, act=act)
+    assert y.permute(0, 2, 3, 1).is_contiguous()
+    xr = x.detach().float().requires_grad_(True)
+    wr, br = gn.weight.detach().float().requires_grad_(True), gn.bias.detach().float().requires_grad_(True)
+    want = F.group_norm(xr, G, wr, br, 1e-5)
+    if act == 'silu':
+        want = F.silu(want)
+    tol = dict(rtol=2 ** -7, atol_rms=2 ** -7) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol_rms=1e-4)
+    _close(y, want, 'forward', **tol)
+    gy = torch.randn(N, C, H, W, device=gpu).to(dtype).contiguous(memory_format=torch.channels_last)
+    y.backward(gy)
+    want.backward(gy.float())
+    _close(x.grad, xr.grad, 'dx', **tol)
+    ptol = dict(rtol=2 ** -6, atol_rms=2 ** -6) if dtype == torch.bfloat16 else dict(rtol=1e-3, atol_rms=1e-4)
+    _close(gn.weight.grad, wr.grad, 'dgamma', **ptol)
+    _close(gn.bias.grad, br.grad, 'dbeta', **ptol)

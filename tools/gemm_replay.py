@@ -118,7 +118,8 @@ def unique_with_counts(trace):
 
 def main():
     """eager replay of a saved unique-descriptor list (bench.py --save-gemm-trace): each descriptor `reps` times over rotating operands"""
-    sys.path.insert(0, '.')
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from diffusion_pipe_amd import ops
     path, div = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 1
     uniq = json.load(open(path))

@@ -113,7 +113,8 @@ def cold_main():
     cases = [(0, 1, 1024, 1280, 1280), (0, 0, 1024, 1280, 1280), (1, 0, 1280, 1280, 1024), (0, 1, 1024, 3840, 1280), (0, 0, 1024, 1280, 3840),
              (1, 0, 3840, 1280, 1024), (0, 1, 1024, 10240, 1280), (1, 0, 10240, 1280, 1024), (0, 0, 1024, 1280, 10240),
              (0, 1, 1024, 1280, 5120), (0, 0, 1024, 5120, 1280), (1, 0, 1280, 5120, 1024), (0, 1, 4096, 640, 2560), (0, 0, 4096, 640, 5120),
-             (1, 0, 640, 640, 4096), (1, 0, 640, 1920, 4096)]
+             (1, 0, 640, 640, 4096), (1, 0, 640, 1920, 4096), (0, 1, 4096, 5120, 640), (1, 0, 5120, 640, 4096), (0, 1, 4096, 1920, 640),
+             (0, 0, 4096, 640, 1920), (0, 0, 4096, 640, 640), (0, 1, 4096, 640, 640)]
     for (ta, tb, M, N, K) in cases:
         wgrad = bool(ta)
         wbytes = (M * N if wgrad else N * K) * 2
@@ -127,11 +128,15 @@ def cold_main():
             ws = [torch.randn((N, K) if tb else (K, N), device=dev, dtype=torch.bfloat16) for _ in range(nbuf)]
             outs = [torch.empty(M, N, device=dev, dtype=torch.bfloat16)] * nbuf
         rec = {'op': 'gemm_cold', 'ta': ta, 'tb': tb, 'M': M, 'N': N, 'K': K, 'nbuf': nbuf}
-        for name, hint in (('auto', 0), ('t64', 2001), ('t128', 3001), ('t128r2', 4001), ('t128k2', 3002), ('t128k3', 3003), ('t64k2', 2002)):
+        for name, hint in (('auto', 0), ('t64', 2001), ('t128', 3001), ('t128r2', 4001), ('t128k2', 3002), ('t128k3', 3003), ('t64k2', 2002),
+                           ('t128r2k2', 4002), ('t128r2k3', 4003), ('t256', 7001), ('t256k2', 7002), ('t256k3', 7003), ('t256x128', 5001), ('t256x128k2', 5002)):
             def run():
                 for i in range(nbuf):
                     ops.mm(a, ws[i], bool(ta), bool(tb), out=outs[i], tile_hint=hint, accumulate=wgrad)
-            rec[name + '_us'] = round(graph_time(run, n=1, reps=3) / nbuf, 1)
+            try:
+                rec[name + '_us'] = round(graph_time(run, n=1, reps=3) / nbuf, 1)
+            except Exception:       # configuration not eligible for this problem
+                rec[name + '_us'] = None
         aa = a.t() if ta else a
 
         def run_t():
