@@ -37,6 +37,9 @@ struct GemmParams {
     const void* residual; long ldr;       // C += residual[m, n] (C's dtype, row pitch ldr, batch strides of C)
     void* colsum; int colsum_acc;          // pipelined TN kernel only: colsum[m] (+)= sum_k A[k][m]  (bias gradient of a wgrad GEMM), operand dtype
     ConvGeom cg;                           // CONV modes only
+#ifdef DPIPE_TIMELINE
+    void* timeline;                        // tools/probes/gemm_timeline.hip only
+#endif
 };
 
 enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_SILU = 3, ACT_QUICK_GELU = 4 };

@@ -28,6 +28,7 @@ bool gemm_pipe_try(GemmParams& p, int transA, int transB, int batch, void* ws, l
     case 129: *rc_out = launch_pipe<T128R2>(p, a_mc, b_mc, batch, s); break;
     case 63: *rc_out = launch_pipe<T64S3>(p, a_mc, b_mc, batch, s); break;
     case 128: *rc_out = launch_pipe<T128>(p, a_mc, b_mc, batch, s); break;
+    case 130: *rc_out = launch_pipe<T128S5>(p, a_mc, b_mc, batch, s); break;
     default: *rc_out = launch_pipe<T64>(p, a_mc, b_mc, batch, s); break;
     }
     return true;
@@ -40,7 +41,7 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
     // tile (measured on the SDXL shapes, tools/kernel_timing.py): 128 x 128 from ~half a wave of workgroups on, or when a
     // long K can be split three ways over few tiles; else 64 x 64 (4 x the workgroups, 2 resident per CU)
     const bool long_k = p.ksteps >= 48;
-    const bool big = force_tile ? force_tile >= 128 : (tiles128 >= 128 || (long_k && tiles128 >= 48));
+    const bool big = force_tile ? (force_tile >= 128) : (tiles128 >= 128 || (long_k && tiles128 >= 48));
     // 256 x 256 (T256S) for DiT-sized forward / dgrad GEMMs: K-contiguous or mixed operands, >= 64 K-steps to amortise the
     // un-overlapped prologue / epilogue of the one resident workgroup, >= half a wave of 256^2 tiles.  Measured
     // (tools/kernel_timing.py large): +9 .. +21 % over T128R2 there (8192^3: 1.27 vs 1.08 PFLOP/s), -2 .. -6 % at K = 3072, and
@@ -56,7 +57,8 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
         if (force_splitk > 0) S = force_splitk;
         else if (!big && tiles <= 128 && p.ksteps >= 32) {   // every slice pays an agent-scope release: only few, long tiles split
             S = (int)(512 / tiles); const int cap = p.ksteps / 8; if (S > cap) S = cap; if (S > 4) S = 4;
-        } else if (big && tiles < 256 && long_k) { S = (int)(384 / tiles); if (S > 3) S = 3; }   // >= 16 K-steps per slice
+        } else if (big && tiles <= 128 && long_k) { S = (int)(384 / tiles); if (S > 3) S = 3; }   // >= 16 K-steps per slice; 160 tiles already
+                                                                                                   // run best unsplit ([4096,5120] x [5120,640]: 54 vs 67 us)
         if (S < 1) S = 1;
         if (S > p.ksteps) S = p.ksteps;
         const long max_slabs = (ws_bytes - COUNTER_BYTES) / slab_bytes;
@@ -74,7 +76,7 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
     p.vecA = c_ok ? 2 : 0;
     if (c_ok && p.residual && reinterpret_cast<uintptr_t>(p.residual) % 8 == 0 && p.ldr % 4 == 0) p.vecA = 3;   // 8-byte residual loads too
     p.vecB = (p.bias && reinterpret_cast<uintptr_t>(p.bias) % 8 == 0) ? 2 : 0;
-    if (force_tile == 257 || force_tile == 256 || force_tile == 63) return force_tile;
+    if (force_tile == 257 || force_tile == 256 || force_tile == 63 || force_tile == 130) return force_tile;
     if (force_tile == 129 || (force_tile == 0 && big && tiles128 >= 256 && (a_mc || b_mc || tiles128 >= 1024))) return 129;
     return big ? 128 : 64;
 }

@@ -30,6 +30,15 @@ namespace dpipe_pipe {   // named: a kernel template argument may not have inter
 constexpr int BK = 64;
 constexpr int COUNTER_BYTES = 4096;
 
+// Cycle stamps for tools/probes/gemm_timeline.hip (compiled only there): wave 0 of every workgroup writes s_memtime at the phase
+// boundaries of the kernel into timeline[blockIdx.x * 64 + slot].
+#ifdef DPIPE_TIMELINE
+#define TL_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.y == 0 && (slot) < 64) \
+    reinterpret_cast<unsigned long long*>(p.timeline)[(long)blockIdx.x * 64 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TL_STAMP(slot) do { } while (0)
+#endif
+
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(3))) bf16x4_t lds_bf16x4_t;
 
@@ -53,6 +62,10 @@ using T128 = Tile<128, 128, 2, 4, 3>;
 using T128R2 = Tile<128, 128, 2, 4, 2>;     // 2-deep ring, 64 KiB -> 2 workgroups per CU: one tile's epilogue / prologue overlaps the other's K-loop.
                                             // Measured (tools/kernel_timing.py cold): 1.3-1.7x over T128 once there are >= 256 tiles and an
                                             // MN-contiguous operand (dgrad / wgrad), 1.2x at 8192^3; slower with few tiles (no second workgroup).
+using T128S5 = Tile<128, 128, 2, 4, 5>;     // 5-deep ring = all 160 KiB of LDS, 4 K-steps (128 KiB) in flight: the timeline probe (tools/probes/gemm_timeline.hip) shows
+                                            // HBM-cold DMA pieces landing ~4 500 cycles after issue -- a 3-deep ring parks every wave ~900 cycles per K-step at vmcnt, this one ~460;
+                                            // selectable (tile_hint 8000 + S), not chosen automatically: whole-kernel time is unchanged (52.9 vs 51.5 us on
+                                            // [1024,1280] x [10240,1280]^T: 2.5 rounds of tiles at one workgroup per CU either way, longer prologue)
 using T64S3 = Tile<64, 64, 2, 2, 3>;         // selectable, not chosen automatically: 3-deep ring (3 workgroups per CU)
 using T256 = Tile<256, 128, 4, 2, 3>;       // selectable, not chosen automatically: 256 x 128, 8 waves of 64 x 64, 144 KiB (T128R2 beats it)
 using T256S = Tile<256, 256, 2, 4, 2>;      // 256 x 256, 8 waves of 128 x 64 (128 accumulator VGPRs), 2 x 64 KiB: twice the MFMA work per DMA'd
@@ -155,6 +168,7 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const GemmParams p) {
     constexpr int BM = TL::BM, BN = TL::BN, STAGES = TL::STAGES, TM = TL::TM, TN = TL::TN, NLOAD = TL::NLOAD;
     static_assert(STAGES >= 2 && STAGES <= 5, "ring depth (the vmcnt ladder covers <= 3 K-steps ahead)");
     __shared__ __attribute__((aligned(1024))) char lds[STAGES * TL::STAGE_BYTES];
+    TL_STAMP(0);
 
     // XCD-aware bijective remap (consecutive ids round-robin over the 8 XCDs): each XCD owns a contiguous run of
     // (tile, slice) pairs; slices of one tile are adjacent, so a tile's slabs stay in one L2.
@@ -334,14 +348,17 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const GemmParams p) {
     for (int s = 0; s < STAGES - 1; ++s)
         if (s < nk) ISSUE_STAGE(s);
 
+    TL_STAMP(1);
     int cur = 0, nxt = STAGES - 1;
     for (int it = 0; it < nk; ++it) {
         // retire this wave's DMA of K-step `it` (later steps stay in flight), then one barrier: every wave's share of
         // step `it` has landed AND every wave has finished reading buffer `nxt` (it computed step it-1 from it).
         wait_dma_ahead<NLOAD>(min(nk - it - 1, STAGES - 2));
+        TL_STAMP(4 + 4 * it);
         __builtin_amdgcn_s_barrier();
+        TL_STAMP(5 + 4 * it);
         const bool refill = it + STAGES - 1 < nk;
-        if (TM * TN < 8 && refill) ISSUE_STAGE(nxt);
+        TL_STAMP(6 + 4 * it);
         const char* imgA = lds + cur * TL::STAGE_BYTES;
         const char* imgB = imgA + TL::IMG_A;
         if constexpr (TM * TN < 8) {
@@ -362,13 +379,17 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const GemmParams p) {
                     for (int i = 0; i < TM; ++i) csum[i] += frag_sum(fa[ks][i]);
             }
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
+            for (int ks = 0; ks < 4; ++ks) {
+                // the refill of ring buffer `nxt` is issued a quarter at a time BETWEEN the k-slices' MFMAs: a DMA piece costs the wave
+                // 75 .. 85 issue cycles (timeline probe), which now run while the matrix pipe works instead of ahead of the whole K-step
+                if (refill) ISSUE_RANGE(nxt, ks * NLOAD / 4, (ks + 1) * NLOAD / 4);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)   // operands swapped: D[row = n][col = m]
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                             __builtin_bit_cast(bf16x8_mfma, fb[ks][j]), __builtin_bit_cast(bf16x8_mfma, fa[ks][i]), acc[i][j], 0, 0, 0);
+            }
         } else {
             // 8 MFMA tiles per wave (256^2 configuration, 128 accumulator VGPRs): fragments are double-buffered per k-slice --
             // slice ks + 1 is read while the 8 MFMAs of slice ks run
@@ -401,9 +422,11 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const GemmParams p) {
                             __builtin_bit_cast(bf16x8_mfma, fb[ks & 1][j]), __builtin_bit_cast(bf16x8_mfma, fa[ks & 1][i]), acc[i][j], 0, 0, 0);
             }
         }
+        TL_STAMP(7 + 4 * it);
         cur = (cur + 1 == STAGES) ? 0 : cur + 1;
         nxt = (nxt + 1 == STAGES) ? 0 : nxt + 1;
     }
+    TL_STAMP(2);
 
 #undef ISSUE_STAGE
 #undef ISSUE_RANGE
@@ -569,6 +592,7 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const GemmParams p) {
                 }
             }
     }
+    TL_STAMP(3);
 }
 
 template <typename TL, int CONV = 0>

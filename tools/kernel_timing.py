@@ -129,7 +129,7 @@ def cold_main():
             outs = [torch.empty(M, N, device=dev, dtype=torch.bfloat16)] * nbuf
         rec = {'op': 'gemm_cold', 'ta': ta, 'tb': tb, 'M': M, 'N': N, 'K': K, 'nbuf': nbuf}
         for name, hint in (('auto', 0), ('t64', 2001), ('t128', 3001), ('t128r2', 4001), ('t128k2', 3002), ('t128k3', 3003), ('t64k2', 2002),
-                           ('t128r2k2', 4002), ('t128r2k3', 4003), ('t256', 7001), ('t256k2', 7002), ('t256k3', 7003), ('t256x128', 5001), ('t256x128k2', 5002)):
+                           ('t128r2k2', 4002), ('t128r2k3', 4003), ('t128s5', 8001), ('t128s5k2', 8002), ('t128s5k3', 8003)):
             def run():
                 for i in range(nbuf):
                     ops.mm(a, ws[i], bool(ta), bool(tb), out=outs[i], tile_hint=hint, accumulate=wgrad)
