@@ -70,7 +70,19 @@ __global__ void __launch_bounds__(NB) gn_nhwc_partial_kernel(const T* __restrict
         for (int j = 0; j < V; ++j) { s[j] = 0.f; q[j] = 0.f; }
         if (live && v < l.nvec) {
             const T* xp = x + (n * HW) * C + (long)v * V;
-            for (long r = r0 + rlane; r < r1; r += l.rl) {
+            long r = r0 + rlane;
+            for (; r + 3L * l.rl < r1; r += 4L * l.rl) {            // 4 independent 16-byte loads in flight per thread
+                Vec16<T> a[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[u].load(xp + (r + (long)u * l.rl) * C);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float f[V]; a[u].unpack(f);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
+                }
+            }
+            for (; r < r1; r += l.rl) {
                 Vec16<T> a; a.load(xp + r * C);
                 float f[V]; a.unpack(f);
 #pragma unroll
@@ -131,7 +143,20 @@ __global__ void __launch_bounds__(NB) gn_nhwc_apply_kernel(const T* __restrict__
         }
         const T* xp = x + (n * HW) * C + (long)v * V;
         T* yp = y + (n * HW) * C + (long)v * V;
-        for (long r = r0 + rlane; r < r1; r += l.rl) {
+        long r = r0 + rlane;
+        for (; r + 3L * l.rl < r1; r += 4L * l.rl) {
+            Vec16<T> a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u].load(xp + (r + (long)u * l.rl) * C);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float f[V]; a[u].unpack(f);
+#pragma unroll
+                for (int j = 0; j < V; ++j) { const float z = f[j] * ga[j] + be[j]; f[j] = ACT ? silu_f(z) : z; }
+                Vec16<T> o; o.pack(f); o.store(yp + (r + (long)u * l.rl) * C);
+            }
+        }
+        for (; r < r1; r += l.rl) {
             Vec16<T> a; a.load(xp + r * C);
             float f[V]; a.unpack(f);
 #pragma unroll
@@ -169,7 +194,23 @@ __global__ void __launch_bounds__(NB) gn_nhwc_bwd_partial_kernel(const T* __rest
             }
             const T* xp = x + (n * HW) * C + (long)v * V;
             const T* gp = dy + (n * HW) * C + (long)v * V;
-            for (long r = r0 + rlane; r < r1; r += l.rl) {
+            long r = r0 + rlane;
+            for (; r + (long)l.rl < r1; r += 2L * l.rl) {            // 2 rows x 2 tensors = 4 loads in flight per thread
+                Vec16<T> a[2], b[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) { a[u].load(xp + (r + (long)u * l.rl) * C); b[u].load(gp + (r + (long)u * l.rl) * C); }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    float fx[V], fg[V]; a[u].unpack(fx); b[u].unpack(fg);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) {
+                        const float xh = (fx[j] - mu[j]) * rs[j];
+                        const float dz = ACT ? fg[j] * silu_grad(xh * ga[j] + be[j]) : fg[j];
+                        s1[j] += dz; s2[j] += dz * xh;
+                    }
+                }
+            }
+            for (; r < r1; r += l.rl) {
                 Vec16<T> a, b; a.load(xp + r * C); b.load(gp + r * C);
                 float fx[V], fg[V]; a.unpack(fx); b.unpack(fg);
 #pragma unroll
@@ -253,7 +294,24 @@ __global__ void __launch_bounds__(NB) gn_nhwc_bwd_apply_kernel(const T* __restri
         const T* xp = x + (n * HW) * C + (long)v * V;
         const T* gp = dy + (n * HW) * C + (long)v * V;
         T* op = dx + (n * HW) * C + (long)v * V;
-        for (long r = r0 + rlane; r < r1; r += l.rl) {
+        long r = r0 + rlane;
+        for (; r + (long)l.rl < r1; r += 2L * l.rl) {
+            Vec16<T> a[2], b[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { a[u].load(xp + (r + (long)u * l.rl) * C); b[u].load(gp + (r + (long)u * l.rl) * C); }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float fx[V], fg[V]; a[u].unpack(fx); b[u].unpack(fg);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const float xh = (fx[j] - mu[j]) * rs[j];
+                    const float dz = ACT ? fg[j] * silu_grad(xh * ga[j] + be[j]) : fg[j];
+                    fx[j] = rs[j] * (ga[j] * dz - ca[j] - xh * cb[j]);
+                }
+                Vec16<T> o; o.pack(fx); o.store(op + (r + (long)u * l.rl) * C);
+            }
+        }
+        for (; r < r1; r += l.rl) {
             Vec16<T> a, b; a.load(xp + r * C); b.load(gp + r * C);
             float fx[V], fg[V]; a.unpack(fx); b.unpack(fg);
 #pragma unroll
@@ -267,11 +325,11 @@ __global__ void __launch_bounds__(NB) gn_nhwc_bwd_apply_kernel(const T* __restri
     }
 }
 
-// rows per block: ~1024 blocks over the tensor, at least 4 rows per row lane
+// rows per block: ~512 blocks over the tensor (the two "final" kernels walk the chunk list), at least 8 rows per row lane (4 loads in flight)
 void plan(int C, long HW, long N, int V, int& rows_per_block, int& chunks) {
     const int nvec = C / V, vpb = nvec < NB ? nvec : NB, rl = NB / vpb;
-    long rpb = cdiv(HW * N, 1024);
-    if (rpb < 4L * rl) rpb = 4L * rl;
+    long rpb = cdiv(HW * N, 512);
+    if (rpb < 8L * rl) rpb = 8L * rl;
     if (rpb > HW) rpb = HW;
     rows_per_block = (int)rpb; chunks = (int)cdiv(HW, rpb);
 }
