@@ -110,8 +110,8 @@ __global__ void __launch_bounds__(NB) gn_bwd_stats_kernel(const T* __restrict__ 
 template <typename T, typename W, int ACT>
 __global__ void __launch_bounds__(NB) gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const W* __restrict__ gamma,
                                                           const W* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                          const float* __restrict__ ws, T* __restrict__ dx, W* __restrict__ dgamma, W* __restrict__ dbeta,
-                                                          long N, int C, long HW, int G, int hsplit, int accumulate) {
+                                                          const float* __restrict__ ws, T* __restrict__ dx, const T* __restrict__ dx_add, W* __restrict__ dgamma,
+                                                          W* __restrict__ dbeta, long N, int C, long HW, int G, int hsplit, int accumulate) {
     constexpr int V = Elem<T>::VEC;
     __shared__ float smem[16];
     const long nc = blockIdx.x;
@@ -141,6 +141,12 @@ __global__ void __launch_bounds__(NB) gn_bwd_apply_kernel(const T* __restrict__ 
             const float xh = (fx[j] - mu) * rs;
             const float dz = ACT ? fg[j] * silu_grad(xh * ga + be) : fg[j];
             fx[j] = rs * (dz * ga - B - xh * A);
+        }
+        if (dx_add) {          // gradient of the branch that bypasses the norm (resnet skip / shortcut), added in the same pass
+            Vec16<T> va; va.load(dx_add + nc * HW + i);
+            float fa[V]; va.unpack(fa);
+#pragma unroll
+            for (int j = 0; j < V; ++j) fx[j] += fa[j];
         }
         Vec16<T> o; o.pack(fx); o.store(dr + i);
     }
@@ -200,7 +206,7 @@ int dpipe_groupnorm_fwd(const void* x, const void* gamma, const void* beta, void
 
 int dpipe_groupnorm_bwd(const void* x, const void* dy, const void* gamma, const void* beta, const float* mean, const float* rstd, void* dx,
                         void* dgamma, void* dbeta, float* workspace, long N, int C, long HW, int G, int act, int dtype, int wdtype,
-                        int accumulate_params, void* stream) {
+                        int accumulate_params, const void* dx_add, void* stream) {
     const int V = dtype == DPIPE_BF16 ? 8 : 4;
     if (!x || !dy || !mean || !rstd || !dx || !workspace || N <= 0 || C <= 0 || G <= 0 || C % G != 0 || HW <= 0 || HW % V != 0) BAD("dpipe_groupnorm_bwd: bad argument");
     if (act != DPIPE_ACT_NONE && act != DPIPE_ACT_SILU) BAD("dpipe_groupnorm_bwd: activation must be none or silu");
@@ -209,7 +215,7 @@ int dpipe_groupnorm_bwd(const void* x, const void* dy, const void* gamma, const 
     dim3 g2((unsigned)(N * C), hsplit);
 #define GN_BWD(TT, WW, AA) do { \
         gn_bwd_stats_kernel<TT, WW, AA><<<g2, NB, 0, s>>>((const TT*)x, (const TT*)dy, (const WW*)gamma, (const WW*)beta, mean, rstd, workspace, C, HW, G, hsplit); \
-        gn_bwd_apply_kernel<TT, WW, AA><<<g2, NB, 0, s>>>((const TT*)x, (const TT*)dy, (const WW*)gamma, (const WW*)beta, mean, rstd, workspace, (TT*)dx, \
+        gn_bwd_apply_kernel<TT, WW, AA><<<g2, NB, 0, s>>>((const TT*)x, (const TT*)dy, (const WW*)gamma, (const WW*)beta, mean, rstd, workspace, (TT*)dx, (const TT*)dx_add, \
                                                            (WW*)dgamma, (WW*)dbeta, N, C, HW, G, hsplit, accumulate_params); } while (0)
 #define GN_BWD_ACT(TT, WW) do { if (act) GN_BWD(TT, WW, 1); else GN_BWD(TT, WW, 0); } while (0)
     if (dtype == DPIPE_BF16 && wdtype == DPIPE_BF16) GN_BWD_ACT(bf16_t, bf16_t);

@@ -270,7 +270,8 @@ __global__ void __launch_bounds__(NB) gn_nhwc_bwd_final_kernel(const float* __re
 template <typename T, typename W, int ACT>
 __global__ void __launch_bounds__(NB) gn_nhwc_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const W* __restrict__ gamma,
                                                                const W* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                               const float* __restrict__ ab, T* __restrict__ dx, int C, long HW, int G, int rows_per_block) {
+                                                               const float* __restrict__ ab, T* __restrict__ dx, const T* __restrict__ dadd, int C, long HW, int G,
+                                                               int rows_per_block) {
     constexpr int V = Elem<T>::VEC;
     const Lay l = layout(C, V);
     const int tv = threadIdx.x % l.vpb, rlane = threadIdx.x / l.vpb;
@@ -294,6 +295,7 @@ __global__ void __launch_bounds__(NB) gn_nhwc_bwd_apply_kernel(const T* __restri
         const T* xp = x + (n * HW) * C + (long)v * V;
         const T* gp = dy + (n * HW) * C + (long)v * V;
         T* op = dx + (n * HW) * C + (long)v * V;
+        const T* ap = dadd ? dadd + (n * HW) * C + (long)v * V : nullptr;     // gradient that reached x around the norm (residual branch)
         long r = r0 + rlane;
         for (; r + (long)l.rl < r1; r += 2L * l.rl) {
             Vec16<T> a[2], b[2];
@@ -308,6 +310,12 @@ __global__ void __launch_bounds__(NB) gn_nhwc_bwd_apply_kernel(const T* __restri
                     const float dz = ACT ? fg[j] * silu_grad(xh * ga[j] + be[j]) : fg[j];
                     fx[j] = rs[j] * (ga[j] * dz - ca[j] - xh * cb[j]);
                 }
+                if (ap) {
+                    Vec16<T> e; e.load(ap + (r + (long)u * l.rl) * C);
+                    float fe[V]; e.unpack(fe);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) fx[j] += fe[j];
+                }
                 Vec16<T> o; o.pack(fx); o.store(op + (r + (long)u * l.rl) * C);
             }
         }
@@ -319,6 +327,12 @@ __global__ void __launch_bounds__(NB) gn_nhwc_bwd_apply_kernel(const T* __restri
                 const float xh = (fx[j] - mu[j]) * rs[j];
                 const float dz = ACT ? fg[j] * silu_grad(xh * ga[j] + be[j]) : fg[j];
                 fx[j] = rs[j] * (ga[j] * dz - ca[j] - xh * cb[j]);
+            }
+            if (ap) {
+                Vec16<T> e; e.load(ap + r * C);
+                float fe[V]; e.unpack(fe);
+#pragma unroll
+                for (int j = 0; j < V; ++j) fx[j] += fe[j];
             }
             Vec16<T> o; o.pack(fx); o.store(op + r * C);
         }
@@ -370,7 +384,7 @@ int dpipe_groupnorm_nhwc_fwd(const void* x, const void* gamma, const void* beta,
 
 int dpipe_groupnorm_nhwc_bwd(const void* x, const void* dy, const void* gamma, const void* beta, const float* mean, const float* rstd,
                              void* dx, void* dgamma, void* dbeta, float* workspace, long N, int C, long HW, int G, int act, int dtype, int wdtype,
-                             int accumulate_params, void* stream) {
+                             int accumulate_params, const void* dx_add, void* stream) {
     if (!x || !dy || !dx || !mean || !rstd || !workspace || N <= 0 || C <= 0 || HW <= 0 || G <= 0 || C % G) BAD("dpipe_groupnorm_nhwc_bwd: bad argument");
     const int V = dtype == DPIPE_BF16 ? 8 : 4;
     if ((dtype != DPIPE_BF16 && dtype != DPIPE_F32) || (wdtype != DPIPE_BF16 && wdtype != DPIPE_F32)) BAD("dpipe_groupnorm_nhwc_bwd: dtype");
@@ -382,7 +396,7 @@ int dpipe_groupnorm_nhwc_bwd(const void* x, const void* dy, const void* gamma, c
 #define GN_BWD(TT, WW, AA) do { \
         gn_nhwc_bwd_partial_kernel<TT, WW, AA><<<grid, NB, 0, s>>>((const TT*)x, (const TT*)dy, (const WW*)gamma, (const WW*)beta, mean, rstd, workspace, C, HW, G, rpb, chunks); \
         gn_nhwc_bwd_final_kernel<WW><<<(unsigned)G, NB, 0, s>>>(workspace, (const WW*)gamma, ab, (WW*)dgamma, (WW*)dbeta, N, C, G, chunks, accumulate_params); \
-        gn_nhwc_bwd_apply_kernel<TT, WW, AA><<<grid, NB, 0, s>>>((const TT*)x, (const TT*)dy, (const WW*)gamma, (const WW*)beta, mean, rstd, ab, (TT*)dx, C, HW, G, rpb); } while (0)
+        gn_nhwc_bwd_apply_kernel<TT, WW, AA><<<grid, NB, 0, s>>>((const TT*)x, (const TT*)dy, (const WW*)gamma, (const WW*)beta, mean, rstd, ab, (TT*)dx, (const TT*)dx_add, C, HW, G, rpb); } while (0)
 #define GN_BWD_ACT(TT, WW) do { if (act == DPIPE_ACT_SILU) GN_BWD(TT, WW, 1); else if (act == DPIPE_ACT_NONE) GN_BWD(TT, WW, 0); else BAD("dpipe_groupnorm_nhwc_bwd: act"); } while (0)
     if (dtype == DPIPE_BF16 && wdtype == DPIPE_BF16) GN_BWD_ACT(bf16_t, bf16_t);
     else if (dtype == DPIPE_BF16) GN_BWD_ACT(bf16_t, float);

@@ -237,11 +237,12 @@ __global__ void __launch_bounds__(NB) lnmod_fwd_kernel(const T* __restrict__ x, 
         v.pack(f); v.store(yr + c);
     }
 }
-// dxhat = gy * (1+scale) * gamma ;  dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat))
+// dxhat = gy * (1+scale) * gamma ;  dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)) (+ gadd: the gradient that reached x
+// through the residual branch around this norm, added here instead of by a separate elementwise kernel)
 template <typename T, typename W, typename M, int LPR>
 __global__ void __launch_bounds__(NB) lnmod_bwd_dx_kernel(const T* __restrict__ x, const T* __restrict__ gy, const W* __restrict__ gamma,
                                                           const M* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                          T* __restrict__ gx, long rows, int cols, long rows_per_mod) {
+                                                          T* __restrict__ gx, const T* __restrict__ gadd, long rows, int cols, long rows_per_mod) {
     constexpr int V = Elem<T>::VEC;
     constexpr int RPB = NB / LPR;
     const int sub = threadIdx.x % LPR;
@@ -272,6 +273,12 @@ __global__ void __launch_bounds__(NB) lnmod_bwd_dx_kernel(const T* __restrict__ 
         for (int j = 0; j < V; ++j) {
             float d = fg[j] * (scale ? 1.f + Elem<M>::to_f(scale[b * cols + c + j]) : 1.f) * (gamma ? Elem<W>::to_f(gamma[c + j]) : 1.f);
             fg[j] = rs * (d - s1 - (fx[j] - mu) * rs * s2);
+        }
+        if (gadd) {
+            Vec16<T> va; va.load(gadd + row * (long)cols + c);
+            float fa[V]; va.unpack(fa);
+#pragma unroll
+            for (int j = 0; j < V; ++j) fg[j] += fa[j];
         }
         vg.pack(fg); vg.store(o + c);
     }
@@ -458,7 +465,7 @@ int dpipe_lnmod_fwd(const void* x, const void* gamma, const void* beta, const vo
 int dpipe_lnmod_bwd(const void* x, const void* gy, const void* gamma, const void* beta, const void* scale,
                     const float* mean, const float* rstd, void* gx, void* dgamma, void* dbeta, void* dscale, void* dshift,
                     float* workspace, long rows, int cols, long rows_per_mod, int dtype, int wdtype, int mdtype, int accumulate_params,
-                    void* stream) {
+                    const void* gx_add, void* stream) {
     const int V = dtype == DPIPE_BF16 ? 8 : 4;
     if (!x || !gy || !mean || !rstd || !gx || rows <= 0 || cols <= 0 || (cols % V) != 0 || rows_per_mod <= 0 || (rows % rows_per_mod) != 0)
         BAD("dpipe_lnmod_bwd: bad argument");
@@ -468,7 +475,7 @@ int dpipe_lnmod_bwd(const void* x, const void* gy, const void* gamma, const void
     const long groups = rows / rows_per_mod;
     const int slabs_all = dpipe_norm_slabs(rows), slabs_mod = dpipe_norm_slabs(rows_per_mod);
 #define LNBWD(TT, WW, MM) do { \
-    lnmod_bwd_dx_kernel<TT, WW, MM, 64><<<grid, NB, 0, s>>>((const TT*)x, (const TT*)gy, (const WW*)gamma, (const MM*)scale, mean, rstd, (TT*)gx, rows, cols, rows_per_mod); \
+    lnmod_bwd_dx_kernel<TT, WW, MM, 64><<<grid, NB, 0, s>>>((const TT*)x, (const TT*)gy, (const WW*)gamma, (const MM*)scale, mean, rstd, (TT*)gx, (const TT*)gx_add, rows, cols, rows_per_mod); \
     if (dscale) { \
         float* p0 = workspace; float* p1 = workspace + groups * slabs_mod * (long)cols; \
         dim3 g2((unsigned)cdiv(cols / V, CR_CT), slabs_mod, (unsigned)groups); \

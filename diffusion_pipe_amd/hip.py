@@ -45,16 +45,16 @@ _SIGNATURES = {
     'dpipe_colsum': (I, [P, L, I, L, P, P, I, I, I, P]),
     'dpipe_lnmod_fwd': (I, [P, P, P, P, P, P, P, P, L, I, L, F, I, I, I, P]),
     'dpipe_lnmod_workspace_floats': (I, [L, I, L]),
-    'dpipe_lnmod_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, L, I, I, I, I, P]),
+    'dpipe_lnmod_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, L, I, I, I, I, P, P]),
     'dpipe_groupnorm_workspace_floats': (L, [L, I, L, I]),
     'dpipe_groupnorm_fwd': (I, [P, P, P, P, P, P, P, L, I, L, I, F, I, I, I, P]),
-    'dpipe_groupnorm_bwd': (I, [P, P, P, P, P, P, P, P, P, P, L, I, L, I, I, I, I, I, P]),
+    'dpipe_groupnorm_bwd': (I, [P, P, P, P, P, P, P, P, P, P, L, I, L, I, I, I, I, I, P, P]),
     'dpipe_conv2d_fwd': (I, [P, L, P, P, P, L, P, L] + [I] * 11 + [P, L, I, P]),
     'dpipe_conv2d_dgrad': (I, [P, L, P, P, L] + [I] * 9 + [P, L, I, P]),
     'dpipe_conv2d_wgrad': (I, [P, L, P, L, P, P] + [I] * 12 + [P, L, I, P]),
     'dpipe_groupnorm_nhwc_workspace_floats': (L, [L, I, L, I]),
     'dpipe_groupnorm_nhwc_fwd': (I, [P, P, P, P, P, P, P, L, I, L, I, F, I, I, I, P]),
-    'dpipe_groupnorm_nhwc_bwd': (I, [P, P, P, P, P, P, P, P, P, P, L, I, L, I, I, I, I, I, P]),
+    'dpipe_groupnorm_nhwc_bwd': (I, [P, P, P, P, P, P, P, P, P, P, L, I, L, I, I, I, I, I, P, P]),
     'dpipe_rope': (I, [P, P, P, P, L, L, L, I, I, I, I, P]),
     'dpipe_softmax_fwd': (I, [P, P, L, I, L, F, I, I, P]),
     'dpipe_softmax_bwd': (I, [P, P, P, L, I, L, F, I, P]),

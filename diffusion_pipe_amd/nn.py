@@ -14,6 +14,7 @@ from . import ops
 
 import os as _os
 _ATEN_GROUPNORM = _os.environ.get('DPIPE_ATEN_GROUPNORM', '0') == '1'
+_NORM_SKIP = _os.environ.get('DPIPE_NORM_SKIP', '1') == '1'      # A/B switch: fold the bypass branch's gradient into the norm backward kernels
 
 
 class Linear(nn.Module):
@@ -117,9 +118,12 @@ class LayerNorm(nn.Module):
         self.weight = nn.Parameter(torch.ones(dim, device=device, dtype=dtype)) if elementwise_affine else None
         self.bias = nn.Parameter(torch.zeros(dim, device=device, dtype=dtype)) if (elementwise_affine and bias) else None
 
-    def forward(self, x, scale=None, shift=None):
-        """Optionally fused AdaLN modulation: LN(x) * (1 + scale) + shift."""
-        return ops.layer_norm_modulate(x, self.weight, self.bias, scale, shift, self.eps)
+    def forward(self, x, scale=None, shift=None, with_skip=False):
+        """Optionally fused AdaLN modulation: LN(x) * (1 + scale) + shift.  with_skip -> (y, x'): hand x' to the residual branch
+        around this norm (pre-norm blocks), so that branch's gradient is added inside the LayerNorm backward kernel."""
+        if with_skip and not _NORM_SKIP:
+            return ops.layer_norm_modulate(x, self.weight, self.bias, scale, shift, self.eps), x
+        return ops.layer_norm_modulate(x, self.weight, self.bias, scale, shift, self.eps, with_skip)
 
 
 class GroupNorm(nn.Module):
@@ -131,13 +135,16 @@ class GroupNorm(nn.Module):
         self.weight = nn.Parameter(torch.ones(num_channels, device=device, dtype=dtype)) if affine else None
         self.bias = nn.Parameter(torch.zeros(num_channels, device=device, dtype=dtype)) if affine else None
 
-    def forward(self, x, act=None):
+    def forward(self, x, act=None, with_skip=False):
         if _ATEN_GROUPNORM:     # A/B switch (DPIPE_ATEN_GROUPNORM=1): ATen's GroupNorm + the separate SiLU kernel
             y = torch.nn.functional.group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
-            return ops.silu(y) if act == 'silu' else y
-        if x.dim() == 4 and not x.is_contiguous() and ops.is_channels_last(x):
-            return ops.group_norm_nhwc(x, self.num_groups, self.weight, self.bias, self.eps, act)      # channels-last UNet (csrc/groupnorm_nhwc.hip)
-        return ops.group_norm(x, self.num_groups, self.weight, self.bias, self.eps, act)
+            y = ops.silu(y) if act == 'silu' else y
+            return (y, x) if with_skip else y
+        nhwc = x.dim() == 4 and not x.is_contiguous() and ops.is_channels_last(x)      # channels-last UNet (csrc/groupnorm_nhwc.hip)
+        fn = ops.group_norm_nhwc if nhwc else ops.group_norm
+        if with_skip and not _NORM_SKIP:
+            return fn(x, self.num_groups, self.weight, self.bias, self.eps, act), x
+        return fn(x, self.num_groups, self.weight, self.bias, self.eps, act, with_skip)
 
 
 class Conv2d(nn.Conv2d):

@@ -499,8 +499,10 @@ class _LNModFn(Function):
     """LayerNorm(x) [* gamma + beta] * (1 + scale) + shift, statistics in fp32 (models/wan/model.py:89-99,295-309)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, scale, shift, eps):
+    def forward(ctx, x, gamma, beta, scale, shift, eps, with_skip=False):
         require_cuda(x, gamma, beta, scale, shift)
+        ctx.set_materialize_grads(False)
+        ctx.with_skip = with_skip
         x2 = _contig(_rows2d(x))
         rows, cols = x2.shape
         sc = sh = None
@@ -523,14 +525,25 @@ class _LNModFn(Function):
         ctx.save_for_backward(x2, gamma, beta, sc, mean, rstd)
         ctx.meta = (x.shape, None if scale is None else scale.shape, None if shift is None else shift.shape,
                     rows_per_mod, wdt, mdt, shift is not None)
+        if with_skip:
+            # second output: x itself, for the residual branch that bypasses the norm.  x then has ONE consumer (this node), and
+            # the branch's gradient arrives here as `gskip` and is added inside the dx kernel (no autograd accumulation kernel)
+            return y.view(x.shape), x.view_as(x)
         return y.view(x.shape)
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gskip=None):
         x2, gamma, beta, sc, mean, rstd = ctx.saved_tensors
         x_shape, scale_shape, shift_shape, rows_per_mod, wdt, mdt, has_shift = ctx.meta
         rows, cols = x2.shape
+        if gy is None:              # the normalised output was unused: only the bypass carries gradient
+            return gskip, None, None, None, None, None, None
         gy2 = _contig(_rows2d(gy))
+        gadd = None
+        if gskip is not None:
+            gadd = _contig(_rows2d(gskip))
+            if gadd.dtype != x2.dtype:
+                gadd = gadd.to(x2.dtype)
         gx = torch.empty_like(x2)
         groups = rows // rows_per_mod
         mod_dtype = torch.bfloat16 if mdt == hip.BF16 else torch.float32
@@ -551,25 +564,27 @@ class _LNModFn(Function):
             ws = torch.empty(lib().dpipe_lnmod_workspace_floats(rows, cols, rows_per_mod), device=x2.device, dtype=torch.float32)
         check(lib().dpipe_lnmod_bwd(ptr(x2), ptr(gy2), ptr(gamma), ptr(beta), ptr(sc), ptr(mean), ptr(rstd), ptr(gx),
                                     ptr(dgamma), ptr(dbeta), ptr(dscale), ptr(dshift), ptr(ws), rows, cols, rows_per_mod,
-                                    dtype_code(x2.dtype), wdt, mdt, int(fused), stream()), 'lnmod_bwd')
+                                    dtype_code(x2.dtype), wdt, mdt, int(fused), ptr(gadd), stream()), 'lnmod_bwd')
         g_scale = dscale.view(scale_shape) if scale_shape is not None else None
         g_shift = dshift.view(shift_shape) if shift_shape is not None else None
         if fused:
             dgamma = dbeta = None
-        return gx.view(x_shape), dgamma, dbeta, g_scale, g_shift, None
+        return gx.view(x_shape), dgamma, dbeta, g_scale, g_shift, None, None
 
 
-def layer_norm_modulate(x, gamma=None, beta=None, scale=None, shift=None, eps=1e-6):
-    """scale/shift: [B, D] (or broadcastable [B, 1, D]) applied to the rows of sample b."""
-    return _LNModFn.apply(x, gamma, beta, scale, shift, eps)
+def layer_norm_modulate(x, gamma=None, beta=None, scale=None, shift=None, eps=1e-6, with_skip=False):
+    """scale/shift: [B, D] (or broadcastable [B, 1, D]) applied to the rows of sample b.  with_skip: -> (y, x') where x' aliases x and
+    is what the residual branch around the norm should consume (its gradient is then added inside the backward kernel)."""
+    return _LNModFn.apply(x, gamma, beta, scale, shift, eps, with_skip)
 
 
 class _GroupNormFn(Function):
     """nn.GroupNorm(G, C) on NCHW (+ fused SiLU): diffusers ResnetBlock2D / Transformer2DModel norms behind models/sdxl.py:797-865."""
 
     @staticmethod
-    def forward(ctx, x, num_groups, weight, bias, eps, act):
+    def forward(ctx, x, num_groups, weight, bias, eps, act, with_skip=False):
         require_cuda(x, weight, bias)
+        ctx.set_materialize_grads(False)
         xc = _contig(x)
         N, C = xc.shape[0], xc.shape[1]
         HW = xc.numel() // (N * C)
@@ -582,15 +597,24 @@ class _GroupNormFn(Function):
                                         ACT[act], dtype_code(x.dtype), wdt, stream()), 'groupnorm_fwd')
         ctx.save_for_backward(xc, weight, bias, mean, rstd)
         ctx.meta = (num_groups, act, wdt)
+        if with_skip:
+            return y, x.view_as(x)              # see _LNModFn: the bypass branch's gradient is folded into the dx kernel
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gskip=None):
         xc, weight, bias, mean, rstd = ctx.saved_tensors
         G, act, wdt = ctx.meta
         N, C = xc.shape[0], xc.shape[1]
         HW = xc.numel() // (N * C)
+        if gy is None:
+            return gskip, None, None, None, None, None, None
         gy = _contig(gy)
+        gadd = None
+        if gskip is not None:
+            gadd = _contig(gskip)
+            if gadd.dtype != xc.dtype:
+                gadd = gadd.to(xc.dtype)
         gx = torch.empty_like(xc)
         fused = False
         dgamma = dbeta = None
@@ -603,15 +627,16 @@ class _GroupNormFn(Function):
                 dbeta = torch.empty_like(bias) if bias is not None else None
         ws = torch.empty(lib().dpipe_groupnorm_workspace_floats(N, C, HW, G), device=xc.device, dtype=torch.float32)
         check(lib().dpipe_groupnorm_bwd(ptr(xc), ptr(gy), ptr(weight), ptr(bias), ptr(mean), ptr(rstd), ptr(gx), ptr(dgamma), ptr(dbeta), ptr(ws),
-                                        N, C, HW, G, ACT[act], dtype_code(xc.dtype), wdt, int(fused), stream()), 'groupnorm_bwd')
+                                        N, C, HW, G, ACT[act], dtype_code(xc.dtype), wdt, int(fused), ptr(gadd), stream()), 'groupnorm_bwd')
         if fused:
             dgamma = dbeta = None
-        return gx, None, dgamma, dbeta, None, None
+        return gx, None, dgamma, dbeta, None, None, None
 
 
-def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, act=None):
-    """x: [N, C, *spatial] contiguous; act: None or 'silu' (applied to the normalised, affine-transformed value)."""
-    return _GroupNormFn.apply(x, num_groups, weight, bias, eps, act)
+def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, act=None, with_skip=False):
+    """x: [N, C, *spatial] contiguous; act: None or 'silu' (applied to the normalised, affine-transformed value).
+    with_skip: -> (y, x') as in layer_norm_modulate."""
+    return _GroupNormFn.apply(x, num_groups, weight, bias, eps, act, with_skip)
 
 
 # ------------------------------------------------------------------------- channels-last (NHWC) UNet ops: GroupNorm, Conv2d
@@ -630,8 +655,9 @@ class _GroupNormNHWCFn(Function):
     """nn.GroupNorm(G, C) (+ fused SiLU) on a channels-last [N, C, H, W] tensor = [N, HW, C] memory (csrc/groupnorm_nhwc.hip)."""
 
     @staticmethod
-    def forward(ctx, x, num_groups, weight, bias, eps, act):
+    def forward(ctx, x, num_groups, weight, bias, eps, act, with_skip=False):
         require_cuda(x, weight, bias)
+        ctx.set_materialize_grads(False)
         xv = nhwc_view(x)
         N, H, W, C = xv.shape
         HW = H * W
@@ -644,14 +670,23 @@ class _GroupNormNHWCFn(Function):
                                              ACT[act], dtype_code(x.dtype), wdt, stream()), 'groupnorm_nhwc_fwd')
         ctx.save_for_backward(xv, weight, bias, mean, rstd)
         ctx.meta = (num_groups, act, wdt)
+        if with_skip:
+            return y.permute(0, 3, 1, 2), x.view_as(x)     # see _LNModFn: the bypass branch's gradient is folded into the dx kernel
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gskip=None):
         xv, weight, bias, mean, rstd = ctx.saved_tensors
         G, act, wdt = ctx.meta
         N, H, W, C = xv.shape
+        if gy is None:
+            return gskip, None, None, None, None, None, None
         gyv = nhwc_view(gy)
+        gadd = None
+        if gskip is not None:
+            gadd = nhwc_view(gskip)
+            if gadd.dtype != xv.dtype:
+                gadd = gadd.to(xv.dtype)
         gx = torch.empty_like(xv)
         fused = False
         dgamma = dbeta = None
@@ -664,15 +699,15 @@ class _GroupNormNHWCFn(Function):
                 dbeta = torch.empty_like(bias) if bias is not None else None
         ws = torch.empty(lib().dpipe_groupnorm_nhwc_workspace_floats(N, C, H * W, G), device=xv.device, dtype=torch.float32)
         check(lib().dpipe_groupnorm_nhwc_bwd(ptr(xv), ptr(gyv), ptr(weight), ptr(bias), ptr(mean), ptr(rstd), ptr(gx), ptr(dgamma), ptr(dbeta), ptr(ws),
-                                             N, C, H * W, G, ACT[act], dtype_code(xv.dtype), wdt, int(fused), stream()), 'groupnorm_nhwc_bwd')
+                                             N, C, H * W, G, ACT[act], dtype_code(xv.dtype), wdt, int(fused), ptr(gadd), stream()), 'groupnorm_nhwc_bwd')
         if fused:
             dgamma = dbeta = None
-        return gx.permute(0, 3, 1, 2), None, dgamma, dbeta, None, None
+        return gx.permute(0, 3, 1, 2), None, dgamma, dbeta, None, None, None
 
 
-def group_norm_nhwc(x, num_groups, weight=None, bias=None, eps=1e-5, act=None):
-    """x: [N, C, H, W] channels-last; returns a channels-last tensor of the same logical shape."""
-    return _GroupNormNHWCFn.apply(x, num_groups, weight, bias, eps, act)
+def group_norm_nhwc(x, num_groups, weight=None, bias=None, eps=1e-5, act=None, with_skip=False):
+    """x: [N, C, H, W] channels-last; returns a channels-last tensor of the same logical shape.  with_skip: -> (y, x') as in layer_norm_modulate."""
+    return _GroupNormNHWCFn.apply(x, num_groups, weight, bias, eps, act, with_skip)
 
 
 def conv2d_eligible(x_dtype, weight, stride, padding, dilation=(1, 1), groups=1):

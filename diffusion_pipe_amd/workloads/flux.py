@@ -148,7 +148,8 @@ class FluxAttention(nn.Module):
 # -------------------------------------------------------------------------------------------------------------- blocks
 class AdaLayerNormZero(nn.Module):
     """emb = linear(silu(temb)) -> n chunks (n = 6: shift / scale / gate of attention and of the MLP; n = 3: single blocks);
-    returns LN(x) * (1 + scale) + shift and the remaining chunks."""
+    returns LN(x) * (1 + scale) + shift, the norm node's alias of x for the residual branch (its gradient is then added inside
+    the LayerNorm backward kernel) and the remaining chunks."""
 
     def __init__(self, dim, chunks=6):
         super().__init__()
@@ -157,7 +158,8 @@ class AdaLayerNormZero(nn.Module):
 
     def forward(self, x, temb):
         parts = self.linear(self.silu(temb)).chunk(self.chunks, dim=1)
-        return (self.norm(x, scale=parts[1], shift=parts[0]), *parts[2:])
+        y, skip = self.norm(x, scale=parts[1], shift=parts[0], with_skip=True)
+        return (y, skip, *parts[2:])
 
 
 class GELUProjection(nn.Module):
@@ -192,14 +194,16 @@ class FluxTransformerBlock(nn.Module):
 
     def forward(self, hidden_states, encoder_hidden_states, temb, image_rotary_emb):
         cos, sin = _half_tables(*image_rotary_emb)
-        h, gate_msa, shift_mlp, scale_mlp, gate_mlp = self.norm1(hidden_states, temb)
-        c, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = self.norm1_context(encoder_hidden_states, temb)
+        h, hidden_states, gate_msa, shift_mlp, scale_mlp, gate_mlp = self.norm1(hidden_states, temb)
+        c, encoder_hidden_states, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = self.norm1_context(encoder_hidden_states, temb)
         L = encoder_hidden_states.shape[1]
         o = self.attn(h, c, cos, sin)
         x = ops.gated_residual(hidden_states, self.attn.to_out[0](o[:, L:].contiguous()), gate_msa)
-        x = ops.gated_residual(x, self.ff(self.norm2(x, scale=scale_mlp, shift=shift_mlp)), gate_mlp)
+        n, x = self.norm2(x, scale=scale_mlp, shift=shift_mlp, with_skip=True)
+        x = ops.gated_residual(x, self.ff(n), gate_mlp)
         e = ops.gated_residual(encoder_hidden_states, self.attn.to_add_out(o[:, :L].contiguous()), c_gate_msa)
-        e = ops.gated_residual(e, self.ff_context(self.norm2_context(e, scale=c_scale_mlp, shift=c_shift_mlp)), c_gate_mlp)
+        n, e = self.norm2_context(e, scale=c_scale_mlp, shift=c_shift_mlp, with_skip=True)
+        e = ops.gated_residual(e, self.ff_context(n), c_gate_mlp)
         return e, x
 
 
@@ -215,7 +219,7 @@ class FluxSingleTransformerBlock(nn.Module):
         cos, sin = _half_tables(*image_rotary_emb)
         L = encoder_hidden_states.shape[1]
         x = torch.cat([encoder_hidden_states, hidden_states], dim=1)
-        n, gate = self.norm(x, temb)
+        n, x, gate = self.norm(x, temb)
         mlp = self.act_mlp(self.proj_mlp(n))
         attn = self.attn(n, None, cos, sin)
         x = ops.gated_residual(x, self.proj_out(torch.cat([attn, mlp], dim=2)), gate)

@@ -72,27 +72,29 @@ class MMDoubleStreamBlock(nn.Module):
             setattr(self, f'{s}_mlp', MLP(hidden_size, mlp_hidden))
 
     def _stream_qkv(self, s, x, shift, scale, cos, sin):
-        h = getattr(self, f'{s}_norm1')(x, scale=scale, shift=shift)
+        h, skip = getattr(self, f'{s}_norm1')(x, scale=scale, shift=shift, with_skip=True)
         q, k, v = _qkv_heads(getattr(self, f'{s}_attn_qkv')(h), self.heads_num)
         q = getattr(self, f'{s}_attn_q_norm')(q)
         k = getattr(self, f'{s}_attn_k_norm')(k)
         if cos is not None:
             q, k = ops.rope(q, cos, sin, interleaved=True), ops.rope(k, cos, sin, interleaved=True)
-        return q, k, v
+        return (q, k, v), skip
 
     def forward(self, img, txt, vec, cos=None, sin=None, text_len=None):
         """img [B, Si, C], txt [B, St, C], vec [B, C]; cos / sin: fp32 [Si, d/2] rotary tables of the image tokens."""
         i_sh1, i_sc1, i_g1, i_sh2, i_sc2, i_g2 = self.img_mod(vec).chunk(6, dim=-1)
         t_sh1, t_sc1, t_g1, t_sh2, t_sc2, t_g2 = self.txt_mod(vec).chunk(6, dim=-1)
-        iq = self._stream_qkv('img', img, i_sh1, i_sc1, cos, sin)
-        tq = self._stream_qkv('txt', txt, t_sh1, t_sc1, None, None)
+        iq, img = self._stream_qkv('img', img, i_sh1, i_sc1, cos, sin)         # img / txt: the norm nodes' aliases for the residual adds
+        tq, txt = self._stream_qkv('txt', txt, t_sh1, t_sc1, None, None)
         attn = joint_attention(iq, tq, text_len)
         Si = img.shape[1]
         img_attn, txt_attn = attn[:, :Si].contiguous(), attn[:, Si:].contiguous()
         img = ops.gated_residual(img, self.img_attn_proj(img_attn), i_g1)
-        img = ops.gated_residual(img, self.img_mlp(self.img_norm2(img, scale=i_sc2, shift=i_sh2)), i_g2)
+        n, img = self.img_norm2(img, scale=i_sc2, shift=i_sh2, with_skip=True)       # residual gradient folded into the LayerNorm backward
+        img = ops.gated_residual(img, self.img_mlp(n), i_g2)
         txt = ops.gated_residual(txt, self.txt_attn_proj(txt_attn), t_g1)
-        txt = ops.gated_residual(txt, self.txt_mlp(self.txt_norm2(txt, scale=t_sc2, shift=t_sh2)), t_g2)
+        n, txt = self.txt_norm2(txt, scale=t_sc2, shift=t_sh2, with_skip=True)
+        txt = ops.gated_residual(txt, self.txt_mlp(n), t_g2)
         return img, txt
 
 
@@ -112,7 +114,8 @@ class MMSingleStreamBlock(nn.Module):
     def forward(self, x, vec, txt_len, cos=None, sin=None, text_len=None):
         """x [B, Si + St, C] with the text tokens last; txt_len = St (python int, as in the reference)."""
         shift, scale, gate = self.modulation(vec).chunk(3, dim=-1)
-        h = self.linear1(self.pre_norm(x, scale=scale, shift=shift))
+        n, x = self.pre_norm(x, scale=scale, shift=shift, with_skip=True)
+        h = self.linear1(n)
         qkv, mlp = torch.split(h, [3 * self.hidden_size, self.mlp_hidden_dim], dim=-1)
         q, k, v = _qkv_heads(qkv.contiguous(), self.heads_num)
         q, k = self.q_norm(q), self.k_norm(k)

@@ -118,8 +118,12 @@ class CLIPEncoderLayer(nn.Module):
         self.layer_norm2, self.mlp = dnn.LayerNorm(c.hidden, eps=1e-5), CLIPMLP(c)
 
     def forward(self, x):
-        x = self.self_attn(self.layer_norm1(x), residual=x)
-        return self.mlp(self.layer_norm2(x), residual=x)
+        # with_skip: the residual branch consumes the norm node's alias of x, so its gradient is added inside the LayerNorm
+        # backward kernel instead of by an autograd accumulation launch
+        h, x = self.layer_norm1(x, with_skip=True)
+        x = self.self_attn(h, residual=x)
+        h, x = self.layer_norm2(x, with_skip=True)
+        return self.mlp(h, residual=x)
 
 
 class CLIPEmbeddings(nn.Module):
@@ -192,10 +196,11 @@ class ResnetBlock2D(nn.Module):
     def forward(self, x, temb):
         x = x.contiguous(memory_format=torch.channels_last)
         t = self.time_emb_proj(self.nonlinearity(temb))
+        h, x = self.norm1(x, act='silu', with_skip=True)          # GroupNorm + SiLU in one pass; the skip branch's gradient is folded into its backward
         if x.shape[0] == 1:        # batch 1: the time-embedding addend is one value per channel -> it joins conv1's bias vector in the epilogue
-            h = self.conv1(self.norm1(x, act='silu'), extra_bias=t.reshape(-1).to(x.dtype))     # GroupNorm + SiLU in one pass
+            h = self.conv1(h, extra_bias=t.reshape(-1).to(x.dtype))
         else:
-            h = self.conv1(self.norm1(x, act='silu')) + t[:, :, None, None].to(x.dtype)
+            h = self.conv1(h) + t[:, :, None, None].to(x.dtype)
         if self.conv_shortcut is not None:
             x = self.conv_shortcut(x)
         return self.conv2(self.norm2(h, act='silu'), residual=x)       # the block's "x + h" rides conv2's epilogue
@@ -210,9 +215,12 @@ class BasicTransformerBlock(nn.Module):
 
     def forward(self, x, encoder_hidden_states):
         # the three "x + f(norm(x))" adds ride the epilogue of f's output projection (GEMM `residual`)
-        x = self.attn1(self.norm1(x), residual=x)
-        x = self.attn2(self.norm2(x), encoder_hidden_states, residual=x)
-        return self.ff(self.norm3(x), residual=x)
+        h, x = self.norm1(x, with_skip=True)            # (and their gradients ride the LayerNorm backward kernels)
+        x = self.attn1(h, residual=x)
+        h, x = self.norm2(x, with_skip=True)
+        x = self.attn2(h, encoder_hidden_states, residual=x)
+        h, x = self.norm3(x, with_skip=True)
+        return self.ff(h, residual=x)
 
 
 class Transformer2DModel(nn.Module):
@@ -229,8 +237,9 @@ class Transformer2DModel(nn.Module):
     def forward(self, x, encoder_hidden_states):
         B, C, H, W = x.shape
         x = x.contiguous(memory_format=torch.channels_last)          # [B, HW, C] memory: the token-major view below is free
-        residual = x.permute(0, 2, 3, 1).reshape(B, H * W, C)
-        h = self.norm(x).permute(0, 2, 3, 1).reshape(B, H * W, C)
+        h, residual = self.norm(x, with_skip=True)
+        residual = residual.permute(0, 2, 3, 1).reshape(B, H * W, C)
+        h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
         h = self.proj_in(h)
         ctx = encoder_hidden_states.to(h.dtype)
         for blk in self.transformer_blocks:

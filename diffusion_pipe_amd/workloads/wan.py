@@ -77,12 +77,16 @@ class WanAttentionBlock(nn.Module):
         """x: [B, S, C]; e: [B, 1, 6, C] (fp32 modulation of the timestep); cos / sin: rope_tables()."""
         m = (self.modulation.unsqueeze(0) + e).chunk(6, dim=2)                 # six [B, 1, 1, C]
         shift1, scale1, gate1, shift2, scale2, gate2 = (t.reshape(t.shape[0], -1) for t in m)
-        y = self.self_attn(self.norm1(x, scale=scale1, shift=shift1), cos, sin)        # LN * (1 + scale) + shift, one pass
-        x = ops.gated_residual(x, y, gate1)                                              # x + y * gate
-        n3 = self.norm3(x) if self.norm3 is not None else x
+        # with_skip: the residual branch takes the norm node's alias of x; its gradient is added inside the LayerNorm backward kernel
+        h, x = self.norm1(x, scale=scale1, shift=shift1, with_skip=True)                 # LN * (1 + scale) + shift, one pass
+        x = ops.gated_residual(x, self.self_attn(h, cos, sin), gate1)                    # x + y * gate
+        if self.norm3 is not None:
+            n3, x = self.norm3(x, with_skip=True)
+        else:
+            n3 = x
         x = ops.gated_residual(x, self.cross_attn(n3, context, context_lens))
-        y = self.ffn(self.norm2(x, scale=scale2, shift=shift2))
-        return ops.gated_residual(x, y, gate2)
+        h, x = self.norm2(x, scale=scale2, shift=shift2, with_skip=True)
+        return ops.gated_residual(x, self.ffn(h), gate2)
 
 
 class Head(nn.Module):

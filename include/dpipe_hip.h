@@ -126,7 +126,9 @@ int dpipe_lnmod_workspace_floats(long rows, int cols, long rows_per_mod);
 int dpipe_lnmod_bwd(const void* x, const void* gy, const void* gamma, const void* beta, const void* scale,
                     const float* mean, const float* rstd, void* gx, void* dgamma, void* dbeta, void* dscale,
                     void* dshift, float* workspace, long rows, int cols, long rows_per_mod, int dtype, int wdtype,
-                    int mdtype, int accumulate_params, void* stream);   /* accumulate_params: dgamma / dbeta += */
+                    int mdtype, int accumulate_params, const void* gx_add, void* stream);
+/* accumulate_params: dgamma / dbeta +=.  gx_add (may be NULL, [rows, cols] like gx): gx = d(norm)/dx + gx_add -- the gradient that
+ * reached x through the residual branch around the norm, folded into this pass. */
 
 /* ---- 2-D convolution as implicit GEMM (NHWC bf16): the nn.Conv2d of diffusers' ResnetBlock2D / Downsample2D / Upsample2D
  * behind the UNet call sites models/sdxl.py:797-865 (the reference reaches MIOpen / cuDNN through torch.nn.functional.conv2d).
@@ -156,7 +158,7 @@ int dpipe_groupnorm_nhwc_fwd(const void* x, const void* gamma, const void* beta,
                              long N, int C, long HW, int G, float eps, int act, int dtype, int wdtype, void* stream);
 int dpipe_groupnorm_nhwc_bwd(const void* x, const void* dy, const void* gamma, const void* beta, const float* mean, const float* rstd,
                              void* dx, void* dgamma, void* dbeta, float* workspace, long N, int C, long HW, int G, int act, int dtype,
-                             int wdtype, int accumulate_params, void* stream);
+                             int wdtype, int accumulate_params, const void* dx_add, void* stream);   /* dx_add: as dpipe_lnmod_bwd's gx_add */
 
 /* ---- GroupNorm (+ fused SiLU) on NCHW activations: nn.GroupNorm(G, C) of the diffusers ResnetBlock2D / Transformer2DModel
  * behind models/sdxl.py:797-865 (and the SiLU that follows it in the resnets).  x, y, dy, dx: [N, C, HW] contiguous, HW a
@@ -169,7 +171,7 @@ int dpipe_groupnorm_fwd(const void* x, const void* gamma, const void* beta, void
                         void* stream);
 int dpipe_groupnorm_bwd(const void* x, const void* dy, const void* gamma, const void* beta, const float* mean,
                         const float* rstd, void* dx, void* dgamma, void* dbeta, float* workspace, long N, int C, long HW,
-                        int G, int act, int dtype, int wdtype, int accumulate_params, void* stream);
+                        int G, int act, int dtype, int wdtype, int accumulate_params, const void* dx_add, void* stream);   /* dx_add: as gx_add above */
 
 /* ---- K3 RoPE (models/wan/model.py:40-67 rope_apply; Flux/HunyuanVideo cos/sin tables) -------------------------
  * x, y: [B, S, H, D] contiguous; cos/sin: [S, D/2] fp32.  interleaved=1 rotates pairs (2i, 2i+1) (view_as_complex),

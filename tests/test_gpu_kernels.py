@@ -605,3 +605,40 @@ def test_group_norm_fused_silu(gpu, dtype, act, shape):
     finally:
         ops.FUSE_GRAD_ACCUM = False
     assert _rel_err(w.grad, 2 * wr.grad) < tol * 2 and _rel_err(b.grad, 2 * br.grad) < tol * 2
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-4), (torch.bfloat16, 3e-2)])
+def test_norms_fold_the_bypass_gradient_into_their_backward(gpu, dtype, tol):
+    """`with_skip`: y, x' = norm(x); out = f(y) + g(x').  x has one autograd consumer (the norm node) and the bypass gradient is
+    added inside the dx kernel (dpipe_lnmod_bwd gx_add / dpipe_groupnorm_bwd dx_add) -- same x.grad as the plain two-consumer graph."""
+    from diffusion_pipe_amd import ops
+    g = torch.Generator().manual_seed(3)
+    # LayerNorm + AdaLN modulation, [B, S, C]
+    x = torch.randn(2, 70, 128, generator=g)
+    gamma, beta = torch.randn(128, generator=g), torch.randn(128, generator=g)
+    scale, shift = torch.randn(2, 128, generator=g) * 0.1, torch.randn(2, 128, generator=g) * 0.1
+    wy, ws = torch.randn(2, 70, 128, generator=g), torch.randn(2, 70, 128, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (128,), gamma, beta, 1e-5) * (1 + scale[:, None]) + shift[:, None]
+    ((yr * wy).sum() + (xr * xr * ws).sum()).backward()
+    xg = x.to(gpu, dtype).requires_grad_(True)
+    y, xs = ops.layer_norm_modulate(xg, gamma.to(gpu, dtype), beta.to(gpu, dtype), scale.to(gpu, dtype), shift.to(gpu, dtype), 1e-5, with_skip=True)
+    assert xs.data_ptr() == xg.data_ptr()
+    ((y.float() * wy.to(gpu)).sum() + (xs.float() ** 2 * ws.to(gpu)).sum()).backward()
+    assert _rel_err(y, yr) < tol and _rel_err(xg.grad, xr.grad) < tol
+    # only the bypass is used: the gradient passes through untouched
+    xg2 = x.to(gpu, dtype).requires_grad_(True)
+    _, xs2 = ops.layer_norm_modulate(xg2, None, None, None, None, 1e-5, with_skip=True)
+    (xs2.float() * ws.to(gpu)).sum().backward()
+    assert _rel_err(xg2.grad, ws) < tol
+    # GroupNorm + SiLU, NCHW
+    x = torch.randn(2, 64, 12, 16, generator=g)
+    gw, gb = torch.randn(64, generator=g), torch.randn(64, generator=g)
+    wy, ws = torch.randn(2, 64, 12, 16, generator=g), torch.randn(2, 64, 12, 16, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = torch.nn.functional.silu(torch.nn.functional.group_norm(xr, 8, gw, gb, 1e-5))
+    ((yr * wy).sum() + (xr * ws).sum()).backward()
+    xg = x.to(gpu, dtype).requires_grad_(True)
+    y, xs = ops.group_norm(xg, 8, gw.to(gpu, dtype), gb.to(gpu, dtype), 1e-5, 'silu', with_skip=True)
+    ((y.float() * wy.to(gpu)).sum() + (xs.float() * ws.to(gpu)).sum()).backward()
+    assert _rel_err(y, yr) < tol and _rel_err(xg.grad, xr.grad) < tol
