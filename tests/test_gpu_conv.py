@@ -115,3 +115,18 @@ def test_group_norm_nhwc_vs_fp32(gpu, case, act, dtype):
     ptol = dict(rtol=2 ** -6, atol_rms=2 ** -6) if dtype == torch.bfloat16 else dict(rtol=1e-3, atol_rms=1e-4)
     _close(gn.weight.grad, wr.grad, 'dgamma', **ptol)
     _close(gn.bias.grad, br.grad, 'dbeta', **ptol)
+
+
+def test_group_norm_nhwc_skip_branch_gradient_is_added_in_the_backward_kernel(gpu):
+    from diffusion_pipe_amd import nn as dnn
+    torch.manual_seed(11)
+    gn = dnn.GroupNorm(32, 320).to(gpu, torch.bfloat16)
+    x = torch.randn(1, 320, 24, 24, device=gpu).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gy = torch.randn_like(x)
+    gs = torch.randn_like(x)
+    y, xs = gn(x, act='silu', with_skip=True)
+    torch.autograd.backward([y, xs], [gy, gs])
+    xr = x.detach().float().requires_grad_(True)
+    want = F.silu(F.group_norm(xr, 32, gn.weight.detach().float(), gn.bias.detach().float(), 1e-5))
+    want.backward(gy.float())
+    _close(x.grad, xr.grad + gs.float(), 'dx + skip gradient')
