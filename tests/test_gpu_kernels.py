@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 def _rel_err(a, b):
     """max |a-b| relative to the scale of the reference (floored so analytically-zero results compare absolutely)."""
-    a, b = a.float(), b.float()
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-3)).item()
 
 
