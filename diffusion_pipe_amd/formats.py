@@ -122,3 +122,182 @@ def save_flux_bfl(save_dir, diffusers_state_dict):
     save_dir = Path(save_dir)
     os.makedirs(save_dir, exist_ok=True)
     save_file({k: v.contiguous() for k, v in flux_diffusers_to_bfl(diffusers_state_dict).items()}, save_dir / 'model.safetensors', metadata={'format': 'pt'})
+
+
+# ------------------------------------------------------------------------------------------------ SDXL full fine-tune -> single-file (ldm) layout
+# models/sdxl.py:16-278 (the reference's copy of diffusers' convert_diffusers_to_original_sdxl.py) and its save_model (:489-525).  The
+# reference drives the renaming with ordered string replacement; here the diffusers names are parsed structurally (block / layer
+# indices), which gives the same names for every UNet / VAE / CLIP parameter (tests compare against the reference's own functions).
+_SDXL_UNET_TOP = {
+    'time_embedding.linear_1': 'time_embed.0', 'time_embedding.linear_2': 'time_embed.2', 'conv_in': 'input_blocks.0.0', 'conv_norm_out': 'out.0',
+    'conv_out': 'out.2', 'add_embedding.linear_1': 'label_emb.0.0', 'add_embedding.linear_2': 'label_emb.0.2',
+}
+_SDXL_RESNET_PARTS = {'norm1': 'in_layers.0', 'conv1': 'in_layers.2', 'norm2': 'out_layers.0', 'conv2': 'out_layers.3',
+                      'time_emb_proj': 'emb_layers.1', 'conv_shortcut': 'skip_connection'}
+
+
+def sdxl_unet_key_to_ldm(key):
+    """diffusers UNet2DConditionModel parameter name -> ldm `model.diffusion_model.*` name (without that prefix)."""
+    stem, _, leaf = key.rpartition('.')
+    if stem in _SDXL_UNET_TOP:
+        return f'{_SDXL_UNET_TOP[stem]}.{leaf}'
+
+    def resnet_tail(tail):
+        part, _, rest = tail.partition('.')
+        return f'{_SDXL_RESNET_PARTS.get(part, part)}.{rest}'
+    m = re.match(r'^down_blocks\.(\d+)\.(resnets|attentions)\.(\d+)\.(.*)$', key)
+    if m:
+        i, kind, j, tail = int(m[1]), m[2], int(m[3]), m[4]
+        return f'input_blocks.{3 * i + j + 1}.0.{resnet_tail(tail)}' if kind == 'resnets' else f'input_blocks.{3 * i + j + 1}.1.{tail}'
+    m = re.match(r'^down_blocks\.(\d+)\.downsamplers\.0\.conv\.(.*)$', key)
+    if m:
+        return f'input_blocks.{3 * (int(m[1]) + 1)}.0.op.{m[2]}'
+    m = re.match(r'^up_blocks\.(\d+)\.(resnets|attentions)\.(\d+)\.(.*)$', key)
+    if m:
+        i, kind, j, tail = int(m[1]), m[2], int(m[3]), m[4]
+        return f'output_blocks.{3 * i + j}.0.{resnet_tail(tail)}' if kind == 'resnets' else f'output_blocks.{3 * i + j}.1.{tail}'
+    m = re.match(r'^up_blocks\.(\d+)\.upsamplers\.0\.(.*)$', key)
+    if m:                                            # SDXL's up blocks 0 / 1 both carry attention, so the up-sampler is always sub-module 2
+        i, tail = int(m[1]), m[2]
+        sub = 2 if (i > 0 or tail.startswith('conv.')) else 1
+        return f'output_blocks.{3 * i + 2}.{sub}.{tail}'
+    m = re.match(r'^mid_block\.attentions\.0\.(.*)$', key)
+    if m:
+        return f'middle_block.1.{m[1]}'
+    m = re.match(r'^mid_block\.resnets\.(\d+)\.(.*)$', key)
+    if m:
+        return f'middle_block.{2 * int(m[1])}.{resnet_tail(m[2])}'
+    return key
+
+
+def sdxl_vae_key_to_ldm(key):
+    """diffusers AutoencoderKL parameter name -> ldm `first_stage_model.*` name (models/sdxl.py:183-226)."""
+    k = key
+    m = re.match(r'^(encoder|decoder)\.(down_blocks|up_blocks)\.(\d+)\.resnets\.(\d+)\.(.*)$', k)
+    if m:
+        side, i, j, tail = m[1], int(m[3]), int(m[4]), m[5]
+        k = f'{side}.down.{i}.block.{j}.{tail}' if m[2] == 'down_blocks' else f'{side}.up.{3 - i}.block.{j}.{tail}'
+    m = re.match(r'^(encoder|decoder)\.down_blocks\.(\d+)\.downsamplers\.0\.(.*)$', k)
+    if m:
+        k = f'{m[1]}.down.{m[2]}.downsample.{m[3]}'
+    m = re.match(r'^(encoder|decoder)\.up_blocks\.(\d+)\.upsamplers\.0\.(.*)$', k)
+    if m:
+        k = f'{m[1]}.up.{3 - int(m[2])}.upsample.{m[3]}'
+    m = re.match(r'^(encoder|decoder)\.mid_block\.resnets\.(\d+)\.(.*)$', k)
+    if m:
+        k = f'{m[1]}.mid.block_{int(m[2]) + 1}.{m[3]}'
+    k = k.replace('conv_shortcut', 'nin_shortcut').replace('conv_norm_out', 'norm_out')
+    if 'attentions' in key:
+        k = k.replace('mid_block.attentions.0.', 'mid.attn_1.')
+        for hf, sd in (('group_norm.', 'norm.'), ('to_q.', 'q.'), ('to_k.', 'k.'), ('to_v.', 'v.'), ('to_out.0.', 'proj_out.')):
+            k = k.replace(hf, sd)
+    return k
+
+
+def sdxl_vae_to_ldm(vae_state_dict):
+    out = {}
+    for key, v in vae_state_dict.items():
+        k = sdxl_vae_key_to_ldm(key)
+        if any(f'mid.attn_1.{w}.weight' in k for w in ('q', 'k', 'v', 'proj_out')) and v.ndim != 1:
+            v = v.reshape(*v.shape, 1, 1)            # HF linear attention weights -> the ldm VAE's 1x1 convolutions
+        out[k] = v
+    return out
+
+
+_OPENCLIP_RENAMES = (('text_model.encoder.layers.', 'transformer.resblocks.'), ('layer_norm1', 'ln_1'), ('layer_norm2', 'ln_2'), ('.fc1.', '.c_fc.'), ('.fc2.', '.c_proj.'),
+                     ('.self_attn', '.attn'), ('text_model.final_layer_norm.', 'ln_final.'), ('text_model.embeddings.token_embedding.weight', 'token_embedding.weight'),
+                     ('text_model.embeddings.position_embedding.weight', 'positional_embedding'))
+_OPENCLIP_RE = re.compile('|'.join(re.escape(hf) for hf, _ in _OPENCLIP_RENAMES))
+_OPENCLIP_MAP = dict(_OPENCLIP_RENAMES)
+
+
+def sdxl_openclip_to_ldm(text_enc_dict):
+    """HF CLIPTextModelWithProjection names -> open_clip names; q / k / v projections fuse into in_proj_weight / in_proj_bias (models/sdxl.py:228-272)."""
+    rename = lambda k: _OPENCLIP_RE.sub(lambda m: _OPENCLIP_MAP[m.group(0)], k)
+    out, fused = {}, {}
+    for k, v in text_enc_dict.items():
+        m = re.match(r'^(.*\.self_attn)\.([qkv])_proj\.(weight|bias)$', k)
+        if m:
+            fused.setdefault((m[1], m[3]), {})[m[2]] = v
+            continue
+        out[rename(k)] = v
+    for kind in ('weight', 'bias'):                  # the reference emits every fused weight before every fused bias
+        for (pre, what), parts in fused.items():
+            if what != kind:
+                continue
+            if set(parts) != set('qkv'):
+                raise RuntimeError('CORRUPTED MODEL: one of the q-k-v values for the text encoder was missing')
+            out[f'{rename(pre)}.in_proj_{what}'] = torch.cat([parts['q'], parts['k'], parts['v']])
+    return out
+
+
+def sdxl_diffusers_to_ldm(diffusers_sd, vae_state_dict=None):
+    """{'unet.*', 'text_encoder.*', 'text_encoder_2.*'} (parameters' original_name keys) -> single-file SDXL state dict (models/sdxl.py:489-523)."""
+    unet, te1, te2 = {}, {}, {}
+    for name, p in diffusers_sd.items():
+        if name.startswith('unet.'):
+            unet[name[len('unet.'):]] = p
+        elif name.startswith('text_encoder.'):
+            te1[name[len('text_encoder.'):]] = p
+        elif name.startswith('text_encoder_2.'):
+            te2[name[len('text_encoder_2.'):]] = p
+        else:
+            raise RuntimeError(f'Unexpected parameter: {name}')
+    out = {'model.diffusion_model.' + sdxl_unet_key_to_ldm(k): v for k, v in unet.items()}
+    if vae_state_dict is not None:
+        out.update({'first_stage_model.' + k: v for k, v in sdxl_vae_to_ldm(vae_state_dict).items()})
+    out.update({'conditioner.embedders.0.transformer.' + k: v for k, v in te1.items()})
+    te2 = {'conditioner.embedders.1.model.' + k: v for k, v in sdxl_openclip_to_ldm(te2).items()}
+    proj = 'conditioner.embedders.1.model.text_projection'
+    if proj + '.weight' in te2:
+        te2[proj] = te2.pop(proj + '.weight').T.contiguous()
+    out.update(te2)
+    return out
+
+
+def save_sdxl_ldm(save_dir, diffusers_sd, vae_state_dict=None):
+    save_dir = Path(save_dir)
+    os.makedirs(save_dir, exist_ok=True)
+    save_file({k: v.contiguous() for k, v in sdxl_diffusers_to_ldm(diffusers_sd, vae_state_dict).items()}, save_dir / 'model.safetensors', metadata={'format': 'pt'})
+
+
+# ------------------------------------------------------------------------------------------------ SDXL LoRA -> kohya file, Flux LoRA -> diffusers file
+def peft_to_kohya(peft_state_dict):
+    """peft LoRA names (adapter name stripped, `unet.` / `text_encoder.` / `text_encoder_2.` prefixes) -> kohya-ss names, the conversion the reference
+    reaches through diffusers.utils.state_dict_utils.convert_state_dict_to_kohya (models/sdxl.py:465-474; diffusers is absent offline: restated from
+    the published utility -- parity unpinned): lora_A / lora_B -> lora_down / lora_up, component prefix -> lora_unet / lora_te1 / lora_te2, every dot
+    but the last two -> '_', and one `<module>.alpha` = rank per lora_down."""
+    out = {}
+    for key, weight in peft_state_dict.items():
+        k = key
+        for hf, kohya in (('lora_A', 'lora_down'), ('lora_B', 'lora_up')):
+            if hf in k:
+                k = k.replace(hf, kohya)
+                break
+        if 'text_encoder_2.' in k:
+            k = k.replace('text_encoder_2.', 'lora_te2.')
+        elif 'text_encoder.' in k:
+            k = k.replace('text_encoder.', 'lora_te1.')
+        elif 'unet' in k:
+            k = k.replace('unet', 'lora_unet')
+        elif 'lora_magnitude_vector' in k:
+            k = k.replace('lora_magnitude_vector', 'dora_scale')
+        k = k.replace('.', '_', k.count('.') - 2)
+        out[k] = weight
+        if 'lora_down' in k:
+            out[f'{k.split(".")[0]}.alpha'] = torch.tensor(len(weight))
+    return out
+
+
+def save_sdxl_kohya_lora(save_dir, peft_state_dict):
+    save_dir = Path(save_dir)
+    os.makedirs(save_dir, exist_ok=True)
+    save_file({k: v.contiguous() for k, v in peft_to_kohya(peft_state_dict).items()}, save_dir / 'lora.safetensors', metadata={'format': 'pt'})
+
+
+def save_flux_diffusers_lora(save_dir, peft_state_dict):
+    """Flux LoRA file as diffusers' FluxPipeline.save_lora_weights(transformer_lora_layers=...) writes it (models/flux.py:231-236; diffusers absent
+    offline, restated: every key prefixed `transformer.`, file pytorch_lora_weights.safetensors) -- parity unpinned."""
+    save_dir = Path(save_dir)
+    os.makedirs(save_dir, exist_ok=True)
+    save_file({'transformer.' + k: v.contiguous() for k, v in peft_state_dict.items()}, save_dir / 'pytorch_lora_weights.safetensors', metadata={'format': 'pt'})

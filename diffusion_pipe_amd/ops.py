@@ -40,7 +40,13 @@ WS_LANE = None
 
 
 def _splitk_workspace(device):
-    key = (device.index, ('lane', WS_LANE) if WS_LANE is not None else torch.cuda.current_stream(device).cuda_stream)
+    cur = torch.cuda.current_stream(device)
+    if WS_LANE is not None:
+        # a lane's graph may fork wgrad onto the side stream (PARALLEL_WGRAD): the two parallel branches need separate ticket counters
+        side = _SIDE_STREAMS.get(device.index)
+        key = (device.index, ('lane', WS_LANE, 'side' if (side is not None and cur == side) else 'main'))
+    else:
+        key = (device.index, cur.cuda_stream)
     ws = _SPLITK_WS.get(key)
     if ws is None:
         ws = torch.zeros(_SPLITK_WS_BYTES, dtype=torch.uint8, device=device)

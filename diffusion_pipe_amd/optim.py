@@ -63,7 +63,9 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
 
     def _buckets(self, lane_grads_of):
-        """[(group, dtype, params, exp_avgs, exp_avg_sqs, lanes)] over parameters that have a gradient."""
+        """[(group, dtype, step, params, exp_avgs, exp_avg_sqs, lanes)] over parameters that have a gradient; parameters of one group are
+        bucketed by dtype AND by their own step count (torch.optim.AdamW keeps the bias correction per parameter: a parameter that first
+        receives a gradient on a later step, or joins a group after a resume, must not borrow its neighbours' step)."""
         out = []
         for group in self.param_groups:
             by_dtype = {}
@@ -76,7 +78,7 @@ class FusedAdamW(torch.optim.Optimizer):
                     st['step'] = 0.0
                     st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)      # channels-last conv weights keep their layout
                     st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                b = by_dtype.setdefault(p.dtype, ([], [], [], [[] for _ in lanes]))
+                b = by_dtype.setdefault((p.dtype, float(st['step'])), ([], [], [], [[] for _ in lanes]))
                 dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
                 if not dense:
                     raise RuntimeError('FusedAdamW needs dense (row-major or channels-last) parameters')
@@ -85,7 +87,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 b[2].append(st['exp_avg_sq'])
                 for lane_list, g in zip(b[3], lanes):
                     lane_list.append(g)
-            out += [(group, dt, *b) for dt, b in by_dtype.items()]
+            out += [(group, dt, step, *b) for (dt, step), b in by_dtype.items()]
         return out
 
     @staticmethod
@@ -112,7 +114,7 @@ class FusedAdamW(torch.optim.Optimizer):
             inner = of
             of = lambda p: inner(p) if only(p) else None
         total = None
-        for _, _, ps, ms, vs, lanes in self._buckets(of):
+        for _, _, _, ps, ms, vs, lanes in self._buckets(of):
             if total is None:
                 total = torch.empty((), device=ps[0].device, dtype=torch.float32)
                 ops.adamw_grads_sumsq(ps, ms, vs, lanes, total, accumulate=False)
@@ -123,16 +125,10 @@ class FusedAdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def fused_update(self, lane_grads=None, total_sumsq=None, max_norm=0.0, zero_grads=True):
         from . import ops
-        for group, _, ps, ms, vs, lanes in self._buckets(self._lanes_from(lane_grads)):
-            step = None
+        for group, _, step, ps, ms, vs, lanes in self._buckets(self._lanes_from(lane_grads)):
             beta1, beta2 = group['betas']
-            for p in group['params']:
-                st = self.state.get(p)
-                if st and 'step' in st:
-                    step = float(st['step']) + 1.0 if step is None else step
-                    break
             ops.adamw_step(ps, ms, vs, lanes, lr=group['lr'], beta1=beta1, beta2=beta2, eps=group['eps'], weight_decay=group['weight_decay'],
-                           step=step, total_sumsq=total_sumsq, max_norm=max_norm, zero_grads=zero_grads)
+                           step=step + 1.0, total_sumsq=total_sumsq, max_norm=max_norm, zero_grads=zero_grads)
         of = self._lanes_from(lane_grads)
         for group in self.param_groups:
             for p in group['params']:

@@ -413,6 +413,11 @@ class FluxWorkload:
         return [{'params': list(parameters)}]
 
     # ---- saved files (models/flux.py:231-290)
+    def save_adapter(self, save_dir, peft_state_dict):
+        """LoRA -> diffusers-format pytorch_lora_weights.safetensors."""
+        from ..formats import save_flux_diffusers_lora
+        save_flux_diffusers_lora(save_dir, peft_state_dict)
+
     def save_model(self, save_dir, diffusers_sd):
         """Full fine-tune -> one BFL-layout model.safetensors."""
         from ..formats import save_flux_bfl

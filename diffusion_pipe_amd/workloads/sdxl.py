@@ -520,6 +520,17 @@ class SDXLWorkload:
                 p.original_name = f'{prefix}.{n}'
         return wrapped
 
+    # ---- saved files (models/sdxl.py:465-525)
+    def save_adapter(self, save_dir, peft_state_dict):
+        """LoRA -> kohya-format lora.safetensors."""
+        from ..formats import save_sdxl_kohya_lora
+        save_sdxl_kohya_lora(save_dir, peft_state_dict)
+
+    def save_model(self, save_dir, diffusers_sd, vae_state_dict=None):
+        """Full fine-tune -> single-file SDXL checkpoint (UNet, both text encoders; the VAE -- not part of the training step here -- when given)."""
+        from ..formats import save_sdxl_ldm
+        save_sdxl_ldm(save_dir, diffusers_sd, vae_state_dict)
+
     def to_layers(self):
         unet = self.unet
         layers = [InitialLayer(unet, self.text_encoder, self.text_encoder_2)]

@@ -49,8 +49,67 @@ def wan_lora_state_dict():
     return sd
 
 
+def sdxl_state_dict():
+    """{original_name: tensor} of a tiny SDXL (same module tree / parameter names as diffusers' UNet2DConditionModel + both CLIP encoders)."""
+    from diffusion_pipe_amd.workloads import sdxl
+    work = sdxl.SDXLWorkload(sdxl.tiny_config(), dtype=torch.float32, seed=21)
+    return {p.original_name: p.detach().clone().contiguous() for m in work.modules().values() for p in m.parameters()}
+
+
+def fake_vae_state_dict():
+    """diffusers AutoencoderKL parameter NAMES touching every renaming rule of models/sdxl.py:183-226 (tiny seeded tensors)."""
+    g = torch.Generator().manual_seed(22)
+    names = []
+    for side, blocks, nres in (('encoder', 'down_blocks', 2), ('decoder', 'up_blocks', 3)):
+        for i in range(4):
+            for j in range(nres):
+                for leaf in ('norm1.weight', 'conv1.weight', 'conv1.bias', 'norm2.bias', 'conv2.weight'):
+                    names.append(f'{side}.{blocks}.{i}.resnets.{j}.{leaf}')
+            names.append(f'{side}.{blocks}.{i}.resnets.0.conv_shortcut.weight')
+            if i < 3:
+                names.append(f'{side}.{blocks}.{i}.{"downsamplers" if side == "encoder" else "upsamplers"}.0.conv.weight')
+        for j in range(2):
+            names += [f'{side}.mid_block.resnets.{j}.norm1.weight', f'{side}.mid_block.resnets.{j}.conv2.bias']
+        names += [f'{side}.mid_block.attentions.0.group_norm.weight', f'{side}.mid_block.attentions.0.group_norm.bias']
+        for proj in ('to_q', 'to_k', 'to_v', 'to_out.0'):
+            names += [f'{side}.mid_block.attentions.0.{proj}.weight', f'{side}.mid_block.attentions.0.{proj}.bias']
+        names += [f'{side}.conv_in.weight', f'{side}.conv_norm_out.weight', f'{side}.conv_out.bias']
+    names += ['quant_conv.weight', 'post_quant_conv.bias']
+    sd = {}
+    for n in names:
+        shape = (8, 8) if ('to_' in n and n.endswith('weight')) else ((8, 4, 3, 3) if n.endswith('conv.weight') or 'conv1.weight' in n or 'conv2.weight' in n else (8,))
+        sd[n] = torch.randn(shape, generator=g)
+    return sd
+
+
+def sdxl_peft_state_dict():
+    """peft-style LoRA tensors of the tiny SDXL as utils/saver.py:66-75 hands them to save_adapter."""
+    from diffusion_pipe_amd.workloads import sdxl
+    work = sdxl.SDXLWorkload(sdxl.tiny_config(), dtype=torch.float32, seed=23)
+    work.configure_adapter({'type': 'lora', 'rank': 4, 'alpha': 4})
+    g = torch.Generator().manual_seed(24)
+    return {p.original_name.replace('.default', ''): torch.randn(p.shape, generator=g)
+            for m in work.modules().values() for p in m.parameters() if p.requires_grad}
+
+
 def main():
     gold = {'torch': torch.__version__, 'safetensors': safetensors.__version__}
+    # ---- SDXL full fine-tune -> single-file (ldm) checkpoint: the reference's save_model with its module-level conversion tables / functions
+    full = os.path.join(REF, 'models', 'sdxl.py')
+    tree = ast.parse(open(full).read(), filename=full)
+    first = next(n.lineno for n in tree.body if isinstance(n, ast.Assign) and any(isinstance(t, ast.Name) and t.id == 'unet_conversion_map' for t in n.targets))
+    last = next(n.end_lineno for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == 'convert_openai_text_enc_state_dict')
+    nodes = [n for n in tree.body if first <= n.lineno and n.end_lineno <= last]
+    ns = {'torch': torch, 're': re, 'save_file': save_file, 'print': lambda *a, **k: None}
+    exec(compile(ast.Module(body=nodes, type_ignores=[]), full, 'exec'), ns)
+    sdxl_save_model, where = lift('models/sdxl.py', 'save_model', cls='SDXLPipeline', namespace=ns)
+    with tempfile.TemporaryDirectory() as d:
+        vae = fake_vae_state_dict()
+        stub = type('S', (), {'vae': type('V', (), {'state_dict': staticmethod(lambda: vae)})()})()
+        sdxl_save_model(stub, Path(d), sdxl_state_dict())
+        f = os.path.join(d, 'model.safetensors')
+        sd = load_file(f)
+        gold['sdxl_ldm'] = {'generated_from': f'models/sdxl.py:{first}-{last} + {where}', 'sha256': sha(f), 'keys': {k: list(v.shape) for k, v in sorted(sd.items())}}
     # ---- Flux full fine-tune -> BFL file
     full = os.path.join(REF, 'models', 'flux.py')
     tree = ast.parse(open(full).read(), filename=full)

@@ -71,3 +71,55 @@ def test_wan_adapter_and_model_files(tmp_path):
         (tmp_path / 'b').mkdir()
         os.replace(tmp_path / 'bad.safetensors', tmp_path / 'b' / 'bad.safetensors')
         work.load_adapter_weights(tmp_path / 'b')
+
+
+def test_sdxl_full_model_is_written_in_the_single_file_ldm_layout(tmp_path):
+    """SDXLWorkload.save_model vs the reference's own save_model + conversion tables (models/sdxl.py:24-276,487-525, lifted): same key set,
+    same shapes, byte-identical file for UNet + VAE + both text encoders (fused open_clip in_proj, transposed text_projection)."""
+    from oracle.make_golden_formats import fake_vae_state_dict, sdxl_state_dict
+    from diffusion_pipe_amd.workloads import sdxl
+    sd, vae = sdxl_state_dict(), fake_vae_state_dict()
+    work = sdxl.SDXLWorkload(sdxl.tiny_config(), dtype=torch.float32, seed=21)
+    work.save_model(tmp_path, sd, vae_state_dict=vae)
+    got = load_file(tmp_path / 'model.safetensors')
+    assert {k: list(v.shape) for k, v in sorted(got.items())} == G['sdxl_ldm']['keys']
+    assert torch.equal(got['model.diffusion_model.input_blocks.4.0.in_layers.2.weight'], sd['unet.down_blocks.1.resnets.0.conv1.weight'])
+    assert torch.equal(got['model.diffusion_model.output_blocks.2.2.conv.weight'], sd['unet.up_blocks.0.upsamplers.0.conv.weight'])
+    assert torch.equal(got['conditioner.embedders.1.model.transformer.resblocks.1.attn.in_proj_bias'],
+                       torch.cat([sd[f'text_encoder_2.text_model.encoder.layers.1.self_attn.{x}_proj.bias'] for x in 'qkv']))
+    assert torch.equal(got['conditioner.embedders.1.model.text_projection'], sd['text_encoder_2.text_projection.weight'].T)
+    assert got['first_stage_model.encoder.mid.attn_1.q.weight'].shape == (8, 8, 1, 1)
+    if same_build:
+        assert _sha(tmp_path / 'model.safetensors') == G['sdxl_ldm']['sha256']
+    with pytest.raises(RuntimeError):
+        formats.sdxl_diffusers_to_ldm({'vae.x': torch.zeros(1)})
+
+
+def test_sdxl_and_flux_adapter_files(tmp_path):
+    """kohya LoRA naming (restated from diffusers' published convert_state_dict_to_kohya; diffusers absent -> parity unpinned): structure checks."""
+    from oracle.make_golden_formats import sdxl_peft_state_dict
+    from diffusion_pipe_amd.workloads import flux, sdxl
+    peft_sd = sdxl_peft_state_dict()
+    work = sdxl.SDXLWorkload(sdxl.tiny_config(), dtype=torch.float32, seed=23)
+    work.save_adapter(tmp_path / 'k', peft_sd)
+    got = load_file(tmp_path / 'k' / 'lora.safetensors')
+    downs = [k for k in got if k.endswith('.lora_down.weight')]
+    assert len(downs) * 2 == len(peft_sd) and len(got) == 3 * len(downs)                      # down, up, alpha per wrapped Linear
+    assert {k.split('_')[0] + '_' + k.split('_')[1] for k in got} == {'lora_unet', 'lora_te1', 'lora_te2'}
+    key = 'unet.down_blocks.1.attentions.0.transformer_blocks.0.attn1.to_q.lora_A.weight'
+    want = 'lora_unet_down_blocks_1_attentions_0_transformer_blocks_0_attn1_to_q'
+    assert torch.equal(got[want + '.lora_down.weight'], peft_sd[key]) and torch.equal(got[want + '.lora_up.weight'], peft_sd[key.replace('lora_A', 'lora_B')])
+    assert got[want + '.alpha'].item() == 4 and got[want + '.alpha'].dtype == torch.int64
+    assert 'lora_te2_text_model_encoder_layers_0_self_attn_q_proj.lora_down.weight' in got
+    assert all(k.count('.') <= 2 for k in got)
+    fwork = flux.FluxWorkload(flux.tiny_flux_config(), dtype=torch.float32)
+    lora = {'transformer_blocks.0.attn.to_q.lora_A.weight': torch.randn(4, 8), 'transformer_blocks.0.attn.to_q.lora_B.weight': torch.randn(8, 4)}
+    fwork.save_adapter(tmp_path / 'f', lora)
+    got = load_file(tmp_path / 'f' / 'pytorch_lora_weights.safetensors')
+    assert sorted(got) == sorted('transformer.' + k for k in lora)
+
+
+def test_saver_rejects_an_adapter_without_save_methods_before_training(tmp_path):
+    from diffusion_pipe_amd.saver import Saver
+    with pytest.raises(NotImplementedError):
+        Saver(None, {}, True, tmp_path, object(), None, None, None)

@@ -110,3 +110,23 @@ def test_engine_lanes_with_fused_step_end_match_torch_adamw_path(gpu):
     assert l1[2] < l1[0] and l0[2] < l0[0]                                                         # both trajectories descend
     for a, b in zip(l1 + n1, l0 + n0):
         assert a == pytest.approx(b, rel=3e-2)
+
+
+def test_fused_adamw_keeps_the_bias_correction_per_parameter(gpu):
+    """A parameter that first receives a gradient on a later step uses ITS step count (torch.optim.AdamW semantics), not its group's."""
+    from diffusion_pipe_amd.optim import FusedAdamW
+    mine = _params(torch.float32, gpu, seed=9)[:3]
+    ref = [torch.nn.Parameter(p.detach().cpu().clone()) for p in mine]
+    kw = dict(lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.01)
+    opt, ropt = FusedAdamW(mine, **kw), torch.optim.AdamW(ref, foreach=False, **kw)
+    g = torch.Generator().manual_seed(2)
+    for step in range(4):
+        for i, (p, r) in enumerate(zip(mine, ref)):
+            late = i == 1 and step < 2                       # parameter 1 joins at step 2
+            r.grad = None if late else torch.randn(r.shape, generator=g)
+            p.grad = None if late else r.grad.to(gpu)
+        opt.step()
+        ropt.step()
+    assert [opt.state[p]['step'] for p in mine] == [4.0, 2.0, 4.0]
+    for p, r in zip(mine, ref):
+        assert torch.allclose(p.detach().cpu(), r.detach(), rtol=2e-6, atol=1e-7)
