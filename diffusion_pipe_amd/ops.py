@@ -958,7 +958,7 @@ class _UnfusedAttnFn(Function):
     on-device cross-check of the flash kernel).  Materialises the [B, H, Sq, Sk] score matrix."""
 
     @staticmethod
-    def forward(ctx, q, k, v, scale, causal):
+    def forward(ctx, q, k, v, scale, causal, kv_len=None):
         require_cuda(q, k, v)
         B, Sq, H, D = q.shape
         Sk = k.shape[1]
@@ -971,6 +971,8 @@ class _UnfusedAttnFn(Function):
         gemm(q, k, False, True, Sq, Sk, D, p, lda=H * D, ldb=H * D, ldc=Skp, batch_outer=B, batch_inner=H,
              stride_a=sq, stride_b=sk, stride_c=sp)
         dt = dtype_code(q.dtype)
+        if kv_len is not None:      # keys past the valid count leave the softmax (exact-parity mode only: one ATen fill on the score matrix)
+            p.masked_fill_(torch.arange(Skp, device=q.device).view(1, 1, 1, Skp) >= kv_len.view(B, 1, 1, 1), float('-inf'))
         check(lib().dpipe_softmax_fwd(ptr(p), ptr(p), B * H * Sq, Sk, Skp, float(scale), Sq if causal else 0, dt, stream()), 'softmax_fwd')
         gemm(p, v, False, False, Sq, D, Sk, o, lda=Skp, ldb=H * D, ldc=H * D, batch_outer=B, batch_inner=H,
              stride_a=sp, stride_b=sk, stride_c=sq)
@@ -994,7 +996,7 @@ class _UnfusedAttnFn(Function):
         check(lib().dpipe_softmax_bwd(ptr(p), ptr(dp), ptr(dp), B * H * Sq, Sk, Skp, float(ctx.scale), dtype_code(q.dtype), stream()), 'softmax_bwd')
         gemm(dp, k, False, False, Sq, D, Sk, dq, lda=Skp, ldb=H * D, ldc=H * D, stride_a=sp, stride_b=sk, stride_c=sq, **kw)
         gemm(dp, q, True, False, Sk, D, Sq, dk, lda=Skp, ldb=H * D, ldc=H * D, stride_a=sp, stride_b=sq, stride_c=sk, **kw)
-        return dq, dk, dv, None, None
+        return dq, dk, dv, None, None, None
 
 
 ATTN_TRACE = None     # like GEMM_TRACE: (B, Sq, Sk, H, D, causal) of every attention call of a step
@@ -1014,9 +1016,7 @@ def attention(q, k, v, kv_len=None, scale=None, impl='auto', causal=False):
         if kv_len is not None and kv_len.dtype != torch.int32:
             kv_len = kv_len.to(torch.int32)
         return _FlashAttnFn.apply(q, k, v, kv_len, scale, causal)
-    if kv_len is not None:
-        raise DpipeHipError('the unfused attention path has no key-length masking')
-    return _UnfusedAttnFn.apply(q, k, v, scale, causal)
+    return _UnfusedAttnFn.apply(q, k, v, scale, causal, kv_len)
 
 
 # ------------------------------------------------------------------------------------------------- loss (K9)
