@@ -269,6 +269,15 @@ class InitialLayer(nn.Module):
         self.time_in, self.vector_in = transformer.time_in, transformer.vector_in
         self.guidance_embed, self.guidance_in = transformer.guidance_embed, transformer.guidance_in
         self.img_in, self.text_projection, self.txt_in = transformer.img_in, transformer.text_projection, transformer.txt_in
+        self._consts = {}
+
+    def _const(self, values, device):
+        """small integer tensors of the stage tuple (token counts, unpatchify grid): built once per value (a host -> device copy cannot be
+        captured into a hipGraph) and constant for a given input shape"""
+        key = (tuple(values) if isinstance(values, (tuple, list)) else values, str(device))
+        if key not in self._consts:
+            self._consts[key] = torch.tensor(values, device=device)
+        return self._consts[key]
 
     def forward(self, inputs):
         for item in inputs:
@@ -278,7 +287,7 @@ class InitialLayer(nn.Module):
         tr = self.transformer[0]
         _, _, ot, oh, ow = x.shape
         tt, th, tw = ot // tr.patch_size[0], oh // tr.patch_size[1], ow // tr.patch_size[2]
-        unpatchify_args = torch.tensor([tt, th, tw], device=x.device)
+        unpatchify_args = self._const([tt, th, tw], x.device)
         assert freqs_cos.ndim == 3
         freqs_cos, freqs_sin = freqs_cos[0], freqs_sin[0]
         dt = self.vector_in.in_layer.weight.dtype
@@ -296,9 +305,9 @@ class InitialLayer(nn.Module):
             raise NotImplementedError(f'Unsupported text_projection: {self.text_projection}')
         txt_seq_len, img_seq_len = txt.shape[1], img.shape[1]
         cu_seqlens = get_cu_seqlens(text_mask, img_seq_len)
-        txt_seq_len = torch.tensor(txt_seq_len, device=img.device)
-        img_seq_len = torch.tensor(img_seq_len, device=img.device)
-        max_seqlen = img_seq_len + txt_seq_len
+        max_seqlen = self._const(img_seq_len + txt_seq_len, img.device)
+        txt_seq_len = self._const(txt_seq_len, img.device)
+        img_seq_len = self._const(img_seq_len, img.device)
         return make_contiguous(img, txt, vec, cu_seqlens, max_seqlen, freqs_cos, freqs_sin, txt_seq_len, img_seq_len, unpatchify_args)
 
 
