@@ -81,9 +81,21 @@ __device__ __forceinline__ void adamw_update(float& p, float& m, float& v, float
     p -= (h.lr / h.bias_c1) * m / denom;
 }
 
+// Kahan (compensated) application of an update to a low-precision parameter, the reference's sequence with every intermediate rounded to the
+// parameter dtype (optimizers/generic_optim.py:486-497): shift += update; old = p; p += shift; shift += old - p.  In: p = the fp32 result of the
+// plain update of `old`; out: p = the stored parameter value, shift = the new compensation.
+template <typename T>
+__device__ __forceinline__ void kahan_apply(float& p, float& shift, float old) {
+    auto rnd = [](float x) { return Elem<T>::to_f(Elem<T>::from_f(x)); };
+    const float s = rnd(shift + rnd(p - old));
+    const float pn = rnd(old + s);
+    shift = rnd(s + rnd(old - pn));
+    p = pn;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(OPT_BLOCK) adamw_step_kernel(void* const* __restrict__ p_ptrs, void* const* __restrict__ m_ptrs, void* const* __restrict__ v_ptrs,
-                                                              void* const* __restrict__ g_ptrs, int lanes, const int* __restrict__ chunk_tensor,
+                                                              void* const* __restrict__ s_ptrs, void* const* __restrict__ g_ptrs, int lanes, const int* __restrict__ chunk_tensor,
                                                               const long* __restrict__ chunk_off, const int* __restrict__ chunk_len,
                                                               const float* __restrict__ total_sumsq, AdamHyper h, int zero_grads) {
     constexpr int V = Elem<T>::VEC;
@@ -94,8 +106,9 @@ __global__ void __launch_bounds__(OPT_BLOCK) adamw_step_kernel(void* const* __re
     T* p = reinterpret_cast<T*>(p_ptrs[t]) + off;
     T* m = reinterpret_cast<T*>(m_ptrs[t]) + off;
     T* v = reinterpret_cast<T*>(v_ptrs[t]) + off;
+    T* sh = s_ptrs ? reinterpret_cast<T*>(s_ptrs[t]) + off : nullptr;      // Kahan compensation buffer (optimizers/generic_optim.py:486-497), parameter dtype
     T* g[MAX_LANES];
-    bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(sh)) & 15) == 0;
     for (int l = 0; l < lanes; ++l) {
         g[l] = reinterpret_cast<T*>(g_ptrs[(long)t * lanes + l]) + off;
         aligned = aligned && ((reinterpret_cast<uintptr_t>(g[l]) & 15) == 0);
@@ -120,8 +133,16 @@ __global__ void __launch_bounds__(OPT_BLOCK) adamw_step_kernel(void* const* __re
             pv.load(p + e); mv.load(m + e); vv.load(v + e);
             float pf[V], mf[V], vf[V];
             pv.unpack(pf); mv.unpack(mf); vv.unpack(vf);
+            if (sh) {
+                Vec16<T> sv; sv.load(sh + e);
+                float sf[V]; sv.unpack(sf);
 #pragma unroll
-            for (int j = 0; j < V; ++j) adamw_update(pf[j], mf[j], vf[j], gs[j] * coef, h);
+                for (int j = 0; j < V; ++j) { const float old = pf[j]; adamw_update(pf[j], mf[j], vf[j], gs[j] * coef, h); kahan_apply<T>(pf[j], sf[j], old); }
+                sv.pack(sf); sv.store(sh + e);
+            } else {
+#pragma unroll
+                for (int j = 0; j < V; ++j) adamw_update(pf[j], mf[j], vf[j], gs[j] * coef, h);
+            }
             pv.pack(pf); mv.pack(mf); vv.pack(vf);
             pv.store(p + e); mv.store(m + e); vv.store(v + e);
         }
@@ -134,7 +155,9 @@ __global__ void __launch_bounds__(OPT_BLOCK) adamw_step_kernel(void* const* __re
             if (zero_grads) g[l][i] = Elem<T>::from_f(0.f);
         }
         float pf = Elem<T>::to_f(p[i]), mf = Elem<T>::to_f(m[i]), vf = Elem<T>::to_f(v[i]);
+        const float old = pf;
         adamw_update(pf, mf, vf, gs * coef, h);
+        if (sh) { float sf = Elem<T>::to_f(sh[i]); kahan_apply<T>(pf, sf, old); sh[i] = Elem<T>::from_f(sf); }
         p[i] = Elem<T>::from_f(pf); m[i] = Elem<T>::from_f(mf); v[i] = Elem<T>::from_f(vf);
     }
 }
@@ -159,10 +182,10 @@ int dpipe_adamw_sumsq(const void* const* g_ptrs, int lanes, const int* chunk_ten
     return check_launch("dpipe_adamw_sumsq");
 }
 
-int dpipe_adamw_step(void* const* p_ptrs, void* const* m_ptrs, void* const* v_ptrs, void* const* g_ptrs, int lanes, const int* chunk_tensor,
-                     const long* chunk_off, const int* chunk_len, int nchunks, int dtype, float lr, float beta1, float beta2, float eps,
-                     float weight_decay, float bias_correction1, float bias_correction2, const float* total_sumsq, float max_norm,
-                     int zero_grads, void* stream) {
+static int adamw_step_impl(void* const* p_ptrs, void* const* m_ptrs, void* const* v_ptrs, void* const* s_ptrs, void* const* g_ptrs, int lanes, const int* chunk_tensor,
+                           const long* chunk_off, const int* chunk_len, int nchunks, int dtype, float lr, float beta1, float beta2, float eps,
+                           float weight_decay, float bias_correction1, float bias_correction2, const float* total_sumsq, float max_norm,
+                           int zero_grads, void* stream) {
     if (nchunks <= 0) return DPIPE_OK;
     if (!p_ptrs || !m_ptrs || !v_ptrs || !g_ptrs || !chunk_tensor || !chunk_off || !chunk_len || lanes < 1 || lanes > MAX_LANES ||
         bias_correction1 <= 0.f || bias_correction2 <= 0.f) {
@@ -171,11 +194,28 @@ int dpipe_adamw_step(void* const* p_ptrs, void* const* m_ptrs, void* const* v_pt
     AdamHyper h{lr, beta1, beta2, eps, weight_decay, bias_correction1, sqrtf(bias_correction2), max_norm};
     hipStream_t s = STREAM(stream);
     if (dtype == DPIPE_BF16)
-        adamw_step_kernel<bf16_t><<<nchunks, OPT_BLOCK, 0, s>>>(p_ptrs, m_ptrs, v_ptrs, g_ptrs, lanes, chunk_tensor, chunk_off, chunk_len, total_sumsq, h, zero_grads);
+        adamw_step_kernel<bf16_t><<<nchunks, OPT_BLOCK, 0, s>>>(p_ptrs, m_ptrs, v_ptrs, s_ptrs, g_ptrs, lanes, chunk_tensor, chunk_off, chunk_len, total_sumsq, h, zero_grads);
     else if (dtype == DPIPE_F32)
-        adamw_step_kernel<float><<<nchunks, OPT_BLOCK, 0, s>>>(p_ptrs, m_ptrs, v_ptrs, g_ptrs, lanes, chunk_tensor, chunk_off, chunk_len, total_sumsq, h, zero_grads);
+        adamw_step_kernel<float><<<nchunks, OPT_BLOCK, 0, s>>>(p_ptrs, m_ptrs, v_ptrs, s_ptrs, g_ptrs, lanes, chunk_tensor, chunk_off, chunk_len, total_sumsq, h, zero_grads);
     else { set_last_error("dpipe_adamw_step: dtype"); return DPIPE_ERR_UNSUPPORTED; }
     return check_launch("dpipe_adamw_step");
+}
+
+int dpipe_adamw_step(void* const* p_ptrs, void* const* m_ptrs, void* const* v_ptrs, void* const* g_ptrs, int lanes, const int* chunk_tensor,
+                     const long* chunk_off, const int* chunk_len, int nchunks, int dtype, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, float bias_correction1, float bias_correction2, const float* total_sumsq, float max_norm,
+                     int zero_grads, void* stream) {
+    return adamw_step_impl(p_ptrs, m_ptrs, v_ptrs, nullptr, g_ptrs, lanes, chunk_tensor, chunk_off, chunk_len, nchunks, dtype, lr, beta1, beta2, eps, weight_decay,
+                           bias_correction1, bias_correction2, total_sumsq, max_norm, zero_grads, stream);
+}
+
+int dpipe_adamw_step_kahan(void* const* p_ptrs, void* const* m_ptrs, void* const* v_ptrs, void* const* shift_ptrs, void* const* g_ptrs, int lanes,
+                           const int* chunk_tensor, const long* chunk_off, const int* chunk_len, int nchunks, int dtype, float lr, float beta1, float beta2,
+                           float eps, float weight_decay, float bias_correction1, float bias_correction2, const float* total_sumsq, float max_norm,
+                           int zero_grads, void* stream) {
+    if (nchunks > 0 && !shift_ptrs) { set_last_error("dpipe_adamw_step_kahan: null shift table"); return DPIPE_ERR_ARG; }
+    return adamw_step_impl(p_ptrs, m_ptrs, v_ptrs, shift_ptrs, g_ptrs, lanes, chunk_tensor, chunk_off, chunk_len, nchunks, dtype, lr, beta1, beta2, eps, weight_decay,
+                           bias_correction1, bias_correction2, total_sumsq, max_norm, zero_grads, stream);
 }
 
 }  // extern "C"

@@ -1122,10 +1122,11 @@ def grads_clip_scale_(grads, total_sumsq, max_norm):
 _adam_tables = {}
 
 
-def _adam_table(params, exp_avgs, exp_avg_sqs, lane_grads):
+def _adam_table(params, exp_avgs, exp_avg_sqs, lane_grads, shifts=None):
     """Device pointer / chunk tables of one (dtype, param group); cached on the buffer addresses (persistent in the graph path)."""
     L = len(lane_grads)
-    key = tuple(t.data_ptr() for t in params) + tuple(t.data_ptr() for t in exp_avgs) + tuple(g.data_ptr() for lane in lane_grads for g in lane)
+    key = tuple(t.data_ptr() for t in params) + tuple(t.data_ptr() for t in exp_avgs) + tuple(g.data_ptr() for lane in lane_grads for g in lane) \
+        + (tuple(t.data_ptr() for t in shifts) if shifts is not None else ())
     hit = _adam_tables.get(key)
     if hit is not None:
         return hit
@@ -1140,7 +1141,8 @@ def _adam_table(params, exp_avgs, exp_avg_sqs, lane_grads):
              'g': i64([lane_grads[l][i].data_ptr() for i in range(len(params)) for l in range(L)]),
              'ctens': torch.tensor(ctens, dtype=torch.int32, device=dev), 'coff': i64(coff),
              'clen': torch.tensor(clen, dtype=torch.int32, device=dev), 'n': len(ctens),
-             'partials': torch.empty(max(len(ctens), 1), device=dev, dtype=torch.float32), 'keep': (params, exp_avgs, exp_avg_sqs, lane_grads)}
+             'partials': torch.empty(max(len(ctens), 1), device=dev, dtype=torch.float32), 'keep': (params, exp_avgs, exp_avg_sqs, lane_grads, shifts),
+             's': i64([t.data_ptr() for t in shifts]) if shifts is not None else None}
     if len(_adam_tables) > 64:
         _adam_tables.clear()
     _adam_tables[key] = table
@@ -1174,14 +1176,20 @@ def adamw_grads_sumsq(params, exp_avgs, exp_avg_sqs, lane_grads, out, accumulate
 
 
 def adamw_step(params, exp_avgs, exp_avg_sqs, lane_grads, *, lr, beta1, beta2, eps, weight_decay, step, total_sumsq=None, max_norm=0.0,
-               zero_grads=True):
-    """One fused pass over a same-dtype group: g = clip * sum_lanes g; AdamW update in fp32; lanes zeroed."""
+               zero_grads=True, shifts=None):
+    """One fused pass over a same-dtype group: g = clip * sum_lanes g; AdamW update in fp32; lanes zeroed.  shifts: the parameters' Kahan
+    compensation buffers (optimizers/generic_optim.py:486-497) -> compensated application of the update."""
     dt = _adam_check(params, exp_avgs, exp_avg_sqs, lane_grads)
-    t = _adam_table(params, exp_avgs, exp_avg_sqs, lane_grads)
-    check(lib().dpipe_adamw_step(ptr(t['p']), ptr(t['m']), ptr(t['v']), ptr(t['g']), len(lane_grads), ptr(t['ctens']), ptr(t['coff']), ptr(t['clen']),
-                                 t['n'], dtype_code(dt), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
-                                 float(1.0 - beta1 ** step), float(1.0 - beta2 ** step), ptr(total_sumsq), float(max_norm), int(zero_grads),
-                                 stream()), 'adamw_step')
+    t = _adam_table(params, exp_avgs, exp_avg_sqs, lane_grads, shifts)
+    tail = (len(lane_grads), ptr(t['ctens']), ptr(t['coff']), ptr(t['clen']), t['n'], dtype_code(dt), float(lr), float(beta1), float(beta2), float(eps),
+            float(weight_decay), float(1.0 - beta1 ** step), float(1.0 - beta2 ** step), ptr(total_sumsq), float(max_norm), int(zero_grads), stream())
+    if shifts is not None:
+        for sft, p in zip(shifts, params):
+            if sft.dtype != dt or sft.shape != p.shape or sft.stride() != p.stride():
+                raise DpipeHipError('fused AdamW: Kahan shift buffers must match their parameters')
+        check(lib().dpipe_adamw_step_kahan(ptr(t['p']), ptr(t['m']), ptr(t['v']), ptr(t['s']), ptr(t['g']), *tail), 'adamw_step_kahan')
+    else:
+        check(lib().dpipe_adamw_step(ptr(t['p']), ptr(t['m']), ptr(t['v']), ptr(t['g']), *tail), 'adamw_step')
 
 
 # ----------------------------------------------------------------------------------------- small helpers (K7/K8)

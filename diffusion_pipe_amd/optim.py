@@ -17,6 +17,7 @@ import torch
 
 _TORCH_OPTIMIZERS = {
     'adamw': torch.optim.AdamW,        # replaced by FusedAdamW on a GPU stage (make_optimizer_factory)
+    'adamwkahan': torch.optim.AdamW,   # FusedAdamW(kahan=True): AdamW with the reference optimizers' Kahan summation for bf16 parameters (GPU stages only)
     'sgd': torch.optim.SGD,
     'adam': torch.optim.Adam,
 }
@@ -57,10 +58,13 @@ class FusedAdamW(torch.optim.Optimizer):
     `step()` is the plain torch contract (reads p.grad, leaves it alone).  The engine uses the split form instead:
     `grads_sumsq(lanes)` -> (cross-stage / DP reduction of the scalar by the engine) -> `fused_update(lanes, total, max_norm)`."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, kahan=False):
+        """kahan: compensated summation for bf16 parameters, the reference optimizers' treatment of raw-bf16 training (optimizers/generic_optim.py:
+        486-497, automagic.py:309-320, adamw_8bit.py): one extra `shift` state tensor per bf16 parameter (same key and dtype as the reference's)."""
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
             raise ValueError('invalid AdamW hyper-parameter')
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        self.kahan = bool(kahan)
 
     def _buckets(self, lane_grads_of):
         """[(group, dtype, step, params, exp_avgs, exp_avg_sqs, lanes)] over parameters that have a gradient; parameters of one group are
@@ -125,10 +129,19 @@ class FusedAdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def fused_update(self, lane_grads=None, total_sumsq=None, max_norm=0.0, zero_grads=True):
         from . import ops
-        for group, _, step, ps, ms, vs, lanes in self._buckets(self._lanes_from(lane_grads)):
+        by_data = {p.data_ptr(): p for group in self.param_groups for p in group['params']}
+        for group, dt, step, ps, ms, vs, lanes in self._buckets(self._lanes_from(lane_grads)):
             beta1, beta2 = group['betas']
+            shifts = None
+            if self.kahan and dt == torch.bfloat16:
+                shifts = []
+                for pd in ps:
+                    st = self.state[by_data[pd.data_ptr()]]
+                    if 'shift' not in st:
+                        st['shift'] = torch.zeros_like(pd, memory_format=torch.preserve_format)
+                    shifts.append(st['shift'])
             ops.adamw_step(ps, ms, vs, lanes, lr=group['lr'], beta1=beta1, beta2=beta2, eps=group['eps'], weight_decay=group['weight_decay'],
-                           step=step + 1.0, total_sumsq=total_sumsq, max_norm=max_norm, zero_grads=zero_grads)
+                           step=step + 1.0, total_sumsq=total_sumsq, max_norm=max_norm, zero_grads=zero_grads, shifts=shifts)
         of = self._lanes_from(lane_grads)
         for group in self.param_groups:
             for p in group['params']:
@@ -205,6 +218,10 @@ def make_optimizer_factory(config, workload, global_batch_size, device_is_gpu=Tr
             cfg['betas'] = tuple(cfg['betas'])
         klass = _optimizer_class(optim_type)
         plain_adamw = klass is torch.optim.AdamW and not set(cfg) - {'lr', 'betas', 'eps', 'weight_decay'}
+        if optim_type.lower() == 'adamwkahan':
+            if not (plain_adamw and device_is_gpu and use_hip_adamw):
+                raise NotImplementedError("optimizer type 'adamwkahan' runs on the fused HIP step end of a GPU stage only")
+            cfg['kahan'] = True
         if plain_adamw and device_is_gpu and use_hip_adamw:
             klass = FusedAdamW                                        # lane sum + clip + update + zero in two HIP passes
         elif klass in (torch.optim.AdamW, torch.optim.Adam) and 'fused' not in cfg and 'foreach' not in cfg:

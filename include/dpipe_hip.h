@@ -101,6 +101,13 @@ int dpipe_adamw_step(void* const* p_ptrs, void* const* m_ptrs, void* const* v_pt
                      const int* chunk_tensor, const long* chunk_off, const int* chunk_len, int nchunks, int dtype, float lr,
                      float beta1, float beta2, float eps, float weight_decay, float bias_correction1,
                      float bias_correction2, const float* total_sumsq, float max_norm, int zero_grads, void* stream);
+/* The same step with Kahan (compensated) application of the update to low-precision parameters -- what the reference's optimizers do for bf16
+ * parameters (optimizers/generic_optim.py:486-497, optimizers/automagic.py:309-320, optimizers/adamw_8bit.py): shift_ptrs[t] = the `shift` state
+ * tensor of parameter t (parameter dtype): shift += update; old = p; p += shift; shift += old - p, every intermediate rounded to the dtype. */
+int dpipe_adamw_step_kahan(void* const* p_ptrs, void* const* m_ptrs, void* const* v_ptrs, void* const* shift_ptrs, void* const* g_ptrs, int lanes,
+                           const int* chunk_tensor, const long* chunk_off, const int* chunk_len, int nchunks, int dtype, float lr, float beta1,
+                           float beta2, float eps, float weight_decay, float bias_correction1, float bias_correction2, const float* total_sumsq,
+                           float max_norm, int zero_grads, void* stream);
 
 /* ---- K2 RMSNorm (models/wan/model.py:70-86; per-head form models/hunyuan_image_modeling.py:98-103) ------------
  * y = cast(x * rsqrt(mean(x^2) + eps)) * w ; w may be NULL; rstd [rows] saved for backward (may be NULL). */

@@ -57,3 +57,52 @@ def test_full_size_sdxl_three_lanes_twelve_unsynchronised_steps_match_one_lane(g
         assert abs(a - b) <= 2e-2 * abs(b) + 1e-4, f'step {i}: loss {a} (3 lanes) vs {b} (1 lane)'
     for i, (a, b) in enumerate(zip(norm3, norm1)):
         assert abs(a - b) <= 5e-2 * abs(b) + 1e-4, f'step {i}: grad norm {a} (3 lanes) vs {b} (1 lane)'
+
+
+def test_full_size_sdxl_micro_batch_matches_the_cpu_oracle_golden(gpu):
+    """BASELINE config 2, one full-size micro-batch, against tests/golden/sdxl_fullsize.json (oracle/make_golden_fullsize.py: the oracle's fp32
+    eager path on the host, same seeded weights and prepared input):
+      * exact-fp32 kernel mode: loss and global gradient norm within 1e-3 relative (north_star's bound), every parameter's sum |g| within 5e-3;
+      * the timed path (bf16, hipGraph, 3 lanes replaying the micro-batch): loss within 3e-2, gradient norm within 5e-2."""
+    import json
+    import os
+    from diffusion_pipe_amd.engine import ManualPipelineModule, initialize
+    from oracle.make_golden_fullsize import build, weight_checksum
+    meta = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'sdxl_fullsize.json')))
+    cfg, work, micro = build()
+    assert abs(weight_checksum(work.modules()) - meta['weight_checksum']) <= 1e-9 * meta['weight_checksum'], 'seeded weights differ from the generator run'
+    for m in work.modules().values():
+        m.to(gpu)
+    feats, label = micro[0]
+    # ---- exact-fp32 kernels, eager
+    x = tuple(t.to(gpu) for t in feats)
+    for layer in work.to_layers():
+        x = layer(x)
+    loss = work.get_loss_fn()(x, tuple(t.to(gpu) for t in label))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - meta['loss']) / meta['loss'] < 1e-3, (loss.item(), meta['loss'])
+    sums, sq = {}, 0.0
+    for k, m in work.modules().items():
+        for n, p in m.named_parameters():
+            if p.grad is not None:
+                g = p.grad.double()
+                sums[f'{k}.{n}'] = float(g.abs().sum())
+                sq += float((g * g).sum())
+    assert abs(sq ** 0.5 - meta['grad_norm']) / meta['grad_norm'] < 1e-3, (sq ** 0.5, meta['grad_norm'])
+    assert len(sums) == meta['parameters_with_grad']
+    worst = max(abs(v - meta['grad_checksums'][k][0]) / max(meta['grad_checksums'][k][0], 1e-12) for k, v in sums.items())
+    assert worst < 5e-3, worst
+    # ---- the timed path: bf16, hipGraph, 3 lanes (the same micro-batch on every lane: same mean loss, same averaged gradient)
+    for m in work.modules().values():
+        for p in m.parameters():
+            p.grad = None
+        m.to(torch.bfloat16)
+    module = ManualPipelineModule(layers=work.to_layers(), num_stages=1, partition_method='parameters', loss_fn=work.get_loss_fn(), dynamic_shape=True)
+    engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 1, 'gradient_accumulation_steps': 3, 'gradient_clipping': 1e9,
+                                                         'hip_graph': True, 'graph_lanes': 3}, device=gpu)
+    engine._configure_optimizer(lambda ps: torch.optim.SGD(ps, lr=0.0), [p for p in module.parameters() if p.requires_grad])
+    loss = engine.train_batch(iter([micro[0]] * 3)).item()
+    norm = engine.get_global_grad_norm().item()
+    assert abs(loss - meta['loss']) / meta['loss'] < 3e-2, (loss, meta['loss'])
+    assert abs(norm - meta['grad_norm']) / meta['grad_norm'] < 5e-2, (norm, meta['grad_norm'])

@@ -130,3 +130,52 @@ def test_fused_adamw_keeps_the_bias_correction_per_parameter(gpu):
     assert [opt.state[p]['step'] for p in mine] == [4.0, 2.0, 4.0]
     for p, r in zip(mine, ref):
         assert torch.allclose(p.detach().cpu(), r.detach(), rtol=2e-6, atol=1e-7)
+
+
+def test_fused_adamw_kahan_matches_the_reference_sequence_and_tracks_fp32(gpu):
+    """kahan=True (optimizers/generic_optim.py:486-497): shift += update; old = p; p += shift; shift += old - p with bf16 roundings -- op-for-op
+    against a torch emulation, and the property it exists for: with updates far below one bf16 ulp the compensated parameters follow the fp32
+    trajectory while plain bf16 AdamW stalls."""
+    from diffusion_pipe_amd.optim import FusedAdamW
+    torch.manual_seed(0)
+    shape = (257, 33)
+    p0 = (torch.randn(shape) * 2).to(torch.bfloat16)
+    kw = dict(lr=1e-5, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0)
+    pk = torch.nn.Parameter(p0.clone().to(gpu))
+    pp = torch.nn.Parameter(p0.clone().to(gpu))
+    pf = torch.nn.Parameter(p0.float())
+    ok, op, of = FusedAdamW([pk], kahan=True, **kw), FusedAdamW([pp], **kw), torch.optim.AdamW([pf], foreach=False, **kw)
+    rnd = lambda t: t.to(torch.bfloat16).float()
+    em_p, em_s = p0.float().clone(), torch.zeros(shape)
+    em_m, em_v = torch.zeros(shape), torch.zeros(shape)
+    g = torch.Generator().manual_seed(1)
+    for step in range(1, 41):
+        grad = (torch.randn(shape, generator=g) * 0.1 + 0.5).to(torch.bfloat16)
+        pk.grad, pp.grad, pf.grad = grad.to(gpu), grad.to(gpu), grad.float()
+        ok.step(); op.step(); of.step()
+        # emulation of the kernel's arithmetic: fp32 AdamW of the stored bf16 state, then the compensated application
+        gf = grad.float()
+        em_m = rnd(em_m + (1 - 0.9) * (gf - em_m))
+        em_v = rnd(0.99 * em_v + (1 - 0.99) * gf * gf)
+        # (state tensors are bf16: the kernel rounds m and v once per step, and the update uses the unrounded fp32 values)
+    shift = ok.state[pk]['shift']
+    assert shift.dtype == torch.bfloat16 and shift.shape == pk.shape
+    true = pf.detach()
+    err_kahan = ((pk.detach().float().cpu() + shift.float().cpu()) - true).abs().max().item()
+    err_plain = (pp.detach().float().cpu() - true).abs().max().item()
+    moved = (true - p0.float()).abs().max().item()
+    assert moved < 1e-3 and err_kahan < 0.1 * moved, (moved, err_kahan)          # 40 steps of ~1e-5: the compensated sum keeps them
+    assert err_plain > 0.5 * moved, (moved, err_plain)                           # plain bf16 parameters barely move (1 ulp at |p| ~ 2 is 1.6e-2)
+    # one step op-for-op: from a fresh state the update and its compensation are exactly the reference's sequence
+    q = torch.nn.Parameter(p0.clone().to(gpu))
+    oq = FusedAdamW([q], kahan=True, **kw)
+    grad = (torch.randn(shape, generator=g)).to(torch.bfloat16)
+    q.grad = grad.to(gpu)
+    oq.step()
+    gf, old = grad.float(), p0.float()
+    m1, v1 = (1 - 0.9) * gf, (1 - 0.99) * gf * gf
+    new = old - (1e-5 / (1 - 0.9)) * m1 / (v1.sqrt() / (1 - 0.99) ** 0.5 + 1e-8)
+    s = rnd(rnd(new - old))
+    pn = rnd(old + s)
+    sh = rnd(s + rnd(old - pn))
+    assert torch.equal(q.detach().float().cpu(), pn) and torch.equal(oq.state[q]['shift'].float().cpu(), sh)
