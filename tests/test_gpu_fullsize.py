@@ -62,7 +62,7 @@ def test_full_size_sdxl_three_lanes_twelve_unsynchronised_steps_match_one_lane(g
 def test_full_size_sdxl_micro_batch_matches_the_cpu_oracle_golden(gpu):
     """BASELINE config 2, one full-size micro-batch, against tests/golden/sdxl_fullsize.json (oracle/make_golden_fullsize.py: the oracle's fp32
     eager path on the host, same seeded weights and prepared input):
-      * exact-fp32 kernel mode: loss and global gradient norm within 1e-3 relative (north_star's bound), every parameter's sum |g| within 5e-3;
+      * exact-fp32 kernel mode: loss and global gradient norm within 1e-3 relative (north_star's bound), every parameter's sum |g| within 5e-3 (+ 1e-8 of the model total);
       * the timed path (bf16, hipGraph, 3 lanes replaying the micro-batch): loss within 3e-2, gradient norm within 5e-2."""
     import json
     import os
@@ -91,8 +91,12 @@ def test_full_size_sdxl_micro_batch_matches_the_cpu_oracle_golden(gpu):
                 sq += float((g * g).sum())
     assert abs(sq ** 0.5 - meta['grad_norm']) / meta['grad_norm'] < 1e-3, (sq ** 0.5, meta['grad_norm'])
     assert len(sums) == meta['parameters_with_grad']
-    worst = max(abs(v - meta['grad_checksums'][k][0]) / max(meta['grad_checksums'][k][0], 1e-12) for k, v in sums.items())
-    assert worst < 5e-3, worst
+    # per parameter: sum |g| within 5e-3 relative, plus an absolute floor of 1e-8 of the model's total for parameters whose gradient is
+    # analytically zero (attention key biases: softmax is invariant to them) and therefore pure rounding noise on both sides
+    total = sum(v[0] for v in meta['grad_checksums'].values())
+    excess = {k: abs(v - meta['grad_checksums'][k][0]) - (5e-3 * meta['grad_checksums'][k][0] + 1e-8 * total) for k, v in sums.items()}
+    worst = max(excess, key=excess.get)
+    assert excess[worst] <= 0, (worst, sums[worst], meta['grad_checksums'][worst][0], total)
     # ---- the timed path: bf16, hipGraph, 3 lanes (the same micro-batch on every lane: same mean loss, same averaged gradient)
     for m in work.modules().values():
         for p in m.parameters():
