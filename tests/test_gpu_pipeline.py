@@ -106,3 +106,19 @@ def test_pp2_fused_step_end_matches_single_stage_engine(gpu, tmp_path):
     for (l0, n0), (l1, n1), (l2, n2) in zip(base['res'], eager2['res'], graph2['res']):
         assert abs(l1 - l0) / abs(l0) < 2e-2 and abs(l2 - l0) / abs(l0) < 2e-2, (l0, l1, l2)
         assert abs(n1 - n0) / n0 < 3e-2 and abs(n2 - n0) / n0 < 3e-2, (n0, n1, n2)
+
+
+def test_bench_multi_rank_path_runs_end_to_end_on_one_shared_gpu(gpu, tmp_path):
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one rank per stage), with both ranks sharing cuda:0
+    (`--test-single-device`: gloo + host-staged stage payloads instead of RCCL): the pp = 2 schedule, stage graphs, step end, cross-rank
+    timing reduction, roofline leg and the rank-0 JSON line all execute -- so the first real multi-GPU run is not also their first run."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', DPIPE_BENCH_WATCHDOG_S='500')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+           os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2', '--config', 'tiny', '--test-single-device', '--no-cpu-baseline']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=560, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(line) == 1, r.stdout[-2000:]
+    out = json.loads(line[0])
+    assert out['n_gpus'] == 2 and out['config']['parallelism'] == 'pp2' and out['config']['gradient_accumulation_steps'] == 12
+    assert out['value'] > 0 and out['loss'] == out['loss'] and out['roofline']['launches_per_step'] > 0
