@@ -20,7 +20,7 @@ import torch.distributed as dist
 
 from . import schedule as sched
 from .module import PipelineModule
-from .p2p import HostStagedLink, StageLink
+from .p2p import HostStagedLink, RcclLink, StageLink
 
 
 # Progress tracing (bench.py / tools: DPIPE_TRACE_STEPS=1): a list that receives (label, HIP event) after every graph replay and
@@ -109,6 +109,7 @@ class PipelineEngine:
         self.use_stage_graphs = want_graph and self.is_pipe_parallel
         self._graphs = {}
         self._stage_slots = {}
+        self._slot_of_buffer = {}           # pipe buffer id -> the slot its last micro-batch ran in (target of in-place receives)
         # stage-graph mode runs the forward half of the schedule (Load / RecvActivation / Forward / SendActivation) and the
         # backward half (RecvGrad / Backward / SendGrad) on two HIP streams: in 1F1B steady state a stage's next forward and
         # its pending backward belong to different micro-batches, so their graphs overlap on the GPU (same effect as the
@@ -140,6 +141,8 @@ class PipelineEngine:
             _ops.FUSE_GRAD_ACCUM = True     # wgrad / bias / norm-weight kernels add straight into existing .grad buffers
             _ops.PARALLEL_WGRAD = self.use_graph and bool(self._config.get('parallel_wgrad', False))   # dgrad || wgrad as parallel graph branches (measured: no gain on MI355X, off)
         link_cls = HostStagedLink if (self._config.get('p2p_via_host', False) and self.device.type == 'cuda') else StageLink
+        if link_cls is StageLink and self.device.type == 'cuda' and self._config.get('p2p_backend', 'torch') == 'rccl':
+            link_cls = RcclLink                 # csrc/comm.hip dpipe_send / dpipe_recv: grouped per tuple, receives straight into the slot buffers
         self.link = link_cls(self.grid, self.device) if self.is_pipe_parallel else None
         self.loss = None
         self.total_loss = None
@@ -501,7 +504,7 @@ class PipelineEngine:
             cur.wait_event(slot['bwd_done'])            # the slot's previous micro-batch finished its backward
         with torch.no_grad():
             for dst, src in zip(slot['inputs'], _as_list(inputs)):
-                if src.numel() > 0:
+                if src.numel() > 0 and src.data_ptr() != dst.data_ptr():          # received in place: nothing to copy
                     dst.copy_(src, non_blocking=True)
             if labels is not None:
                 for dst, src in zip(slot['labels'], _as_list(labels)):
@@ -509,6 +512,7 @@ class PipelineEngine:
                         dst.copy_(src, non_blocking=True)
         slot['fwd'].replay()
         slot['fwd_done'] = cur.record_event()
+        self._slot_of_buffer[buffer_id] = slot
         self.pipe_buffers['inputs'][buffer_id] = slot['inputs'][0] if slot['single_in'] else slot['inputs']   # their .grad feeds SendGrad
         self.pipe_buffers['outputs'][buffer_id] = slot['out']
         self.pipe_buffers['slot'][buffer_id] = slot
@@ -523,7 +527,8 @@ class PipelineEngine:
                 f'stage {self.stage_id}: {len(slot["gout"])} floating-point outputs but {len(grads)} received gradients'
             with torch.no_grad():
                 for dst, src in zip(slot['gout'], grads):
-                    dst.copy_(src, non_blocking=True)
+                    if src.data_ptr() != dst.data_ptr():
+                        dst.copy_(src, non_blocking=True)
             self.pipe_buffers['grads'][buffer_id] = None
         slot['bwd'].replay()
         slot['bwd_done'] = cur.record_event()
@@ -599,7 +604,11 @@ class PipelineEngine:
             self.pipe_buffers['outputs'][buffer_id] = None
 
     def _exec_recv_activations(self, buffer_id):
-        recvd = self.link.recv_tuple(self.prev_stage, tag='act')
+        slot = self._slot_of_buffer.get(buffer_id) if (self.use_stage_graphs and not self._eval_mode) else None
+        if slot is not None:         # receive straight into the slot's static inputs (no staging copy); ordered after the slot's previous backward
+            recvd = self.link.recv_tuple(self.prev_stage, tag='act', into=slot['inputs'], after=slot['bwd_done'])
+        else:
+            recvd = self.link.recv_tuple(self.prev_stage, tag='act')
         if not self._eval_mode:
             for t in _as_list(recvd):
                 t.requires_grad = t.is_floating_point()
@@ -617,7 +626,11 @@ class PipelineEngine:
     def _exec_recv_grads(self, buffer_id):
         outputs = self.pipe_buffers['outputs'][buffer_id]
         templates = [t for t in _as_list(outputs) if _is_float(t)]
-        self.pipe_buffers['grads'][buffer_id] = self.link.recv_like(templates, self.next_stage)
+        slot = self.pipe_buffers['slot'][buffer_id] if self.use_stage_graphs else None
+        if slot is not None and slot['gout'] is not None:        # straight into the backward graph's static output-gradient buffers
+            self.pipe_buffers['grads'][buffer_id] = self.link.recv_like(templates, self.next_stage, into=slot['gout'], after=slot['bwd_done'])
+        else:
+            self.pipe_buffers['grads'][buffer_id] = self.link.recv_like(templates, self.next_stage)
 
     def _exec_reduce_tied_grads(self):
         pass   # the reference's adapters register no tied layers

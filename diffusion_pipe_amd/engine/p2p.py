@@ -117,7 +117,9 @@ class StageLink:
         if tensors:
             self._isend(tensors, peer)
 
-    def recv_tuple(self, peer_stage, tag):
+    def recv_tuple(self, peer_stage, tag, into=None, after=None):
+        """into: buffers to receive into when their layout equals the announced one (a stage graph's static inputs: no staging copy);
+        after: event the receive must wait for before it may overwrite them."""
         peer = self.grid.stage_to_global(peer_stage)
         key = (peer, tag)
         layout = self._recv_meta.get(key)
@@ -127,17 +129,30 @@ class StageLink:
             layout = decode_meta(header.tolist())     # host read: once per boundary per shape epoch
             self._recv_meta[key] = layout
         specs, is_tuple = layout
-        buffers = [torch.empty(shape, dtype=dtype, device=self.device) for dtype, shape in specs]
+        direct = into is not None and len(into) == len(specs) and all(
+            b.dtype == dtype and tuple(b.shape) == tuple(shape) and b.is_contiguous() for b, (dtype, shape) in zip(into, specs))
+        buffers = list(into) if direct else [torch.empty(shape, dtype=dtype, device=self.device) for dtype, shape in specs]
         if buffers:
-            self._recv(buffers, peer)
+            self._recv_after(buffers, peer, after if direct else None)
         return tuple(buffers) if is_tuple else buffers[0]
 
-    def recv_like(self, templates, peer_stage):
+    def _recv_after(self, buffers, peer, after):
+        if after is None:
+            return self._recv(buffers, peer)
+        if isinstance(self, RcclLink):
+            return self._recv(buffers, peer, after)
+        if self.comm_stream is not None:
+            self.comm_stream.wait_event(after)
+        return self._recv(buffers, peer)
+
+    def recv_like(self, templates, peer_stage, into=None, after=None):
         """Receive tensors whose layouts are known locally (gradients of tensors this stage sent)."""
         peer = self.grid.stage_to_global(peer_stage)
-        buffers = [torch.empty_like(t, memory_format=torch.contiguous_format) for t in templates]
+        direct = into is not None and len(into) == len(templates) and all(
+            b.dtype == t.dtype and b.shape == t.shape and b.is_contiguous() for b, t in zip(into, templates))
+        buffers = list(into) if direct else [torch.empty_like(t, memory_format=torch.contiguous_format) for t in templates]
         if buffers:
-            self._recv(buffers, peer)
+            self._recv_after(buffers, peer, after if direct else None)
         return buffers
 
     def send_plain(self, tensors, peer_stage):
@@ -145,6 +160,83 @@ class StageLink:
         tensors = [t if t.is_contiguous() else t.contiguous() for t in tensors]
         if tensors:
             self._isend(tensors, peer)
+
+
+class RcclLink(StageLink):
+    """P2P endpoint on the C-ABI RCCL wrappers (csrc/comm.hip: dpipe_send / dpipe_recv) instead of torch.distributed's
+    isend / irecv: one 2-rank communicator per neighbour stage, every tuple leaves as ONE grouped RCCL operation on the communication stream
+    (the `batch_isend_irecv` shape), and a receive lands directly in the buffers the caller names (`into=`: a stage graph's static inputs)
+    with no staging copy.  Communicator ids travel over the torch.distributed control plane (`dist.broadcast_object_list`) once.
+    Selected with engine config `p2p_backend: 'rccl'`."""
+
+    def __init__(self, grid, device):
+        super().__init__(grid, device)
+        from .. import hip
+        self._hip = hip
+        self._comms = {}            # peer global rank -> (comm handle, peer's rank inside the pair communicator)
+
+    def _comm(self, peer):
+        hit = self._comms.get(peer)
+        if hit is not None:
+            return hit
+        import ctypes
+        me = self.grid.global_rank
+        lo, hi = min(me, peer), max(me, peer)
+        box = [None]
+        if me == lo:
+            buf = ctypes.create_string_buffer(128)
+            self._hip.check(self._hip.lib().dpipe_comm_unique_id(buf), 'comm_unique_id')
+            box[0] = buf.raw
+        group = self._pair_group(lo, hi)
+        dist.broadcast_object_list(box, src=lo, group=group)
+        comm = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            self._hip.check(self._hip.lib().dpipe_comm_init(ctypes.byref(comm), 2, 0 if me == lo else 1, box[0]), 'comm_init')
+        self._comms[peer] = (comm, 1 if me == lo else 0)
+        return self._comms[peer]
+
+    _PAIR_GROUPS = {}
+
+    def _pair_group(self, lo, hi):
+        """control-plane group of a neighbour pair; new_group is collective over the world, so every rank creates every pair's group once, in order"""
+        if not RcclLink._PAIR_GROUPS:
+            world = dist.get_world_size()
+            for a in range(world - 1):
+                RcclLink._PAIR_GROUPS[(a, a + 1)] = dist.new_group([a, a + 1], backend='gloo')
+        if (lo, hi) not in RcclLink._PAIR_GROUPS:
+            raise RuntimeError(f'stages on ranks {lo} and {hi} are not neighbours')
+        return RcclLink._PAIR_GROUPS[(lo, hi)]
+
+    def _grouped(self, tensors, peer, op):
+        comm, peer_rank = self._comm(peer)
+        lib, st = self._hip.lib(), self.comm_stream.cuda_stream
+        self._hip.check(lib.dpipe_group_start(), 'group_start')
+        for t in tensors:
+            w = _wire(t)
+            self._hip.check(op(lib)(comm, w.data_ptr(), w.numel() * w.element_size(), peer_rank, st), 'send / recv')
+        self._hip.check(lib.dpipe_group_end(), 'group_end')
+
+    def _isend(self, tensors, peer):
+        ev = torch.cuda.current_stream(self.device).record_event()
+        self.comm_stream.wait_event(ev)
+        self._grouped(tensors, peer, lambda lib: lib.dpipe_send)
+        for t in tensors:
+            t.record_stream(self.comm_stream)
+        self._pending.append(([], tensors))              # kept alive until flush(); completion is stream-ordered
+
+    def _recv(self, buffers, peer, after=None):
+        if after is not None:
+            self.comm_stream.wait_event(after)           # the buffers' previous consumer (a stage graph replay) has finished
+        self._grouped(buffers, peer, lambda lib: lib.dpipe_recv)
+        done = self.comm_stream.record_event()
+        for b in buffers:
+            b.record_stream(self.comm_stream)
+        torch.cuda.current_stream(self.device).wait_event(done)
+
+    def flush(self):
+        if self._pending:
+            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+        self._pending.clear()
 
 
 class HostStagedLink(StageLink):

@@ -23,6 +23,13 @@ _SIGNATURES = {
     'dpipe_version': (I, []),
     'dpipe_last_error': (c_char_p, []),
     'dpipe_device_info': (I, [I, POINTER(c_int), c_char_p, I]),
+    'dpipe_comm_unique_id': (I, [P]),
+    'dpipe_comm_init': (I, [POINTER(c_void_p), I, I, P]),
+    'dpipe_comm_destroy': (I, [P]),
+    'dpipe_group_start': (I, []),
+    'dpipe_group_end': (I, []),
+    'dpipe_send': (I, [P, P, L, I, P]),
+    'dpipe_recv': (I, [P, P, L, I, P]),
     'dpipe_loss_workspace_floats': (I, [L, L]),
     'dpipe_loss_fwd': (I, [P, I, P, P, P, L, L, I, F, P, P, P, P]),
     'dpipe_loss_bwd': (I, [P, I, P, P, P, P, L, L, I, F, P, P]),

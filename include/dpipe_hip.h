@@ -36,6 +36,20 @@ const char* dpipe_last_error(void);
 /* Number of compute units / name of device `dev`; used by the host to sanity-check it runs on gfx950. */
 int dpipe_device_info(int dev, int* cu_count, char* arch_name, int arch_name_len);
 
+/* ---- C1 / C2 stage-to-stage point-to-point over RCCL / xGMI -- the per-micro-batch SendActivation / RecvActivation / SendGrad / RecvGrad of the
+ * reference's schedule (utils/patches.py:126-160 -> DeepSpeed p2p.send / recv -> torch.distributed isend / irecv -> NCCL).  One communicator
+ * per neighbour pair (world = 2) or per pipe group; `id128` = the 128-byte ncclUniqueId made by one rank (dpipe_comm_unique_id) and handed to
+ * the others out of band.  dpipe_send / dpipe_recv move `nbytes` untyped bytes to / from rank `peer` of the communicator, asynchronously on
+ * `stream`; the sends and receives of one stage-boundary tuple are bracketed by dpipe_group_start / dpipe_group_end so RCCL issues them as one
+ * operation (required when a rank both sends to and receives from the same peer).  Return codes >= 1000 are 1000 + ncclResult_t. */
+int dpipe_comm_unique_id(void* id128);
+int dpipe_comm_init(void** comm, int world, int rank, const void* id128);
+int dpipe_comm_destroy(void* comm);
+int dpipe_group_start(void);
+int dpipe_group_end(void);
+int dpipe_send(void* comm, const void* buf, long nbytes, int peer, void* stream);
+int dpipe_recv(void* comm, void* buf, long nbytes, int peer, void* stream);
+
 /* ---- K9 loss -------------------------------------------------------------------------------------------------
  * loss = (1/rows) * sum_r row_weight[r] * (1/cols) * sum_c elem(out[r,c] - target[r,c]) * mask[r,c]
  * Replaces F.mse_loss/huber_loss/smooth_l1_loss(reduction='none') * mask -> mean of models/base.py:418-436 (rows=1)
