@@ -143,6 +143,7 @@ class StageLink:
             return self._recv(buffers, peer, after)
         if self.comm_stream is not None:
             self.comm_stream.wait_event(after)
+            torch.cuda.current_stream(self.device).wait_event(after)     # host-staged endpoints copy on the current stream
         return self._recv(buffers, peer)
 
     def recv_like(self, templates, peer_stage, into=None, after=None):
