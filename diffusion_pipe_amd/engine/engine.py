@@ -379,6 +379,8 @@ class PipelineEngine:
         for p in params:                                  # this lane's accumulators become the parameters' .grad
             p.grad = lane['grads'].get(id(p))
         _ops.WS_LANE = lane['id'] if self.graph_lanes > 1 else None
+        from . import offload as _offload
+        _offload.POOL_TAG = ('lane', lane['id'])          # host-offloaded checkpoints: pinned buffers private to this lane's graph
         saved = {k: g.clone() for k, g in lane['grads'].items()}      # micro-batches this lane already accumulated
         saved_loss = lane['loss'].clone()
 
@@ -412,6 +414,7 @@ class PipelineEngine:
                     lane['grads'][k] = p.grad
         lane['loss'].copy_(saved_loss)
         _ops.WS_LANE = None
+        _offload.POOL_TAG = None
         return {'graph': graph, 'inputs': static_in, 'labels': static_lab}
 
     # ------------------------------------------------------------------------- hipGraph path, pipeline stages

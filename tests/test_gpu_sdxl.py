@@ -178,3 +178,40 @@ def test_clip_text_encoders_match_hf_transformers_vectors(gpu, dtype, tol):
             got = p.grad.float().cpu() if p.grad is not None else torch.zeros_like(want)
             err2, ref2 = err2 + (got - want).double().pow(2).sum().item(), ref2 + want.double().pow(2).sum().item()
         assert (err2 / ref2) ** 0.5 < tol, tag
+
+
+def test_host_offloaded_checkpointing_runs_inside_the_hipgraph_path(gpu):
+    """BASELINE config 5's "activation offload to host DRAM" on the engine's fast path: offloaded_checkpoint (the reference's unsloth_checkpoint
+    contract, utils/unsloth_utils.py:24-79 hooked up at train.py:586-603) captured into the per-lane micro-batch graphs -- pinned buffers from the
+    per-lane pool, D2H / H2D as memcpy nodes -- must reproduce the plain graph path's loss and gradient norm on every step (replays included)."""
+    from functools import partial
+    from diffusion_pipe_amd.data import split_batch
+    from diffusion_pipe_amd.engine import ManualPipelineModule, initialize, offloaded_checkpoint
+    from diffusion_pipe_amd.engine import offload
+    from diffusion_pipe_amd.workloads import sdxl
+    cfg = sdxl.tiny_config()
+    gas = 4
+
+    def run(ckpt):
+        work = sdxl.SDXLWorkload(cfg, dtype=torch.bfloat16, seed=2, device=gpu)
+        kw = {}
+        if ckpt:
+            kw = dict(activation_checkpoint_interval=1, checkpointable_layers=work.checkpointable_layers,
+                      activation_checkpoint_func=partial(offloaded_checkpoint, threshold=1000))
+        module = ManualPipelineModule(layers=work.to_layers(), num_stages=1, partition_method='uniform', loss_fn=work.get_loss_fn(), dynamic_shape=True, **kw)
+        engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 1, 'gradient_accumulation_steps': gas, 'gradient_clipping': 1.0,
+                                                             'hip_graph': True, 'graph_lanes': 2}, device=gpu)
+        engine._configure_optimizer(lambda ps: torch.optim.SGD(ps, lr=1e-3), [p for p in module.parameters()])
+        out = []
+        for step in range(3):
+            torch.manual_seed(50 + step)
+            feats, label = work.prepare_inputs(sdxl.synthetic_batch(cfg, batch_size=gas, latent_hw=32, seed=20 + step))
+            loss = engine.train_batch(iter(split_batch((feats, label), gas)))
+            out.append((loss.item(), engine.get_global_grad_norm().item()))
+        return out
+
+    base = run(False)
+    got = run(True)
+    assert any(k[0] == ('lane', 0) for k in offload._FREE) and any(k[0] == ('lane', 1) for k in offload._FREE)      # per-lane pinned pools were used
+    for (l0, n0), (l1, n1) in zip(base, got):
+        assert abs(l1 - l0) / abs(l0) < 2e-3 and abs(n1 - n0) / n0 < 5e-3, (base, got)

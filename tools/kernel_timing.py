@@ -91,7 +91,10 @@ def attn_main():
     dev = torch.device('cuda:0')
     F = torch.nn.functional
     for (B, Sq, Sk, H, D, causal, cnt) in [(1, 1024, 1024, 20, 64, 0, 60), (1, 4096, 4096, 10, 64, 0, 10), (1, 1024, 77, 20, 64, 0, 60),
-                                           (1, 4096, 77, 10, 64, 0, 10), (1, 77, 77, 20, 64, 1, 32), (1, 77, 77, 12, 64, 1, 12)]:
+                                           (1, 4096, 77, 10, 64, 0, 10), (1, 77, 77, 20, 64, 1, 32), (1, 77, 77, 12, 64, 1, 12),
+                                           # head_dim 128, long sequences: Flux 1024^2 (4096 image + 512 text tokens, 24 heads), Wan-14B 512x512x33f (9216 tokens, 40 heads),
+                                           # HunyuanVideo 720p x 65f (61 456 tokens; 2 of its 24 heads as a probe)
+                                           (1, 4608, 4608, 24, 128, 0, 0), (1, 9216, 9216, 40, 128, 0, 0), (1, 61456, 61456, 2, 128, 0, 0)]:
         q = torch.randn(B, Sq, H, D, device=dev, dtype=torch.bfloat16, requires_grad=True)
         k = torch.randn(B, Sk, H, D, device=dev, dtype=torch.bfloat16, requires_grad=True)
         v = torch.randn(B, Sk, H, D, device=dev, dtype=torch.bfloat16, requires_grad=True)
@@ -101,7 +104,9 @@ def attn_main():
             tf_us = graph_time(lambda: F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), is_causal=bool(causal)), n=10)
         fb_us = graph_time(lambda: ops.attention(q, k, v, impl='flash', causal=bool(causal)).backward(go), n=10)
         tfb_us = graph_time(lambda: F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), is_causal=bool(causal)).backward(go.transpose(1, 2)), n=10)
-        print(json.dumps({'op': 'attn', 'Sq': Sq, 'Sk': Sk, 'H': H, 'causal': causal, 'cnt': cnt, 'fwd_us': round(f_us, 1), 'bwd_us': round(fb_us - f_us, 1),
+        fl = 4.0 * Sq * Sk * D * H * B * (0.5 if causal else 1.0)
+        print(json.dumps({'op': 'attn', 'Sq': Sq, 'Sk': Sk, 'H': H, 'D': D, 'causal': causal, 'cnt': cnt, 'fwd_us': round(f_us, 1), 'bwd_us': round(fb_us - f_us, 1),
+                          'fwd_TF': round(fl / f_us / 1e6, 1), 'bwd_TF': round(2.5 * fl / max(fb_us - f_us, 1e-9) / 1e6, 1), 'torch_fwd_TF': round(fl / tf_us / 1e6, 1),
                           'torch_fwd_us': round(tf_us, 1), 'torch_bwd_us': round(tfb_us - tf_us, 1),
                           'tot_ms': round(cnt * fb_us / 1e3, 2), 'torch_tot_ms': round(cnt * tfb_us / 1e3, 2)}), flush=True)
 
