@@ -384,8 +384,14 @@ class PipelineEngine:
         saved = {k: g.clone() for k, g in lane['grads'].items()}      # micro-batches this lane already accumulated
         saved_loss = lane['loss'].clone()
 
+        ckpt = getattr(self.module, 'activation_checkpoint_interval', 0) > 0
+
+        def leaf(t):       # as _exec_load_micro_batch: Function-style checkpoint wrappers only build a backward node when an input needs one
+            t = t.detach()
+            return t.requires_grad_(True) if (ckpt and t.is_floating_point()) else t
+
         def body():
-            x = static_in[0].detach() if single else tuple(t.detach() for t in static_in)
+            x = leaf(static_in[0]) if single else tuple(leaf(t) for t in static_in)
             out = self.module(x)
             loss = self.module.loss_fn(out, static_lab[0] if single_label else static_lab)
             lane['loss'].add_(loss.detach().to(torch.float32))
