@@ -441,6 +441,8 @@ class PipelineEngine:
         kernels) and leaves the input gradients in static tensors for SendGrad."""
         first, last = self.is_first_stage(), self.is_last_stage()
         torch.cuda.synchronize(self.device)               # capture with both halves of the schedule idle
+        from . import offload as _offload
+        _offload.POOL_TAG = ('slot', len(self._stage_slots))      # host-offloaded checkpoints: pinned buffers private to this slot's graphs
         params = [p for p in self.module.parameters() if p.requires_grad]
         saved_grads = {id(p): p.grad.clone() for p in params if p.grad is not None}     # micro-batches already accumulated
         saved_loss = self._g_total_loss.clone()
@@ -501,6 +503,7 @@ class PipelineEngine:
                 else:
                     p.grad.zero_()
         self._g_total_loss.copy_(saved_loss)
+        _offload.POOL_TAG = None
         return {'fwd': fwd_graph, 'bwd': bwd_graph, 'inputs': static_in, 'labels': static_lab, 'out': out, 'gout': static_gout,
                 'single_in': single_in, 'fwd_done': None, 'bwd_done': None}
 
