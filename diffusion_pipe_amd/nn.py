@@ -168,9 +168,30 @@ class Conv2d(nn.Conv2d):
         bias = self.bias
         if extra_bias is not None:                      # per-channel addend folded into the bias vector (time embedding of a resnet, batch 1)
             bias = extra_bias if bias is None else bias + extra_bias
-        if x.is_cuda and ops.conv2d_eligible(x.dtype, self.weight, self.stride, self.padding, self.dilation, self.groups) \
-                and self.padding_mode == 'zeros' and not isinstance(self.padding, str):
+        plain = self.padding_mode == 'zeros' and not isinstance(self.padding, str)
+        if x.is_cuda and plain and ops.conv2d_eligible(x.dtype, self.weight, self.stride, self.padding, self.dilation, self.groups):
             return ops.conv2d_nhwc(x, self.weight, bias, self.stride[0], self.padding[0], upsample, residual)
+        Cout, Cin, kh, kw = self.weight.shape
+        bf16 = x.is_cuda and plain and x.dtype == torch.bfloat16 and self.weight.dtype == torch.bfloat16 and self.groups == 1 and tuple(self.dilation) == (1, 1) \
+            and self.stride[0] == self.stride[1] and self.stride[0] in (1, 2) and self.padding[0] == self.padding[1]
+        if bf16 and Cin % 64 == 0:
+            # few output channels (the UNet's conv_out: 320 -> 4): zero-pad Cout to one 64-wide tile, run the implicit-GEMM kernels, slice
+            pad = -Cout % 64
+            w = torch.nn.functional.pad(self.weight, (0, 0, 0, 0, 0, 0, 0, pad)).contiguous(memory_format=torch.channels_last)
+            b = torch.nn.functional.pad(bias, (0, pad)) if bias is not None else None
+            y = ops.conv2d_nhwc(x, w, b, self.stride[0], self.padding[0], upsample, None)[:, :Cout].contiguous(memory_format=torch.channels_last)
+            return y if residual is None else y + residual
+        if bf16 and upsample == 1 and Cin * kh * kw <= 512:
+            # few input channels (the UNet's conv_in: 4 -> 320): the im2col matrix is tiny ([pixels, Cin kh kw] padded to one or two 64-wide
+            # K-steps), so the convolution is one MFMA GEMM over it; unfold / pad and their adjoints are ATen kernels on a few hundred KB
+            B, _, H, W = x.shape
+            col = torch.nn.functional.unfold(x.contiguous(), (kh, kw), padding=self.padding, stride=self.stride)        # [B, Cin kh kw, L]
+            K = Cin * kh * kw
+            col = torch.nn.functional.pad(col.transpose(1, 2), (0, -K % 64))                                            # [B, L, K64]
+            w2 = torch.nn.functional.pad(self.weight.reshape(Cout, K), (0, -K % 64))
+            Ho = (H + 2 * self.padding[0] - kh) // self.stride[0] + 1
+            y = ops.linear(col, w2, bias).view(B, Ho, -1, Cout).permute(0, 3, 1, 2)                                     # channels-last [B, Cout, Ho, Wo]
+            return y if residual is None else y + residual
         if upsample > 1:
             x = torch.nn.functional.interpolate(x, scale_factor=float(upsample), mode='nearest')
         y = self._conv_forward(x.contiguous(memory_format=torch.channels_last), self.weight, bias)

@@ -130,3 +130,25 @@ def test_group_norm_nhwc_skip_branch_gradient_is_added_in_the_backward_kernel(gp
     want = F.silu(F.group_norm(xr, 32, gn.weight.detach().float(), gn.bias.detach().float(), 1e-5))
     want.backward(gy.float())
     _close(x.grad, xr.grad + gs.float(), 'dx + skip gradient')
+
+
+@pytest.mark.parametrize('cin,cout', [(4, 64), (4, 320), (320, 4), (64, 4)])
+def test_unet_edge_convolutions_run_on_the_mfma_kernels(gpu, cin, cout):
+    """conv_in (4 -> 320: im2col matrix of a few hundred KB + one GEMM) and conv_out (320 -> 4: Cout zero-padded to one 64-wide tile) of the SDXL UNet
+    (models/sdxl.py:692-700,985-995 call sites): no library convolution left in the bf16 step; parity vs fp32 conv2d incl. all gradients."""
+    from diffusion_pipe_amd import nn as dnn
+    torch.manual_seed(cin * 7 + cout)
+    conv = dnn.Conv2d(cin, cout, 3, padding=1).to(gpu, torch.bfloat16)
+    x = torch.randn(2, cin, 24, 20, device=gpu).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = conv(x)
+    xr = x.detach().float().requires_grad_(True)
+    wr = conv.weight.detach().float().contiguous().requires_grad_(True)
+    br = conv.bias.detach().float().requires_grad_(True)
+    want = F.conv2d(xr, wr, br, padding=1)
+    _close(y, want, 'forward')
+    gy = torch.randn_like(want).to(torch.bfloat16)
+    y.backward(gy)
+    want.backward(gy.float())
+    _close(x.grad, xr.grad, 'dgrad')
+    _close(conv.weight.grad, wr.grad, 'wgrad')
+    _close(conv.bias.grad, br.grad, 'bias grad')
