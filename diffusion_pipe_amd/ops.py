@@ -716,6 +716,10 @@ def group_norm_nhwc(x, num_groups, weight=None, bias=None, eps=1e-5, act=None, w
     return _GroupNormNHWCFn.apply(x, num_groups, weight, bias, eps, act, with_skip)
 
 
+# tools/conv_timing.py forces tile configurations through these (0 = the dispatcher's own choice): (forward, dgrad, wgrad) tile_hint codes of dpipe_gemm_ex
+CONV_TILE_HINTS = (0, 0, 0)
+
+
 def conv2d_eligible(x_dtype, weight, stride, padding, dilation=(1, 1), groups=1):
     """The implicit-GEMM convolution (csrc/conv_pipe.hip) takes bf16, stride 1 / 2, square padding, Cin % 64 == 0 and Cout % 64 == 0."""
     Cout, Cin, kh, kw = weight.shape
@@ -753,7 +757,7 @@ class _Conv2dNHWCFn(Function):
             bias = bias.to(x.dtype)
         ws = _splitk_workspace(x.device)
         check(lib().dpipe_conv2d_fwd(ptr(xv), Cin, ptr(weight), ptr(bias), ptr(rv), Cout, ptr(y), Cout, B, H, W, Cin, Cout, kh, kw, stride, pad, upsample,
-                                     0, ptr(ws), ws.numel(), 0, stream()), 'conv2d_fwd')
+                                     0, ptr(ws), ws.numel(), CONV_TILE_HINTS[0], stream()), 'conv2d_fwd')
         ctx.save_for_backward(xv, weight, bias)
         ctx.geom = (stride, pad, upsample, residual is not None)
         return y.permute(0, 3, 1, 2)
@@ -773,7 +777,7 @@ class _Conv2dNHWCFn(Function):
             Hi, Wi = H * upsample, W * upsample
             dxu = torch.empty((B, Hi, Wi, Cin), device=xv.device, dtype=xv.dtype)
             check(lib().dpipe_conv2d_dgrad(ptr(gyv), Cout, ptr(weight), ptr(dxu), Cin, B, Hi, Wi, Cin, Cout, kh, kw, stride, pad,
-                                           ptr(ws), ws.numel(), 0, stream()), 'conv2d_dgrad')
+                                           ptr(ws), ws.numel(), CONV_TILE_HINTS[1], stream()), 'conv2d_dgrad')
             if upsample > 1:       # adjoint of the nearest up-sampling: sum over each 2 x 2 block
                 dxu = dxu.view(B, H, upsample, W, upsample, Cin).sum(dim=(2, 4))
             gx = dxu.permute(0, 3, 1, 2)
@@ -784,7 +788,7 @@ class _Conv2dNHWCFn(Function):
             w_out = tw if tw is not None else torch.empty_like(weight)           # preserve_format: channels-last like the weight
             b_out = (tb if tb is not None else torch.empty_like(bias)) if need_b else None
             check(lib().dpipe_conv2d_wgrad(ptr(gyv), Cout, ptr(xv), Cin, ptr(w_out), ptr(b_out), B, H, W, Cin, Cout, kh, kw, stride, pad, upsample,
-                                           int(tw is not None), int(tb is not None), ptr(ws), ws.numel(), 0, stream()), 'conv2d_wgrad')
+                                           int(tw is not None), int(tb is not None), ptr(ws), ws.numel(), CONV_TILE_HINTS[2], stream()), 'conv2d_wgrad')
             gw = None if tw is not None else w_out
             gb = None if (tb is not None or not need_b) else b_out
         gres = gy if (has_res and ctx.needs_input_grad[3]) else None

@@ -180,11 +180,12 @@ def large_main():
         print(json.dumps(rec), flush=True)
 
 
-if 'large' in sys.argv[1:]:
-    large_main()
-elif 'cold' in sys.argv[1:]:
-    cold_main()
-elif 'attn' in sys.argv[1:]:
-    attn_main()
-else:
-    main()
+if __name__ == '__main__':
+    if 'large' in sys.argv[1:]:
+        large_main()
+    elif 'cold' in sys.argv[1:]:
+        cold_main()
+    elif 'attn' in sys.argv[1:]:
+        attn_main()
+    else:
+        main()
