@@ -57,8 +57,13 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
         if (force_splitk > 0) S = force_splitk;
         else if (!big && tiles <= 128 && p.ksteps >= 32) {   // every slice pays an agent-scope release: only few, long tiles split
             S = (int)(512 / tiles); const int cap = p.ksteps / 8; if (S > cap) S = cap; if (S > 4) S = 4;
-        } else if (big && tiles <= 128 && long_k) { S = (int)(384 / tiles); if (S > 3) S = 3; }   // >= 16 K-steps per slice; 160 tiles already
-                                                                                                   // run best unsplit ([4096,5120] x [5120,640]: 54 vs 67 us)
+        } else if (big && long_k && tiles <= 128) {
+            S = (int)(256 / tiles); if (S > 3) S = 3; if (S < 2) S = 2;      // one round of workgroups: 80 tiles x 3, 120 x 2 (measured: tools/kernel_timing.py, tools/conv_timing.py)
+        } else if (big && long_k && tiles < 256) {
+            // 129 .. 255 tiles: split only when every slice keeps >= 48 K-steps ([4096,5120] x [5120,640], 160 tiles x 80 steps, runs best unsplit: 54 vs 67 us;
+            // the 3x3 convolutions' 135 .. 225 tiles x 180 .. 256 steps gain 25 .. 45 % from 2 - 3 slices)
+            S = (int)(512 / tiles); const int cap = p.ksteps / 48; if (S > cap) S = cap; if (S > 3) S = 3;
+        }
         if (S < 1) S = 1;
         if (S > p.ksteps) S = p.ksteps;
         const long max_slabs = (ws_bytes - COUNTER_BYTES) / slab_bytes;

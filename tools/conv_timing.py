@@ -31,32 +31,36 @@ def main():
         ho = y0.shape[2]
         fl = 2.0 * ho * ho * cout * cin * k * k
         rec = {'op': 'conv', 'hw': hw, 'cin': cin, 'cout': cout, 'k': k, 'stride': stride, 'ups': ups, 'cnt': cnt, 'gflop': round(fl / 1e9, 2)}
+        from diffusion_pipe_amd.hip import check, lib, ptr, stream
+        xv = ops.nhwc_view(x)
+        gyv = ops.nhwc_view(gy)
+        y = torch.empty_like(gyv)
+        hi = hw * ups
+        dx = torch.empty((1, hi, hi, cin), device=dev, dtype=torch.bfloat16)
+        dws = [torch.zeros_like(c.weight) for c in convs]
+        db = torch.zeros(cout, device=dev, dtype=torch.bfloat16)
+        ws = ops._splitk_workspace(dev)
         for name, hint in HINTS:
-            res = []
-            for which in range(3):
-                hints = [0, 0, 0]
-                hints[which] = hint
-                ops.CONV_TILE_HINTS = tuple(hints)
-                try:
-                    if which == 0:
-                        def run():
-                            for c in convs:
-                                ops._Conv2dNHWCFn.apply(x, c.weight, c.bias, None, stride, pad, ups)
-                        us = graph_time(run, n=1, reps=3) / nbuf
-                    else:
-                        xr = x.detach().requires_grad_(which == 1)
+            def fwd():
+                for c in convs:
+                    check(lib().dpipe_conv2d_fwd(ptr(xv), cin, ptr(c.weight), ptr(c.bias), None, cout, ptr(y), cout, 1, hw, hw, cin, cout, k, k, stride, pad, ups, 0,
+                                                 ptr(ws), ws.numel(), hint, stream()), 'fwd')
 
-                        def run():      # forward (auto tiles) + the one backward GEMM under test; the forward's time is subtracted
-                            for c in convs:
-                                c.weight.requires_grad_(which == 2); c.bias.requires_grad_(which == 2)
-                                ops._Conv2dNHWCFn.apply(xr, c.weight, c.bias, None, stride, pad, ups).backward(gy)
-                                c.weight.grad = None; c.bias.grad = None; xr.grad = None
-                        us = graph_time(run, n=1, reps=3) / nbuf - rec.get('auto', [0, 0, 0])[0]
-                    res.append(round(us, 1))
+            def dgrad():
+                for c in convs:
+                    check(lib().dpipe_conv2d_dgrad(ptr(gyv), cout, ptr(c.weight), ptr(dx), cin, 1, hi, hi, cin, cout, k, k, stride, pad, ptr(ws), ws.numel(), hint, stream()), 'dgrad')
+
+            def wgrad():
+                for c, dw in zip(convs, dws):
+                    check(lib().dpipe_conv2d_wgrad(ptr(gyv), cout, ptr(xv), cin, ptr(dw), ptr(db), 1, hw, hw, cin, cout, k, k, stride, pad, ups, 1, 1,
+                                                   ptr(ws), ws.numel(), hint, stream()), 'wgrad')
+            res = []
+            for fn in (fwd, dgrad, wgrad):
+                try:
+                    res.append(round(graph_time(fn, n=1, reps=3) / nbuf, 1))
                 except Exception:
                     res.append(None)
             rec[name] = res
-            ops.CONV_TILE_HINTS = (0, 0, 0)
         xt = x if ups == 1 else F.interpolate(x, scale_factor=2.0, mode='nearest').contiguous(memory_format=torch.channels_last)
         with torch.no_grad():
             rec['torch_fwd'] = round(graph_time(lambda: [F.conv2d(xt, c.weight, c.bias, stride=stride, padding=pad) for c in convs], n=1, reps=3) / nbuf, 1)
