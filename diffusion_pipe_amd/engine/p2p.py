@@ -78,6 +78,7 @@ class StageLink:
             works = [dist.isend(_wire(t), dst=peer) for t in tensors]
         self._pending.append((works, tensors))
 
+    @torch.no_grad()            # the buffers may be a stage graph's static inputs (leaves that require grad)
     def _recv(self, buffers, peer):
         if self.on_gpu:
             with torch.cuda.stream(self.comm_stream):
