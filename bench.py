@@ -6,13 +6,15 @@
 
 A "step" is one optimizer step of the hot path (`engine.train_batch`): GAS micro-batches of one 1024x1024 image each
 (latents [1,4,128,128], 75-token prompts through both trained CLIP text encoders) through the SDXL UNet split over N
-pipeline stages, 1F1B schedule, fused loss, gradient clip, AdamW -- full fine-tune, bf16, synthetic data, random
-weights.  GAS = 6 * N so per-GPU work is constant as N grows ("weak"); at N = 1 the six micro-batches of a step run on
-three concurrent hipGraph lanes (same-box sweep: GAS 4 / 2 lanes 11.65, GAS 6 / 2 lanes 12.08, GAS 6 / 3 lanes 13.63, GAS 8 / 4
-lanes 11.86 images/s).  Prints ONE JSON line on rank 0.
+pipeline stages, 1F1B schedule, fused loss, gradient clip, AdamW -- full fine-tune, bf16, synthetic data resident in HBM before the
+timed region, random weights.  GAS = 6 * N so per-GPU work is constant as N grows ("weak"); at N = 1 the six micro-batches of a step
+run on three concurrent hipGraph lanes.  The host waits for the end of step n - 1 before it enqueues step n (engine
+`max_steps_in_flight = 1`).  Prints ONE JSON line on rank 0.
 
-Extra objects: `roofline` (dominant kernel = the hand-written MFMA GEMM, timed with HIP events around every launch of
-the last timed step) and `cpu_baseline` (the oracle's fp32 eager path on the host cores, bounded sample, N=1 only).
+Extra objects: `roofline` (dominant kernel = the hand-written MFMA GEMM: the step's recorded GEMM launch list replayed as one
+GEMM-only hipGraph between HIP events, `traffic` from the committed rocprofv3 --pmc passes over the same list) and `cpu_baseline`
+(the oracle's fp32 eager path on the host cores, one whole image, N=1 only).  Watchdogs: wall clock (DPIPE_BENCH_WATCHDOG_S, 900 s)
+and progress (DPIPE_BENCH_STALL_S, 90 s without a retired graph replay -> exit 3 with the stuck launch named).
 """
 import argparse
 import json

@@ -18,7 +18,7 @@ from . import eager_step, sdxl_ref
 def sdxl_cpu_baseline(cfg, latent_hw=128, threads=None, micro_batch=None):
     """-> cpu_baseline dict.  `micro_batch`: one prepared (features, label) pair as the engine receives it."""
     # many-core hosts (the GPU box has 256 hardware threads) run these mid-sized fp32 ops fastest on a subset
-    threads = threads or min(os.cpu_count() or 1, 64)
+    threads = threads or min(os.cpu_count() or 1, int(os.environ.get('DPIPE_CPU_BASELINE_THREADS', '32')))
     prev = torch.get_num_threads()
     torch.set_num_threads(threads)
     try:
