@@ -28,7 +28,7 @@ def main():
             m = re.search(r'remark:\s+([A-Za-z \[\]/]+): (\d+)', line)
             if m and cur is not None and m.group(1).strip() in FIELDS:
                 cur[FIELDS[m.group(1).strip()]] = int(m.group(2))
-    out = sys.argv[1] if len(sys.argv) > 1 else str(ROOT / 'profiles' / 'r1_kernel_resources.csv')
+    out = sys.argv[1] if len(sys.argv) > 1 else str(ROOT / 'profiles' / 'r2_kernel_resources.csv')
     cols = ['file', 'kernel'] + list(FIELDS.values())
     with open(out, 'w', newline='') as fh:
         w = csv.DictWriter(fh, fieldnames=cols)
