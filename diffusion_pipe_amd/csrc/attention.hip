@@ -14,14 +14,15 @@
 // ds_read_b64_tr_b16.  K/V tiles are staged global -> registers -> LDS with 16-byte accesses, the next tile's
 // loads being issued before the current tile's MFMAs.  Backward = three kernels without atomics (deterministic):
 // delta = rowsum(dO * O); a query-outer kernel for dQ; a key-outer kernel for dK and dV.
+#include <cstdlib>
 #include "dpipe_common.h"
+#include "lds_dma_tiles.h"
 #include "../../include/dpipe_hip.h"
 
 using namespace dpipe;
+using namespace dpipe_tiles;
 
 namespace {
-
-typedef __attribute__((address_space(3))) bf16x4_t lds_bf16x4_t;
 
 struct AttnParams {
     const bf16_t *q, *k, *v, *o, *dout;
@@ -210,6 +211,178 @@ __global__ void __launch_bounds__(NW * 64, D == 64 ? 2 : 1) attn_fwd_kernel(cons
                 *reinterpret_cast<uint2*>(O + 32 * db + 8 * eg + 4 * h) = w;
             }
         if (h == 0) p.lse[((long)b * p.H + hh) * p.Sq + qrow] = (m + __builtin_amdgcn_logf(l)) * LN2;   // v_log_f32 = log2
+    }
+}
+
+// ================================================================================================ forward, long sequences
+// 64 query rows per wave (two 32-column score blocks sharing every K / V fragment read: the 32-row kernel above reads 32 KiB of LDS per
+// wave per 64-key tile for 32 MFMAs = the CU's whole 128 B/clk once four waves run), 256 per workgroup; K / V tiles go global -> LDS by
+// `buffer_load_dwordx4 ... lds` into a two-deep ring in the GEMM's two image formats (lds_dma_tiles.h: K as K-contiguous images read with
+// ds_read_b128, V as an MN-contiguous image read transposed with ds_read_b64_tr_b16), one barrier per tile, the next tile's DMA in flight
+// under the current tile's MFMAs -- no staging VGPRs, no ds_write pass.  Keys past kv_len come back as zeros from the buffer bounds check.
+// Within a tile both 32-key blocks' score MFMAs are issued before the first softmax, so exponentials overlap matrix work of the same wave.
+template <int D>
+__global__ void __launch_bounds__(256, D == 64 ? 2 : 1) attn_fwd_dma_kernel(const AttnParams p) {
+    constexpr int KT = 64, NKS = D / 16, NDB = D / 32;
+    constexpr int IMG = KT * D * 2, STAGE = 2 * IMG;      // K image(s) then V image
+    constexpr int PP = IMG / 1024 / 4;                    // 1 KiB DMA pieces per wave per operand per tile
+    __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
+
+    // XCD-aware order (consecutive ids round-robin over the 8 XCDs): an XCD works through a contiguous run of (head, query block) pairs, so the
+    // query blocks of one head -- which stream the same K / V -- share one L2
+    const int nq = (p.Sq + 255) / 256;
+    const int total = nq * p.H * p.B;
+    const int orig = blockIdx.x, xq = total / 8, xr = total % 8, xcd = orig % 8;
+    const int L = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + orig / 8;
+    const int qblk = L % nq, hh = (L / nq) % p.H, b = L / (nq * p.H);
+
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = lane & 31, h = lane >> 5;
+    const int q0w = qblk * 256 + wid * 64;                // first query row of this wave
+    const int kvl = p.kv_len ? min(p.kv_len[b], p.Sk) : p.Sk;
+    const bf16_t* Q = p.q + b * p.q_sb + hh * p.q_sh;
+    const bf16_t* K = p.k + b * p.k_sb + hh * p.k_sh;
+    const bf16_t* V = p.v + b * p.v_sb + hh * p.v_sh;
+    const float sl2 = p.scale * LOG2E;
+
+    bf16x8_t qf[2][NKS];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qrow = q0w + 32 * qb + i;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+            qf[qb][ks] = qrow < p.Sq ? *reinterpret_cast<const bf16x8_t*>(Q + (long)qrow * p.q_ss + 16 * ks + 8 * h) : zero_frag();
+    }
+    f32x16 oacc[2][NDB];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) oacc[qb][db] = zero16();
+    float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+
+    int nkt = (kvl + KT - 1) / KT;
+    if (p.causal) nkt = min(nkt, min(qblk * 256 + 255, p.Sq - 1) / KT + 1);      // tiles at or below the diagonal of the workgroup's last row
+
+    // rows >= kvl lie beyond the extent (row offsets grow with the row): the bounds check zero-fills them
+    const unsigned k_bytes = kvl > 0 ? (unsigned)(((long)(kvl - 1) * p.k_ss + D) * 2) : 0u;
+    const unsigned v_bytes = kvl > 0 ? (unsigned)(((long)(kvl - 1) * p.v_ss + D) * 2) : 0u;
+    const auto rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(K), (short)0, (int)k_bytes, 0x00020000);
+    const auto rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(V), (short)0, (int)v_bytes, 0x00020000);
+    unsigned voK[PP], voV[PP];
+#pragma unroll
+    for (int j = 0; j < PP; ++j) {
+        const int P = j * 4 + wid;                         // piece P of the tile: K slice P / 8 (64 head-dim columns each), rows 8 (P % 8) ..
+        voK[j] = dma_voffset<false, KT>(P % 8, lane, 0, p.k_ss) + (unsigned)(P / 8) * 128u;
+        voV[j] = dma_voffset<true, D>(P, lane, 0, p.v_ss);
+    }
+    const unsigned stepK = (unsigned)(KT * p.k_ss * 2), stepV = (unsigned)(KT * p.v_ss * 2);
+    // (the DMA builtin must only see non-dependent operands: see gemm_pipe_kernel.h)
+#define ISSUE_TILE(buf)                                                                                                   \
+    do {                                                                                                                  \
+        char* base_ = lds + (buf) * STAGE + wid * 1024;                                                                   \
+        _Pragma("unroll") for (int j = 0; j < PP; ++j) {                                                                  \
+            char* dk_ = base_ + j * 4096;                                                                                 \
+            const unsigned ok_ = voK[j]; voK[j] += stepK;                                                                 \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_void_t*)dk_, 16, ok_, 0, 0, 0);                            \
+        }                                                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < PP; ++j) {                                                                  \
+            char* dv_ = base_ + IMG + j * 4096;                                                                           \
+            const unsigned ov_ = voV[j]; voV[j] += stepV;                                                                 \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_void_t*)dv_, 16, ov_, 0, 0, 0);                            \
+        }                                                                                                                 \
+    } while (0)
+
+    if (nkt > 0) ISSUE_TILE(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile kt (the only DMA in flight here)
+        __builtin_amdgcn_s_barrier();                      // every wave's pieces landed; everyone is done reading the other buffer
+        if (kt + 1 < nkt) ISSUE_TILE((kt + 1) & 1);
+        const char* Kl = lds + (kt & 1) * STAGE;
+        const char* Vl = Kl + IMG;
+        const int key00 = kt * KT;
+        if (p.causal && key00 > q0w + 63) continue;        // wave-uniform: the whole tile is above the diagonal for every row of the wave
+
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int key0 = key00 + 32 * kb;
+            if (key0 >= kvl) break;                        // workgroup-uniform: nothing valid in this block
+            if (p.causal && key0 > q0w + 63) break;
+            // ---- scores of this 32-key block x both 32-query blocks (K fragments shared by the two query blocks)
+            f32x16 sc[2];
+            sc[0] = zero16(); sc[1] = zero16();
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const bf16x8_t kf = read_frag<false, KT>(Kl + (ks / 4) * (KT * 128), 32 * kb, ks & 3, lane);
+                sc[0] = mfma16(kf, qf[0][ks], sc[0]);
+                sc[1] = mfma16(kf, qf[1][ks], sc[1]);
+            }
+            bf16x8_t pf[2][2];
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                f32x16& s = sc[qb];
+                const int qrow = q0w + 32 * qb + i;
+                float mx = -INFINITY;
+                const bool full = key0 + 32 <= kvl && (!p.causal || key0 + 31 <= q0w + 32 * qb);
+                if (full) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { const float v = s[e] * sl2; s[e] = v; mx = fmaxf(mx, v); }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        const bool ok = key < kvl && (!p.causal || key <= qrow);
+                        const float v = ok ? s[e] * sl2 : -INFINITY;
+                        s[e] = v; mx = fmaxf(mx, v);
+                    }
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m[qb], mx);      // finite from the first block on (key 0 is valid for every row)
+                float rs = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { const float pe = __builtin_amdgcn_exp2f(s[e] - m_new); s[e] = pe; rs += pe; }
+                rs += __shfl_xor(rs, 32, 64);
+                if (__all(m_new == m[qb])) {
+                    l[qb] += rs;
+                } else {
+                    const float alpha = __builtin_amdgcn_exp2f(m[qb] - m_new);
+                    l[qb] = l[qb] * alpha + rs; m[qb] = m_new;
+#pragma unroll
+                    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) oacc[qb][db][e] *= alpha;
+                }
+                pf[qb][0] = pack_frag(s, 0); pf[qb][1] = pack_frag(s, 8);
+            }
+            // ---- O^T += V^T . P^T (V fragments shared by the two query blocks)
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                const bf16x8_t v0 = read_frag_tr_acc<D>(Vl, 32 * db, 32 * kb, lane);
+                const bf16x8_t v1 = read_frag_tr_acc<D>(Vl, 32 * db, 32 * kb + 16, lane);
+                oacc[0][db] = mfma16(v0, pf[0][0], oacc[0][db]);
+                oacc[1][db] = mfma16(v0, pf[1][0], oacc[1][db]);
+                oacc[0][db] = mfma16(v1, pf[0][1], oacc[0][db]);
+                oacc[1][db] = mfma16(v1, pf[1][1], oacc[1][db]);
+            }
+        }
+    }
+#undef ISSUE_TILE
+
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qrow = q0w + 32 * qb + i;
+        if (qrow < p.Sq) {
+            const float inv = 1.f / l[qb];
+            bf16_t* O = p.out + b * p.o_sb + hh * p.o_sh + (long)qrow * p.o_ss;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int eg = 0; eg < 4; ++eg) {
+                    uint2 w;
+                    w.x = pack_bf16x2(oacc[qb][db][4 * eg] * inv, oacc[qb][db][4 * eg + 1] * inv);
+                    w.y = pack_bf16x2(oacc[qb][db][4 * eg + 2] * inv, oacc[qb][db][4 * eg + 3] * inv);
+                    *reinterpret_cast<uint2*>(O + 32 * db + 8 * eg + 4 * h) = w;
+                }
+            if (h == 0) p.lse[((long)b * p.H + hh) * p.Sq + qrow] = (m[qb] + __builtin_amdgcn_logf(l[qb])) * LN2;
+        }
     }
 }
 
@@ -524,6 +697,16 @@ int dpipe_attn_fwd(const void* q, const void* k, const void* v, void* o, float* 
     p.B = B; p.H = H; p.Sq = Sq; p.Sk = Sk; p.scale = scale; p.causal = causal;
     p.q_sb = q_sb; p.q_ss = q_ss; p.q_sh = q_sh; p.k_sb = k_sb; p.k_ss = k_ss; p.k_sh = k_sh;
     p.v_sb = v_sb; p.v_ss = v_ss; p.v_sh = v_sh; p.o_sb = o_sb; p.o_ss = o_ss; p.o_sh = o_sh;
+    // long sequences: the LDS-DMA kernel (256 queries per workgroup) once its workgroups alone fill most of the chip and the K / V extents
+    // fit the 32-bit buffer offsets; DPIPE_ATTN_FWD_DMA = 0 / 1 forces the choice (A/B timing)
+    static const int dma_mode = [] { const char* e = getenv("DPIPE_ATTN_FWD_DMA"); return e ? atoi(e) : -1; }();
+    const bool fits = ((long)(Sk - 1) * k_ss + D) * 2 < (1l << 31) && ((long)(Sk - 1) * v_ss + D) * 2 < (1l << 31);
+    const long wg256 = (long)cdiv(Sq, 256) * H * B;
+    if (fits && (dma_mode == 1 || (dma_mode != 0 && wg256 >= 192))) {
+        if (D == 64) attn_fwd_dma_kernel<64><<<(unsigned)wg256, 256, 0, STREAM(stream)>>>(p);
+        else attn_fwd_dma_kernel<128><<<(unsigned)wg256, 256, 0, STREAM(stream)>>>(p);
+        return check_launch("dpipe_attn_fwd");
+    }
     // 128 queries per workgroup (4 waves) when that alone fills the chip, else 64 (2 waves): twice the workgroups
     const bool small = cdiv(Sq, 128) * H * B < 256;
     if (small) {

@@ -22,6 +22,7 @@
 // Workgroup = 256 threads = 4 waves (2 x 2), 64 x 64 per wave, v_mfma_f32_32x32x16_bf16, fp32 accumulate.
 #pragma once
 #include "gemm_internal.h"
+#include "lds_dma_tiles.h"
 
 using namespace dpipe;
 
@@ -39,8 +40,7 @@ constexpr int COUNTER_BYTES = 4096;
 #define TL_STAMP(slot) do { } while (0)
 #endif
 
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(3))) bf16x4_t lds_bf16x4_t;
+using namespace dpipe_tiles;   // LDS image formats of the DMA'd operand tiles (lds_dma_tiles.h)
 
 // Tile geometry.  T64: 64 x 64 tile, 4 waves (2 x 2, 32 x 32 each), 4-deep ring of 16 KiB stages -> 2 workgroups per CU;
 // the small-problem configuration (4 x the workgroups of T128: aggregate L1/L2 bandwidth of more CUs is what bounds a
@@ -70,56 +70,6 @@ using T64S3 = Tile<64, 64, 2, 2, 3>;         // selectable, not chosen automatic
 using T256 = Tile<256, 128, 4, 2, 3>;       // selectable, not chosen automatically: 256 x 128, 8 waves of 64 x 64, 144 KiB (T128R2 beats it)
 using T256S = Tile<256, 256, 2, 4, 2>;      // 256 x 256, 8 waves of 128 x 64 (128 accumulator VGPRs), 2 x 64 KiB: twice the MFMA work per DMA'd
                                             // byte of the 128^2 tile -- the large-GEMM configuration (DiT-sized linears: Flux / Wan / HunyuanVideo)
-
-// Byte offset (from the operand base of this batch) of the 16 bytes lane `lane` fetches for DMA piece q of an image of
-// ROWS mn-rows at K-step 0.  The DMA writes lane L of piece q to LDS byte (q * 1024 + 16 L); the logical chunk fetched
-// is the inverse of the read-side swizzle.
-template <bool MC, int ROWS>
-__device__ __forceinline__ unsigned dma_voffset(int q, int lane, int mn0, long ld) {
-    if (!MC) {   // image [ROWS mn-rows][128 B]: physical 16-B chunk pc of row holds logical chunk pc ^ ((row >> 1) & 7)
-        const int row = 8 * q + (lane >> 3);
-        const int pc = lane & 7;
-        const int lc = pc ^ ((row >> 1) & 7);
-        return (unsigned)(((long)(mn0 + row) * ld + lc * 8) * 2);
-    } else {     // image [64 k-rows][ROWS * 2 B]: physical 64-B granule pg of a k-row holds logical granule pg ^ f(krow)
-        constexpr int CPR = ROWS / 8;            // 16-B chunks per k-row (16 or 8)
-        constexpr int G = ROWS / 32;             // 64-B granules per k-row (4 or 2)
-        const int krow = q * (64 / CPR) + lane / CPR;
-        const int pc = lane % CPR;
-        const int f = G >= 4 ? (krow & 3) : ((krow >> 1) & 1);
-        const int lc = (((pc >> 2) ^ f) << 2) | (pc & 3);
-        return (unsigned)(((long)krow * ld + mn0 + lc * 8) * 2);
-    }
-}
-
-// MFMA operand fragment (32 mn-rows x 16 k): lane (i = lane & 31, h = lane >> 5) gets k = 16 ks + 8 h .. + 8 of row mn + i.
-template <bool MC, int ROWS>
-__device__ __forceinline__ bf16x8_t read_frag(const char* img, int mn, int ks, int lane) {
-    if (!MC) {
-        // mn is a multiple of 32, so the swizzle term (row >> 1) & 7 depends on the lane only and 2 ks + h == (2 ks) ^ h:
-        // the lane part of the address is one of 4 values (per ks) shared by every fragment of both operands; mn * 128
-        // is wave-uniform / an immediate offset
-        const int l31 = lane & 31;
-        const int x = (lane >> 5) ^ ((l31 >> 1) & 7);
-        const int lane_off = l31 * 128 + ((x ^ (2 * ks)) << 4);
-        return *reinterpret_cast<const bf16x8_t*>(img + mn * 128 + lane_off);
-    } else {
-        // ds_read_b64_tr_b16: in a 16-lane group lane t supplies the address of 4 contiguous bf16 of k-row (t >> 2) at
-        // columns 4 (t & 3) of a [4][16] block and receives column t of it (the 4 k values of one mn index).
-        constexpr int RB = ROWS * 2, G = ROWS / 32;
-        const int t = lane & 15, g = lane >> 4;
-        const int krow = 16 * ks + 8 * (g >> 1) + (t >> 2);
-        const int col_b = (16 * (g & 1) + 4 * (t & 3)) * 2;          // byte column inside the 64-B granule
-        const int f = G >= 4 ? (krow & 3) : ((krow >> 1) & 1);       // identical for krow + 4
-        const char* p = img + krow * RB + ((mn >> 5) ^ f) * 64 + col_b;
-        const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(p));
-        const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_t*)(p + 4 * RB));
-        bf16x8_t out;
-        out[0] = lo[0]; out[1] = lo[1]; out[2] = lo[2]; out[3] = lo[3];
-        out[4] = hi[0]; out[5] = hi[1]; out[6] = hi[2]; out[7] = hi[3];
-        return out;
-    }
-}
 
 // sum of the 8 bf16 of an MFMA operand fragment (fp32)
 __device__ __forceinline__ float frag_sum(bf16x8_t f) {
