@@ -221,46 +221,49 @@ __global__ void __launch_bounds__(NW * 64, D == 64 ? 2 : 1) attn_fwd_kernel(cons
 // ds_read_b128, V as an MN-contiguous image read transposed with ds_read_b64_tr_b16), one barrier per tile, the next tile's DMA in flight
 // under the current tile's MFMAs -- no staging VGPRs, no ds_write pass.  Keys past kv_len come back as zeros from the buffer bounds check.
 // Within a tile both 32-key blocks' score MFMAs are issued before the first softmax, so exponentials overlap matrix work of the same wave.
-template <int D>
-__global__ void __launch_bounds__(256, D == 64 ? 2 : 1) attn_fwd_dma_kernel(const AttnParams p) {
+template <int D, int QB, int NW>
+__global__ void __launch_bounds__(NW * 64, (D == 64 && NW == 4) ? 2 : 1) attn_fwd_dma_kernel(const AttnParams p) {
+    constexpr int QW = 32 * QB, QWG = QW * NW;          // query rows per wave / per workgroup
     constexpr int KT = 64, NKS = D / 16, NDB = D / 32;
     constexpr int IMG = KT * D * 2, STAGE = 2 * IMG;      // K image(s) then V image
-    constexpr int PP = IMG / 1024 / 4;                    // 1 KiB DMA pieces per wave per operand per tile
+    constexpr int PP = IMG / 1024 / NW;                   // 1 KiB DMA pieces per wave per operand per tile
     __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
 
     // XCD-aware order (consecutive ids round-robin over the 8 XCDs): an XCD works through a contiguous run of (head, query block) pairs, so the
     // query blocks of one head -- which stream the same K / V -- share one L2
-    const int nq = (p.Sq + 255) / 256;
+    const int nq = (p.Sq + QWG - 1) / QWG;
     const int total = nq * p.H * p.B;
     const int orig = blockIdx.x, xq = total / 8, xr = total % 8, xcd = orig % 8;
     const int L = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + orig / 8;
     const int qblk = L % nq, hh = (L / nq) % p.H, b = L / (nq * p.H);
 
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = lane & 31, h = lane >> 5;
-    const int q0w = qblk * 256 + wid * 64;                // first query row of this wave
+    const int q0w = qblk * QWG + wid * QW;                // first query row of this wave
     const int kvl = p.kv_len ? min(p.kv_len[b], p.Sk) : p.Sk;
     const bf16_t* Q = p.q + b * p.q_sb + hh * p.q_sh;
     const bf16_t* K = p.k + b * p.k_sb + hh * p.k_sh;
     const bf16_t* V = p.v + b * p.v_sb + hh * p.v_sh;
     const float sl2 = p.scale * LOG2E;
 
-    bf16x8_t qf[2][NKS];
+    bf16x8_t qf[QB][NKS];
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < QB; ++qb) {
         const int qrow = q0w + 32 * qb + i;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
             qf[qb][ks] = qrow < p.Sq ? *reinterpret_cast<const bf16x8_t*>(Q + (long)qrow * p.q_ss + 16 * ks + 8 * h) : zero_frag();
     }
-    f32x16 oacc[2][NDB];
+    f32x16 oacc[QB][NDB];
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
+    for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
         for (int db = 0; db < NDB; ++db) oacc[qb][db] = zero16();
-    float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+    float m[QB], l[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) { m[qb] = -INFINITY; l[qb] = 0.f; }
 
     int nkt = (kvl + KT - 1) / KT;
-    if (p.causal) nkt = min(nkt, min(qblk * 256 + 255, p.Sq - 1) / KT + 1);      // tiles at or below the diagonal of the workgroup's last row
+    if (p.causal) nkt = min(nkt, min(qblk * QWG + QWG - 1, p.Sq - 1) / KT + 1);      // tiles at or below the diagonal of the workgroup's last row
 
     // rows >= kvl lie beyond the extent (row offsets grow with the row): the bounds check zero-fills them
     const unsigned k_bytes = kvl > 0 ? (unsigned)(((long)(kvl - 1) * p.k_ss + D) * 2) : 0u;
@@ -270,7 +273,7 @@ __global__ void __launch_bounds__(256, D == 64 ? 2 : 1) attn_fwd_dma_kernel(cons
     unsigned voK[PP], voV[PP];
 #pragma unroll
     for (int j = 0; j < PP; ++j) {
-        const int P = j * 4 + wid;                         // piece P of the tile: K slice P / 8 (64 head-dim columns each), rows 8 (P % 8) ..
+        const int P = j * NW + wid;                         // piece P of the tile: K slice P / 8 (64 head-dim columns each), rows 8 (P % 8) ..
         voK[j] = dma_voffset<false, KT>(P % 8, lane, 0, p.k_ss) + (unsigned)(P / 8) * 128u;
         voV[j] = dma_voffset<true, D>(P, lane, 0, p.v_ss);
     }
@@ -280,12 +283,12 @@ __global__ void __launch_bounds__(256, D == 64 ? 2 : 1) attn_fwd_dma_kernel(cons
     do {                                                                                                                  \
         char* base_ = lds + (buf) * STAGE + wid * 1024;                                                                   \
         _Pragma("unroll") for (int j = 0; j < PP; ++j) {                                                                  \
-            char* dk_ = base_ + j * 4096;                                                                                 \
+            char* dk_ = base_ + j * NW * 1024;                                                                                 \
             const unsigned ok_ = voK[j]; voK[j] += stepK;                                                                 \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_void_t*)dk_, 16, ok_, 0, 0, 0);                            \
         }                                                                                                                 \
         _Pragma("unroll") for (int j = 0; j < PP; ++j) {                                                                  \
-            char* dv_ = base_ + IMG + j * 4096;                                                                           \
+            char* dv_ = base_ + IMG + j * NW * 1024;                                                                           \
             const unsigned ov_ = voV[j]; voV[j] += stepV;                                                                 \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_void_t*)dv_, 16, ov_, 0, 0, 0);                            \
         }                                                                                                                 \
@@ -299,25 +302,27 @@ __global__ void __launch_bounds__(256, D == 64 ? 2 : 1) attn_fwd_dma_kernel(cons
         const char* Kl = lds + (kt & 1) * STAGE;
         const char* Vl = Kl + IMG;
         const int key00 = kt * KT;
-        if (p.causal && key00 > q0w + 63) continue;        // wave-uniform: the whole tile is above the diagonal for every row of the wave
+        if (p.causal && key00 > q0w + QW - 1) continue;        // wave-uniform: the whole tile is above the diagonal for every row of the wave
 
+        // scores of a 32-key block x the wave's query blocks (K fragments shared by the query blocks)
+#define SCORES(kb)                                                                                                        \
+        do {                                                                                                              \
+            _Pragma("unroll") for (int qb = 0; qb < QB; ++qb) sc[qb] = zero16();                                      \
+            _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks) {                                                          \
+                const bf16x8_t kf = read_frag<false, KT>(Kl + (ks / 4) * (KT * 128), 32 * (kb), ks & 3, lane);            \
+                _Pragma("unroll") for (int qb = 0; qb < QB; ++qb) sc[qb] = mfma16(kf, qf[qb][ks], sc[qb]);        \
+            }                                                                                                             \
+        } while (0)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             const int key0 = key00 + 32 * kb;
             if (key0 >= kvl) break;                        // workgroup-uniform: nothing valid in this block
-            if (p.causal && key0 > q0w + 63) break;
-            // ---- scores of this 32-key block x both 32-query blocks (K fragments shared by the two query blocks)
-            f32x16 sc[2];
-            sc[0] = zero16(); sc[1] = zero16();
+            if (p.causal && key0 > q0w + QW - 1) break;
+            f32x16 sc[QB];
+            SCORES(kb);
+            bf16x8_t pf[QB][2];
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                const bf16x8_t kf = read_frag<false, KT>(Kl + (ks / 4) * (KT * 128), 32 * kb, ks & 3, lane);
-                sc[0] = mfma16(kf, qf[0][ks], sc[0]);
-                sc[1] = mfma16(kf, qf[1][ks], sc[1]);
-            }
-            bf16x8_t pf[2][2];
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
+            for (int qb = 0; qb < QB; ++qb) {
                 f32x16& s = sc[qb];
                 const int qrow = q0w + 32 * qb + i;
                 float mx = -INFINITY;
@@ -357,17 +362,18 @@ __global__ void __launch_bounds__(256, D == 64 ? 2 : 1) attn_fwd_dma_kernel(cons
             for (int db = 0; db < NDB; ++db) {
                 const bf16x8_t v0 = read_frag_tr_acc<D>(Vl, 32 * db, 32 * kb, lane);
                 const bf16x8_t v1 = read_frag_tr_acc<D>(Vl, 32 * db, 32 * kb + 16, lane);
-                oacc[0][db] = mfma16(v0, pf[0][0], oacc[0][db]);
-                oacc[1][db] = mfma16(v0, pf[1][0], oacc[1][db]);
-                oacc[0][db] = mfma16(v1, pf[0][1], oacc[0][db]);
-                oacc[1][db] = mfma16(v1, pf[1][1], oacc[1][db]);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) oacc[qb][db] = mfma16(v0, pf[qb][0], oacc[qb][db]);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) oacc[qb][db] = mfma16(v1, pf[qb][1], oacc[qb][db]);
             }
         }
     }
 #undef ISSUE_TILE
+#undef SCORES
 
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < QB; ++qb) {
         const int qrow = q0w + 32 * qb + i;
         if (qrow < p.Sq) {
             const float inv = 1.f / l[qb];
@@ -697,14 +703,22 @@ int dpipe_attn_fwd(const void* q, const void* k, const void* v, void* o, float* 
     p.B = B; p.H = H; p.Sq = Sq; p.Sk = Sk; p.scale = scale; p.causal = causal;
     p.q_sb = q_sb; p.q_ss = q_ss; p.q_sh = q_sh; p.k_sb = k_sb; p.k_ss = k_ss; p.k_sh = k_sh;
     p.v_sb = v_sb; p.v_ss = v_ss; p.v_sh = v_sh; p.o_sb = o_sb; p.o_ss = o_ss; p.o_sh = o_sh;
-    // long sequences: the LDS-DMA kernel (256 queries per workgroup) once its workgroups alone fill most of the chip and the K / V extents
-    // fit the 32-bit buffer offsets; DPIPE_ATTN_FWD_DMA = 0 / 1 forces the choice (A/B timing)
+    // The LDS-DMA kernel: 8 waves x 32 query rows (two waves per SIMD: one wave's softmax runs under the other's MFMAs) once 256-row workgroups alone
+    // fill most of the chip, else 4 waves x 32 rows (twice the workgroups, 2 - 3 of them per CU).  Measured (tools/kernel_timing.py attn, profiles/):
+    // head dim 128 at 4.6k / 9.2k / 61k tokens 737 / 914 / 990 TFLOP/s (the register-staged kernel below: 385 / 448 / 474); SDXL's 1024 x 1024 x 20 heads
+    // 23.8 us (34.0).  The K / V extents must fit the 32-bit buffer offsets.  DPIPE_ATTN_FWD_DMA = 0 selects the register-staged kernel (A/B timing).
     static const int dma_mode = [] { const char* e = getenv("DPIPE_ATTN_FWD_DMA"); return e ? atoi(e) : -1; }();
     const bool fits = ((long)(Sk - 1) * k_ss + D) * 2 < (1l << 31) && ((long)(Sk - 1) * v_ss + D) * 2 < (1l << 31);
-    const long wg256 = (long)cdiv(Sq, 256) * H * B;
-    if (fits && (dma_mode == 1 || (dma_mode != 0 && wg256 >= 192))) {
-        if (D == 64) attn_fwd_dma_kernel<64><<<(unsigned)wg256, 256, 0, STREAM(stream)>>>(p);
-        else attn_fwd_dma_kernel<128><<<(unsigned)wg256, 256, 0, STREAM(stream)>>>(p);
+    if (fits && dma_mode != 0) {
+        hipStream_t st = STREAM(stream);
+        const long wg256 = (long)cdiv(Sq, 256) * H * B, wg128 = (long)cdiv(Sq, 128) * H * B;
+        if (wg256 >= 192) {
+            if (D == 64) attn_fwd_dma_kernel<64, 1, 8><<<(unsigned)wg256, 512, 0, st>>>(p);
+            else attn_fwd_dma_kernel<128, 1, 8><<<(unsigned)wg256, 512, 0, st>>>(p);
+        } else {
+            if (D == 64) attn_fwd_dma_kernel<64, 1, 4><<<(unsigned)wg128, 256, 0, st>>>(p);
+            else attn_fwd_dma_kernel<128, 1, 4><<<(unsigned)wg128, 256, 0, st>>>(p);
+        }
         return check_launch("dpipe_attn_fwd");
     }
     // 128 queries per workgroup (4 waves) when that alone fills the chip, else 64 (2 waves): twice the workgroups
@@ -755,9 +769,15 @@ int dpipe_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
     const bool small_q = cdiv(Sq, 128) * H * B < 256;
     dim3 gq((unsigned)cdiv(Sq, small_q ? 64 : 128), (unsigned)H, (unsigned)B), gk((unsigned)(cdiv(Sk, 32 * NW) * p.qsplit), (unsigned)H, (unsigned)B);
     const unsigned gred = (unsigned)cdiv((long)B * H * Sk * (D / 4), 256);
+    // head dim 128: the 4-wave dQ kernel needs > 256 registers (one wave per SIMD); 8 waves x 32 rows fit 2 per SIMD (220 VGPRs) -- DPIPE_ATTN_DQ8 = 0 for A/B timing
+    static const bool dq8_on = [] { const char* e = getenv("DPIPE_ATTN_DQ8"); return !e || atoi(e) != 0; }();
+    const bool dq8 = dq8_on && (long)cdiv(Sq, 256) * H * B >= 192;
+    dim3 gq8((unsigned)cdiv(Sq, 256), (unsigned)H, (unsigned)B);
 #define ATTN_BWD(DD) do { \
         attn_delta_kernel<DD><<<(unsigned)cdiv(rows, 16), 256, 0, s>>>(p); \
-        if (small_q) attn_bwd_dq_kernel<DD, 2><<<gq, 128, 0, s>>>(p); else attn_bwd_dq_kernel<DD, 4><<<gq, 256, 0, s>>>(p); \
+        if (small_q) attn_bwd_dq_kernel<DD, 2><<<gq, 128, 0, s>>>(p); \
+        else if (DD == 128 && dq8) attn_bwd_dq_kernel<DD, 8><<<gq8, 512, 0, s>>>(p); \
+        else attn_bwd_dq_kernel<DD, 4><<<gq, 256, 0, s>>>(p); \
         attn_bwd_dkv_kernel<DD, NW><<<gk, NW * 64, 0, s>>>(p); \
         if (p.qsplit > 1) attn_dkv_reduce_kernel<DD><<<gred, 256, 0, s>>>(p); } while (0)
     if (D == 64) ATTN_BWD(64); else ATTN_BWD(128);
