@@ -516,8 +516,12 @@ __global__ void __launch_bounds__(NW * 64, D == 64 ? 2 : 1) attn_bwd_dq_kernel(c
 // ================================================================================================ backward: dK, dV
 // Key-outer.  S[q][key] = Q . K^T (lane owns one key column);  dV^T[d][key] += dO^T[d][q] . P[q][key];
 // dK^T[d][key] += Q^T[d][q] . dS[q][key]
-template <int D, int NW>
+// MODE 0: dK and dV in one pass.  MODE 1 / 2: dV only / dK only -- at head dim 128 the one-pass kernel holds K, V fragments and two accumulators
+// (> 256 registers: one wave per SIMD); the two half kernels fit two waves per SIMD with 8 waves per workgroup, and recomputing S once more
+// (+25 % MFMA work) costs less than the idle matrix pipe of the single resident wave.
+template <int D, int NW, int MODE = 0>
 __global__ void __launch_bounds__(NW * 64, D == 64 ? 2 : 1) attn_bwd_dkv_kernel(const AttnParams p) {
+    constexpr bool DO_K = MODE != 1, DO_V = MODE != 2;
     constexpr int NT = NW * 64, QT = 64;
     constexpr int QRS = 2 * D + 16;
     __shared__ __attribute__((aligned(16))) char lds[2 * QT * QRS + 2 * QT * 4];
@@ -581,7 +585,7 @@ __global__ void __launch_bounds__(NW * 64, D == 64 ? 2 : 1) attn_bwd_dkv_kernel(
 #pragma unroll
             for (int ks = 0; ks < D / 16; ++ks) {
                 s = mfma16(frag_rows<QRS>(Ql, 32 * qb, 16 * ks, lane), kf[ks], s);
-                dp = mfma16(frag_rows<QRS>(DOl, 32 * qb, 16 * ks, lane), vf[ks], dp);
+                if constexpr (DO_K) dp = mfma16(frag_rows<QRS>(DOl, 32 * qb, 16 * ks, lane), vf[ks], dp);
             }
             f32x16 pr;
             // wave-uniform: all 32 keys of the wave are valid (padding queries carry lse = +inf -> p = 0) and nothing is causal
@@ -608,10 +612,14 @@ __global__ void __launch_bounds__(NW * 64, D == 64 ? 2 : 1) attn_bwd_dkv_kernel(
             const bf16x8_t p0 = pack_frag(pr, 0), p1 = pack_frag(pr, 8), ds0 = pack_frag(s, 0), ds1 = pack_frag(s, 8);
 #pragma unroll
             for (int db = 0; db < D / 32; ++db) {
-                dvacc[db] = mfma16(frag_cols_tr<QRS>(DOl, 32 * qb, 32 * db, lane), p0, dvacc[db]);
-                dvacc[db] = mfma16(frag_cols_tr<QRS>(DOl, 32 * qb + 16, 32 * db, lane), p1, dvacc[db]);
-                dkacc[db] = mfma16(frag_cols_tr<QRS>(Ql, 32 * qb, 32 * db, lane), ds0, dkacc[db]);
-                dkacc[db] = mfma16(frag_cols_tr<QRS>(Ql, 32 * qb + 16, 32 * db, lane), ds1, dkacc[db]);
+                if constexpr (DO_V) {
+                    dvacc[db] = mfma16(frag_cols_tr<QRS>(DOl, 32 * qb, 32 * db, lane), p0, dvacc[db]);
+                    dvacc[db] = mfma16(frag_cols_tr<QRS>(DOl, 32 * qb + 16, 32 * db, lane), p1, dvacc[db]);
+                }
+                if constexpr (DO_K) {
+                    dkacc[db] = mfma16(frag_cols_tr<QRS>(Ql, 32 * qb, 32 * db, lane), ds0, dkacc[db]);
+                    dkacc[db] = mfma16(frag_cols_tr<QRS>(Ql, 32 * qb + 16, 32 * db, lane), ds1, dkacc[db]);
+                }
             }
         }
     }
@@ -623,9 +631,9 @@ __global__ void __launch_bounds__(NW * 64, D == 64 ? 2 : 1) attn_bwd_dkv_kernel(
             for (int db = 0; db < D / 32; ++db)
 #pragma unroll
                 for (int eg = 0; eg < 4; ++eg) {
-                    *reinterpret_cast<float4*>(PK + 32 * db + 8 * eg + 4 * h) =
+                    if constexpr (DO_K) *reinterpret_cast<float4*>(PK + 32 * db + 8 * eg + 4 * h) =
                         make_float4(dkacc[db][4 * eg], dkacc[db][4 * eg + 1], dkacc[db][4 * eg + 2], dkacc[db][4 * eg + 3]);
-                    *reinterpret_cast<float4*>(PV + 32 * db + 8 * eg + 4 * h) =
+                    if constexpr (DO_V) *reinterpret_cast<float4*>(PV + 32 * db + 8 * eg + 4 * h) =
                         make_float4(dvacc[db][4 * eg], dvacc[db][4 * eg + 1], dvacc[db][4 * eg + 2], dvacc[db][4 * eg + 3]);
                 }
         }
@@ -643,8 +651,8 @@ __global__ void __launch_bounds__(NW * 64, D == 64 ? 2 : 1) attn_bwd_dkv_kernel(
                 wk.y = pack_bf16x2(dkacc[db][4 * eg + 2] * p.scale, dkacc[db][4 * eg + 3] * p.scale);
                 wv.x = pack_bf16x2(dvacc[db][4 * eg], dvacc[db][4 * eg + 1]);
                 wv.y = pack_bf16x2(dvacc[db][4 * eg + 2], dvacc[db][4 * eg + 3]);
-                *reinterpret_cast<uint2*>(DK + 32 * db + 8 * eg + 4 * h) = wk;
-                *reinterpret_cast<uint2*>(DV + 32 * db + 8 * eg + 4 * h) = wv;
+                if constexpr (DO_K) *reinterpret_cast<uint2*>(DK + 32 * db + 8 * eg + 4 * h) = wk;
+                if constexpr (DO_V) *reinterpret_cast<uint2*>(DV + 32 * db + 8 * eg + 4 * h) = wv;
             }
     }
 }
@@ -773,12 +781,17 @@ int dpipe_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
     static const bool dq8_on = [] { const char* e = getenv("DPIPE_ATTN_DQ8"); return !e || atoi(e) != 0; }();
     const bool dq8 = dq8_on && (long)cdiv(Sq, 256) * H * B >= 192;
     dim3 gq8((unsigned)cdiv(Sq, 256), (unsigned)H, (unsigned)B);
+    // head dim 128, long key sequences: dV and dK as two 8-wave kernels (two waves per SIMD) -- DPIPE_ATTN_DKV_SPLIT = 0 for A/B timing
+    static const bool split_on = [] { const char* e = getenv("DPIPE_ATTN_DKV_SPLIT"); return !e || atoi(e) != 0; }();
+    const bool dkv_split = split_on && p.qsplit == 1 && (long)cdiv(Sk, 256) * H * B >= 192;
+    dim3 gk8((unsigned)cdiv(Sk, 256), (unsigned)H, (unsigned)B);
 #define ATTN_BWD(DD) do { \
         attn_delta_kernel<DD><<<(unsigned)cdiv(rows, 16), 256, 0, s>>>(p); \
         if (small_q) attn_bwd_dq_kernel<DD, 2><<<gq, 128, 0, s>>>(p); \
         else if (DD == 128 && dq8) attn_bwd_dq_kernel<DD, 8><<<gq8, 512, 0, s>>>(p); \
         else attn_bwd_dq_kernel<DD, 4><<<gq, 256, 0, s>>>(p); \
-        attn_bwd_dkv_kernel<DD, NW><<<gk, NW * 64, 0, s>>>(p); \
+        if (DD == 128 && dkv_split) { attn_bwd_dkv_kernel<DD, 8, 1><<<gk8, 512, 0, s>>>(p); attn_bwd_dkv_kernel<DD, 8, 2><<<gk8, 512, 0, s>>>(p); } \
+        else attn_bwd_dkv_kernel<DD, NW><<<gk, NW * 64, 0, s>>>(p); \
         if (p.qsplit > 1) attn_dkv_reduce_kernel<DD><<<gred, 256, 0, s>>>(p); } while (0)
     if (D == 64) ATTN_BWD(64); else ATTN_BWD(128);
 #undef ATTN_BWD

@@ -346,7 +346,8 @@ ATTN_CASES = [  # (B, Sq, Sk, H, D, kv_len)
     (1, 1024, 77, 20, 64, None), (1, 4096, 77, 10, 64, None), (2, 1000, 100, 3, 128, [77, 100]), (1, 1024, 1024, 20, 64, None),
     (3, 700, 77, 30, 64, None),
     # enough 256-row workgroups (>= 192) for the 8-wave long-sequence kernels (forward LDS-DMA ring, head-dim-128 dQ), ragged tails and key masks
-    (1, 3100, 3100, 16, 128, None), (2, 1601, 900, 28, 64, [900, 333]), (2, 1700, 700, 16, 128, [650, 700])]
+    (1, 3100, 3100, 16, 128, None), (2, 1601, 900, 28, 64, [900, 333]), (2, 1700, 700, 16, 128, [650, 700]),
+    (2, 1300, 1700, 14, 128, [1650, 1700])]   # >= 192 256-key workgroups: dV / dK as two 8-wave kernels
 
 
 @pytest.mark.parametrize('case', ATTN_CASES)
