@@ -513,6 +513,133 @@ __global__ void __launch_bounds__(NW * 64, D == 64 ? 2 : 1) attn_bwd_dq_kernel(c
     }
 }
 
+// ================================================================================================ backward: dQ, LDS-DMA form
+// Same computation as attn_bwd_dq_kernel, tiles streamed like the forward: per 64-key tile the K tile lands twice -- as K-contiguous image(s) for
+// S^T = K . Q^T and as the MN-contiguous image whose transposed read feeds dQ^T += K^T . dS^T without bank conflicts -- plus V K-contiguous for
+// dP^T = V . dO^T; two-deep ring (6 images), one barrier per tile.
+template <int D, int NW>
+__global__ void __launch_bounds__(NW * 64, (D == 64 && NW == 4) ? 2 : 1) attn_bwd_dq_dma_kernel(const AttnParams p) {
+    constexpr int QWG = 32 * NW, KT = 64, NKS = D / 16, NDB = D / 32;
+    constexpr int IMG = KT * D * 2, STAGE = 3 * IMG, PP = IMG / 1024 / NW;
+    __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
+
+    const int nq = (p.Sq + QWG - 1) / QWG;
+    const int total = nq * p.H * p.B;
+    const int orig = blockIdx.x, xq = total / 8, xr = total % 8, xcd = orig % 8;
+    const int L = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + orig / 8;
+    const int qblk = L % nq, hh = (L / nq) % p.H, b = L / (nq * p.H);
+
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = lane & 31, h = lane >> 5;
+    const int q0w = qblk * QWG + wid * 32;
+    const int qrow = q0w + i;
+    const bool qlive = qrow < p.Sq;
+    const int kvl = p.kv_len ? min(p.kv_len[b], p.Sk) : p.Sk;
+    const bf16_t* Q = p.q + b * p.q_sb + hh * p.q_sh;
+    const bf16_t* K = p.k + b * p.k_sb + hh * p.k_sh;
+    const bf16_t* V = p.v + b * p.v_sb + hh * p.v_sh;
+    const bf16_t* DO = p.dout + b * p.do_sb + hh * p.do_sh;
+    const float sl2 = p.scale * LOG2E;
+
+    bf16x8_t qf[NKS], dof[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        qf[ks] = qlive ? *reinterpret_cast<const bf16x8_t*>(Q + (long)qrow * p.q_ss + 16 * ks + 8 * h) : zero_frag();
+        dof[ks] = qlive ? *reinterpret_cast<const bf16x8_t*>(DO + (long)qrow * p.do_ss + 16 * ks + 8 * h) : zero_frag();
+    }
+    const long stat = ((long)b * p.H + hh) * p.Sq + (qlive ? qrow : 0);
+    const float lse2 = qlive ? p.lse[stat] * LOG2E : INFINITY;
+    const float dl = qlive ? p.delta[stat] : 0.f;
+
+    f32x16 dqacc[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) dqacc[db] = zero16();
+
+    int nkt = (kvl + KT - 1) / KT;
+    if (p.causal) nkt = min(nkt, min(qblk * QWG + QWG - 1, p.Sq - 1) / KT + 1);
+
+    const unsigned k_bytes = kvl > 0 ? (unsigned)(((long)(kvl - 1) * p.k_ss + D) * 2) : 0u;
+    const unsigned v_bytes = kvl > 0 ? (unsigned)(((long)(kvl - 1) * p.v_ss + D) * 2) : 0u;
+    const auto rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(K), (short)0, (int)k_bytes, 0x00020000);
+    const auto rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(V), (short)0, (int)v_bytes, 0x00020000);
+    unsigned voKc[PP], voKm[PP], voVc[PP];
+#pragma unroll
+    for (int j = 0; j < PP; ++j) {
+        const int P = j * NW + wid;
+        voKc[j] = dma_voffset<false, KT>(P % 8, lane, 0, p.k_ss) + (unsigned)(P / 8) * 128u;
+        voKm[j] = dma_voffset<true, D>(P, lane, 0, p.k_ss);
+        voVc[j] = dma_voffset<false, KT>(P % 8, lane, 0, p.v_ss) + (unsigned)(P / 8) * 128u;
+    }
+    const unsigned stepK = (unsigned)(KT * p.k_ss * 2), stepV = (unsigned)(KT * p.v_ss * 2);
+#define ISSUE_TILE(buf)                                                                                                   \
+    do {                                                                                                                  \
+        char* base_ = lds + (buf) * STAGE + wid * 1024;                                                                   \
+        _Pragma("unroll") for (int j = 0; j < PP; ++j) {                                                                  \
+            char* d0_ = base_ + j * NW * 1024;                                                                            \
+            char* d1_ = d0_ + IMG;                                                                                        \
+            char* d2_ = d0_ + 2 * IMG;                                                                                    \
+            const unsigned o0_ = voKc[j], o1_ = voKm[j], o2_ = voVc[j];                                                   \
+            voKc[j] += stepK; voKm[j] += stepK; voVc[j] += stepV;                                                         \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_void_t*)d0_, 16, o0_, 0, 0, 0);                            \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_void_t*)d1_, 16, o1_, 0, 0, 0);                            \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_void_t*)d2_, 16, o2_, 0, 0, 0);                            \
+        }                                                                                                                 \
+    } while (0)
+
+    if (nkt > 0) ISSUE_TILE(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nkt) ISSUE_TILE((kt + 1) & 1);
+        const char* Kc = lds + (kt & 1) * STAGE;
+        const char* Km = Kc + IMG;
+        const char* Vc = Kc + 2 * IMG;
+        if (p.causal && kt * KT > q0w + 31) continue;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int key0 = kt * KT + 32 * kb;
+            if (key0 >= kvl) break;
+            if (p.causal && key0 > q0w + 31) break;
+            f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                s = mfma16(read_frag<false, KT>(Kc + (ks / 4) * (KT * 128), 32 * kb, ks & 3, lane), qf[ks], s);
+                dp = mfma16(read_frag<false, KT>(Vc + (ks / 4) * (KT * 128), 32 * kb, ks & 3, lane), dof[ks], dp);
+            }
+            if (key0 + 32 <= kvl && (!p.causal || key0 + 31 <= q0w)) {      // wave-uniform: block fully valid
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s[e] = __builtin_amdgcn_exp2f(s[e] * sl2 - lse2) * (dp[e] - dl);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = key0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const bool ok = key < kvl && (!p.causal || key <= qrow);
+                    const float pe = ok ? __builtin_amdgcn_exp2f(s[e] * sl2 - lse2) : 0.f;
+                    s[e] = pe * (dp[e] - dl);
+                }
+            }
+            const bf16x8_t ds0 = pack_frag(s, 0), ds1 = pack_frag(s, 8);
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                dqacc[db] = mfma16(read_frag_tr_acc<D>(Km, 32 * db, 32 * kb, lane), ds0, dqacc[db]);
+                dqacc[db] = mfma16(read_frag_tr_acc<D>(Km, 32 * db, 32 * kb + 16, lane), ds1, dqacc[db]);
+            }
+        }
+    }
+#undef ISSUE_TILE
+    if (qlive) {
+        bf16_t* DQ = p.dq + b * p.dq_sb + hh * p.dq_sh + (long)qrow * p.dq_ss;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int eg = 0; eg < 4; ++eg) {
+                uint2 w;
+                w.x = pack_bf16x2(dqacc[db][4 * eg] * p.scale, dqacc[db][4 * eg + 1] * p.scale);
+                w.y = pack_bf16x2(dqacc[db][4 * eg + 2] * p.scale, dqacc[db][4 * eg + 3] * p.scale);
+                *reinterpret_cast<uint2*>(DQ + 32 * db + 8 * eg + 4 * h) = w;
+            }
+    }
+}
+
 // ================================================================================================ backward: dK, dV
 // Key-outer.  S[q][key] = Q . K^T (lane owns one key column);  dV^T[d][key] += dO^T[d][q] . P[q][key];
 // dK^T[d][key] += Q^T[d][q] . dS[q][key]
@@ -657,6 +784,188 @@ __global__ void __launch_bounds__(NW * 64, D == 64 ? 2 : 1) attn_bwd_dkv_kernel(
     }
 }
 
+// ================================================================================================ backward: dK, dV, LDS-DMA form
+// Same computation and MODEs as attn_bwd_dkv_kernel; per 64-query tile the ring stage holds Q K-contiguous (S = Q . K^T), and per MODE dO
+// MN-contiguous (dV^T += dO^T . P), dO K-contiguous (dP = dO . V^T), Q MN-contiguous (dK^T += Q^T . dS), plus the tile's lse / delta rows
+// (256-byte DMA pieces).  Query rows past Sq arrive as zeros (Q, dO, lse, delta): P = 1 there but dO = 0 and dS = 0, so they add nothing.
+template <int D, int NW, int MODE>
+__global__ void __launch_bounds__(NW * 64, (D == 64 && NW == 4) ? 2 : 1) attn_bwd_dkv_dma_kernel(const AttnParams p) {
+    constexpr bool DO_K = MODE != 1, DO_V = MODE != 2;
+    constexpr int QT = 64, NKS = D / 16, NDB = D / 32;
+    constexpr int IMG = QT * D * 2, NIMG = 1 + (DO_V ? 1 : 0) + (DO_K ? 2 : 0), STAGE = NIMG * IMG + 1024, PP = IMG / 1024 / NW;
+    constexpr int O_DOM = IMG, O_DOC = (1 + (DO_V ? 1 : 0)) * IMG, O_QM = O_DOC + IMG, O_STAT = NIMG * IMG;
+    __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
+
+    const int b = blockIdx.z, hh = blockIdx.y;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = lane & 31, h = lane >> 5;
+    const int kblock = blockIdx.x / p.qsplit, qs = blockIdx.x % p.qsplit;
+    const int key = kblock * 32 * NW + wid * 32 + i;
+    const int kvl = p.kv_len ? min(p.kv_len[b], p.Sk) : p.Sk;
+    const bool klive = key < kvl;
+    const bf16_t* Q = p.q + b * p.q_sb + hh * p.q_sh;
+    const bf16_t* K = p.k + b * p.k_sb + hh * p.k_sh;
+    const bf16_t* V = p.v + b * p.v_sb + hh * p.v_sh;
+    const bf16_t* DO = p.dout + b * p.do_sb + hh * p.do_sh;
+    const float* LSE = p.lse + ((long)b * p.H + hh) * p.Sq;
+    const float* DL = p.delta + ((long)b * p.H + hh) * p.Sq;
+    const float sl2 = p.scale * LOG2E;
+
+    bf16x8_t kf[NKS], vf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        kf[ks] = klive ? *reinterpret_cast<const bf16x8_t*>(K + (long)key * p.k_ss + 16 * ks + 8 * h) : zero_frag();
+        vf[ks] = klive ? *reinterpret_cast<const bf16x8_t*>(V + (long)key * p.v_ss + 16 * ks + 8 * h) : zero_frag();
+    }
+    f32x16 dkacc[NDB], dvacc[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) { dkacc[db] = zero16(); dvacc[db] = zero16(); }
+
+    const int nqt_all = (p.Sq + QT - 1) / QT;
+    const int per = (nqt_all + p.qsplit - 1) / p.qsplit;
+    const int qt0 = qs * per, nqt = min(nqt_all, qt0 + per);      // this workgroup's query tiles [qt0, nqt)
+
+    const unsigned q_bytes = (unsigned)(((long)(p.Sq - 1) * p.q_ss + D) * 2), do_bytes = (unsigned)(((long)(p.Sq - 1) * p.do_ss + D) * 2);
+    const auto rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Q), (short)0, (int)q_bytes, 0x00020000);
+    const auto rsDO = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(DO), (short)0, (int)do_bytes, 0x00020000);
+    const auto rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(LSE), (short)0, p.Sq * 4, 0x00020000);
+    const auto rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DL), (short)0, p.Sq * 4, 0x00020000);
+    unsigned voQc[PP], voQm[PP], voDc[PP], voDm[PP];
+#pragma unroll
+    for (int j = 0; j < PP; ++j) {
+        const int P = j * NW + wid;
+        voQc[j] = dma_voffset<false, QT>(P % 8, lane, qt0 * QT, p.q_ss) + (unsigned)(P / 8) * 128u;
+        voQm[j] = dma_voffset<true, D>(P, lane, 0, p.q_ss) + (unsigned)((long)qt0 * QT * p.q_ss * 2);
+        voDc[j] = dma_voffset<false, QT>(P % 8, lane, qt0 * QT, p.do_ss) + (unsigned)(P / 8) * 128u;
+        voDm[j] = dma_voffset<true, D>(P, lane, 0, p.do_ss) + (unsigned)((long)qt0 * QT * p.do_ss * 2);
+    }
+    const unsigned stepQ = (unsigned)(QT * p.q_ss * 2), stepD = (unsigned)(QT * p.do_ss * 2);
+    unsigned voS = (unsigned)((qt0 * QT + lane) * 4);
+#define ISSUE_TILE(buf)                                                                                                   \
+    do {                                                                                                                  \
+        char* base_ = lds + (buf) * STAGE + wid * 1024;                                                                   \
+        _Pragma("unroll") for (int j = 0; j < PP; ++j) {                                                                  \
+            char* d0_ = base_ + j * NW * 1024;                                                                            \
+            const unsigned o0_ = voQc[j]; voQc[j] += stepQ;                                                               \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_void_t*)d0_, 16, o0_, 0, 0, 0);                            \
+            if constexpr (DO_V) {                                                                                         \
+                char* d1_ = d0_ + O_DOM;                                                                                  \
+                const unsigned o1_ = voDm[j]; voDm[j] += stepD;                                                           \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsDO, (lds_void_t*)d1_, 16, o1_, 0, 0, 0);                       \
+            }                                                                                                             \
+            if constexpr (DO_K) {                                                                                         \
+                char* d2_ = d0_ + O_DOC;                                                                                  \
+                char* d3_ = d0_ + O_QM;                                                                                   \
+                const unsigned o2_ = voDc[j], o3_ = voQm[j]; voDc[j] += stepD; voQm[j] += stepQ;                          \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsDO, (lds_void_t*)d2_, 16, o2_, 0, 0, 0);                       \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_void_t*)d3_, 16, o3_, 0, 0, 0);                        \
+            }                                                                                                             \
+        }                                                                                                                 \
+        if (wid == 0) {                                                                                                   \
+            char* ds_ = lds + (buf) * STAGE + O_STAT;                                                                     \
+            const unsigned os_ = voS;                                                                                     \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsL, (lds_void_t*)ds_, 4, os_, 0, 0, 0);                             \
+        }                                                                                                                 \
+        if (DO_K && wid == 1) {                                                                                           \
+            char* dd_ = lds + (buf) * STAGE + O_STAT + 256;                                                               \
+            const unsigned od_ = voS;                                                                                     \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (lds_void_t*)dd_, 4, od_, 0, 0, 0);                             \
+        }                                                                                                                 \
+        voS += QT * 4;                                                                                                    \
+    } while (0)
+
+    if (qt0 < nqt) ISSUE_TILE(0);
+    for (int qt = qt0; qt < nqt; ++qt) {
+        const int buf = (qt - qt0) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (qt + 1 < nqt) ISSUE_TILE(buf ^ 1);
+        const char* Qc = lds + buf * STAGE;
+        const char* DOm = Qc + O_DOM;
+        const char* DOc = Qc + O_DOC;
+        const char* Qm = Qc + O_QM;
+        const float* lse_l = reinterpret_cast<const float*>(Qc + O_STAT);
+        const float* dl_l = lse_l + 64;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            if (qt * QT + 32 * qb >= p.Sq) break;
+            f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                s = mfma16(read_frag<false, QT>(Qc + (ks / 4) * (QT * 128), 32 * qb, ks & 3, lane), kf[ks], s);
+                if constexpr (DO_K) dp = mfma16(read_frag<false, QT>(DOc + (ks / 4) * (QT * 128), 32 * qb, ks & 3, lane), vf[ks], dp);
+            }
+            f32x16 pr;
+            // wave-uniform: all 32 keys of the wave are valid and nothing is causal (padding queries: see the header)
+            const bool full = !p.causal && (key - i) + 32 <= kvl;
+#pragma unroll
+            for (int eg = 0; eg < 4; ++eg) {
+                const float4 l4 = *reinterpret_cast<const float4*>(&lse_l[32 * qb + 8 * eg + 4 * h]);
+                float4 d4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (DO_K) d4 = *reinterpret_cast<const float4*>(&dl_l[32 * qb + 8 * eg + 4 * h]);
+                const float ll[4] = {l4.x * LOG2E, l4.y * LOG2E, l4.z * LOG2E, l4.w * LOG2E}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = 4 * eg + j;
+                    float pe;
+                    if (full) {
+                        pe = __builtin_amdgcn_exp2f(s[e] * sl2 - ll[j]);
+                    } else {
+                        const int qq = qt * QT + 32 * qb + 8 * eg + 4 * h + j;
+                        const bool ok = klive && qq < p.Sq && (!p.causal || key <= qq);
+                        pe = ok ? __builtin_amdgcn_exp2f(s[e] * sl2 - ll[j]) : 0.f;
+                    }
+                    pr[e] = pe; s[e] = pe * (dp[e] - dd[j]);
+                }
+            }
+            const bf16x8_t p0 = pack_frag(pr, 0), p1 = pack_frag(pr, 8), ds0 = pack_frag(s, 0), ds1 = pack_frag(s, 8);
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                if constexpr (DO_V) {
+                    dvacc[db] = mfma16(read_frag_tr_acc<D>(DOm, 32 * db, 32 * qb, lane), p0, dvacc[db]);
+                    dvacc[db] = mfma16(read_frag_tr_acc<D>(DOm, 32 * db, 32 * qb + 16, lane), p1, dvacc[db]);
+                }
+                if constexpr (DO_K) {
+                    dkacc[db] = mfma16(read_frag_tr_acc<D>(Qm, 32 * db, 32 * qb, lane), ds0, dkacc[db]);
+                    dkacc[db] = mfma16(read_frag_tr_acc<D>(Qm, 32 * db, 32 * qb + 16, lane), ds1, dkacc[db]);
+                }
+            }
+        }
+    }
+#undef ISSUE_TILE
+    if (p.qsplit > 1) {
+        if (key < p.Sk) {            // fp32 partial of this query slice; attn_dkv_reduce_kernel sums the slices in order
+            float* PK = p.part + ((((long)b * p.H + hh) * p.qsplit + qs) * 2) * p.Sk * D + (long)key * D;
+            float* PV = PK + (long)p.Sk * D;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int eg = 0; eg < 4; ++eg) {
+                    if constexpr (DO_K) *reinterpret_cast<float4*>(PK + 32 * db + 8 * eg + 4 * h) =
+                        make_float4(dkacc[db][4 * eg], dkacc[db][4 * eg + 1], dkacc[db][4 * eg + 2], dkacc[db][4 * eg + 3]);
+                    if constexpr (DO_V) *reinterpret_cast<float4*>(PV + 32 * db + 8 * eg + 4 * h) =
+                        make_float4(dvacc[db][4 * eg], dvacc[db][4 * eg + 1], dvacc[db][4 * eg + 2], dvacc[db][4 * eg + 3]);
+                }
+        }
+        return;
+    }
+    if (key < p.Sk) {
+        bf16_t* DK = p.dk + b * p.dk_sb + hh * p.dk_sh + (long)key * p.dk_ss;
+        bf16_t* DV = p.dv + b * p.dv_sb + hh * p.dv_sh + (long)key * p.dv_ss;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int eg = 0; eg < 4; ++eg) {
+                uint2 wk, wv;
+                wk.x = pack_bf16x2(dkacc[db][4 * eg] * p.scale, dkacc[db][4 * eg + 1] * p.scale);
+                wk.y = pack_bf16x2(dkacc[db][4 * eg + 2] * p.scale, dkacc[db][4 * eg + 3] * p.scale);
+                wv.x = pack_bf16x2(dvacc[db][4 * eg], dvacc[db][4 * eg + 1]);
+                wv.y = pack_bf16x2(dvacc[db][4 * eg + 2], dvacc[db][4 * eg + 3]);
+                if constexpr (DO_K) *reinterpret_cast<uint2*>(DK + 32 * db + 8 * eg + 4 * h) = wk;
+                if constexpr (DO_V) *reinterpret_cast<uint2*>(DV + 32 * db + 8 * eg + 4 * h) = wv;
+            }
+    }
+}
+
 // dK / dV = sum over query slices of the fp32 partials (slice order: deterministic), one thread per 4 head-dim elements
 template <int D>
 __global__ void __launch_bounds__(256) attn_dkv_reduce_kernel(const AttnParams p) {
@@ -781,16 +1090,25 @@ int dpipe_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
     static const bool dq8_on = [] { const char* e = getenv("DPIPE_ATTN_DQ8"); return !e || atoi(e) != 0; }();
     const bool dq8 = dq8_on && (long)cdiv(Sq, 256) * H * B >= 192;
     dim3 gq8((unsigned)cdiv(Sq, 256), (unsigned)H, (unsigned)B);
+    // LDS-DMA forms of the backward kernels (K / V extents within the 32-bit buffer offsets) -- DPIPE_ATTN_BWD_DMA = 0 for A/B timing
+    static const bool bwd_dma_on = [] { const char* e = getenv("DPIPE_ATTN_BWD_DMA"); return !e || atoi(e) != 0; }();
+    const bool bwd_dma = bwd_dma_on && ((long)(Sk - 1) * k_ss + D) * 2 < (1l << 31) && ((long)(Sk - 1) * v_ss + D) * 2 < (1l << 31);
+    const long wg256 = (long)cdiv(Sq, 256) * H * B, wg128 = (long)cdiv(Sq, 128) * H * B;
+    const bool bwd_dma_q = bwd_dma_on && ((long)(Sq - 1) * q_ss + D) * 2 < (1l << 31) && ((long)(Sq - 1) * do_ss + D) * 2 < (1l << 31);   // the dK / dV kernels stream Q and dO
     // head dim 128, long key sequences: dV and dK as two 8-wave kernels (two waves per SIMD) -- DPIPE_ATTN_DKV_SPLIT = 0 for A/B timing
     static const bool split_on = [] { const char* e = getenv("DPIPE_ATTN_DKV_SPLIT"); return !e || atoi(e) != 0; }();
     const bool dkv_split = split_on && p.qsplit == 1 && (long)cdiv(Sk, 256) * H * B >= 192;
     dim3 gk8((unsigned)cdiv(Sk, 256), (unsigned)H, (unsigned)B);
 #define ATTN_BWD(DD) do { \
         attn_delta_kernel<DD><<<(unsigned)cdiv(rows, 16), 256, 0, s>>>(p); \
-        if (small_q) attn_bwd_dq_kernel<DD, 2><<<gq, 128, 0, s>>>(p); \
+        if (bwd_dma && dq8) attn_bwd_dq_dma_kernel<DD, 8><<<(unsigned)wg256, 512, 0, s>>>(p); \
+        else if (bwd_dma) attn_bwd_dq_dma_kernel<DD, 4><<<(unsigned)wg128, 256, 0, s>>>(p); \
+        else if (small_q) attn_bwd_dq_kernel<DD, 2><<<gq, 128, 0, s>>>(p); \
         else if (DD == 128 && dq8) attn_bwd_dq_kernel<DD, 8><<<gq8, 512, 0, s>>>(p); \
         else attn_bwd_dq_kernel<DD, 4><<<gq, 256, 0, s>>>(p); \
-        if (DD == 128 && dkv_split) { attn_bwd_dkv_kernel<DD, 8, 1><<<gk8, 512, 0, s>>>(p); attn_bwd_dkv_kernel<DD, 8, 2><<<gk8, 512, 0, s>>>(p); } \
+        if (DD == 128 && dkv_split && bwd_dma_q) { attn_bwd_dkv_dma_kernel<DD, 8, 1><<<gk8, 512, 0, s>>>(p); attn_bwd_dkv_dma_kernel<DD, 8, 2><<<gk8, 512, 0, s>>>(p); } \
+        else if (DD == 128 && dkv_split) { attn_bwd_dkv_kernel<DD, 8, 1><<<gk8, 512, 0, s>>>(p); attn_bwd_dkv_kernel<DD, 8, 2><<<gk8, 512, 0, s>>>(p); } \
+        else if (bwd_dma_q) attn_bwd_dkv_dma_kernel<DD, NW, 0><<<gk, NW * 64, 0, s>>>(p); \
         else attn_bwd_dkv_kernel<DD, NW><<<gk, NW * 64, 0, s>>>(p); \
         if (p.qsplit > 1) attn_dkv_reduce_kernel<DD><<<gred, 256, 0, s>>>(p); } while (0)
     if (D == 64) ATTN_BWD(64); else ATTN_BWD(128);
