@@ -548,7 +548,19 @@ __global__ void __launch_bounds__(NW * 64, (D == 64 && NW == 4) ? 2 : 1) attn_bw
     }
     const long stat = ((long)b * p.H + hh) * p.Sq + (qlive ? qrow : 0);
     const float lse2 = qlive ? p.lse[stat] * LOG2E : INFINITY;
-    const float dl = qlive ? p.delta[stat] : 0.f;
+    // delta = rowsum(dO * O), fused here (the lane pair (i, h) holds the whole dO row): one launch less per attention backward; written for the dK kernels
+    float dl = 0.f;
+    if (qlive) {
+        const bf16_t* O = p.o + b * p.o_sb + hh * p.o_sh + (long)qrow * p.o_ss;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const bf16x8_t of = *reinterpret_cast<const bf16x8_t*>(O + 16 * ks + 8 * h);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl += bf16_to_f32((bf16_t)of[e]) * bf16_to_f32((bf16_t)dof[ks][e]);
+        }
+    }
+    dl += __shfl_xor(dl, 32, 64);
+    if (qlive && h == 0) p.delta[stat] = dl;
 
     f32x16 dqacc[NDB];
 #pragma unroll
@@ -1100,7 +1112,7 @@ int dpipe_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
     const bool dkv_split = split_on && p.qsplit == 1 && (long)cdiv(Sk, 256) * H * B >= 192;
     dim3 gk8((unsigned)cdiv(Sk, 256), (unsigned)H, (unsigned)B);
 #define ATTN_BWD(DD) do { \
-        attn_delta_kernel<DD><<<(unsigned)cdiv(rows, 16), 256, 0, s>>>(p); \
+        if (!bwd_dma) attn_delta_kernel<DD><<<(unsigned)cdiv(rows, 16), 256, 0, s>>>(p);   /* the LDS-DMA dQ kernel computes delta itself */ \
         if (bwd_dma && dq8) attn_bwd_dq_dma_kernel<DD, 8><<<(unsigned)wg256, 512, 0, s>>>(p); \
         else if (bwd_dma) attn_bwd_dq_dma_kernel<DD, 4><<<(unsigned)wg128, 256, 0, s>>>(p); \
         else if (small_q) attn_bwd_dq_kernel<DD, 2><<<gq, 128, 0, s>>>(p); \
