@@ -106,6 +106,7 @@ __global__ void __launch_bounds__(NB) gn_nhwc_final_kernel(const float* __restri
     const long n = row / G; const int g = (int)(row % G);
     const int cpg = C / G;
     float s = 0.f, q = 0.f;
+#pragma unroll 8                                                         // independent loads: 8 in flight per thread instead of one L2 round trip per iteration
     for (int idx = threadIdx.x; idx < chunks * cpg; idx += NB) {      // the group's sums need no per-channel separation; fixed thread -> index map
         const int k = idx / cpg, c = g * cpg + idx % cpg;
         s += ws[((n * chunks + k) * 2) * C + c]; q += ws[((n * chunks + k) * 2 + 1) * C + c];
@@ -249,8 +250,10 @@ __global__ void __launch_bounds__(NB) gn_nhwc_bwd_final_kernel(const float* __re
     float dgs = 0.f, dbs = 0.f;
     for (long n = 0; n < N; ++n) {
         float s1 = 0.f, s2 = 0.f;
-        if (on)
+        if (on) {
+#pragma unroll 8
             for (int k = kl; k < chunks; k += kls) { s1 += ws[((n * chunks + k) * 2) * C + c]; s2 += ws[((n * chunks + k) * 2 + 1) * C + c]; }
+        }
         __syncthreads();
         part[0][threadIdx.x] = s1; part[1][threadIdx.x] = s2;
         __syncthreads();

@@ -206,26 +206,51 @@ __global__ void __launch_bounds__(NB) lnmod_fwd_kernel(const T* __restrict__ x, 
     const long row = (long)blockIdx.x * RPB + threadIdx.x / LPR;
     const bool live = row < rows;
     const T* xr = x + (live ? row : 0) * (long)cols;
+    // rows of up to RC vectors per lane (cols <= 2048 bf16 / 1024 fp32: every SDXL width) stay in registers across the three passes: one global read
+    // instead of three dependent load -> reduce round trips (the kernel is latency-bound: 4 rows per workgroup, one workgroup per CU)
+    constexpr int RC = 4;
+    const bool cached = cols <= LPR * V * RC;
+    Vec16<T> rv[RC];
     float s = 0.f;
-    for (int c = sub * V; c < cols; c += LPR * V) {
-        Vec16<T> v; v.load(xr + c); float f[V]; v.unpack(f);
+    if (cached) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) s += f[j];
+        for (int k = 0; k < RC; ++k) {
+            const int c = (sub + k * LPR) * V;
+            if (c < cols) { rv[k].load(xr + c); float f[V]; rv[k].unpack(f);
+#pragma unroll
+                for (int j = 0; j < V; ++j) s += f[j]; }
+        }
+    } else {
+        for (int c = sub * V; c < cols; c += LPR * V) {
+            Vec16<T> v; v.load(xr + c); float f[V]; v.unpack(f);
+#pragma unroll
+            for (int j = 0; j < V; ++j) s += f[j];
+        }
     }
     const float mu = group_sum<LPR>(s) / (float)cols;
     float ss = 0.f;
-    for (int c = sub * V; c < cols; c += LPR * V) {
-        Vec16<T> v; v.load(xr + c); float f[V]; v.unpack(f);
+    if (cached) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) { float d = f[j] - mu; ss += d * d; }
+        for (int k = 0; k < RC; ++k) {
+            const int c = (sub + k * LPR) * V;
+            if (c < cols) { float f[V]; rv[k].unpack(f);
+#pragma unroll
+                for (int j = 0; j < V; ++j) { float d = f[j] - mu; ss += d * d; } }
+        }
+    } else {
+        for (int c = sub * V; c < cols; c += LPR * V) {
+            Vec16<T> v; v.load(xr + c); float f[V]; v.unpack(f);
+#pragma unroll
+            for (int j = 0; j < V; ++j) { float d = f[j] - mu; ss += d * d; }
+        }
     }
     const float rstd = rsqrtf(group_sum<LPR>(ss) / (float)cols + eps);
     if (!live) return;
     if (sub == 0) { if (mean_out) mean_out[row] = mu; if (rstd_out) rstd_out[row] = rstd; }
     const long b = row / rows_per_mod;
     T* yr = y + row * (long)cols;
-    for (int c = sub * V; c < cols; c += LPR * V) {
-        Vec16<T> v; v.load(xr + c); float f[V]; v.unpack(f);
+    auto emit = [&](int c, Vec16<T>& v) {
+        float f[V]; v.unpack(f);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             float n = (f[j] - mu) * rstd;
@@ -235,6 +260,15 @@ __global__ void __launch_bounds__(NB) lnmod_fwd_kernel(const T* __restrict__ x, 
             f[j] = n;
         }
         v.pack(f); v.store(yr + c);
+    };
+    if (cached) {
+#pragma unroll
+        for (int k = 0; k < RC; ++k) {
+            const int c = (sub + k * LPR) * V;
+            if (c < cols) emit(c, rv[k]);
+        }
+    } else {
+        for (int c = sub * V; c < cols; c += LPR * V) { Vec16<T> v; v.load(xr + c); emit(c, v); }
     }
 }
 // dxhat = gy * (1+scale) * gamma ;  dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)) (+ gadd: the gradient that reached x
@@ -252,22 +286,32 @@ __global__ void __launch_bounds__(NB) lnmod_bwd_dx_kernel(const T* __restrict__ 
     const T* xr = x + r * (long)cols; const T* gr = gy + r * (long)cols;
     const float mu = mean[r], rs = rstd[r];
     const long b = r / rows_per_mod;
+    constexpr int RC = 4;                         // see lnmod_fwd_kernel: rows that fit stay in registers between the two passes
+    const bool cached = cols <= LPR * V * RC;
+    Vec16<T> rx[RC], rg[RC];
     float s1 = 0.f, s2 = 0.f;
-    for (int c = sub * V; c < cols; c += LPR * V) {
-        Vec16<T> vx, vg; vx.load(xr + c); vg.load(gr + c);
+    auto pass1 = [&](int c, const Vec16<T>& vx, const Vec16<T>& vg) {
         float fx[V], fg[V]; vx.unpack(fx); vg.unpack(fg);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             float d = fg[j] * (scale ? 1.f + Elem<M>::to_f(scale[b * cols + c + j]) : 1.f) * (gamma ? Elem<W>::to_f(gamma[c + j]) : 1.f);
             s1 += d; s2 += d * (fx[j] - mu) * rs;
         }
+    };
+    if (cached) {
+#pragma unroll
+        for (int k = 0; k < RC; ++k) {
+            const int c = (sub + k * LPR) * V;
+            if (c < cols) { rx[k].load(xr + c); rg[k].load(gr + c); pass1(c, rx[k], rg[k]); }
+        }
+    } else {
+        for (int c = sub * V; c < cols; c += LPR * V) { Vec16<T> vx, vg; vx.load(xr + c); vg.load(gr + c); pass1(c, vx, vg); }
     }
     s1 = group_sum<LPR>(s1) / (float)cols;
     s2 = group_sum<LPR>(s2) / (float)cols;
     if (!live) return;
     T* o = gx + row * (long)cols;
-    for (int c = sub * V; c < cols; c += LPR * V) {
-        Vec16<T> vx, vg; vx.load(xr + c); vg.load(gr + c);
+    auto pass2 = [&](int c, const Vec16<T>& vx, Vec16<T>& vg) {
         float fx[V], fg[V]; vx.unpack(fx); vg.unpack(fg);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
@@ -281,6 +325,15 @@ __global__ void __launch_bounds__(NB) lnmod_bwd_dx_kernel(const T* __restrict__ 
             for (int j = 0; j < V; ++j) fg[j] += fa[j];
         }
         vg.pack(fg); vg.store(o + c);
+    };
+    if (cached) {
+#pragma unroll
+        for (int k = 0; k < RC; ++k) {
+            const int c = (sub + k * LPR) * V;
+            if (c < cols) pass2(c, rx[k], rg[k]);
+        }
+    } else {
+        for (int c = sub * V; c < cols; c += LPR * V) { Vec16<T> vx, vg; vx.load(xr + c); vg.load(gr + c); pass2(c, vx, vg); }
     }
 }
 

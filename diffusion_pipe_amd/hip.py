@@ -10,7 +10,10 @@ from pathlib import Path
 
 import torch
 
-LIB_PATH = Path(__file__).resolve().parent / 'libdpipe_hip.so'
+import os
+
+# DPIPE_HIP_LIB: another build of the same library (A/B kernel timings against a previous build); the default is the in-tree .so
+LIB_PATH = Path(os.environ.get('DPIPE_HIP_LIB') or Path(__file__).resolve().parent / 'libdpipe_hip.so')
 
 BF16, F32 = 0, 1
 ACT = {None: 0, 'none': 0, 'gelu_tanh': 1, 'gelu': 2, 'gelu_erf': 2, 'silu': 3, 'quick_gelu': 4}
