@@ -8,7 +8,7 @@ if [ "$1" != "pmc-only" ]; then
   find $O/prof -name '*kernel_trace.csv' -delete; find $O/prof -name '*.db' -delete
 fi
 T=$R/profiles/r2_gemm_trace_sdxl_step.json
-if [ -f $T ]; then
+if [ -f $T ] && [ "$1" != "trace-only" ]; then
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c -f csv -d $O/pmc_$c -o pmc -- python $R/tools/gemm_replay.py $T 6 > $O/pmc_$c.log 2>&1
     python $R/tools/pmc_agg.py $O/pmc_$c $O/pmc_${c}_agg.csv >> $O/pmc_$c.log 2>&1
