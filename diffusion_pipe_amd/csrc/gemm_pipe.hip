@@ -24,6 +24,7 @@ bool gemm_pipe_try(GemmParams& p, int transA, int transB, int batch, void* ws, l
     const int tile = gemm_pipe_plan(p, a_mc, b_mc, batch, ws, ws_bytes, force_splitk, force_tile);
     switch (tile) {
     case 257: *rc_out = launch_pipe<T256S>(p, a_mc, b_mc, batch, s); break;
+    case 258: *rc_out = launch_pipe<T256K>(p, a_mc, b_mc, batch, s); break;
     case 256: *rc_out = launch_pipe<T256>(p, a_mc, b_mc, batch, s); break;
     case 129: *rc_out = launch_pipe<T128R2>(p, a_mc, b_mc, batch, s); break;
     case 63: *rc_out = launch_pipe<T64S3>(p, a_mc, b_mc, batch, s); break;
@@ -47,8 +48,11 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
     // (tools/kernel_timing.py large): +9 .. +21 % over T128R2 there (8192^3: 1.27 vs 1.08 PFLOP/s), -2 .. -6 % at K = 3072, and
     // wgrad (both operands MN-contiguous) stays faster on T128R2
     const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * batch;
-    if (force_tile == 0 && !a_mc && p.ksteps >= 64 && tiles256 >= 128) force_tile = 257;
-    const int bm = (force_tile == 256 || force_tile == 257) ? 256 : big ? 128 : 64, bn = force_tile == 256 ? 128 : bm;
+    // ... and on the 4-deep ring of half K-steps (T256K) when B is MN-contiguous (dgrad): its DMA pieces are whole k-rows either way, and three half steps in
+    // flight shorten the vmcnt wait: +5 .. +6 % (9216 x 5120 x 13824 NN: 996 vs 940 TFLOP/s).  A K-contiguous operand pays for half steps with 64-byte pieces
+    // (half a cache line per row per step) and twice the barriers: NT is 8 % slower on T256K and stays on T256S (8192^3: 1 292 vs 1 184)
+    if (force_tile == 0 && !a_mc && p.ksteps >= 64 && tiles256 >= 128) force_tile = b_mc ? 258 : 257;
+    const int bm = (force_tile == 256 || force_tile == 257 || force_tile == 258) ? 256 : big ? 128 : 64, bn = force_tile == 256 ? 128 : bm;
     p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bn - 1) / bn;
     const long tiles = (long)p.tiles_m * p.tiles_n * batch;
     const long slab_bytes = ((long)bm * bn + bm) * 4;
@@ -81,6 +85,7 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
     p.vecA = c_ok ? 2 : 0;
     if (c_ok && p.residual && reinterpret_cast<uintptr_t>(p.residual) % 8 == 0 && p.ldr % 4 == 0) p.vecA = 3;   // 8-byte residual loads too
     p.vecB = (p.bias && reinterpret_cast<uintptr_t>(p.bias) % 8 == 0) ? 2 : 0;
+    if (force_tile == 258) { p.ksteps *= 2; p.ksteps_per_split *= 2; return 258; }      // T256K counts K in 32-wide half steps (slices keep their K ranges)
     if (force_tile == 257 || force_tile == 256 || force_tile == 63 || force_tile == 130) return force_tile;
     if (force_tile == 129 || (force_tile == 0 && big && tiles128 >= 256 && (a_mc || b_mc || tiles128 >= 1024))) return 129;
     return big ? 128 : 64;

@@ -46,8 +46,8 @@ using namespace dpipe_tiles;   // LDS image formats of the DMA'd operand tiles (
 // the small-problem configuration (4 x the workgroups of T128: aggregate L1/L2 bandwidth of more CUs is what bounds a
 // GEMM whose whole operand set is a few MB).  T128: 128 x 128 tile, 8 waves (2 x 4, 64 x 32 each) = 2 waves per SIMD so
 // one wave's DMA issue (60..180 cycles per 1 KiB piece, MI355X_MICROARCH.md) hides under the other's MFMAs; 3 x 32 KiB.
-template <int BM_, int BN_, int WM_, int WN_, int STAGES_> struct Tile {
-    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, STAGES = STAGES_;
+template <int BM_, int BN_, int WM_, int WN_, int STAGES_, int BK_ = 64> struct Tile {
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, STAGES = STAGES_, BK = BK_;   // BK: k extent of a ring stage (64, or 32 for the 4-deep 256^2 ring)
     static constexpr int NW = WM * WN, NT = NW * 64;
     static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;       // 32x32 MFMA tiles per wave
     static constexpr int IMG_A = BM * BK * 2, IMG_B = BN * BK * 2, STAGE_BYTES = IMG_A + IMG_B;
@@ -68,6 +68,9 @@ using T128S5 = Tile<128, 128, 2, 4, 5>;     // 5-deep ring = all 160 KiB of LDS,
                                             // [1024,1280] x [10240,1280]^T: 2.5 rounds of tiles at one workgroup per CU either way, longer prologue)
 using T64S3 = Tile<64, 64, 2, 2, 3>;         // selectable, not chosen automatically: 3-deep ring (3 workgroups per CU)
 using T256 = Tile<256, 128, 4, 2, 3>;       // selectable, not chosen automatically: 256 x 128, 8 waves of 64 x 64, 144 KiB (T128R2 beats it)
+using T256K = Tile<256, 256, 2, 4, 4, 32>;  // the same 256 x 256 tile on a 4-deep ring of HALF K-steps (32 k, 32 KiB each; the same 128 KiB of LDS): three half steps in flight instead of
+                                            // one whole step -- the 2-deep ring parks every wave ~1 100 cycles per K-step at vmcnt (timeline probe), its refill can only be issued
+                                            // once the whole previous step has been consumed
 using T256S = Tile<256, 256, 2, 4, 2>;      // 256 x 256, 8 waves of 128 x 64 (128 accumulator VGPRs), 2 x 64 KiB: twice the MFMA work per DMA'd
                                             // byte of the 128^2 tile -- the large-GEMM configuration (DiT-sized linears: Flux / Wan / HunyuanVideo)
 
@@ -112,10 +115,12 @@ template <int NLOAD> __device__ __forceinline__ void wait_dma_ahead(int ahead) {
 // a row that falls into the zero padding gets a DMA source offset beyond the buffer extent, which the buffer bounds check turns into
 // zeros, so no im2col matrix and no padded copy ever exists.  CONV = 2: wgrad, one GEMM per tap (grid.y): the B operand's K-ROWS are
 // the gathered pixels (k = output pixel, n = input channel), A = dy read MN-contiguous.
-template <int BM_, int BN_, int WM_, int WN_, int STAGES_, bool A_MC, bool B_MC, int CONV = 0>
+template <int BM_, int BN_, int WM_, int WN_, int STAGES_, bool A_MC, bool B_MC, int CONV = 0, int BKT = 64>
 __global__ void __launch_bounds__(512) gemm_pipe_kernel(const GemmParams p) {
-    using TL = Tile<BM_, BN_, WM_, WN_, STAGES_>;
+    using TL = Tile<BM_, BN_, WM_, WN_, STAGES_, BKT>;
     constexpr int BM = TL::BM, BN = TL::BN, STAGES = TL::STAGES, TM = TL::TM, TN = TL::TN, NLOAD = TL::NLOAD;
+    constexpr int BK = BKT, KS = BKT / 16;          // (shadows the namespace default) k extent of a stage, 16-wide k-slices per stage
+    static_assert(CONV == 0 || BKT == 64, "the convolution gathers are written for 64-channel K-steps");
     static_assert(STAGES >= 2 && STAGES <= 5, "ring depth (the vmcnt ladder covers <= 3 K-steps ahead)");
     __shared__ __attribute__((aligned(1024))) char lds[STAGES * TL::STAGE_BYTES];
     TL_STAMP(0);
@@ -168,10 +173,10 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const GemmParams p) {
     const unsigned stepB = B_MC ? (unsigned)(BK * p.ldb * 2) : (unsigned)(BK * 2);
     unsigned voA[TL::PA], voB[TL::PB];
 #pragma unroll
-    for (int j = 0; j < TL::PA; ++j) voA[j] = dma_voffset<A_MC, BM>(j * TL::NW + wid, lane, m0, p.lda) + (CONV == 1 ? 0u : (unsigned)kbeg * stepA);
+    for (int j = 0; j < TL::PA; ++j) voA[j] = dma_voffset<A_MC, BM, BKT>(j * TL::NW + wid, lane, m0, p.lda) + (CONV == 1 ? 0u : (unsigned)kbeg * stepA);
 #pragma unroll
     for (int j = 0; j < TL::PB; ++j)
-        voB[j] = dma_voffset<B_MC, BN>(j * TL::NW + wid, lane, n0, p.ldb) + ((CONV == 2 || (CONV == 1 && B_MC)) ? 0u : (unsigned)kbeg * stepB);
+        voB[j] = dma_voffset<B_MC, BN, BKT>(j * TL::NW + wid, lane, n0, p.ldb) + ((CONV == 2 || (CONV == 1 && B_MC)) ? 0u : (unsigned)kbeg * stepB);
 
     // ---- implicit-GEMM convolution: gathered-pixel state of this lane's DMA pieces
     const ConvGeom& cg = p.cg;
@@ -314,25 +319,25 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const GemmParams p) {
         if constexpr (TM * TN < 8) {
             // all fragment reads of the K-step are issued up front: the MFMAs of k-slice ks start as soon as their
             // fragments land while the later slices are still in flight (counted lgkmcnt by the compiler)
-            bf16x8_t fa[4][TM], fb[4][TN];
+            bf16x8_t fa[KS][TM], fb[KS][TN];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[ks][i] = read_frag<A_MC, BM>(imgA, wm0 + i * 32, ks, lane);
+                for (int i = 0; i < TM; ++i) fa[ks][i] = read_frag<A_MC, BM, BKT>(imgA, wm0 + i * 32, ks, lane);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[ks][j] = read_frag<B_MC, BN>(imgB, wn0 + j * 32, ks, lane);
+                for (int j = 0; j < TN; ++j) fb[ks][j] = read_frag<B_MC, BN, BKT>(imgB, wn0 + j * 32, ks, lane);
             }
             if (do_colsum) {
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
+                for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                     for (int i = 0; i < TM; ++i) csum[i] += frag_sum(fa[ks][i]);
             }
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            for (int ks = 0; ks < KS; ++ks) {
                 // the refill of ring buffer `nxt` is issued a quarter at a time BETWEEN the k-slices' MFMAs: a DMA piece costs the wave
                 // 75 .. 85 issue cycles (timeline probe), which now run while the matrix pipe works instead of ahead of the whole K-step
-                if (refill) ISSUE_RANGE(nxt, ks * NLOAD / 4, (ks + 1) * NLOAD / 4);
+                if (refill) ISSUE_RANGE(nxt, ks * NLOAD / KS, (ks + 1) * NLOAD / KS);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -345,20 +350,20 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const GemmParams p) {
             // slice ks + 1 is read while the 8 MFMAs of slice ks run
             bf16x8_t fa[2][TM], fb[2][TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[0][i] = read_frag<A_MC, BM>(imgA, wm0 + i * 32, 0, lane);
+            for (int i = 0; i < TM; ++i) fa[0][i] = read_frag<A_MC, BM, BKT>(imgA, wm0 + i * 32, 0, lane);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[0][j] = read_frag<B_MC, BN>(imgB, wn0 + j * 32, 0, lane);
+            for (int j = 0; j < TN; ++j) fb[0][j] = read_frag<B_MC, BN, BKT>(imgB, wn0 + j * 32, 0, lane);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            for (int ks = 0; ks < KS; ++ks) {
                 // this wave's share of the next K-step's DMA is spread over the first two k-slices: a piece costs the issuing wave
                 // 60 .. 180 cycles (MI355X_MICROARCH.md), which now falls into the shadow of the other wave's MFMAs instead of
                 // both waves of a SIMD issuing all their pieces right after the barrier
                 if (refill && ks < 2) ISSUE_RANGE(nxt, ks * NLOAD / 2, (ks + 1) * NLOAD / 2);   // first half of the K-step: the second half is the landing window
-                if (ks + 1 < 4) {
+                if (ks + 1 < KS) {
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) fa[(ks + 1) & 1][i] = read_frag<A_MC, BM>(imgA, wm0 + i * 32, ks + 1, lane);
+                    for (int i = 0; i < TM; ++i) fa[(ks + 1) & 1][i] = read_frag<A_MC, BM, BKT>(imgA, wm0 + i * 32, ks + 1, lane);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) fb[(ks + 1) & 1][j] = read_frag<B_MC, BN>(imgB, wn0 + j * 32, ks + 1, lane);
+                    for (int j = 0; j < TN; ++j) fb[(ks + 1) & 1][j] = read_frag<B_MC, BN, BKT>(imgB, wn0 + j * 32, ks + 1, lane);
                 }
                 if (do_colsum) {
 #pragma unroll
@@ -548,7 +553,7 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const GemmParams p) {
 template <typename TL, int CONV = 0>
 int launch_pipe(const GemmParams& p, bool a_mc, bool b_mc, int batch, hipStream_t s) {
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n * p.splitk), (unsigned)batch);
-#define DPIPE_PIPE_LAUNCH(AM, BMC) gemm_pipe_kernel<TL::BM, TL::BN, TL::WM, TL::WN, TL::STAGES, AM, BMC, CONV><<<grid, TL::NT, 0, s>>>(p)
+#define DPIPE_PIPE_LAUNCH(AM, BMC) gemm_pipe_kernel<TL::BM, TL::BN, TL::WM, TL::WN, TL::STAGES, AM, BMC, CONV, TL::BK><<<grid, TL::NT, 0, s>>>(p)
     if constexpr (CONV == 1) {          // A rows gathered: A is K-contiguous; B = weight K-contiguous (forward) or MN-contiguous (dgrad)
         if (b_mc) DPIPE_PIPE_LAUNCH(false, true); else DPIPE_PIPE_LAUNCH(false, false);
         return check_launch("dpipe_conv2d");

@@ -18,14 +18,20 @@ typedef __attribute__((address_space(3))) bf16x4_t lds_bf16x4_t;
 // Byte offset (from the operand base of this batch) of the 16 bytes lane `lane` fetches for DMA piece q of an image of
 // ROWS mn-rows at K-step 0.  The DMA writes lane L of piece q to LDS byte (q * 1024 + 16 L); the logical chunk fetched
 // is the inverse of the read-side swizzle.
-template <bool MC, int ROWS>
+template <bool MC, int ROWS, int KT = 64>
 __device__ __forceinline__ unsigned dma_voffset(int q, int lane, int mn0, long ld) {
-    if (!MC) {   // image [ROWS mn-rows][128 B]: physical 16-B chunk pc of row holds logical chunk pc ^ ((row >> 1) & 7)
+    static_assert(KT == 64 || KT == 32, "k extent of one image");
+    if (!MC && KT == 64) {   // image [ROWS mn-rows][128 B]: physical 16-B chunk pc of row holds logical chunk pc ^ ((row >> 1) & 7)
         const int row = 8 * q + (lane >> 3);
         const int pc = lane & 7;
         const int lc = pc ^ ((row >> 1) & 7);
         return (unsigned)(((long)(mn0 + row) * ld + lc * 8) * 2);
-    } else {     // image [64 k-rows][ROWS * 2 B]: physical 64-B granule pg of a k-row holds logical granule pg ^ f(krow)
+    } else if (!MC) {        // KT = 32: image [ROWS mn-rows][64 B] (a piece = 16 rows): rows r, r + 4, r + 8, r + 12 share a bank group -> chunk ^= (row >> 2) & 3
+        const int row = 16 * q + (lane >> 2);
+        const int pc = lane & 3;
+        const int lc = pc ^ ((row >> 2) & 3);
+        return (unsigned)(((long)(mn0 + row) * ld + lc * 8) * 2);
+    } else {                 // (KT k-rows: the same format, KT / 64 as many pieces)     // image [64 k-rows][ROWS * 2 B]: physical 64-B granule pg of a k-row holds logical granule pg ^ f(krow)
         constexpr int CPR = ROWS / 8;            // 16-B chunks per k-row (16 or 8)
         constexpr int G = ROWS / 32;             // 64-B granules per k-row (4 or 2)
         const int krow = q * (64 / CPR) + lane / CPR;
@@ -37,9 +43,13 @@ __device__ __forceinline__ unsigned dma_voffset(int q, int lane, int mn0, long l
 }
 
 // MFMA operand fragment (32 mn-rows x 16 k): lane (i = lane & 31, h = lane >> 5) gets k = 16 ks + 8 h .. + 8 of row mn + i.
-template <bool MC, int ROWS>
+template <bool MC, int ROWS, int KT = 64>
 __device__ __forceinline__ bf16x8_t read_frag(const char* img, int mn, int ks, int lane) {
-    if (!MC) {
+    if (!MC && KT == 32) {
+        const int l31 = lane & 31;
+        const int x = (2 * ks + (lane >> 5)) ^ ((l31 >> 2) & 3);
+        return *reinterpret_cast<const bf16x8_t*>(img + mn * 64 + l31 * 64 + (x << 4));
+    } else if (!MC) {
         // mn is a multiple of 32, so the swizzle term (row >> 1) & 7 depends on the lane only and 2 ks + h == (2 ks) ^ h:
         // the lane part of the address is one of 4 values (per ks) shared by every fragment of both operands; mn * 128
         // is wave-uniform / an immediate offset

@@ -169,7 +169,7 @@ def large_main():
         want = (aa[:256].float() @ bb.float())
         fl = 2.0 * M * N * K
         rec = {'op': 'gemm_large', 'ta': ta, 'tb': tb, 'M': M, 'N': N, 'K': K}
-        for name, hint in (('auto', 0), ('t128', 3001), ('t128r2', 4001), ('t256x128', 5001), ('t256', 7001)):
+        for name, hint in (('auto', 0), ('t128', 3001), ('t128r2', 4001), ('t256x128', 5001), ('t256', 7001), ('t256k32', 9001)):
             out.zero_()
             ops.mm(a, b, bool(ta), bool(tb), out=out, tile_hint=hint)
             err = ((out[:256].float() - want).abs().max() / want.abs().max()).item()
