@@ -30,7 +30,7 @@ int launch_conv(GemmParams& p, bool b_mc, int batch, void* ws, long ws_bytes, in
         // measured on the SDXL convolutions (tools/conv_timing.py): the 256^2 tile loses on the UNet's 320 / 640-wide outputs (37 % of a 256-wide tile is padding:
         // 152 vs 95 us for 128^2 x 640 -> 320), and the forward's gathered A rows favour two workgroups per CU (2-deep ring) from one round of tiles on
         const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
-        if (tile == 257) tile = gemm_pipe_plan(p, a_mc, b_mc, batch, ws, ws_bytes, 0, 129);      // re-plan (tile grid, split-K, slab budget) for 128^2
+        if (tile == 257 || tile == 258) tile = gemm_pipe_plan(p, a_mc, b_mc, batch, ws, ws_bytes, 0, 129);      // re-plan (tile grid, split-K, slab budget) for 128^2 (258 = the half-K-step ring: plain GEMM only)
         if (CONV == 1 && !b_mc && tile == 128 && tiles128 >= 256 && tiles128 < 512 && p.splitk == 1) tile = 129;
     }
     switch (tile) {
