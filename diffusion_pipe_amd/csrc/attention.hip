@@ -1036,7 +1036,7 @@ int dpipe_attn_fwd(const void* q, const void* k, const void* v, void* o, float* 
     // fill most of the chip, else 4 waves x 32 rows (twice the workgroups, 2 - 3 of them per CU).  Measured (tools/kernel_timing.py attn, profiles/):
     // head dim 128 at 4.6k / 9.2k / 61k tokens 737 / 914 / 990 TFLOP/s (the register-staged kernel below: 385 / 448 / 474); SDXL's 1024 x 1024 x 20 heads
     // 23.8 us (34.0).  The K / V extents must fit the 32-bit buffer offsets.  DPIPE_ATTN_FWD_DMA = 0 selects the register-staged kernel (A/B timing).
-    static const int dma_mode = [] { const char* e = getenv("DPIPE_ATTN_FWD_DMA"); return e ? atoi(e) : -1; }();
+    const int dma_mode = option(DPIPE_OPT_ATTN_FWD_DMA, 1);
     const bool fits = ((long)(Sk - 1) * k_ss + D) * 2 < (1l << 31) && ((long)(Sk - 1) * v_ss + D) * 2 < (1l << 31);
     if (fits && dma_mode != 0) {
         hipStream_t st = STREAM(stream);
@@ -1099,16 +1099,16 @@ int dpipe_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
     dim3 gq((unsigned)cdiv(Sq, small_q ? 64 : 128), (unsigned)H, (unsigned)B), gk((unsigned)(cdiv(Sk, 32 * NW) * p.qsplit), (unsigned)H, (unsigned)B);
     const unsigned gred = (unsigned)cdiv((long)B * H * Sk * (D / 4), 256);
     // head dim 128: the 4-wave dQ kernel needs > 256 registers (one wave per SIMD); 8 waves x 32 rows fit 2 per SIMD (220 VGPRs) -- DPIPE_ATTN_DQ8 = 0 for A/B timing
-    static const bool dq8_on = [] { const char* e = getenv("DPIPE_ATTN_DQ8"); return !e || atoi(e) != 0; }();
+    const bool dq8_on = option(DPIPE_OPT_ATTN_DQ8, 1) != 0;
     const bool dq8 = dq8_on && (long)cdiv(Sq, 256) * H * B >= 192;
     dim3 gq8((unsigned)cdiv(Sq, 256), (unsigned)H, (unsigned)B);
     // LDS-DMA forms of the backward kernels (K / V extents within the 32-bit buffer offsets) -- DPIPE_ATTN_BWD_DMA = 0 for A/B timing
-    static const bool bwd_dma_on = [] { const char* e = getenv("DPIPE_ATTN_BWD_DMA"); return !e || atoi(e) != 0; }();
+    const bool bwd_dma_on = option(DPIPE_OPT_ATTN_BWD_DMA, 1) != 0;
     const bool bwd_dma = bwd_dma_on && ((long)(Sk - 1) * k_ss + D) * 2 < (1l << 31) && ((long)(Sk - 1) * v_ss + D) * 2 < (1l << 31);
     const long wg256 = (long)cdiv(Sq, 256) * H * B, wg128 = (long)cdiv(Sq, 128) * H * B;
     const bool bwd_dma_q = bwd_dma_on && ((long)(Sq - 1) * q_ss + D) * 2 < (1l << 31) && ((long)(Sq - 1) * do_ss + D) * 2 < (1l << 31);   // the dK / dV kernels stream Q and dO
     // head dim 128, long key sequences: dV and dK as two 8-wave kernels (two waves per SIMD) -- DPIPE_ATTN_DKV_SPLIT = 0 for A/B timing
-    static const bool split_on = [] { const char* e = getenv("DPIPE_ATTN_DKV_SPLIT"); return !e || atoi(e) != 0; }();
+    const bool split_on = option(DPIPE_OPT_ATTN_DKV_SPLIT, 1) != 0;
     const bool dkv_split = split_on && p.qsplit == 1 && (long)cdiv(Sk, 256) * H * B >= 192;
     dim3 gk8((unsigned)cdiv(Sk, 256), (unsigned)H, (unsigned)B);
 #define ATTN_BWD(DD) do { \

@@ -22,6 +22,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 void set_last_error(const char* msg);
+int option(int id, int dflt);          // runtime.hip: dpipe_set_option value, else the option's environment variable, else dflt
 int check_launch(const char* what);
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) {

@@ -3,6 +3,7 @@
 #include "../../include/dpipe_hip.h"
 #include <string.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 namespace dpipe {
 static thread_local char g_last_error[512] = "";
@@ -18,10 +19,26 @@ int check_launch(const char* what) {
     snprintf(g_last_error, sizeof(g_last_error), "%s: %s", what, hipGetErrorString(e));
     return (int)e;
 }
+// Process-wide kernel-selection options (dpipe_set_option): A/B timing and tests of the fallback kernels.  -1 = unset: the environment variable of the
+// same meaning, if any, then the built-in default (see include/dpipe_hip.h for the names).
+static int g_options[DPIPE_OPTION_COUNT] = {-1, -1, -1, -1};
+static const char* const g_option_env[DPIPE_OPTION_COUNT] = {"DPIPE_ATTN_FWD_DMA", "DPIPE_ATTN_BWD_DMA", "DPIPE_ATTN_DQ8", "DPIPE_ATTN_DKV_SPLIT"};
+int option(int id, int dflt) {
+    if (id < 0 || id >= DPIPE_OPTION_COUNT) return dflt;
+    if (g_options[id] >= 0) return g_options[id];
+    const char* e = getenv(g_option_env[id]);
+    return e ? atoi(e) : dflt;
+}
 }  // namespace dpipe
 
 extern "C" {
 int dpipe_version(void) { return 1; }
+int dpipe_set_option(int id, int value) {
+    if (id < 0 || id >= DPIPE_OPTION_COUNT) { dpipe::set_last_error("dpipe_set_option: unknown option"); return DPIPE_ERR_ARG; }
+    dpipe::g_options[id] = value;
+    return DPIPE_OK;
+}
+int dpipe_get_option(int id) { return dpipe::option(id, -1); }
 const char* dpipe_last_error(void) { return dpipe::g_last_error; }
 int dpipe_device_info(int dev, int* cu_count, char* arch_name, int arch_name_len) {
     hipDeviceProp_t prop;

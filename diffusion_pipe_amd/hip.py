@@ -16,6 +16,7 @@ import os
 LIB_PATH = Path(os.environ.get('DPIPE_HIP_LIB') or Path(__file__).resolve().parent / 'libdpipe_hip.so')
 
 BF16, F32 = 0, 1
+OPT_ATTN_FWD_DMA, OPT_ATTN_BWD_DMA, OPT_ATTN_DQ8, OPT_ATTN_DKV_SPLIT = 0, 1, 2, 3     # dpipe_set_option ids (include/dpipe_hip.h)
 ACT = {None: 0, 'none': 0, 'gelu_tanh': 1, 'gelu': 2, 'gelu_erf': 2, 'silu': 3, 'quick_gelu': 4}
 LOSS_KIND = {'mse': 0, 'huber': 1, 'smooth_l1': 2}
 
@@ -25,6 +26,8 @@ P, I, L, F = c_void_p, c_int, c_long, c_float
 _SIGNATURES = {
     'dpipe_version': (I, []),
     'dpipe_last_error': (c_char_p, []),
+    'dpipe_set_option': (I, [I, I]),
+    'dpipe_get_option': (I, [I]),
     'dpipe_device_info': (I, [I, POINTER(c_int), c_char_p, I]),
     'dpipe_comm_unique_id': (I, [P]),
     'dpipe_comm_init': (I, [POINTER(c_void_p), I, I, P]),

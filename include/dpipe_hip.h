@@ -33,6 +33,15 @@ extern "C" {
 
 int dpipe_version(void);
 const char* dpipe_last_error(void);
+/* Kernel-selection options (process-wide; for A/B timing and for testing the fallback kernels -- every default is the measured-faster choice).
+ * value -1 = unset: the environment variable of the same name (DPIPE_ATTN_FWD_DMA ...) if present, else the default. */
+#define DPIPE_OPT_ATTN_FWD_DMA 0    /* 1 (default): LDS-DMA flash-attention forward; 0: register-staged kernel */
+#define DPIPE_OPT_ATTN_BWD_DMA 1    /* 1 (default): LDS-DMA dQ / dK / dV kernels (delta fused into dQ); 0: register-staged kernels + attn_delta */
+#define DPIPE_OPT_ATTN_DQ8 2        /* register-staged path, head dim 128: 1 (default) 8-wave dQ kernel for long sequences */
+#define DPIPE_OPT_ATTN_DKV_SPLIT 3  /* head dim 128, long key sequences: 1 (default) dV and dK as two 8-wave kernels; 0: one pass */
+#define DPIPE_OPTION_COUNT 4
+int dpipe_set_option(int option, int value);
+int dpipe_get_option(int option);    /* the effective explicit / environment value, -1 if neither is set */
 /* Number of compute units / name of device `dev`; used by the host to sanity-check it runs on gfx950. */
 int dpipe_device_info(int dev, int* cu_count, char* arch_name, int arch_name_len);
 

@@ -378,6 +378,48 @@ def test_flash_attention_fwd_bwd(gpu, case):
                 assert k.grad[bi, n:].abs().max().item() == 0.0 and v.grad[bi, n:].abs().max().item() == 0.0
 
 
+@pytest.fixture
+def staged_attention_kernels():
+    """Select the register-staged attention kernels (the fallback when K / V extents exceed the 32-bit buffer offsets of the LDS-DMA kernels) through the
+    C ABI's dpipe_set_option; unset again afterwards."""
+    from diffusion_pipe_amd import hip
+    ids = (hip.OPT_ATTN_FWD_DMA, hip.OPT_ATTN_BWD_DMA)
+    for i in ids:
+        hip.check(hip.lib().dpipe_set_option(i, 0), 'set_option')
+    assert hip.lib().dpipe_get_option(hip.OPT_ATTN_FWD_DMA) == 0
+    yield
+    for i in ids:
+        hip.check(hip.lib().dpipe_set_option(i, -1), 'set_option')
+
+
+@pytest.mark.parametrize('case', [ATTN_CASES[0], ATTN_CASES[1], ATTN_CASES[3], ATTN_CASES[7], ATTN_CASES[9], ATTN_CASES[12], ATTN_CASES[15]])
+def test_flash_attention_register_staged_fallback(gpu, staged_attention_kernels, case):
+    test_flash_attention_fwd_bwd(gpu, case)
+
+
+@pytest.mark.parametrize('dma', [0, 1])
+def test_flash_attention_kernel_families_agree(gpu, dma):
+    """Same inputs through both kernel families: outputs and gradients within bf16 rounding of each other (and of the fp32 reference, checked above)."""
+    from diffusion_pipe_amd import hip, ops
+    g = torch.Generator().manual_seed(11)
+    q, k, v = (torch.randn(2, 520, 6, 128, generator=g).to(gpu, torch.bfloat16).requires_grad_(True) for _ in range(3))
+    go = torch.randn(2, 520, 6, 128, generator=g).to(gpu, torch.bfloat16)
+    try:
+        for i in (hip.OPT_ATTN_FWD_DMA, hip.OPT_ATTN_BWD_DMA):
+            hip.check(hip.lib().dpipe_set_option(i, dma), 'set_option')
+        o = ops.attention(q, k, v, impl='flash', causal=True)
+        o.backward(go)
+    finally:
+        for i in (hip.OPT_ATTN_FWD_DMA, hip.OPT_ATTN_BWD_DMA):
+            hip.check(hip.lib().dpipe_set_option(i, -1), 'set_option')
+    qr, kr, vr = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+    orf = F.scaled_dot_product_attention(qr.transpose(1, 2), kr.transpose(1, 2), vr.transpose(1, 2), is_causal=True).transpose(1, 2)
+    orf.backward(go.float())
+    assert _rel_err(o, orf) < 2e-2
+    for got, want in ((q.grad, qr.grad), (k.grad, kr.grad), (v.grad, vr.grad)):
+        assert _rel_err(got, want) < 3e-2
+
+
 def test_flash_attention_strided_views_and_rescale_spike(gpu):
     from diffusion_pipe_amd import ops
     g = torch.Generator().manual_seed(77)
