@@ -162,6 +162,77 @@ __global__ void __launch_bounds__(OPT_BLOCK) adamw_step_kernel(void* const* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 8-bit block-wise AdamW
+// The reference's `adamw8bit` / `adamw8bitkahan` optimizers (train.py:673-686 -> bitsandbytes.optim.AdamW8bit, optimizers/adamw_8bit.py): moments stored as
+// uint8 codes of a 256-entry dynamic map plus one fp32 absmax per 256 elements.  bitsandbytes is absent here, so this follows the library's published
+// algorithm as restated in oracle/adam8bit_ref.py (parity unpinned).  One workgroup = one 256-element block per iteration, one element per thread:
+// dequantise -> moments -> block absmax (wave max + LDS) -> parameter update (+ decoupled decay) -> requantise to the nearest code.
+// `shift` != NULL: the reference's Kahan variant -- the library kernel updates the shift buffer instead of the parameter (weight decay included), then
+// p' = p + shift, shift' = shift + (p - p') in the parameter's dtype.
+__device__ __forceinline__ int nearest_code(const float* q, float x) {
+    int lo = 0, hi = 255;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int mid = (lo + hi) >> 1;
+        if (q[mid] <= x) lo = mid; else hi = mid;
+    }
+    return (q[hi] - x) < (x - q[lo]) ? hi : lo;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) adamw8bit_kernel(T* __restrict__ p, const T* __restrict__ g, uint8_t* __restrict__ c1, uint8_t* __restrict__ c2,
+                                                        float* __restrict__ absmax1, float* __restrict__ absmax2, const float* __restrict__ qmap1,
+                                                        const float* __restrict__ qmap2, T* __restrict__ shift, long n, float beta1, float beta2, float eps,
+                                                        float lr, float weight_decay, float step_size, float correction2, float gnorm_scale) {
+    __shared__ float q1[256], q2[256], red[2][4];
+    q1[threadIdx.x] = qmap1[threadIdx.x]; q2[threadIdx.x] = qmap2[threadIdx.x];
+    __syncthreads();
+    const long nblocks = (n + 255) / 256;
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const long i = blk * 256 + threadIdx.x;
+        const bool live = i < n;
+        const float gv = live ? Elem<T>::to_f(g[i]) : 0.f;
+        const bool fin = isfinite(gv);
+        float m = 0.f, v = 0.f;
+        if (live && fin) {
+            const float gs = gv * gnorm_scale;
+            m = q1[c1[i]] * absmax1[blk]; v = q2[c2[i]] * absmax2[blk];
+            m = m * beta1 + (1.f - beta1) * gs;
+            v = v * beta2 + (1.f - beta2) * gs * gs;
+        }
+        float a1 = fabsf(m), a2 = v;      // v >= 0
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a1 = fmaxf(a1, __shfl_xor(a1, o, 64)); a2 = fmaxf(a2, __shfl_xor(a2, o, 64)); }
+        __syncthreads();                   // every thread has read absmax[blk] and the previous iteration's red[]
+        if (lane == 0) { red[0][wid] = a1; red[1][wid] = a2; }
+        __syncthreads();
+        const float new1 = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+        const float new2 = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+        if (threadIdx.x == 0) { absmax1[blk] = new1; absmax2[blk] = new2; }
+        if (!live) continue;
+        T* target = shift ? shift : p;
+        float t = Elem<T>::to_f(target[i]);
+        if (fin) {
+            t = Elem<T>::to_f(Elem<T>::from_f(t + step_size * (m / (sqrtf(v) + correction2 * eps))));
+            if (weight_decay > 0.f) t = Elem<T>::to_f(Elem<T>::from_f(t * (1.f - lr * weight_decay)));
+        }
+        if (shift) {
+            const float pv = Elem<T>::to_f(p[i]);
+            const float pn = Elem<T>::to_f(Elem<T>::from_f(pv + t));
+            const float diff = Elem<T>::to_f(Elem<T>::from_f(pv - pn));
+            p[i] = Elem<T>::from_f(pn);
+            shift[i] = Elem<T>::from_f(t + diff);
+        } else {
+            p[i] = Elem<T>::from_f(t);
+        }
+        int k1 = nearest_code(q1, new1 > 0.f ? m / new1 : 0.f);
+        const int k2 = nearest_code(q2, new2 > 0.f ? v / new2 : 0.f);
+        if (signbit(q1[k1]) != signbit(m)) k1 = m > 0.f ? min(k1 + 1, 255) : max(k1 - 1, 0);   // the first moment keeps its sign through quantisation
+        c1[i] = (uint8_t)k1; c2[i] = (uint8_t)k2;
+    }
+}
+
 }  // namespace
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
@@ -216,6 +287,25 @@ int dpipe_adamw_step_kahan(void* const* p_ptrs, void* const* m_ptrs, void* const
     if (nchunks > 0 && !shift_ptrs) { set_last_error("dpipe_adamw_step_kahan: null shift table"); return DPIPE_ERR_ARG; }
     return adamw_step_impl(p_ptrs, m_ptrs, v_ptrs, shift_ptrs, g_ptrs, lanes, chunk_tensor, chunk_off, chunk_len, nchunks, dtype, lr, beta1, beta2, eps, weight_decay,
                            bias_correction1, bias_correction2, total_sumsq, max_norm, zero_grads, stream);
+}
+
+int dpipe_adamw8bit_step(void* p, const void* g, void* state1, void* state2, float* absmax1, float* absmax2, const float* qmap1, const float* qmap2,
+                         void* shift, long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float gnorm_scale, int dtype,
+                         void* stream) {
+    if (!p || !g || !state1 || !state2 || !absmax1 || !absmax2 || !qmap1 || !qmap2 || n <= 0 || step < 1) { set_last_error("dpipe_adamw8bit_step: bad argument"); return DPIPE_ERR_ARG; }
+    const float correction1 = 1.f - powf(beta1, (float)step), correction2 = sqrtf(1.f - powf(beta2, (float)step));
+    const float step_size = -lr * correction2 / correction1;
+    const long nblocks = (n + 255) / 256;
+    const unsigned grid = (unsigned)(nblocks < 4096 ? nblocks : 4096);
+    hipStream_t s = STREAM(stream);
+    if (dtype == DPIPE_BF16)
+        adamw8bit_kernel<bf16_t><<<grid, 256, 0, s>>>((bf16_t*)p, (const bf16_t*)g, (uint8_t*)state1, (uint8_t*)state2, absmax1, absmax2, qmap1, qmap2, (bf16_t*)shift, n,
+                                                      beta1, beta2, eps, lr, weight_decay, step_size, correction2, gnorm_scale);
+    else if (dtype == DPIPE_F32)
+        adamw8bit_kernel<float><<<grid, 256, 0, s>>>((float*)p, (const float*)g, (uint8_t*)state1, (uint8_t*)state2, absmax1, absmax2, qmap1, qmap2, (float*)shift, n,
+                                                     beta1, beta2, eps, lr, weight_decay, step_size, correction2, gnorm_scale);
+    else { set_last_error("dpipe_adamw8bit_step: dtype"); return DPIPE_ERR_UNSUPPORTED; }
+    return check_launch("dpipe_adamw8bit_step");
 }
 
 }  // extern "C"

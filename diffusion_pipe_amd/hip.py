@@ -53,6 +53,7 @@ _SIGNATURES = {
     'dpipe_adamw_sumsq': (I, [P, I, P, P, P, I, I, P, P, I, P]),
     'dpipe_adamw_step': (I, [P, P, P, P, I, P, P, P, I, I, F, F, F, F, F, F, F, P, F, I, P]),
     'dpipe_adamw_step_kahan': (I, [P, P, P, P, P, I, P, P, P, I, I, F, F, F, F, F, F, F, P, F, I, P]),
+    'dpipe_adamw8bit_step': (I, [P, P, P, P, P, P, P, P, P, L, F, F, F, F, F, I, F, I, P]),
     'dpipe_rmsnorm_fwd': (I, [P, P, P, P, L, I, F, I, I, P]),
     'dpipe_norm_slabs': (I, [L]),
     'dpipe_rmsnorm_bwd': (I, [P, P, P, P, P, P, P, L, I, I, I, I, P]),

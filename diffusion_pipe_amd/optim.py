@@ -8,8 +8,9 @@ Mirrors what the reference's `train.py` builds around `model_engine._configure_o
   * LR schedule (train.py:849-862): constant / linear / cosine, optional linear warm-up chained with SequentialLR.
 The update itself stays a PyTorch optimizer on the raw bf16 parameters, as in the reference (no fp32 master weights:
 the reference's ds_config has no fp16 / bf16 / ZeRO section, train.py:423-429).  On ROCm the `fused=True` multi-tensor
-AdamW is the fast path; optimizers that only exist as CUDA extensions in the reference (bitsandbytes 8-bit, optimi) are
-reported as unavailable instead of being silently replaced.
+AdamW is the fast path; bitsandbytes' 8-bit block-wise AdamW (`adamw8bit`, `adamw8bitkahan`) is a HIP kernel of this repo (`AdamW8bit`,
+csrc/optim.hip); optimizers that only exist as other CUDA extensions in the reference (optimi, torchao offload) are reported as unavailable instead of
+being silently replaced.
 """
 from collections import defaultdict
 
@@ -22,8 +23,7 @@ _TORCH_OPTIMIZERS = {
     'adam': torch.optim.Adam,
 }
 _NEEDS_EXTERNAL = {
-    'adamw8bit': 'bitsandbytes', 'adamw_optimi': 'optimi', 'stableadamw': 'optimi', 'adamw8bitkahan': 'bitsandbytes',
-    'offload': 'torchao', 'automagic': None, 'genericoptim': None,
+    'adamw_optimi': 'optimi', 'stableadamw': 'optimi', 'offload': 'torchao', 'automagic': None, 'genericoptim': None,
 }
 
 
@@ -158,6 +158,118 @@ class FusedAdamW(torch.optim.Optimizer):
         return loss
 
 
+
+def create_dynamic_map(signed=True, max_exponent_bits=7, total_bits=8):
+    """The 256 code values of bitsandbytes' dynamic 8-bit data type (`bitsandbytes.functional.create_dynamic_map`, the same construction with the same
+    torch calls): signed for the first Adam moment, unsigned for the second.  Sorted fp32 tensor in [-1, 1] / [0, 1]."""
+    data = []
+    non_sign_bits = total_bits - 1
+    additional_items = 2 ** (non_sign_bits - max_exponent_bits) - 1
+    i = 0
+    for i in range(max_exponent_bits):
+        fraction_items = int(2 ** (i + non_sign_bits - max_exponent_bits) + 1 if signed else 2 ** (i + non_sign_bits - max_exponent_bits + 1) + 1)
+        boundaries = torch.linspace(0.1, 1, fraction_items)
+        means = (boundaries[:-1] + boundaries[1:]) / 2.0
+        data += ((10 ** (-(max_exponent_bits - 1) + i)) * means).tolist()
+        if signed:
+            data += (-(10 ** (-(max_exponent_bits - 1) + i)) * means).tolist()
+    if additional_items > 0:
+        boundaries = torch.linspace(0.1, 1, additional_items + 1)
+        means = (boundaries[:-1] + boundaries[1:]) / 2.0
+        data += ((10 ** (-(max_exponent_bits - 1) + i)) * means).tolist()
+        if signed:
+            data += (-(10 ** (-(max_exponent_bits - 1) + i)) * means).tolist()
+    data.append(0)
+    data.append(1.0)
+    assert len(data) == 2 ** total_bits
+    data.sort()
+    return torch.tensor(data, dtype=torch.float32)
+
+
+class AdamW8bit(torch.optim.Optimizer):
+    """The reference's `adamw8bit` (bitsandbytes.optim.AdamW8bit, train.py:673-676) and `adamw8bitkahan` (optimizers/adamw_8bit.py:6-124) on MI355X:
+    block-wise 8-bit Adam moments (uint8 codes of two 256-entry dynamic maps + one fp32 absmax per 256 elements: 2.03 bytes of optimizer state per
+    parameter instead of AdamW's 4 in bf16 / 8 in fp32), decoupled weight decay, updated by one HIP kernel per parameter tensor (dpipe_adamw8bit_step).
+    State keys follow bitsandbytes (`state1`, `state2`, `absmax1`, `absmax2`, `qmap1`, `qmap2`, `step`; `shift` for the Kahan variant); parameters with
+    fewer than `min_8bit_size` elements keep fp32 moments (the library's optimizer_update_32bit), updated here with torch ops.
+    bitsandbytes is not available offline: the algorithm follows its published kernels as restated in oracle/adam8bit_ref.py (parity unpinned)."""
+
+    BLOCK = 256
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, kahan=False, min_8bit_size=4096):
+        if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
+            raise ValueError('invalid AdamW hyper-parameter')
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        self.kahan, self.min_8bit_size = bool(kahan), int(min_8bit_size)
+        self._qmaps = {}
+
+    def _maps(self, device):
+        if device not in self._qmaps:
+            self._qmaps[device] = (create_dynamic_map(True).to(device), create_dynamic_map(False).to(device))
+        return self._qmaps[device]
+
+    def _init_state(self, p):
+        st = self.state[p]
+        st['step'] = 0
+        n = p.numel()
+        if n < self.min_8bit_size:
+            st['state1'] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.preserve_format)
+            st['state2'] = torch.zeros_like(p, dtype=torch.float32, memory_format=torch.preserve_format)
+        else:
+            blocks = -(-n // self.BLOCK)
+            st['state1'] = torch.zeros(n, dtype=torch.uint8, device=p.device)
+            st['state2'] = torch.zeros(n, dtype=torch.uint8, device=p.device)
+            st['absmax1'] = torch.zeros(blocks, dtype=torch.float32, device=p.device)
+            st['absmax2'] = torch.zeros(blocks, dtype=torch.float32, device=p.device)
+            st['qmap1'], st['qmap2'] = self._maps(p.device)
+        if self.kahan:
+            st['shift'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return st
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from . import hip
+        loss = closure() if closure is not None else None
+        for group in self.param_groups:
+            lr, (b1, b2), eps, wd = group['lr'], group['betas'], group['eps'], group['weight_decay']
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda:
+                    raise RuntimeError('AdamW8bit: the 8-bit step is a HIP kernel (no CPU fallback)')
+                if not p.is_contiguous() or not p.grad.is_contiguous():
+                    raise RuntimeError('AdamW8bit: parameters and gradients must be contiguous')
+                st = self.state[p] if len(self.state[p]) else self._init_state(p)
+                st['step'] += 1
+                t = st['step']
+                shift = st.get('shift')
+                if st['state1'].dtype == torch.uint8:
+                    hip.check(hip.lib().dpipe_adamw8bit_step(hip.ptr(p), hip.ptr(p.grad), hip.ptr(st['state1']), hip.ptr(st['state2']), hip.ptr(st['absmax1']),
+                                                             hip.ptr(st['absmax2']), hip.ptr(st['qmap1']), hip.ptr(st['qmap2']), hip.ptr(shift), p.numel(),
+                                                             float(lr), float(b1), float(b2), float(eps), float(wd), int(t), 1.0, hip.dtype_code(p.dtype),
+                                                             hip.stream()), 'adamw8bit_step')
+                    continue
+                # small tensors: fp32 moments (optimizer_update_32bit)
+                g = p.grad.float()
+                m, v = st['state1'], st['state2']
+                m.mul_(b1).add_(g, alpha=1.0 - b1)
+                v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+                c1 = 1.0 - b1 ** t
+                c2 = (1.0 - b2 ** t) ** 0.5
+                target = shift if shift is not None else p
+                new = (target.float() + (-lr * c2 / c1) * (m / (v.sqrt() + eps * c2))).to(p.dtype)
+                if wd > 0:
+                    new = (new.float() * (1.0 - lr * wd)).to(p.dtype)
+                if shift is not None:
+                    shift.copy_(new)
+                    buf = p.clone()
+                    p.add_(shift)
+                    shift.add_(buf.sub_(p))
+                else:
+                    p.copy_(new)
+        return loss
+
+
 def computed_beta2(global_batch_size, beta2_half_life):
     """beta2 such that the second-moment EMA halves every `beta2_half_life` examples (train.py:658-663)."""
     return 0.5 ** (global_batch_size / beta2_half_life)
@@ -216,8 +328,17 @@ def make_optimizer_factory(config, workload, global_batch_size, device_is_gpu=Tr
             cfg['betas'] = betas
         if 'betas' in cfg:
             cfg['betas'] = tuple(cfg['betas'])
-        klass = _optimizer_class(optim_type)
+        klass = _optimizer_class(optim_type) if optim_type.lower() not in ('adamw8bit', 'adamw8bitkahan') else None
         plain_adamw = klass is torch.optim.AdamW and not set(cfg) - {'lr', 'betas', 'eps', 'weight_decay'}
+        if optim_type.lower() in ('adamw8bit', 'adamw8bitkahan'):
+            # train.py:673-686: bitsandbytes.optim.AdamW8bit / optimizers/adamw_8bit.AdamW8bitKahan -> the HIP kernel of this repo
+            if not device_is_gpu:
+                raise NotImplementedError(f"optimizer type '{optim_type}' is a HIP kernel: GPU stages only")
+            extra = set(cfg) - {'lr', 'betas', 'eps', 'weight_decay', 'min_8bit_size'}
+            if extra:
+                raise NotImplementedError(f"optimizer type '{optim_type}': unsupported options {sorted(extra)}")
+            groups = split_weight_decay(workload.get_param_groups(model_parameters))
+            return AdamW8bit(groups, kahan=optim_type.lower() == 'adamw8bitkahan', **cfg)
         if optim_type.lower() == 'adamwkahan':
             if not (plain_adamw and device_is_gpu and use_hip_adamw):
                 raise NotImplementedError("optimizer type 'adamwkahan' runs on the fused HIP step end of a GPU stage only")

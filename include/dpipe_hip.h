@@ -132,6 +132,15 @@ int dpipe_adamw_step_kahan(void* const* p_ptrs, void* const* m_ptrs, void* const
                            float beta2, float eps, float weight_decay, float bias_correction1, float bias_correction2, const float* total_sumsq,
                            float max_norm, int zero_grads, void* stream);
 
+/* 8-bit block-wise AdamW -- the reference's `adamw8bit` / `adamw8bitkahan` (train.py:673-686: bitsandbytes.optim.AdamW8bit, optimizers/adamw_8bit.py:6-124;
+ * the library's optimizer_update_8bit_blockwise).  One parameter tensor per call: `state1` / `state2` = n uint8 codes of the two 256-entry maps `qmap1`
+ * (signed dynamic) / `qmap2` (unsigned dynamic), `absmax1` / `absmax2` = one fp32 per block of 256 elements; `step` = this update's 1-based count (bias
+ * corrections are computed here); `shift` != NULL selects the reference's Kahan variant (the update lands in `shift`, then p' = p + shift,
+ * shift' = shift + (p - p') in the parameter dtype).  Gradient clipping is the caller's (`gnorm_scale` multiplies the gradient, 1.0 = none). */
+int dpipe_adamw8bit_step(void* p, const void* g, void* state1, void* state2, float* absmax1, float* absmax2, const float* qmap1, const float* qmap2,
+                         void* shift, long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float gnorm_scale, int dtype,
+                         void* stream);
+
 /* ---- K2 RMSNorm (models/wan/model.py:70-86; per-head form models/hunyuan_image_modeling.py:98-103) ------------
  * y = cast(x * rsqrt(mean(x^2) + eps)) * w ; w may be NULL; rstd [rows] saved for backward (may be NULL). */
 int dpipe_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, long rows, int cols, float eps, int dtype,

@@ -49,9 +49,15 @@ def test_beta2_half_life_and_unavailable_optimizers():
     opt = optim.make_optimizer_factory(cfg, work, global_batch_size=16, device_is_gpu=False)(params)
     assert math.isclose(opt.param_groups[0]['betas'][1], 0.5 ** (16 / 2000))
     assert cfg['optimizer']['betas'] == [0.9, 0.99]          # the caller's config is not mutated between stages
-    for kind in ('AdamW8bit', 'adamw_optimi', 'StableAdamW'):
+    for kind in ('adamw_optimi', 'StableAdamW'):
         with pytest.raises(NotImplementedError, match='not available'):
             optim.make_optimizer_factory({'optimizer': {'type': kind, 'lr': 1e-4}}, work, 4)(params)
+    # the 8-bit AdamW is a HIP kernel: constructed for GPU stages, refused (not silently replaced) elsewhere
+    with pytest.raises(NotImplementedError, match='GPU stages only'):
+        optim.make_optimizer_factory({'optimizer': {'type': 'AdamW8bit', 'lr': 1e-4}}, work, 4, device_is_gpu=False)(params)
+    for kind, kahan in (('AdamW8bit', False), ('AdamW8bitKahan', True)):
+        o8 = optim.make_optimizer_factory({'optimizer': {'type': kind, 'lr': 1e-4, 'betas': [0.9, 0.99], 'weight_decay': 0.01}}, work, 4)(params)
+        assert isinstance(o8, optim.AdamW8bit) and o8.kahan is kahan and {g['weight_decay'] for g in o8.param_groups} == {0.01, 0}
     sgd = optim.make_optimizer_factory({'optimizer': {'type': 'SGD', 'lr': 1e-3, 'momentum': 0.9}}, work, 4)(params)
     assert isinstance(sgd, torch.optim.SGD)
 
@@ -131,3 +137,34 @@ def test_flux_prepare_inputs_host_logic_matches_oracle():
     t = work.prepare_inputs(batch, timestep_quantile=0.5)[0][3]
     assert torch.allclose(t, torch.full((3,), 0.5))
     assert len(work.to_layers()) == 1 + cfg.num_layers + cfg.num_single_layers + 1
+
+
+def test_dynamic_8bit_maps_and_the_8bit_adam_restatement():
+    """The two 256-entry code maps (product = oracle construction), the nearest-code quantiser, and the oracle's 8-bit AdamW against fp32 AdamW:
+    same trajectory within the quantisation error of the moments (the library is absent: nothing here pins it, see oracle/adam8bit_ref.py)."""
+    import numpy as np
+    from oracle import adam8bit_ref as ref
+    q1, q2 = ref.create_dynamic_map(True), ref.create_dynamic_map(False)
+    for got, want in ((optim.create_dynamic_map(True).numpy(), q1), (optim.create_dynamic_map(False).numpy(), q2)):
+        assert got.shape == (256,) and np.allclose(got, want, rtol=2e-7, atol=0)
+    assert (np.diff(q1) > 0).all() and (np.diff(q2) >= 0).all() and q1[0] < -0.99 and q1[-1] == 1.0 and q2[0] == 0.0 and q2[-1] == 1.0
+    assert q1[127] == 0.0 and np.allclose(q1[128:255], -q1[126::-1])           # 127 negative codes, zero, 127 positive codes, 1.0
+    x = np.random.default_rng(0).uniform(-1, 1, 4000).astype(np.float32)
+    k = ref.quantize_nearest(q1, x)
+    assert (np.abs(q1[k] - x) <= np.abs(q1[None, :] - x[:, None]).min(axis=1) + 1e-9).all()
+    assert (ref.quantize_nearest(q1, q1) == np.arange(256)).all()                # codes are fixed points
+    # trajectory vs fp32 AdamW on a quadratic: p -> target
+    rng = np.random.default_rng(1)
+    target = rng.normal(size=8192).astype(np.float32)
+    p8 = [np.zeros(8192, np.float32)]
+    pk = [np.zeros(8192, np.float32)]
+    o8 = ref.AdamW8bitRef(p8, lr=5e-2, betas=(0.9, 0.99), weight_decay=0.0, dtype='f32')
+    ok = ref.AdamW8bitRef(pk, lr=5e-2, betas=(0.9, 0.99), weight_decay=0.0, kahan=True, dtype='bf16')
+    pt = torch.zeros(8192, requires_grad=True)
+    ot = torch.optim.AdamW([pt], lr=5e-2, betas=(0.9, 0.99), weight_decay=0.0)
+    for _ in range(60):
+        o8.step([p8[0] - target]); ok.step([ref.round_to(pk[0] - target, 'bf16')])
+        pt.grad = (pt.detach() - torch.from_numpy(target)); ot.step()
+    err32 = float((pt.detach() - torch.from_numpy(target)).abs().mean())
+    assert abs(float(np.abs(p8[0] - target).mean()) - err32) < 0.02 and float(np.abs(pk[0] - target).mean()) < err32 + 0.03
+    assert float(np.abs(p8[0] - pt.detach().numpy()).max()) < 0.15               # 8-bit moments: same path within a few per cent of the step sizes
