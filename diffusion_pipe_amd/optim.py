@@ -237,20 +237,23 @@ class AdamW8bit(torch.optim.Optimizer):
                     continue
                 if not p.is_cuda:
                     raise RuntimeError('AdamW8bit: the 8-bit step is a HIP kernel (no CPU fallback)')
-                if not p.is_contiguous() or not p.grad.is_contiguous():
-                    raise RuntimeError('AdamW8bit: parameters and gradients must be contiguous')
+                # element-wise over the storage order: any dense layout (row-major, or the channels-last storage of this repo's convolution weights) as long
+                # as the gradient shares it (the reference instead forces both to row-major, adamw_8bit.py:19-20)
+                if not (p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))):
+                    raise RuntimeError('AdamW8bit: parameters must be dense (row-major or channels-last)')
+                grad = p.grad if p.grad.stride() == p.stride() else torch.empty_like(p).copy_(p.grad)
                 st = self.state[p] if len(self.state[p]) else self._init_state(p)
                 st['step'] += 1
                 t = st['step']
                 shift = st.get('shift')
                 if st['state1'].dtype == torch.uint8:
-                    hip.check(hip.lib().dpipe_adamw8bit_step(hip.ptr(p), hip.ptr(p.grad), hip.ptr(st['state1']), hip.ptr(st['state2']), hip.ptr(st['absmax1']),
+                    hip.check(hip.lib().dpipe_adamw8bit_step(hip.ptr(p), hip.ptr(grad), hip.ptr(st['state1']), hip.ptr(st['state2']), hip.ptr(st['absmax1']),
                                                              hip.ptr(st['absmax2']), hip.ptr(st['qmap1']), hip.ptr(st['qmap2']), hip.ptr(shift), p.numel(),
                                                              float(lr), float(b1), float(b2), float(eps), float(wd), int(t), 1.0, hip.dtype_code(p.dtype),
                                                              hip.stream()), 'adamw8bit_step')
                     continue
                 # small tensors: fp32 moments (optimizer_update_32bit)
-                g = p.grad.float()
+                g = grad.float()
                 m, v = st['state1'], st['state2']
                 m.mul_(b1).add_(g, alpha=1.0 - b1)
                 v.mul_(b2).addcmul_(g, g, value=1.0 - b2)

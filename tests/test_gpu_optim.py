@@ -254,3 +254,37 @@ def test_adamw8bit_trains_like_fp32_adamw(gpu):
     st = o8.state[p8]
     moment_bytes = st['state1'].numel() + st['state2'].numel() + 4 * (st['absmax1'].numel() + st['absmax2'].numel())
     assert moment_bytes / p8.numel() < 2.04
+
+
+def test_engine_step_with_the_8bit_optimizer(gpu):
+    """SDXL (tiny) on the hipGraph path (2 lanes), optimizer.type = 'adamw8bitkahan' as in the reference's TOML: the engine sums the lanes, clips, then
+    AdamW8bit.step() runs the 8-bit kernel on every parameter tensor; the loss descends like the fused bf16 AdamW run and large tensors hold uint8 state."""
+    from diffusion_pipe_amd import optim
+    from diffusion_pipe_amd.data import split_batch
+    from diffusion_pipe_amd.engine import ManualPipelineModule, initialize
+    from diffusion_pipe_amd.workloads import sdxl
+    cfg = sdxl.tiny_config()
+    gas = 4
+    out = {}
+    for kind in ('adamw8bitkahan', 'adamw'):
+        work = sdxl.SDXLWorkload(cfg, model_config={'min_snr_gamma': 5.0}, dtype=torch.bfloat16, seed=2)
+        work.train_config = {'optimizer': {'type': kind, 'lr': 2e-4, 'betas': [0.9, 0.99], 'weight_decay': 0.01, 'eps': 1e-8}}
+        module = ManualPipelineModule(layers=work.to_layers(), num_stages=1, partition_method='parameters', loss_fn=work.get_loss_fn(), dynamic_shape=True)
+        engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 1, 'gradient_accumulation_steps': gas,
+                                                             'gradient_clipping': 0.5, 'hip_graph': True, 'graph_lanes': 2}, device=gpu)
+        params = [p for p in module.parameters() if p.requires_grad]
+        engine._configure_optimizer(optim.make_optimizer_factory(work.train_config, work, gas), params)
+        torch.manual_seed(7)
+        micro = split_batch(work.prepare_inputs(sdxl.synthetic_batch(cfg, batch_size=gas, latent_hw=32, seed=3, ids_len=75)), gas)
+        out[kind] = [engine.train_batch(iter(copy.deepcopy(micro))).item() for _ in range(4)]
+        if kind == 'adamw8bitkahan':
+            assert isinstance(engine.optimizer, optim.AdamW8bit)
+            states = [(p, engine.optimizer.state[p]) for p in params if len(engine.optimizer.state[p])]       # (parameters that never saw a gradient hold no state)
+            assert len(states) > 0.9 * len(params)
+            kinds = {st['state1'].dtype for p, st in states if p.numel() >= 4096}
+            assert kinds == {torch.uint8} and all('shift' in st for _, st in states)
+    l8, lf = out['adamw8bitkahan'], out['adamw']
+    assert l8[0] == pytest.approx(lf[0], rel=1e-3)
+    assert l8[3] < l8[0] and lf[3] < lf[0]
+    for a, b in zip(l8, lf):
+        assert a == pytest.approx(b, rel=5e-2)
