@@ -226,6 +226,23 @@ class AdamW8bit(torch.optim.Optimizer):
             st['shift'] = torch.zeros_like(p, memory_format=torch.preserve_format)
         return st
 
+    def load_state_dict(self, state_dict):
+        """torch.optim.Optimizer.load_state_dict casts every tensor of the state to the parameter's dtype (codes, absmax and maps would become bf16):
+        reload those from the checkpoint with their own dtypes (bitsandbytes overrides load_state_dict for the same reason); `shift` follows the parameter."""
+        from itertools import chain
+        super().load_state_dict(state_dict)
+        saved_ids = list(chain.from_iterable(g['params'] for g in state_dict['param_groups']))
+        params = list(chain.from_iterable(g['params'] for g in self.param_groups))
+        for sid, p in zip(saved_ids, params):
+            for key, value in state_dict['state'].get(sid, {}).items():
+                if torch.is_tensor(value) and key != 'shift':
+                    self.state[p][key] = value.detach().clone().to(device=p.device)
+            st = self.state[p]
+            if 'qmap1' in st:                                   # one shared copy of the two maps per device
+                st['qmap1'], st['qmap2'] = self._maps(p.device)
+            if 'step' in st and torch.is_tensor(st['step']):
+                st['step'] = int(st['step'].item())
+
     @torch.no_grad()
     def step(self, closure=None):
         from . import hip

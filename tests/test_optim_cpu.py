@@ -1,4 +1,5 @@
 """Optimizer / LR-schedule factory and the LoRA wrapping structure -- host logic only (no kernels run)."""
+import copy
 import math
 
 import pytest
@@ -168,3 +169,32 @@ def test_dynamic_8bit_maps_and_the_8bit_adam_restatement():
     err32 = float((pt.detach() - torch.from_numpy(target)).abs().mean())
     assert abs(float(np.abs(p8[0] - target).mean()) - err32) < 0.02 and float(np.abs(pk[0] - target).mean()) < err32 + 0.03
     assert float(np.abs(p8[0] - pt.detach().numpy()).max()) < 0.15               # 8-bit moments: same path within a few per cent of the step sizes
+
+
+def test_adamw8bit_state_dict_round_trip_keeps_the_state_dtypes():
+    """torch's Optimizer.load_state_dict would cast uint8 codes / fp32 absmax to the parameter dtype; AdamW8bit reloads them as saved (resume must be lossless)."""
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(64, 80).to(torch.bfloat16)), torch.nn.Parameter(torch.randn(100).to(torch.bfloat16))]
+    a = optim.AdamW8bit(ps, lr=1e-3, kahan=True)
+    for p in ps:                                                  # (the step itself is a HIP kernel; fill the state by hand)
+        st = a._init_state(p)
+        st['step'] = 7
+        if st['state1'].dtype == torch.uint8:
+            st['state1'].random_(0, 256); st['state2'].random_(0, 256)
+            st['absmax1'].uniform_(1e-4, 1e-3); st['absmax2'].uniform_(1e-9, 1e-7)
+        else:
+            st['state1'].normal_(); st['state2'].uniform_()
+        st['shift'].normal_(std=1e-3)
+    sd = copy.deepcopy(a.state_dict())
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    b = optim.AdamW8bit(qs, lr=1e-3, kahan=True)
+    b.load_state_dict(sd)
+    for p, q in zip(ps, qs):
+        sa, sb = a.state[p], b.state[q]
+        assert sb['step'] == 7 and set(sa) == set(sb)
+        for k, v in sa.items():
+            if torch.is_tensor(v):
+                assert sb[k].dtype == v.dtype and torch.equal(sb[k], v), k
+    big = b.state[qs[0]]
+    assert big['state1'].dtype == torch.uint8 and big['absmax1'].dtype == torch.float32 and big['qmap1'].dtype == torch.float32 and big['shift'].dtype == torch.bfloat16
+    assert b.state[qs[1]]['state1'].dtype == torch.float32                                      # < min_8bit_size: fp32 moments
