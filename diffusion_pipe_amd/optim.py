@@ -226,6 +226,44 @@ class AdamW8bit(torch.optim.Optimizer):
             st['shift'] = torch.zeros_like(p, memory_format=torch.preserve_format)
         return st
 
+    @staticmethod
+    @torch.no_grad()
+    def _step_fp32_moments(items, lr, b1, b2, eps, wd):
+        """The library's 32-bit path (optimizer_update_32bit, ADAM) for the tensors below min_8bit_size -- biases, norm weights: ~1 500 of SDXL's 2 600
+        tensors -- as multi-tensor (`torch._foreach_*`) passes instead of a dozen launches per tensor.  items: [(p, grad, state)] whose state already counts
+        this step.  Update and weight decay land in `shift` for the Kahan variant, each rounded to the parameter dtype, then the compensated add."""
+        by_step = {}
+        for it in items:
+            by_step.setdefault(it[2]['step'], []).append(it)
+        for t, its in by_step.items():
+            ps, ms, vs = [p for p, _, _ in its], [st['state1'] for _, _, st in its], [st['state2'] for _, _, st in its]
+            shifts = [st.get('shift') for _, _, st in its]
+            kahan = shifts[0] is not None
+            targets = shifts if kahan else ps
+            gs = [torch.empty_like(m) for m in ms]
+            torch._foreach_copy_(gs, [g for _, g, _ in its])                  # fp32 gradients
+            torch._foreach_mul_(ms, b1); torch._foreach_add_(ms, gs, alpha=1.0 - b1)
+            torch._foreach_mul_(vs, b2); torch._foreach_addcmul_(vs, gs, gs, value=1.0 - b2)
+            c1 = 1.0 - b1 ** t
+            c2 = (1.0 - b2 ** t) ** 0.5
+            denom = torch._foreach_sqrt(vs)
+            torch._foreach_add_(denom, eps * c2)
+            upd = torch._foreach_div(ms, denom)
+            torch._foreach_mul_(upd, -lr * c2 / c1)
+            torch._foreach_copy_(gs, targets)                                 # (gs reused as the fp32 working copy of the updated tensor)
+            torch._foreach_add_(gs, upd)
+            torch._foreach_copy_(targets, gs)                                 # rounds to the parameter dtype
+            if wd > 0:
+                torch._foreach_copy_(gs, targets)
+                torch._foreach_mul_(gs, 1.0 - lr * wd)
+                torch._foreach_copy_(targets, gs)
+            if kahan:
+                bufs = [torch.empty_like(p) for p in ps]
+                torch._foreach_copy_(bufs, ps)
+                torch._foreach_add_(ps, shifts)
+                torch._foreach_sub_(bufs, ps)
+                torch._foreach_add_(shifts, bufs)
+
     def load_state_dict(self, state_dict):
         """torch.optim.Optimizer.load_state_dict casts every tensor of the state to the parameter's dtype (codes, absmax and maps would become bf16):
         reload those from the checkpoint with their own dtypes (bitsandbytes overrides load_state_dict for the same reason); `shift` follows the parameter."""
@@ -249,6 +287,7 @@ class AdamW8bit(torch.optim.Optimizer):
         loss = closure() if closure is not None else None
         for group in self.param_groups:
             lr, (b1, b2), eps, wd = group['lr'], group['betas'], group['eps'], group['weight_decay']
+            small = []                                          # tensors below min_8bit_size: fp32 moments, updated together by multi-tensor ops
             for p in group['params']:
                 if p.grad is None:
                     continue
@@ -269,24 +308,9 @@ class AdamW8bit(torch.optim.Optimizer):
                                                              float(lr), float(b1), float(b2), float(eps), float(wd), int(t), 1.0, hip.dtype_code(p.dtype),
                                                              hip.stream()), 'adamw8bit_step')
                     continue
-                # small tensors: fp32 moments (optimizer_update_32bit)
-                g = grad.float()
-                m, v = st['state1'], st['state2']
-                m.mul_(b1).add_(g, alpha=1.0 - b1)
-                v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
-                c1 = 1.0 - b1 ** t
-                c2 = (1.0 - b2 ** t) ** 0.5
-                target = shift if shift is not None else p
-                new = (target.float() + (-lr * c2 / c1) * (m / (v.sqrt() + eps * c2))).to(p.dtype)
-                if wd > 0:
-                    new = (new.float() * (1.0 - lr * wd)).to(p.dtype)
-                if shift is not None:
-                    shift.copy_(new)
-                    buf = p.clone()
-                    p.add_(shift)
-                    shift.add_(buf.sub_(p))
-                else:
-                    p.copy_(new)
+                small.append((p, grad, st))
+            if small:
+                self._step_fp32_moments(small, lr, b1, b2, eps, wd)
         return loss
 
 

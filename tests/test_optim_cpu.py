@@ -198,3 +198,37 @@ def test_adamw8bit_state_dict_round_trip_keeps_the_state_dtypes():
     big = b.state[qs[0]]
     assert big['state1'].dtype == torch.uint8 and big['absmax1'].dtype == torch.float32 and big['qmap1'].dtype == torch.float32 and big['shift'].dtype == torch.bfloat16
     assert b.state[qs[1]]['state1'].dtype == torch.float32                                      # < min_8bit_size: fp32 moments
+
+
+@pytest.mark.parametrize('kahan', [False, True])
+def test_adamw8bit_small_tensor_path_matches_the_oracle(kahan):
+    """Tensors below min_8bit_size keep fp32 moments (the library's 32-bit path); the product updates them with multi-tensor ops -- device independent, so
+    checked here on CPU against oracle/adam8bit_ref.py over 5 steps with bf16 parameters (parameters identical but for rare one-ulp flips)."""
+    import numpy as np
+    from oracle import adam8bit_ref as ref
+    g = torch.Generator().manual_seed(5)
+    shapes = [(100,), (33, 7), (4095,)]
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g).to(torch.bfloat16)) for s in shapes]
+    opt = optim.AdamW8bit(ps, lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01, kahan=kahan)
+    pr = [p.detach().float().numpy().reshape(-1).copy() for p in ps]
+    oref = ref.AdamW8bitRef(pr, lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01, kahan=kahan, dtype='bf16')
+    for _ in range(5):
+        grads = [torch.randn(s, generator=g).to(torch.bfloat16) for s in shapes]
+        items = []
+        for p, gr in zip(ps, grads):
+            st = opt.state[p] if len(opt.state[p]) else opt._init_state(p)
+            st['step'] += 1
+            items.append((p, gr, st))
+        optim.AdamW8bit._step_fp32_moments(items, 1e-2, 0.9, 0.99, 1e-8, 0.01)
+        oref.step([gr.float().numpy().reshape(-1) for gr in grads])
+        for p, r, st, sr in zip(ps, pr, [opt.state[p] for p in ps], oref.state):
+            got = p.detach().float().numpy().reshape(-1)
+            assert (np.abs(got - r) <= 2.0 ** -7 * np.abs(r) + 1e-12).all() and (got == r).mean() > 0.99
+            np.testing.assert_allclose(st['state1'].numpy().reshape(-1), sr['m'], rtol=1e-5, atol=1e-8)
+            np.testing.assert_allclose(st['state2'].numpy().reshape(-1), sr['v'], rtol=1e-5, atol=1e-10)
+            r[:] = got                                                     # re-synchronise (a one-ulp flip must not compound)
+            sr['m'], sr['v'] = st['state1'].numpy().reshape(-1).copy(), st['state2'].numpy().reshape(-1).copy()
+            if kahan:
+                gs = st['shift'].float().numpy().reshape(-1)
+                assert (np.abs(gs - sr['shift']) <= 2.0 ** -7 * (np.abs(sr['shift']) + np.abs(r)) + 1e-12).all()
+                sr['shift'] = gs.copy()
