@@ -21,6 +21,16 @@ def _rel_err(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-3)).item()
 
 
+def _assert_close_elementwise(out, ref):
+    """Per-element bound (a max-abs over the global max hides errors in small outputs): |out - ref| <= 2^-7 |ref| + 2^-7 rms(ref).
+    The kernel accumulates in fp32 and rounds once to bf16 (2^-9 relative), so this holds with a wide margin at every K tested (the convolution tests hold
+    the same kernel to the same bound at K up to 23 040)."""
+    out, ref = out.float(), ref.float()
+    tol = 2.0 ** -7 * ref.abs() + 2.0 ** -7 * ref.pow(2).mean().sqrt().clamp_min(1e-6)
+    bad = (out - ref).abs() > tol
+    assert not bad.any(), f'{int(bad.sum())} / {bad.numel()} elements outside the per-element bound, worst {(out - ref).abs().max().item():.4g}'
+
+
 def _operands(gpu, ta, tb, M, N, K, seed):
     g = torch.Generator(device='cpu').manual_seed(seed)
     a = torch.randn((K, M) if ta else (M, K), generator=g).to(gpu, torch.bfloat16)
@@ -51,6 +61,7 @@ def test_pipe_gemm_matches_fp32_matmul(gpu, trans, shape, split, tile):
     torch.cuda.synchronize()
     assert out.shape == (M, N)
     assert _rel_err(out, ref) < 1.6e-2
+    _assert_close_elementwise(out, ref)
 
 
 @pytest.mark.parametrize('K', [77, 8, 200, 1024, 4100])
