@@ -271,8 +271,22 @@ def main():
                          'method': 'GEMM-only hipGraph of the step\'s recorded launch list, HIP events on the replay stream, HBM-cold operands'},
         }
         if world == 1 and not args.no_cpu_baseline:
+            # parity of the TIMED path, in every run: the product's current weights go to the host as fp32, the GPU engine (bf16 kernels,
+            # hipGraph, lanes -- exactly what was timed) evaluates ONE step whose micro-batches are all `cpu_sample`, and the oracle's fp32
+            # eager path evaluates the same micro-batch on the same weights inside the cpu_baseline leg: loss and pre-clip gradient norm
+            # must agree (the step's mean loss over identical micro-batches = that micro-batch's loss; GAS x (g / GAS) = g)
+            state = {k: {n: v.detach().to('cpu', torch.float32) for n, v in m.state_dict().items()} for k, m in work.modules().items()}
+            engine.reset_activation_shape()
+            p_loss = engine.train_batch(iter([cpu_sample] * gas))
+            p_norm = engine.get_global_grad_norm()
+            torch.cuda.synchronize()
+            p_loss, p_norm = float(p_loss.item()), float(p_norm.item())
             from oracle.cpu_baseline import sdxl_cpu_baseline
-            out['cpu_baseline'] = sdxl_cpu_baseline(cfg, latent_hw=latent, micro_batch=cpu_sample)
+            out['cpu_baseline'] = cb = sdxl_cpu_baseline(cfg, latent_hw=latent, micro_batch=cpu_sample, state=state)
+            out['parity'] = {'loss_gpu': p_loss, 'loss_cpu': cb['loss'], 'loss_rel': abs(p_loss - cb['loss']) / abs(cb['loss']),
+                             'grad_norm_gpu': p_norm, 'grad_norm_cpu': cb['grad_norm'], 'grad_norm_rel': abs(p_norm - cb['grad_norm']) / cb['grad_norm'],
+                             'what': 'timed path (bf16 kernels, hipGraph, lanes) vs the oracle fp32 eager path: same weights (the product state dict after the '
+                                     'timed steps), same micro-batch; pre-clip global gradient norm'}
         print(json.dumps(out), flush=True)
     faulthandler.cancel_dump_traceback_later()
     if world > 1:

@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(NW * 64, D == 64 ? 2 : 1) attn_fwd_kernel(cons
     }
 
     if (qrow < p.Sq) {
-        const float inv = 1.f / l;
+        const float inv = l > 0.f ? 1.f / l : 0.f;          // a sample without valid keys (kv_len[b] == 0): O = 0, lse = +inf -> P = exp(s - lse) = 0 in the backward kernels
         bf16_t* O = p.out + b * p.o_sb + hh * p.o_sh + (long)qrow * p.o_ss;
 #pragma unroll
         for (int db = 0; db < D / 32; ++db)
@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(NW * 64, D == 64 ? 2 : 1) attn_fwd_kernel(cons
                 w.y = pack_bf16x2(oacc[db][4 * eg + 2] * inv, oacc[db][4 * eg + 3] * inv);
                 *reinterpret_cast<uint2*>(O + 32 * db + 8 * eg + 4 * h) = w;
             }
-        if (h == 0) p.lse[((long)b * p.H + hh) * p.Sq + qrow] = (m + __builtin_amdgcn_logf(l)) * LN2;   // v_log_f32 = log2
+        if (h == 0) p.lse[((long)b * p.H + hh) * p.Sq + qrow] = l > 0.f ? (m + __builtin_amdgcn_logf(l)) * LN2 : INFINITY;   // v_log_f32 = log2
     }
 }
 
@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(NW * 64, (D == 64 && NW == 4) ? 2 : 1) attn_fw
     for (int qb = 0; qb < QB; ++qb) {
         const int qrow = q0w + 32 * qb + i;
         if (qrow < p.Sq) {
-            const float inv = 1.f / l[qb];
+            const float inv = l[qb] > 0.f ? 1.f / l[qb] : 0.f;      // no valid key: O = 0, lse = +inf (see attn_fwd)
             bf16_t* O = p.out + b * p.o_sb + hh * p.o_sh + (long)qrow * p.o_ss;
 #pragma unroll
             for (int db = 0; db < NDB; ++db)
@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(NW * 64, (D == 64 && NW == 4) ? 2 : 1) attn_fw
                     w.y = pack_bf16x2(oacc[qb][db][4 * eg + 2] * inv, oacc[qb][db][4 * eg + 3] * inv);
                     *reinterpret_cast<uint2*>(O + 32 * db + 8 * eg + 4 * h) = w;
                 }
-            if (h == 0) p.lse[((long)b * p.H + hh) * p.Sq + qrow] = (m[qb] + __builtin_amdgcn_logf(l[qb])) * LN2;
+            if (h == 0) p.lse[((long)b * p.H + hh) * p.Sq + qrow] = l[qb] > 0.f ? (m[qb] + __builtin_amdgcn_logf(l[qb])) * LN2 : INFINITY;
         }
     }
 }

@@ -57,7 +57,7 @@ bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 extern "C" {
 
 int dpipe_conv2d_fwd(const void* x, long ldx, const void* w, const void* bias, const void* residual, long ldr, void* y, long ldy,
-                     int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int upsample, int act,
+                     int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int upsample, int act, int flags,
                      void* ws, long ws_bytes, int tile_hint, void* stream) {
     if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || pad < 0) BAD("dpipe_conv2d_fwd: bad argument");
     const int sl = ilog2_exact(stride), ul = ilog2_exact(upsample);
@@ -70,13 +70,14 @@ int dpipe_conv2d_fwd(const void* x, long ldx, const void* w, const void* bias, c
     p.A = x; p.lda = ldx; p.B = w; p.ldb = (long)kh * kw * Cin; p.C = y; p.ldc = ldy;
     p.M = B * Ho * Wo; p.N = Cout; p.K = kh * kw * Cin;
     p.bias = bias; p.act = act; p.residual = residual; p.ldr = ldr;
+    p.out_f32 = (flags & DPIPE_CONV_OUT_F32) ? 1 : 0; p.accumulate = (flags & DPIPE_CONV_ACCUMULATE) ? 1 : 0;
     p.cg = ConvGeom{Ho, Wo, H, W, kw, kh * kw, Cin / 64, sl, ul, pad, 0, 0, 0, ((long)B * H * W - 1) * ldx + Cin, 0};
     if (p.cg.a_ext * 2 >= (1L << 31) || (long)Cout * p.ldb * 2 >= (1L << 31)) UNSUP("dpipe_conv2d_fwd: operand beyond 2 GiB");
     return launch_conv<1>(p, false, 1, ws, ws_bytes, tile_hint, reinterpret_cast<hipStream_t>(stream));
 }
 
 int dpipe_conv2d_dgrad(const void* dy, long lddy, const void* w, void* dx, long lddx,
-                       int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
+                       int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int flags,
                        void* ws, long ws_bytes, int tile_hint, void* stream) {
     if (!dy || !w || !dx || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || pad < 0) BAD("dpipe_conv2d_dgrad: bad argument");
     const int sl = ilog2_exact(stride);
@@ -87,6 +88,7 @@ int dpipe_conv2d_dgrad(const void* dy, long lddy, const void* w, void* dx, long 
     GemmParams p; base_params(p);
     p.A = dy; p.lda = lddy; p.B = w; p.ldb = (long)kh * kw * Cin; p.C = dx; p.ldc = lddx;
     p.M = B * H * W; p.N = Cin; p.K = kh * kw * Cout;
+    p.out_f32 = (flags & DPIPE_CONV_OUT_F32) ? 1 : 0; p.accumulate = (flags & DPIPE_CONV_ACCUMULATE) ? 1 : 0;
     p.cg = ConvGeom{H, W, Ho, Wo, kw, kh * kw, Cout / 64, sl, 0, pad, 1, 0, (long)Cin, ((long)B * Ho * Wo - 1) * lddy + Cout, (long)Cout * kh * kw * Cin};
     if (p.cg.a_ext * 2 >= (1L << 31) || p.cg.b_ext * 2 >= (1L << 31)) UNSUP("dpipe_conv2d_dgrad: operand beyond 2 GiB");
     return launch_conv<1>(p, true, 1, ws, ws_bytes, tile_hint, reinterpret_cast<hipStream_t>(stream));
@@ -94,7 +96,7 @@ int dpipe_conv2d_dgrad(const void* dy, long lddy, const void* w, void* dx, long 
 
 int dpipe_conv2d_wgrad(const void* dy, long lddy, const void* x, long ldx, void* dw, void* dbias,
                        int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int upsample,
-                       int accumulate, int bias_accumulate, void* ws, long ws_bytes, int tile_hint, void* stream) {
+                       int accumulate, int bias_accumulate, int out_f32, void* ws, long ws_bytes, int tile_hint, void* stream) {
     if (!dy || !x || !dw || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || pad < 0) BAD("dpipe_conv2d_wgrad: bad argument");
     const int sl = ilog2_exact(stride), ul = ilog2_exact(upsample);
     if (sl < 0 || ul < 0) UNSUP("dpipe_conv2d_wgrad: stride and upsample must be 1 or 2");
@@ -107,7 +109,8 @@ int dpipe_conv2d_wgrad(const void* dy, long lddy, const void* x, long ldx, void*
     p.A = dy; p.lda = lddy; p.B = x; p.ldb = ldx; p.C = dw; p.ldc = (long)taps * Cin;
     p.M = Cout; p.N = Cin; p.K = B * Ho * Wo;
     p.batch_inner = taps; p.sCi = Cin;
-    p.accumulate = accumulate; p.colsum = dbias; p.colsum_acc = bias_accumulate;
+    if (out_f32 && dbias) BAD("dpipe_conv2d_wgrad: the fused bias gradient is written in the operand dtype; pass dbias = NULL with out_f32");
+    p.accumulate = accumulate; p.colsum = dbias; p.colsum_acc = bias_accumulate; p.out_f32 = out_f32 ? 1 : 0;
     p.cg = ConvGeom{Ho, Wo, H, W, kw, taps, 0, sl, ul, pad, 0, 0, 0, 0, ((long)B * H * W - 1) * ldx + Cin};
     if (((long)(p.K + 63) * lddy + Cout + 256) * 2 >= (1L << 31) || p.cg.b_ext * 2 >= (1L << 31)) UNSUP("dpipe_conv2d_wgrad: operand beyond 2 GiB");
     return launch_conv<2>(p, true, taps, ws, ws_bytes, tile_hint, reinterpret_cast<hipStream_t>(stream));

@@ -32,7 +32,7 @@ int option(int id, int dflt) {
 }  // namespace dpipe
 
 extern "C" {
-int dpipe_version(void) { return 1; }
+int dpipe_version(void) { return DPIPE_ABI_VERSION; }
 int dpipe_set_option(int id, int value) {
     if (id < 0 || id >= DPIPE_OPTION_COUNT) { dpipe::set_last_error("dpipe_set_option: unknown option"); return DPIPE_ERR_ARG; }
     dpipe::g_options[id] = value;

@@ -16,6 +16,8 @@ import os
 LIB_PATH = Path(os.environ.get('DPIPE_HIP_LIB') or Path(__file__).resolve().parent / 'libdpipe_hip.so')
 
 BF16, F32 = 0, 1
+ABI_VERSION = 3                      # DPIPE_ABI_VERSION of include/dpipe_hip.h this binding was written against
+CONV_OUT_F32, CONV_ACCUMULATE = 1, 2  # dpipe_conv2d_fwd / _dgrad `flags`
 OPT_ATTN_FWD_DMA, OPT_ATTN_BWD_DMA, OPT_ATTN_DQ8, OPT_ATTN_DKV_SPLIT = 0, 1, 2, 3     # dpipe_set_option ids (include/dpipe_hip.h)
 ACT = {None: 0, 'none': 0, 'gelu_tanh': 1, 'gelu': 2, 'gelu_erf': 2, 'silu': 3, 'quick_gelu': 4}
 LOSS_KIND = {'mse': 0, 'huber': 1, 'smooth_l1': 2}
@@ -64,9 +66,9 @@ _SIGNATURES = {
     'dpipe_groupnorm_workspace_floats': (L, [L, I, L, I]),
     'dpipe_groupnorm_fwd': (I, [P, P, P, P, P, P, P, L, I, L, I, F, I, I, I, P]),
     'dpipe_groupnorm_bwd': (I, [P, P, P, P, P, P, P, P, P, P, L, I, L, I, I, I, I, I, P, P]),
-    'dpipe_conv2d_fwd': (I, [P, L, P, P, P, L, P, L] + [I] * 11 + [P, L, I, P]),
-    'dpipe_conv2d_dgrad': (I, [P, L, P, P, L] + [I] * 9 + [P, L, I, P]),
-    'dpipe_conv2d_wgrad': (I, [P, L, P, L, P, P] + [I] * 12 + [P, L, I, P]),
+    'dpipe_conv2d_fwd': (I, [P, L, P, P, P, L, P, L] + [I] * 12 + [P, L, I, P]),
+    'dpipe_conv2d_dgrad': (I, [P, L, P, P, L] + [I] * 10 + [P, L, I, P]),
+    'dpipe_conv2d_wgrad': (I, [P, L, P, L, P, P] + [I] * 13 + [P, L, I, P]),
     'dpipe_groupnorm_nhwc_workspace_floats': (L, [L, I, L, I]),
     'dpipe_groupnorm_nhwc_fwd': (I, [P, P, P, P, P, P, P, L, I, L, I, F, I, I, I, P]),
     'dpipe_groupnorm_nhwc_bwd': (I, [P, P, P, P, P, P, P, P, P, P, L, I, L, I, I, I, I, I, P, P]),
@@ -106,6 +108,9 @@ def lib():
             raise DpipeHipError(f'{LIB_PATH} does not export {name}; rebuild the extension') from e
         fn.restype = res
         fn.argtypes = args
+    got = handle.dpipe_version()
+    if got != ABI_VERSION:         # e.g. an older build named by DPIPE_HIP_LIB: its entry points would read shifted arguments
+        raise DpipeHipError(f'{LIB_PATH} has C-ABI version {got}, this binding needs {ABI_VERSION}; rebuild the extension')
     _lib = handle
     return _lib
 

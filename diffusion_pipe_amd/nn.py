@@ -3,7 +3,7 @@ libraries the reference adapters wrap (diffusers / HF transformers), so state di
 
 Compute dtype = parameter dtype (bf16 for training, fp32 for the exact-parity mode): there is no autocast layer;
 inputs are cast to the weight dtype at the first GEMM of a block, norms keep fp32 statistics.
-Convolutions and GroupNorm stay on PyTorch-ROCm (MIOpen / native kernels) as SURVEY.md section 0 allows.
+Convolutions (implicit GEMM on the MFMA tile kernel, channels-last) and GroupNorm are kernels of this repo as well, in both modes.
 """
 import math
 
@@ -151,8 +151,9 @@ class Conv2d(nn.Conv2d):
     """nn.Conv2d (same parameter names / logical shapes, so checkpoints map 1:1) whose weight is STORED channels-last and whose bf16
     forward / backward run as implicit GEMM on the MFMA tile kernel (csrc/conv_pipe.hip) over channels-last activations.  Returns a
     channels-last [B, Cout, Ho, Wo] tensor.  `upsample=2` folds diffusers' nearest 2x Upsample2D into the convolution's gather;
-    `residual` / `extra_bias` ride the epilogue.  Shapes the kernel does not take (the UNet's 4-channel conv_in / conv_out, fp32
-    exact-parity mode) go through torch's convolution on the same channels-last tensors."""
+    `residual` / `extra_bias` ride the epilogue.  fp32 tensors (exact-parity mode) take the same kernels as three bf16 hi / lo split launches
+    accumulated in fp32 (ops._Conv2dNHWCFn); the UNet's 4-channel conv_in / conv_out run as a tiny im2col GEMM / a Cout-padded tile.  What is
+    left for torch's convolution: grouped / dilated / non-square-padded convolutions, none of which the reference's models have on this path."""
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
@@ -172,16 +173,16 @@ class Conv2d(nn.Conv2d):
         if x.is_cuda and plain and ops.conv2d_eligible(x.dtype, self.weight, self.stride, self.padding, self.dilation, self.groups):
             return ops.conv2d_nhwc(x, self.weight, bias, self.stride[0], self.padding[0], upsample, residual)
         Cout, Cin, kh, kw = self.weight.shape
-        bf16 = x.is_cuda and plain and x.dtype == torch.bfloat16 and self.weight.dtype == torch.bfloat16 and self.groups == 1 and tuple(self.dilation) == (1, 1) \
-            and self.stride[0] == self.stride[1] and self.stride[0] in (1, 2) and self.padding[0] == self.padding[1]
-        if bf16 and Cin % 64 == 0:
+        ours = x.is_cuda and plain and x.dtype == self.weight.dtype and x.dtype in (torch.bfloat16, torch.float32) and self.groups == 1 \
+            and tuple(self.dilation) == (1, 1) and self.stride[0] == self.stride[1] and self.stride[0] in (1, 2) and self.padding[0] == self.padding[1]
+        if ours and Cin % 64 == 0:
             # few output channels (the UNet's conv_out: 320 -> 4): zero-pad Cout to one 64-wide tile, run the implicit-GEMM kernels, slice
             pad = -Cout % 64
             w = torch.nn.functional.pad(self.weight, (0, 0, 0, 0, 0, 0, 0, pad)).contiguous(memory_format=torch.channels_last)
             b = torch.nn.functional.pad(bias, (0, pad)) if bias is not None else None
             y = ops.conv2d_nhwc(x, w, b, self.stride[0], self.padding[0], upsample, None)[:, :Cout].contiguous(memory_format=torch.channels_last)
             return y if residual is None else y + residual
-        if bf16 and upsample == 1 and Cin * kh * kw <= 512:
+        if ours and upsample == 1 and Cin * kh * kw <= 512:
             # few input channels (the UNet's conv_in: 4 -> 320): the im2col matrix is tiny ([pixels, Cin kh kw] padded to one or two 64-wide
             # K-steps), so the convolution is one MFMA GEMM over it; unfold / pad and their adjoints are ATen kernels on a few hundred KB
             B, _, H, W = x.shape

@@ -721,9 +721,10 @@ CONV_TILE_HINTS = (0, 0, 0)
 
 
 def conv2d_eligible(x_dtype, weight, stride, padding, dilation=(1, 1), groups=1):
-    """The implicit-GEMM convolution (csrc/conv_pipe.hip) takes bf16, stride 1 / 2, square padding, Cin % 64 == 0 and Cout % 64 == 0."""
+    """The implicit-GEMM convolution (csrc/conv_pipe.hip) takes bf16 -- or fp32 (exact-parity mode: three bf16 hi / lo split launches
+    accumulated in fp32) --, stride 1 / 2, square padding, Cin % 64 == 0 and Cout % 64 == 0."""
     Cout, Cin, kh, kw = weight.shape
-    return (x_dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and groups == 1 and tuple(dilation) == (1, 1)
+    return (x_dtype == weight.dtype and x_dtype in (torch.bfloat16, torch.float32) and groups == 1 and tuple(dilation) == (1, 1)
             and stride[0] == stride[1] and stride[0] in (1, 2) and padding[0] == padding[1] and Cin % 64 == 0 and Cout % 64 == 0)
 
 
@@ -731,9 +732,23 @@ def _dense_like(t, ref):
     return t is not None and t.dtype == ref.dtype and t.shape == ref.shape and t.stride() == ref.stride()
 
 
+def _split_bf16(t):
+    """fp32 -> (hi, lo) bf16 pair with hi + lo = t up to 2^-17 relative (strides preserved: channels-last stays channels-last)."""
+    if t is None:
+        return None, None
+    hi = t.to(torch.bfloat16)
+    return hi, (t - hi.float()).to(torch.bfloat16)
+
+
+def _conv_fwd_launch(xv, Cin, weight, bias, rv, y, B, H, W, Cout, kh, kw, stride, pad, upsample, flags, ws):
+    check(lib().dpipe_conv2d_fwd(ptr(xv), Cin, ptr(weight), ptr(bias), ptr(rv), Cout, ptr(y), Cout, B, H, W, Cin, Cout, kh, kw, stride, pad, upsample,
+                                 0, flags, ptr(ws), ws.numel(), CONV_TILE_HINTS[0], stream()), 'conv2d_fwd')
+
+
 class _Conv2dNHWCFn(Function):
     """nn.Conv2d on channels-last activations as implicit GEMM (forward, dgrad, wgrad + fused bias gradient); `upsample` = 2 folds the
-    nearest-neighbour 2x up-sampling of diffusers' Upsample2D into the gather; `residual` rides the epilogue."""
+    nearest-neighbour 2x up-sampling of diffusers' Upsample2D into the gather; `residual` rides the epilogue.  fp32 tensors (exact-parity
+    mode) run the SAME bf16 MFMA kernels three times over hi / lo splits of the operands, accumulating in fp32 (include/dpipe_hip.h)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, stride, pad, upsample):
@@ -756,8 +771,14 @@ class _Conv2dNHWCFn(Function):
         if bias is not None and bias.dtype != x.dtype:
             bias = bias.to(x.dtype)
         ws = _splitk_workspace(x.device)
-        check(lib().dpipe_conv2d_fwd(ptr(xv), Cin, ptr(weight), ptr(bias), ptr(rv), Cout, ptr(y), Cout, B, H, W, Cin, Cout, kh, kw, stride, pad, upsample,
-                                     0, ptr(ws), ws.numel(), CONV_TILE_HINTS[0], stream()), 'conv2d_fwd')
+        geo = (B, H, W, Cout, kh, kw, stride, pad, upsample)
+        if x.dtype == torch.float32:
+            (xh, xl), (wh, wl), (bh, bl) = _split_bf16(xv), _split_bf16(weight), _split_bf16(bias)
+            _conv_fwd_launch(xh, Cin, wh, bh, rv, y, *geo, hip.CONV_OUT_F32, ws)
+            _conv_fwd_launch(xl, Cin, wh, bl, None, y, *geo, hip.CONV_OUT_F32 | hip.CONV_ACCUMULATE, ws)
+            _conv_fwd_launch(xh, Cin, wl, None, None, y, *geo, hip.CONV_OUT_F32 | hip.CONV_ACCUMULATE, ws)
+        else:
+            _conv_fwd_launch(xv, Cin, weight, bias, rv, y, *geo, 0, ws)
         ctx.save_for_backward(xv, weight, bias)
         ctx.geom = (stride, pad, upsample, residual is not None)
         return y.permute(0, 3, 1, 2)
@@ -771,13 +792,24 @@ class _Conv2dNHWCFn(Function):
         gyv = nhwc_view(gy)
         if gyv.dtype != xv.dtype:
             gyv = gyv.to(xv.dtype)
+        f32 = xv.dtype == torch.float32
         ws = _splitk_workspace(xv.device)
         gx = gw = gb = None
+        if f32:
+            (gh, gl), (wh, wl) = _split_bf16(gyv), _split_bf16(weight)
         if ctx.needs_input_grad[0]:
             Hi, Wi = H * upsample, W * upsample
             dxu = torch.empty((B, Hi, Wi, Cin), device=xv.device, dtype=xv.dtype)
-            check(lib().dpipe_conv2d_dgrad(ptr(gyv), Cout, ptr(weight), ptr(dxu), Cin, B, Hi, Wi, Cin, Cout, kh, kw, stride, pad,
-                                           ptr(ws), ws.numel(), CONV_TILE_HINTS[1], stream()), 'conv2d_dgrad')
+
+            def dgrad(g, w, flags):
+                check(lib().dpipe_conv2d_dgrad(ptr(g), Cout, ptr(w), ptr(dxu), Cin, B, Hi, Wi, Cin, Cout, kh, kw, stride, pad, flags,
+                                               ptr(ws), ws.numel(), CONV_TILE_HINTS[1], stream()), 'conv2d_dgrad')
+            if f32:
+                dgrad(gh, wh, hip.CONV_OUT_F32)
+                dgrad(gl, wh, hip.CONV_OUT_F32 | hip.CONV_ACCUMULATE)
+                dgrad(gh, wl, hip.CONV_OUT_F32 | hip.CONV_ACCUMULATE)
+            else:
+                dgrad(gyv, weight, 0)
             if upsample > 1:       # adjoint of the nearest up-sampling: sum over each 2 x 2 block
                 dxu = dxu.view(B, H, upsample, W, upsample, Cin).sum(dim=(2, 4))
             gx = dxu.permute(0, 3, 1, 2)
@@ -787,8 +819,23 @@ class _Conv2dNHWCFn(Function):
             tb = _accum_target(bias) if need_b else None
             w_out = tw if tw is not None else torch.empty_like(weight)           # preserve_format: channels-last like the weight
             b_out = (tb if tb is not None else torch.empty_like(bias)) if need_b else None
-            check(lib().dpipe_conv2d_wgrad(ptr(gyv), Cout, ptr(xv), Cin, ptr(w_out), ptr(b_out), B, H, W, Cin, Cout, kh, kw, stride, pad, upsample,
-                                           int(tw is not None), int(tb is not None), ptr(ws), ws.numel(), CONV_TILE_HINTS[2], stream()), 'conv2d_wgrad')
+
+            def wgrad(g, xs, acc, bo, bacc, out_f32):
+                check(lib().dpipe_conv2d_wgrad(ptr(g), Cout, ptr(xs), Cin, ptr(w_out), ptr(bo), B, H, W, Cin, Cout, kh, kw, stride, pad, upsample,
+                                               int(acc), int(bacc), int(out_f32), ptr(ws), ws.numel(), CONV_TILE_HINTS[2], stream()), 'conv2d_wgrad')
+            if f32:
+                xh, xl = _split_bf16(xv)
+                wgrad(gh, xh, tw is not None, None, 0, 1)
+                wgrad(gl, xh, True, None, 0, 1)
+                wgrad(gh, xl, True, None, 0, 1)
+                if need_b:                       # the fused bias gradient is written in the operand dtype: fp32 takes the column-sum kernel
+                    g2 = gyv.reshape(-1, Cout)
+                    if tb is not None:
+                        column_sum(g2, out=tb)
+                    else:
+                        b_out = column_sum(g2)
+            else:
+                wgrad(gyv, xv, tw is not None, b_out, tb is not None, 0)
             gw = None if tw is not None else w_out
             gb = None if (tb is not None or not need_b) else b_out
         gres = gy if (has_res and ctx.needs_input_grad[3]) else None
@@ -804,7 +851,7 @@ def _accum_target_dense(param):
 
 
 def conv2d_nhwc(x, weight, bias=None, stride=1, padding=0, upsample=1, residual=None):
-    """x: [B, Cin, H, W] channels-last bf16, weight: [Cout, Cin, kh, kw] channels-last -> [B, Cout, Ho, Wo] channels-last."""
+    """x: [B, Cin, H, W] channels-last bf16 (or fp32, see _Conv2dNHWCFn), weight: [Cout, Cin, kh, kw] channels-last -> [B, Cout, Ho, Wo] channels-last."""
     return _Conv2dNHWCFn.apply(x, weight, bias, residual, int(stride), int(padding), int(upsample))
 
 

@@ -31,6 +31,8 @@ extern "C" {
 #define DPIPE_LOSS_HUBER 1
 #define DPIPE_LOSS_SMOOTH_L1 2
 
+/* ABI version: bumped whenever a signature of this header changes; the host binding refuses a library of another version. */
+#define DPIPE_ABI_VERSION 3
 int dpipe_version(void);
 const char* dpipe_last_error(void);
 /* Kernel-selection options (process-wide; for A/B timing and for testing the fallback kernels -- every default is the measured-faster choice).
@@ -178,16 +180,22 @@ int dpipe_lnmod_bwd(const void* x, const void* gy, const void* gamma, const void
  * split-K workspace (`splitk_ws`, see dpipe_gemm_ex) and `tile_hint` as dpipe_gemm_ex.
  *   fwd  : y = act(conv(x, w) + bias) (+ residual [B, Ho, Wo, Cout] with pitch ldr);            needs Cin % 64 == 0
  *   dgrad: dx [B, H, W, Cin] = conv_transpose(dy, w)  (no fused up-sampling: H, W = the conv's input size);  needs Cout % 64 == 0, Cin % 8 == 0
- *   wgrad: dw [Cout, kh, kw, Cin] (+)= dy^T * gathered x, dbias [Cout] (+)= column sums of dy (NULL = skip); needs Cin % 8 == 0, Cout % 8 == 0 */
+ *   wgrad: dw [Cout, kh, kw, Cin] (+)= dy^T * gathered x, dbias [Cout] (+)= column sums of dy (NULL = skip); needs Cin % 8 == 0, Cout % 8 == 0
+ * `flags` (fwd / dgrad) / `out_f32` (wgrad): the result (and the forward's residual) is fp32 and, with DPIPE_CONV_ACCUMULATE, added to what the
+ * output already holds.  That is what the exact-parity mode builds an fp32 convolution from: x = x_hi + x_lo, w = w_hi + w_lo (bf16 pairs),
+ * conv(x, w) = conv(x_hi, w_hi) + conv(x_lo, w_hi) + conv(x_hi, w_lo) accumulated in fp32 (the dropped lo x lo term and the rounding of the lo
+ * parts are <= 2^-16 relative per product) -- the same MFMA kernels, no library convolution. */
+#define DPIPE_CONV_OUT_F32 1
+#define DPIPE_CONV_ACCUMULATE 2
 int dpipe_conv2d_fwd(const void* x, long ldx, const void* w, const void* bias, const void* residual, long ldr, void* y, long ldy,
-                     int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int upsample, int act,
+                     int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int upsample, int act, int flags,
                      void* splitk_ws, long splitk_ws_bytes, int tile_hint, void* stream);
 int dpipe_conv2d_dgrad(const void* dy, long lddy, const void* w, void* dx, long lddx,
-                       int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad,
+                       int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int flags,
                        void* splitk_ws, long splitk_ws_bytes, int tile_hint, void* stream);
 int dpipe_conv2d_wgrad(const void* dy, long lddy, const void* x, long ldx, void* dw, void* dbias,
                        int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int upsample,
-                       int accumulate, int bias_accumulate, void* splitk_ws, long splitk_ws_bytes, int tile_hint, void* stream);
+                       int accumulate, int bias_accumulate, int out_f32, void* splitk_ws, long splitk_ws_bytes, int tile_hint, void* stream);
 
 /* ---- GroupNorm (+ fused SiLU) on NHWC activations: the same nn.GroupNorm(G, C) call sites as below for the channels-last UNet.
  * x, y, dy, dx: [N, HW, C] contiguous, C a multiple of the 16-byte vector and <= 8192; other arguments as dpipe_groupnorm_fwd / _bwd;

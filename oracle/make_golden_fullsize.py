@@ -1,7 +1,8 @@
 """ORACLE fixture generator (test infrastructure): BASELINE config 2 at FULL size through the reference-style CPU path -- SDXL 1024x1024
 (latent 128), the full `SDXLConfig()` (2.6 B parameters), ONE micro-batch of one image: oracle/sdxl_ref.py driven by
 oracle/eager_step.eager_train_step (sequential to_layers() + SDXL loss + backward, fp32) on seeded weights and a seeded prepared input.
-Records loss, the global gradient norm and per-parameter gradient checksums (sum |g|, sum g) in tests/golden/sdxl_fullsize.json -- no
+Records loss, the global gradient norm and per-parameter gradient checksums (sum |g|, sum g, a seeded projection <g, r>, ||g||_2:
+oracle/checksums.py) in tests/golden/sdxl_fullsize.json -- no
 tensors: weights and inputs are rebuilt from the seeds (a weight checksum guards the RNG stream).  ~25 GB of host memory, minutes of CPU.
 
     python oracle/make_golden_fullsize.py
@@ -16,6 +17,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 from oracle import eager_step, sdxl_ref                             # noqa: E402
+from oracle.checksums import checksum4                               # noqa: E402
 
 OUT = os.path.join(HERE, '..', 'tests', 'golden')
 WEIGHT_SEED, DATA_SEED, PREP_SEED = 0, 100, 1234
@@ -52,8 +54,7 @@ def main():
     for k, m in ref.modules().items():
         for n, p in m.named_parameters():
             if p.grad is not None:
-                g = p.grad.double()
-                grads[f'{k}.{n}'] = [float(g.abs().sum()), float(g.sum())]
+                grads[f'{k}.{n}'] = checksum4(p.grad, f'{k}.{n}')      # [sum |g|, sum g, <g, r>, ||g||_2]
     meta = {'generated_by': 'oracle/make_golden_fullsize.py (oracle/sdxl_ref.py + oracle/eager_step.py; reference call sites models/sdxl.py:591-602,632-651)',
             'seeds': {'weights': WEIGHT_SEED, 'data': DATA_SEED, 'prepare_inputs': PREP_SEED}, 'torch': torch.__version__, 'weight_checksum': wsum,
             'loss': float(loss), 'grad_norm': float(norm), 'parameters_with_grad': len(grads), 'grad_checksums': grads}

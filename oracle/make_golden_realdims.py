@@ -7,7 +7,7 @@
     reference's pipeline layers, 4 096 image + 512 text tokens, through oracle/flux_ref.py (diffusers restated: parity unpinned) -- output, loss, gradients.
 
 Nothing large is stored: weights and inputs are rebuilt from seeds by `wan_case()` / `flux_case()` (shared with the GPU test), the JSON holds the loss and
-(sum |t|, sum t) checksums of the outputs and of every gradient.  ~15 GB of host memory, a few minutes of CPU.
+(sum |t|, sum t, seeded projection <t, r>, ||t||_2) checksums (oracle/checksums.py) of the outputs and of every gradient.  ~15 GB of host memory, a few minutes of CPU.
 
     python oracle/make_golden_realdims.py
 """
@@ -24,9 +24,9 @@ OUT = os.path.join(HERE, '..', 'tests', 'golden', 'realdims.json')
 WAN = dict(dim=5120, ffn_dim=13824, num_heads=40, grid=(9, 32, 16), ctx_len=512, eps=1e-6, seed=77)
 
 
-def checksum(t):
-    t = t.detach().double()
-    return [float(t.abs().sum()), float(t.sum())]
+def checksum(t, name):
+    from oracle.checksums import checksum4
+    return checksum4(t, name)           # [sum |t|, sum t, <t, r(name)>, ||t||_2]
 
 
 def seeded_state(shapes, seed):
@@ -87,8 +87,8 @@ def main():
     loss = (y * inp['wy']).sum()
     loss.backward()
     gold['wan14b_block'] = {'case': c, 'source': 'models/wan/model.py:277-312 WanAttentionBlock (imported), attention = models/wan/attention.py:128-174 in fp32',
-                            'loss': float(loss), 'y': checksum(y), 'grad_x': checksum(x.grad), 'grad_e': checksum(e.grad), 'grad_context': checksum(ctx.grad),
-                            'param_grads': {n: checksum(p.grad) for n, p in block.named_parameters()},
+                            'loss': float(loss), 'y': checksum(y, 'y'), 'grad_x': checksum(x.grad, 'grad_x'), 'grad_e': checksum(e.grad, 'grad_e'), 'grad_context': checksum(ctx.grad, 'grad_context'),
+                            'param_grads': {n: checksum(p.grad, n) for n, p in block.named_parameters()},
                             'state_checksum': float(sum(v.double().abs().sum() for v in state.values()))}
     print('wan14b block: loss', float(loss), flush=True)
     del block, x, e, ctx, y
@@ -102,8 +102,8 @@ def main():
         xx = layer(xx)
     loss = ((xx - target) ** 2).mean()
     loss.backward()
-    gold['flux_blocks'] = {'source': 'oracle/flux_ref.py (diffusers FluxTransformer2DModel restated; wrappers pinned by models/flux.py:456-548)', 'loss': float(loss), 'out': checksum(xx),
-                           'param_grads': {n: checksum(p.grad) for n, p in ref.transformer.named_parameters() if p.grad is not None},
+    gold['flux_blocks'] = {'source': 'oracle/flux_ref.py (diffusers FluxTransformer2DModel restated; wrappers pinned by models/flux.py:456-548)', 'loss': float(loss), 'out': checksum(xx, 'out'),
+                           'param_grads': {n: checksum(p.grad, n) for n, p in ref.transformer.named_parameters() if p.grad is not None},
                            'state_checksum': float(sum(v.double().abs().sum() for v in work.transformer.state_dict().values()))}
     print('flux blocks: loss', float(loss), flush=True)
     with open(OUT, 'w') as fh:

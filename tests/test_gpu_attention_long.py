@@ -1,0 +1,113 @@
+"""Flash attention (csrc/attention.hip) at the sequence lengths BASELINE configs 3 - 5 launch it with -- Flux 4 608 tokens x 24 heads, Wan2.1-14B
+9 216 x 40, HunyuanVideo 61 456 (2 of its 24 heads), head dim 128; SDXL 4 096 x 10 at head dim 64 -- against a plain PyTorch fp32 reference of
+the same contraction (models/wan/attention.py:128-174 is the reference's own formula: softmax(q k^T / sqrt(d)) v), evaluated in query chunks so
+the [Sq, Sk] score matrix never exists whole, with the hand-written backward of that formula (dV = P^T dO, dS = P o (dO V^T - rowsum(dO o O)),
+dQ = dS K, dK = dS^T Q).
+
+Bound, PER ELEMENT (not max-abs over the global max): |got - want| <= 2^-7 rms(want) + 2^-7 |want| for the output and 2^-6 / 2^-6 for the
+gradients (bf16 P / dS operands inside the kernels, bf16 results); the achieved worst ratios are printed and recorded."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference(q, k, v, go, kv_len=None, qchunk=4096):
+    """q [B, Sq, H, D], k / v [B, Sk, H, D], go [B, Sq, H, D] (any float dtype) -> fp32 (o, dq, dk, dv)."""
+    B, Sq, H, D = q.shape
+    Sk = k.shape[1]
+    scale = 1.0 / math.sqrt(D)
+    o, dq = torch.zeros(B, Sq, H, D, device=q.device), torch.zeros(B, Sq, H, D, device=q.device)
+    dk, dv = torch.zeros(B, Sk, H, D, device=q.device), torch.zeros(B, Sk, H, D, device=q.device)
+    for b in range(B):
+        n = Sk if kv_len is None else int(kv_len[b])
+        if n == 0:
+            continue                      # no valid key: output and every gradient of this sample are zero by definition
+        for h in range(H):
+            Q, K, V, G = q[b, :, h].float(), k[b, :n, h].float(), v[b, :n, h].float(), go[b, :, h].float()
+            dK, dV = torch.zeros_like(K), torch.zeros_like(V)
+            for q0 in range(0, Sq, qchunk):
+                Qc, Gc = Q[q0:q0 + qchunk], G[q0:q0 + qchunk]
+                P = torch.softmax((Qc @ K.t()) * scale, dim=-1)
+                Oc = P @ V
+                dV += P.t() @ Gc
+                dS = P * (Gc @ V.t() - (Gc * Oc).sum(-1, keepdim=True))
+                o[b, q0:q0 + qchunk, h] = Oc
+                dq[b, q0:q0 + qchunk, h] = (dS @ K) * scale
+                dK += (dS.t() @ Qc) * scale
+                del P, dS
+            dk[b, :n, h], dv[b, :n, h] = dK, dV
+    return o, dq, dk, dv
+
+
+def _worst(got, want):
+    """max over elements of |got - want| / (rms(want) + |want|)"""
+    got, want = got.float(), want.float()
+    rms = want.pow(2).mean().sqrt().clamp_min(1e-12)
+    return ((got - want).abs() / (rms + want.abs())).max().item()
+
+
+LONG_CASES = [  # (B, Sq, Sk, H, D, kv_len, label)
+    (1, 4096, 4096, 10, 64, None, 'sdxl_self_4096x10_d64'),
+    (1, 4608, 4608, 24, 128, None, 'flux_4608x24_d128'),
+    (1, 9216, 9216, 40, 128, None, 'wan14b_9216x40_d128'),
+    (1, 9216, 512, 40, 128, None, 'wan14b_cross_9216x512_d128'),
+    (1, 61456, 61456, 2, 128, None, 'hunyuanvideo_61456x2_d128'),
+    (1, 61456, 61456, 2, 128, [61300], 'hunyuanvideo_61456x2_d128_padded_text'),
+]
+
+
+@pytest.mark.parametrize('case', LONG_CASES, ids=lambda c: c[-1])
+def test_flash_attention_long_sequences_per_element(gpu, case, record_property):
+    from diffusion_pipe_amd import ops
+    B, Sq, Sk, H, D, kvl, label = case
+    g = torch.Generator().manual_seed(Sq + 7 * Sk + H)
+    q, k, v = (torch.randn(B, s, H, D, generator=g).to(gpu, torch.bfloat16).requires_grad_(True) for s in (Sq, Sk, Sk))
+    go = torch.randn(B, Sq, H, D, generator=g).to(gpu, torch.bfloat16)
+    kv_len = torch.tensor(kvl, dtype=torch.int32, device=gpu) if kvl is not None else None
+    o = ops.attention(q, k, v, kv_len=kv_len, impl='flash')
+    o.backward(go)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ro, rdq, rdk, rdv = _reference(q.detach(), k.detach(), v.detach(), go, kvl)
+    errs = {'o': _worst(o.detach(), ro), 'dq': _worst(q.grad, rdq), 'dk': _worst(k.grad, rdk), 'dv': _worst(v.grad, rdv)}
+    print(f'attention {label}: worst |err| / (rms + |ref|): ' + ', '.join(f'{n} {e:.3g}' for n, e in errs.items()))
+    for n, e in errs.items():
+        record_property(f'attn_{label}_{n}', e)
+    assert errs['o'] < 2 ** -7, errs
+    assert max(errs['dq'], errs['dk'], errs['dv']) < 2 ** -6, errs
+    if kvl is not None:
+        for bi, n in enumerate(kvl):
+            assert k.grad[bi, n:].abs().max().item() == 0.0 and v.grad[bi, n:].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize('D', [64, 128])
+@pytest.mark.parametrize('dma', [1, 0])
+def test_sample_without_valid_keys_gives_zero_output_and_gradients(gpu, D, dma):
+    """kv_len[b] == 0 (an empty prompt in masked cross attention): the softmax has nothing to normalise -- the kernels must return O = 0 and
+    zero gradients for that sample, not 0 * inf, and leave the other samples of the batch untouched."""
+    from diffusion_pipe_amd import hip, ops
+    g = torch.Generator().manual_seed(5 + D)
+    B, Sq, Sk, H = 3, 300, 96, 4
+    q, k, v = (torch.randn(B, s, H, D, generator=g).to(gpu, torch.bfloat16).requires_grad_(True) for s in (Sq, Sk, Sk))
+    go = torch.randn(B, Sq, H, D, generator=g).to(gpu, torch.bfloat16)
+    kvl = [0, 50, 96]
+    try:
+        for i in (hip.OPT_ATTN_FWD_DMA, hip.OPT_ATTN_BWD_DMA):
+            hip.check(hip.lib().dpipe_set_option(i, dma), 'set_option')
+        o = ops.attention(q, k, v, kv_len=torch.tensor(kvl, dtype=torch.int32, device=gpu), impl='flash')
+        o.backward(go)
+    finally:
+        for i in (hip.OPT_ATTN_FWD_DMA, hip.OPT_ATTN_BWD_DMA):
+            hip.check(hip.lib().dpipe_set_option(i, -1), 'set_option')
+    torch.cuda.synchronize()
+    for t in (o, q.grad, k.grad, v.grad):
+        assert torch.isfinite(t.float()).all()
+        assert t[0].abs().max().item() == 0.0
+    with torch.no_grad():
+        ro, rdq, rdk, rdv = _reference(q.detach(), k.detach(), v.detach(), go, kvl)
+    assert _worst(o.detach(), ro) < 2 ** -7
+    for got, want in ((q.grad, rdq), (k.grad, rdk), (v.grad, rdv)):
+        assert _worst(got, want) < 2 ** -6

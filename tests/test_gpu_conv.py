@@ -55,6 +55,65 @@ def test_conv2d_forward_backward_vs_fp32(gpu, case):
     assert conv.weight.grad.stride() == conv.weight.stride()        # gradient keeps the channels-last layout of the parameter
 
 
+FP32_CASES = [(1, 32, 32, 320, 640, 3, 1, 1, 1), (2, 20, 12, 64, 192, 3, 1, 1, 1), (1, 17, 23, 128, 64, 3, 2, 1, 1), (2, 9, 7, 64, 128, 3, 1, 1, 2),
+              (1, 32, 32, 960, 320, 1, 1, 0, 1), (1, 64, 64, 1920, 640, 3, 1, 1, 1)]
+
+
+@pytest.mark.parametrize('case', FP32_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_conv2d_fp32_mode_is_three_split_launches_of_the_same_kernels(gpu, case, record_property):
+    """Exact-parity mode: fp32 activations / weights run the implicit-GEMM MFMA kernels as bf16 hi / lo split launches accumulated in fp32
+    (no library convolution).  Reference = fp64 convolution of the same fp32 operands; bound 1e-4 of the output RMS + 1e-4 relative
+    (the split drops lo x lo: <= 2^-16 per product), i.e. two orders below north_star's 1e-3."""
+    from diffusion_pipe_amd import nn as dnn, ops
+    B, H, W, Cin, Cout, k, stride, pad, ups = case
+    torch.manual_seed(sum(case) + 1)
+    conv = dnn.Conv2d(Cin, Cout, k, stride=stride, padding=pad).to(gpu, torch.float32)
+    assert ops.conv2d_eligible(torch.float32, conv.weight, conv.stride, conv.padding)
+    x = torch.randn(B, Cin, H, W, device=gpu).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    res = torch.randn(B, Cout, (H * ups + 2 * pad - k) // stride + 1, (W * ups + 2 * pad - k) // stride + 1, device=gpu) \
+        .contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = conv(x, upsample=ups, residual=res)
+    assert y.dtype == torch.float32 and y.permute(0, 2, 3, 1).is_contiguous()
+    xr, rr = x.detach().double().requires_grad_(True), res.detach().double().requires_grad_(True)
+    wr, br = conv.weight.detach().double().contiguous().requires_grad_(True), conv.bias.detach().double().requires_grad_(True)
+    xin = F.interpolate(xr, scale_factor=float(ups), mode='nearest') if ups > 1 else xr
+    want = F.conv2d(xin, wr, br, stride=stride, padding=pad) + rr
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    want.backward(gy.double())
+    worst = 0.0
+    for got, ref, what in ((y, want, 'forward'), (x.grad, xr.grad, 'dgrad'), (conv.weight.grad, wr.grad, 'wgrad'), (conv.bias.grad, br.grad, 'bias grad'),
+                           (res.grad, rr.grad, 'residual grad')):
+        ref = ref.detach()
+        rms = ref.pow(2).mean().sqrt().clamp_min(1e-12)
+        err = ((got.detach().double() - ref).abs() / (rms + ref.abs())).max().item()
+        worst = max(worst, err)
+        assert err < 1e-4, f'{what}: worst error {err:.3g} of (rms + |ref|)'
+    record_property('fp32_split_conv_worst_rel_err', worst)
+    print(f'fp32 split conv {case}: worst error {worst:.3g} of (rms + |ref|)')
+    assert conv.weight.grad.stride() == conv.weight.stride()
+
+
+def test_conv2d_fp32_edge_convolutions_run_on_the_gemm_kernels(gpu):
+    """The UNet's 4-channel conv_in (im2col + one fp32 MFMA GEMM) and conv_out (Cout padded to one tile) in exact-parity mode."""
+    from diffusion_pipe_amd import nn as dnn
+    torch.manual_seed(11)
+    for Cin, Cout in ((4, 320), (320, 4)):
+        conv = dnn.Conv2d(Cin, Cout, 3, padding=1).to(gpu, torch.float32)
+        x = torch.randn(1, Cin, 24, 24, device=gpu).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        y = conv(x)
+        xr = x.detach().double().requires_grad_(True)
+        wr, br = conv.weight.detach().double().contiguous().requires_grad_(True), conv.bias.detach().double().requires_grad_(True)
+        want = F.conv2d(xr, wr, br, padding=1)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        want.backward(gy.double())
+        for got, ref, what in ((y, want, 'forward'), (x.grad, xr.grad, 'dgrad'), (conv.weight.grad, wr.grad, 'wgrad'), (conv.bias.grad, br.grad, 'bias grad')):
+            ref = ref.detach()
+            err = ((got.detach().double() - ref).abs() / (ref.pow(2).mean().sqrt() + ref.abs())).max().item()
+            assert err < 1e-4, f'{Cin}->{Cout} {what}: {err:.3g}'
+
+
 def test_conv2d_residual_extra_bias_and_fused_accumulation(gpu):
     from diffusion_pipe_amd import nn as dnn, ops
     torch.manual_seed(3)

@@ -59,14 +59,65 @@ def test_full_size_sdxl_three_lanes_twelve_unsynchronised_steps_match_one_lane(g
         assert abs(a - b) <= 5e-2 * abs(b) + 1e-4, f'step {i}: grad norm {a} (3 lanes) vs {b} (1 lane)'
 
 
-def test_full_size_sdxl_micro_batch_matches_the_cpu_oracle_golden(gpu):
+# Bounds of the golden comparison.  fp32 = the exact-parity kernel mode (north_star: 1e-3 on loss and gradient norm); bf16 = the TIMED path (bf16 kernels,
+# hipGraph, 3 lanes).  Per parameter, against the golden's [sum |g|, sum g, <g, r>, ||g||_2] rows (oracle/checksums.py): abs-sum and L2 norm relative,
+# signed sum relative to sum |g|, projection error in units of ||g_ref|| / sqrt(12) (a sample of the tensor's relative L2 error, sign / placement included).
+# The bf16 bounds are ~3x the errors observed on MI355X (printed by the test, recorded in DESIGN.md section 6).
+FP32_BOUNDS = dict(loss=1e-3, norm=1e-3, abs_sum=5e-3, signed_sum=5e-3, proj=1.5e-2, l2=5e-3)
+BF16_BOUNDS = dict(loss=1e-2, norm=2e-2, abs_sum=6e-2, signed_sum=6e-2, proj=1.5e-1, l2=6e-2)
+
+
+def _compare_grad_rows(rows, meta, bounds, what):
+    """rows: {name: checksum4 row} of this run.  Returns the worst observed error per kind; asserts the bounds (+ an absolute floor of 1e-8 of the model's
+    total sum |g| for parameters whose gradient is analytically zero -- attention key biases: softmax is invariant to them -- and therefore rounding noise)."""
+    from oracle.checksums import relative_errors
+    gold = meta['grad_checksums']
+    assert len(rows) == meta['parameters_with_grad'], (len(rows), meta['parameters_with_grad'])
+    total = sum(v[0] for v in gold.values())
+    floor = 1e-8 * total
+    worst = dict(abs_sum=(0.0, ''), signed_sum=(0.0, ''), proj=(0.0, ''), l2=(0.0, ''))
+    bad = []
+    for name, got in rows.items():
+        ref = gold[name]
+        if ref[0] <= floor and got[0] <= 4 * floor:
+            continue
+        e = dict(zip(('abs_sum', 'signed_sum', 'proj', 'l2'), relative_errors(got, ref)))
+        for k, v in e.items():
+            if v > worst[k][0]:
+                worst[k] = (v, name)
+            slack = floor / max(ref[0], 1e-300) if k != 'proj' else floor / max(ref[3] / 12 ** 0.5, 1e-300)
+            if v > bounds[k] + slack:
+                bad.append((name, k, v))
+    print(f'{what}: worst per-parameter errors ' + ', '.join(f'{k} {v:.3g} ({n})' for k, (v, n) in worst.items()))
+    assert not bad, f'{what}: {len(bad)} parameter checks beyond the bounds, e.g. {bad[:5]}'
+    return {k: v for k, (v, _) in worst.items()}
+
+
+class _ChecksumOptimizer(torch.optim.Optimizer):
+    """Leaves the parameters alone; step() records the checksum rows of the step's (lane-summed) gradients -- they are zeroed right after."""
+
+    def __init__(self, params, names):
+        super().__init__(params, {})
+        self.names, self.rows = names, {}
+
+    def step(self, closure=None):
+        from oracle.checksums import checksum4
+        for group in self.param_groups:
+            for p in group['params']:
+                if p.grad is not None:
+                    self.rows[self.names[id(p)]] = checksum4(p.grad, self.names[id(p)])
+
+
+def test_full_size_sdxl_micro_batch_matches_the_cpu_oracle_golden(gpu, record_property):
     """BASELINE config 2, one full-size micro-batch, against tests/golden/sdxl_fullsize.json (oracle/make_golden_fullsize.py: the oracle's fp32
-    eager path on the host, same seeded weights and prepared input):
-      * exact-fp32 kernel mode: loss and global gradient norm within 1e-3 relative (north_star's bound), every parameter's sum |g| within 5e-3 (+ 1e-8 of the model total);
-      * the timed path (bf16, hipGraph, 3 lanes replaying the micro-batch): loss within 3e-2, gradient norm within 5e-2."""
+    eager path on the host, same seeded weights and prepared input) -- loss, global gradient norm and, for every one of the 2 375 parameters with a
+    gradient, sum |g|, sum g, a seeded projection <g, r> and ||g||_2:
+      * exact-fp32 kernel mode (fp32 MFMA GEMM, unfused attention, the implicit-GEMM convolution as bf16 hi / lo split launches): FP32_BOUNDS;
+      * the timed path (bf16, hipGraph, 3 lanes replaying the micro-batch): BF16_BOUNDS."""
     import json
     import os
     from diffusion_pipe_amd.engine import ManualPipelineModule, initialize
+    from oracle.checksums import checksum4
     from oracle.make_golden_fullsize import build, weight_checksum
     meta = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'sdxl_fullsize.json')))
     cfg, work, micro = build()
@@ -81,32 +132,38 @@ def test_full_size_sdxl_micro_batch_matches_the_cpu_oracle_golden(gpu):
     loss = work.get_loss_fn()(x, tuple(t.to(gpu) for t in label))
     loss.backward()
     torch.cuda.synchronize()
-    assert abs(loss.item() - meta['loss']) / meta['loss'] < 1e-3, (loss.item(), meta['loss'])
-    sums, sq = {}, 0.0
+    rows, sq = {}, 0.0
     for k, m in work.modules().items():
         for n, p in m.named_parameters():
             if p.grad is not None:
-                g = p.grad.double()
-                sums[f'{k}.{n}'] = float(g.abs().sum())
-                sq += float((g * g).sum())
-    assert abs(sq ** 0.5 - meta['grad_norm']) / meta['grad_norm'] < 1e-3, (sq ** 0.5, meta['grad_norm'])
-    assert len(sums) == meta['parameters_with_grad']
-    # per parameter: sum |g| within 5e-3 relative, plus an absolute floor of 1e-8 of the model's total for parameters whose gradient is
-    # analytically zero (attention key biases: softmax is invariant to them) and therefore pure rounding noise on both sides
-    total = sum(v[0] for v in meta['grad_checksums'].values())
-    excess = {k: abs(v - meta['grad_checksums'][k][0]) - (5e-3 * meta['grad_checksums'][k][0] + 1e-8 * total) for k, v in sums.items()}
-    worst = max(excess, key=excess.get)
-    assert excess[worst] <= 0, (worst, sums[worst], meta['grad_checksums'][worst][0], total)
+                rows[f'{k}.{n}'] = checksum4(p.grad, f'{k}.{n}')
+                sq += rows[f'{k}.{n}'][3] ** 2
+    e_loss, e_norm = abs(loss.item() - meta['loss']) / meta['loss'], abs(sq ** 0.5 - meta['grad_norm']) / meta['grad_norm']
+    print(f'fp32 kernel path vs oracle: loss rel. error {e_loss:.3g}, gradient-norm rel. error {e_norm:.3g}')
+    assert e_loss < FP32_BOUNDS['loss'], (loss.item(), meta['loss'])
+    assert e_norm < FP32_BOUNDS['norm'], (sq ** 0.5, meta['grad_norm'])
+    w32 = _compare_grad_rows(rows, meta, FP32_BOUNDS, 'fp32 kernel path')
     # ---- the timed path: bf16, hipGraph, 3 lanes (the same micro-batch on every lane: same mean loss, same averaged gradient)
-    for m in work.modules().values():
+    names = {}
+    for k, m in work.modules().items():
         for p in m.parameters():
             p.grad = None
         m.to(torch.bfloat16)
+        for n, p in m.named_parameters():
+            names[id(p)] = f'{k}.{n}'
     module = ManualPipelineModule(layers=work.to_layers(), num_stages=1, partition_method='parameters', loss_fn=work.get_loss_fn(), dynamic_shape=True)
     engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 1, 'gradient_accumulation_steps': 3, 'gradient_clipping': 1e9,
                                                          'hip_graph': True, 'graph_lanes': 3}, device=gpu)
-    engine._configure_optimizer(lambda ps: torch.optim.SGD(ps, lr=0.0), [p for p in module.parameters() if p.requires_grad])
+    opt = engine._configure_optimizer(lambda ps: _ChecksumOptimizer(ps, names), [p for p in module.parameters() if p.requires_grad])
     loss = engine.train_batch(iter([micro[0]] * 3)).item()
     norm = engine.get_global_grad_norm().item()
-    assert abs(loss - meta['loss']) / meta['loss'] < 3e-2, (loss, meta['loss'])
-    assert abs(norm - meta['grad_norm']) / meta['grad_norm'] < 5e-2, (norm, meta['grad_norm'])
+    e_loss16, e_norm16 = abs(loss - meta['loss']) / meta['loss'], abs(norm - meta['grad_norm']) / meta['grad_norm']
+    print(f'timed path (bf16, hipGraph, 3 lanes) vs oracle: loss rel. error {e_loss16:.3g}, gradient-norm rel. error {e_norm16:.3g}')
+    assert e_loss16 < BF16_BOUNDS['loss'], (loss, meta['loss'])
+    assert e_norm16 < BF16_BOUNDS['norm'], (norm, meta['grad_norm'])
+    w16 = _compare_grad_rows(opt.rows, meta, BF16_BOUNDS, 'timed bf16 path')
+    for k, v in (('fp32_loss', e_loss), ('fp32_norm', e_norm), ('bf16_loss', e_loss16), ('bf16_norm', e_norm16)):
+        record_property(k, v)
+    for tag, w in (('fp32', w32), ('bf16', w16)):
+        for k, v in w.items():
+            record_property(f'{tag}_{k}', v)

@@ -1,10 +1,10 @@
 """GPU: block arithmetic at the REAL widths of BASELINE configs 3 and 4 (head_dim 128) against tests/golden/realdims.json
 (oracle/make_golden_realdims.py): the Wan2.1-14B DiT block (dim 5120, ffn 13824, 40 heads, 4 608 tokens, 512 text tokens) vs the reference's OWN
 `WanAttentionBlock` run on CPU; one Flux double + one single stream block at 3072 = 24 x 128 (4 096 image + 512 text tokens) vs the oracle's restatement.
-Weights and inputs are rebuilt from the generator's seeds; compared: loss, and (sum |t|) checksums of the output and of every gradient.
+Weights and inputs are rebuilt from the generator's seeds; compared: loss, and the (sum |t|, sum t, seeded projection, L2 norm) rows of the output and of every gradient.
 
 Tolerances: exact-fp32 kernel mode 1e-3 on the loss (north_star's bound) and 5e-3 on each checksum; bf16 mode (the flash-attention / LDS-DMA GEMM path that
-trains) 3e-2 on the loss and 8e-2 on each checksum (+ an absolute floor of 1e-6 of the largest checksum for gradients that are analytically ~0)."""
+trains) 3e-2 on the loss and 5e-2 on each checksum (+ an absolute floor of 1e-6 of the largest checksum for gradients that are analytically ~0)."""
 import json
 import os
 
@@ -15,12 +15,26 @@ pytestmark = pytest.mark.gpu
 G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'realdims.json')))
 
 
-def _check(got, want, tol, floor, what):
-    err = abs(float(got.detach().double().abs().sum()) - want[0])
-    assert err <= tol * want[0] + floor, (what, float(got.detach().double().abs().sum()), want[0])
+WORST = {}
 
 
-@pytest.mark.parametrize('dtype,ltol,ctol', [(torch.float32, 1e-3, 5e-3), (torch.bfloat16, 3e-2, 8e-2)])
+def _check(got, want, tol, floor, what, tag=''):
+    """want = the golden's [sum |t|, sum t, <t, r>, ||t||_2] row (oracle/checksums.py): abs-sum and L2 norm relative, signed sum relative to sum |t|,
+    projection error in units of ||t_ref|| / sqrt(12) within 3 tol (three sigma of a tensor whose relative L2 error is tol) -- the last two see sign
+    flips and transposed / permuted blocks that sum |t| is blind to."""
+    from oracle.checksums import checksum4, relative_errors
+    row = checksum4(got, what)
+    e_abs, e_sum, e_proj, e_l2 = relative_errors(row, want)
+    w = WORST.setdefault(tag, [0.0, 0.0, 0.0, 0.0])
+    for i, e in enumerate((e_abs, e_sum, e_proj, e_l2)):
+        w[i] = max(w[i], e)
+    assert abs(row[0] - want[0]) <= tol * want[0] + floor, (what, 'sum |t|', row[0], want[0])
+    assert abs(row[1] - want[1]) <= tol * want[0] + floor, (what, 'sum t', row[1], want[1])
+    assert abs(row[3] - want[3]) <= tol * want[3] + floor, (what, 'L2 norm', row[3], want[3])
+    assert abs(row[2] - want[2]) <= 3 * tol * want[3] / 12 ** 0.5 + floor, (what, 'projection', row[2], want[2])
+
+
+@pytest.mark.parametrize('dtype,ltol,ctol', [(torch.float32, 1e-3, 5e-3), (torch.bfloat16, 3e-2, 5e-2)])
 def test_wan14b_width_block_matches_the_reference_block(gpu, dtype, ltol, ctol):
     from diffusion_pipe_amd.workloads import wan
     from oracle.make_golden_realdims import WAN, wan_case
@@ -42,15 +56,18 @@ def test_wan14b_width_block_matches_the_reference_block(gpu, dtype, ltol, ctol):
     torch.cuda.synchronize()
     assert abs(loss.item() - ref['loss']) <= ltol * abs(ref['loss']), (loss.item(), ref['loss'])
     floor = 1e-6 * max(v[0] for v in ref['param_grads'].values())
-    _check(y, ref['y'], ctol, 0.0, 'y')
-    _check(x.grad, ref['grad_x'], ctol, floor, 'grad x')
-    _check(e.grad, ref['grad_e'], ctol, floor, 'grad e')
-    _check(ctx.grad, ref['grad_context'], ctol, floor, 'grad context')
+    tag = f'wan14b {dtype}'
+    print(f'wan14b block {dtype}: loss rel. error {abs(loss.item() - ref["loss"]) / abs(ref["loss"]):.3g}')
+    _check(y, ref['y'], ctol, 0.0, 'y', tag)
+    _check(x.grad, ref['grad_x'], ctol, floor, 'grad_x', tag)
+    _check(e.grad, ref['grad_e'], ctol, floor, 'grad_e', tag)
+    _check(ctx.grad, ref['grad_context'], ctol, floor, 'grad_context', tag)
     for n, p in block.named_parameters():
-        _check(p.grad, ref['param_grads'][n], ctol, floor, n)
+        _check(p.grad, ref['param_grads'][n], ctol, floor, n, tag)
+    print(f'{tag}: worst (abs-sum, signed-sum, projection, L2) errors {[round(v, 5) for v in WORST[tag]]}')
 
 
-@pytest.mark.parametrize('dtype,ltol,ctol', [(torch.float32, 1e-3, 5e-3), (torch.bfloat16, 3e-2, 8e-2)])
+@pytest.mark.parametrize('dtype,ltol,ctol', [(torch.float32, 1e-3, 5e-3), (torch.bfloat16, 3e-2, 5e-2)])
 def test_flux_width_double_and_single_block_match_the_oracle(gpu, dtype, ltol, ctol):
     from oracle.make_golden_realdims import flux_case
     ref = G['flux_blocks']
@@ -64,8 +81,11 @@ def test_flux_width_double_and_single_block_match_the_oracle(gpu, dtype, ltol, c
     loss.backward()
     torch.cuda.synchronize()
     assert abs(loss.item() - ref['loss']) <= ltol * ref['loss'], (loss.item(), ref['loss'])
-    _check(x, ref['out'], ctol, 0.0, 'output')
+    tag = f'flux {dtype}'
+    print(f'flux blocks {dtype}: loss rel. error {abs(loss.item() - ref["loss"]) / ref["loss"]:.3g}')
+    _check(x, ref['out'], ctol, 0.0, 'out', tag)
     floor = 1e-6 * max(v[0] for v in ref['param_grads'].values())
     for n, p in work.transformer.named_parameters():
         if n in ref['param_grads']:
-            _check(p.grad, ref['param_grads'][n], ctol, floor, n)
+            _check(p.grad, ref['param_grads'][n], ctol, floor, n, tag)
+    print(f'{tag}: worst (abs-sum, signed-sum, projection, L2) errors {[round(v, 5) for v in WORST[tag]]}')
