@@ -43,12 +43,18 @@ def parse():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--gas', type=int, default=0, help='micro-batches per step (default 6 * gpus)')
     ap.add_argument('--config', default='full', choices=['full', 'tiny'])
+    ap.add_argument('--workload', default='sdxl', choices=['sdxl', 'flux', 'wan', 'hv'],
+                    help='sdxl = BASELINE config 2 (the metric\'s configuration, the default); flux / wan / hv = BASELINE configs 3 / 4 / 5 as real steps on '
+                         'this GPU (pp = 1): Flux.1-dev 1024x1024 LoRA, Wan2.1-14B t2v 512x512x33f LoRA, HunyuanVideo 720p x 65f full fine-tune with '
+                         'checkpointing + host-offloaded activations')
+    ap.add_argument('--lora-rank', type=int, default=32)
+    ap.add_argument('--full-ft', action='store_true', help='flux / wan: train every weight instead of LoRA adapters (activation checkpointing on)')
     ap.add_argument('--latent', type=int, default=128)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--activation-checkpointing', action='store_true')
     ap.add_argument('--partition', default='parameters')
     ap.add_argument('--no-graph', action='store_true', help='disable hipGraph capture of the micro-batch fwd+bwd')
-    ap.add_argument('--lanes', type=int, default=3, help='concurrent micro-batch lanes of the single-stage hipGraph path')
+    ap.add_argument('--lanes', type=int, default=0, help='concurrent micro-batch lanes of the single-stage hipGraph path (default: 3 for sdxl, 1 for the DiT workloads)')
     ap.add_argument('--test-single-device', action='store_true',
                     help='TEST ONLY: all ranks share cuda:0, collectives over gloo, stage payloads staged through the host')
     ap.add_argument('--torch-adamw', action='store_true', help='A/B switch: torch.optim.AdamW(fused=True) + separate lane-sum / clip / zero passes')
@@ -99,6 +105,184 @@ def start_progress_monitor(engine_mod, stall_s):
     return th
 
 
+def build_dit_workload(args, device):
+    """-> (workload, label, make_batch(bs, seed), module kwargs, full_ft, default gas, use hipGraph)"""
+    tiny = args.config == 'tiny'
+    bf16 = torch.bfloat16
+    adapter = {'type': 'lora', 'rank': args.lora_rank, 'alpha': args.lora_rank, 'dtype': bf16}
+    kwargs, full_ft = {}, args.full_ft
+    if args.workload == 'flux':
+        from diffusion_pipe_amd.workloads import flux as W
+        cfg = W.tiny_flux_config() if tiny else W.FluxConfig()
+        work = W.FluxWorkload(cfg, model_config={'guidance': 1.0}, dtype=bf16, seed=0, device=device)
+        hw, tt = ((16, 16), 24) if tiny else ((128, 128), 512)
+        make = lambda bs, seed: W.synthetic_flux_batch(cfg, batch_size=bs, latent_hw=hw, text_tokens=tt, seed=seed)
+        label = f'Flux.1-dev {hw[0] * 8}x{hw[1] * 8} ({cfg.num_layers} double + {cfg.num_single_layers} single MMDiT blocks, dim {cfg.dim}, {hw[0] * hw[1] // 4} image + {tt} text tokens)'
+        gas, graph = 2, True
+    elif args.workload == 'wan':
+        from diffusion_pipe_amd.workloads import wan as W
+        cfg = W.tiny_wan_config() if tiny else W.WanConfig()
+        work = W.WanWorkload(cfg, dtype=bf16, seed=0, device=device)
+        fr, hw, tt = (2, (12, 16), 20) if tiny else (9, (64, 64), 512)
+        make = lambda bs, seed: W.synthetic_wan_batch(cfg, batch_size=bs, frames=fr, latent_hw=hw, text_tokens=tt, seed=seed)
+        label = (f'Wan2.1-14B t2v {hw[0] * 8}x{hw[1] * 8}x{(fr - 1) * 4 + 1}f ({cfg.num_layers} DiT blocks, dim {cfg.dim}, ffn {cfg.ffn_dim}, '
+                 f'{fr * hw[0] * hw[1] // 4} video + {tt} text tokens)')
+        gas, graph = 2, True
+    else:
+        from diffusion_pipe_amd.workloads import hunyuan_video as W
+        from diffusion_pipe_amd.engine.offload import offloaded_checkpoint
+        cfg = W.tiny_hv_config() if tiny else W.HunyuanVideoConfig()
+        work = W.HunyuanVideoWorkload(cfg, model_config={'guidance': 1.0}, dtype=bf16, seed=0, device=device)
+        thw, tt = ((3, 8, 8), 12) if tiny else ((17, 90, 160), 256)
+        make = lambda bs, seed: W.synthetic_hv_batch(cfg, batch_size=bs, latent_thw=thw, text_tokens=tt, valid_text=(tt,), seed=seed)
+        label = (f'HunyuanVideo t2v {thw[1] * 8}x{thw[2] * 8}x{(thw[0] - 1) * 4 + 1}f ({cfg.mm_double_blocks_depth} double + {cfg.mm_single_blocks_depth} single '
+                 f'MMDiT blocks, dim {cfg.hidden_size}, {thw[0] * thw[1] * thw[2] // 4} video + {tt} text tokens)')
+        full_ft, gas, graph = True, 1, False
+        if tiny:
+            from diffusion_pipe_amd.engine import offload as _off
+            _off.OFFLOAD_THRESHOLD = 1024              # the tiny test config must exercise the host-offload path too
+    if full_ft:
+        # full fine-tune of a 12 - 14 B transformer at video token counts: per-layer activation checkpointing; HunyuanVideo (config 5) additionally parks the
+        # checkpoints in host DRAM (the reference's activation_checkpointing = 'unsloth': train.py:586-603, utils/unsloth_utils.py:24-79)
+        from functools import partial
+        fn = offloaded_checkpoint if args.workload == 'hv' else partial(torch.utils.checkpoint.checkpoint, use_reentrant=False)
+        kwargs = dict(activation_checkpoint_interval=1, checkpointable_layers=work.checkpointable_layers, activation_checkpoint_func=fn)
+    else:
+        work.configure_adapter(adapter)
+    return work, label, make, kwargs, full_ft, gas, graph
+
+
+def run_dit_workload(args, device, world, rank):
+    """BASELINE configs 3 / 4 / 5 as real `train_batch` steps on ONE MI355X (pp = 1; 288 GB of HBM hold what the reference spreads over 2 / 4 / 8 GPUs):
+    real depth, real token counts, synthetic latents / text embeddings resident in HBM, random weights, AdamW.  Prints the same JSON line: samples/s,
+    the step's algorithmic FLOPs (from the traced forward: GEMM 2 M N K + attention 4 Sq Sk D H; x 3 full fine-tune, x 2 LoRA, recompute not counted),
+    `roofline` for the step's dominant kernel family (MFMA GEMM or flash attention, whichever takes longer in the replay of the step's own launch list),
+    peak HBM use, and a bounded `cpu_baseline` (one oracle block)."""
+    import gc
+    from diffusion_pipe_amd import hip, ops, optim
+    from diffusion_pipe_amd.data import split_batch
+    from diffusion_pipe_amd.engine import ManualPipelineModule, initialize
+    from diffusion_pipe_amd.engine import engine as engine_mod, offload as offload_mod
+    hip.lib()
+    assert world == 1, 'the DiT workloads run pp = 1 on one GPU (bench.py --workload sdxl is the multi-GPU line)'
+    t_build = time.perf_counter()
+    work, label, make, kwargs, full_ft, gas_default, graph = build_dit_workload(args, device)
+    graph = graph and not args.no_graph
+    gas = args.gas or gas_default
+    lanes = args.lanes or 1
+    n_params = sum(p.numel() for p in work.transformer.parameters())
+    n_train = sum(p.numel() for p in work.transformer.parameters() if p.requires_grad)
+    module = ManualPipelineModule(layers=work.to_layers(), num_stages=1, partition_method=args.partition, loss_fn=work.get_loss_fn(), dynamic_shape=True, **kwargs)
+    engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 1, 'gradient_accumulation_steps': gas, 'gradient_clipping': 1.0,
+                                                         'steps_per_print': 1 << 30, 'hip_graph': graph, 'graph_lanes': lanes,
+                                                         'max_steps_in_flight': args.steps_in_flight}, device=device)
+    work.train_config = {'optimizer': {'type': 'adamw', 'lr': 1e-5, 'betas': [0.9, 0.99], 'weight_decay': 0.01, 'eps': 1e-8}}
+    engine._configure_optimizer(optim.make_optimizer_factory(work.train_config, work, global_batch_size=gas), [p for p in module.parameters() if p.requires_grad])
+    torch.manual_seed(1234)
+    pool = []
+    for s_ in range(2):
+        feats, label_t = work.prepare_inputs(make(gas, 100 + s_))
+        step = split_batch((feats, label_t), gas)
+        pool.append([tuple(tuple(t.to(device) for t in part) for part in mb) for mb in step])
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+    start_progress_monitor(engine_mod, float(os.environ.get('DPIPE_BENCH_STALL_S', '600')))
+
+    def one_step(i):
+        engine.reset_activation_shape()
+        return engine.train_batch(iter(pool[i % len(pool)]))
+
+    trace_in_timed = not graph            # eager launches pass through ops.gemm / ops.attention anyway: record the last timed step's launch list
+    loss = None
+    for i in range(args.warmup):
+        loss = one_step(i)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats(device)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        if trace_in_timed and i == args.steps - 1:
+            ops.GEMM_TRACE, ops.ATTN_TRACE = [], []
+        loss = one_step(args.warmup + i)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    engine_mod.TRACE = None
+    peak_hbm = torch.cuda.max_memory_allocated(device)
+    gnorm = engine.get_global_grad_norm()
+    gnorm = float(gnorm.item()) if gnorm is not None else float('nan')
+    if not trace_in_timed:
+        # one eager step records the launch list the graphs replay; the lanes' graphs (and their static activation pools) are not needed any more
+        engine._lanes = []
+        import gc as _gc
+        _gc.collect()
+        torch.cuda.empty_cache()
+        ops.GEMM_TRACE, ops.ATTN_TRACE = [], []
+        was = engine.use_graph
+        engine.use_graph = False
+        for p_ in module.parameters():
+            p_.grad = None
+        one_step(0)
+        engine.use_graph = was
+        torch.cuda.synchronize()
+    gemm_trace, attn_trace, ops.GEMM_TRACE, ops.ATTN_TRACE = ops.GEMM_TRACE, ops.ATTN_TRACE, None, None
+    pinned = sum(t.numel() * t.element_size() for bufs in offload_mod._FREE.values() for t in bufs)
+
+    # algorithmic FLOPs of one sample's forward: the layers once, no autograd, no checkpoint wrapper
+    ops.GEMM_TRACE, ops.ATTN_TRACE = [], []
+    with torch.no_grad():
+        x = pool[0][0][0]
+        x = x[0] if len(x) == 1 else x
+        for layer in module.forward_funcs:
+            x = layer(x)
+    torch.cuda.synchronize()
+    from tools import attn_replay, gemm_replay
+    fwd_gemm = sum(gemm_replay.flops(d) for d in ops.GEMM_TRACE)
+    fwd_attn = sum(attn_replay.flops_fwd(e) for e in ops.ATTN_TRACE)
+    ops.GEMM_TRACE, ops.ATTN_TRACE = None, None
+    del x
+    sample_flops = (3.0 if full_ft else 2.0) * (fwd_gemm + fwd_attn)
+
+    # free the training state before the replay legs allocate their scratch (static graph pools, optimizer state, gradients)
+    value = gas / (elapsed / args.steps)
+    loss_v = float(loss.item())
+    del engine, module, pool
+    work.transformer = None
+    gc.collect()
+    torch.cuda.empty_cache()
+    g_rt = gemm_replay.time_in_graph(gemm_trace, device, reps=1 if sum(gemm_replay.flops(d) for d in gemm_trace) > 5e14 else 3, arena_bytes=8 << 30)
+    a_rt = attn_replay.time_list(attn_trace, device, reps=1 if sample_flops > 1e15 else 3)
+    peak = 2500.0
+    g_tf = g_rt['flops'] / (g_rt['ms'] * 1e-3) / 1e12 if g_rt['ms'] > 0 else 0.0
+    a_tf = a_rt['flops'] / (a_rt['ms'] * 1e-3) / 1e12 if a_rt['ms'] > 0 else 0.0
+    dom_attn = a_rt['ms'] > g_rt['ms']
+    roof = {'bound': 'mfma', 'peak': peak, 'unit': 'TFLOP/s', 'traffic': None,
+            'gemm': {'kernel': 'gemm_pipe_kernel<bf16> (dpipe_gemm_ex)', 'achieved': round(g_tf, 1), 'frac': round(g_tf / peak, 4), 'launches_per_step': g_rt['launches'],
+                     'gpu_ms_per_step': round(g_rt['ms'], 2), 'avg_launch_us': round(g_rt['ms'] * 1e3 / max(g_rt['launches'], 1), 1)},
+            'attention': {'kernel': 'attn_fwd_dma / attn_bwd_dq_dma / attn_bwd_dkv_dma (dpipe_attn_fwd / dpipe_attn_bwd)', 'achieved': round(a_tf, 1), 'frac': round(a_tf / peak, 4),
+                          'calls_per_step': a_rt['calls'], 'gpu_ms_per_step': round(a_rt['ms'], 2), 'per_shape': a_rt['per_shape'],
+                          'flop_count': 'forward 4 Sq Sk D H, backward 2.5 x forward (the kernels recompute S three times: 64 MFMAs issued per 40 counted)'},
+            'method': 'the step\'s recorded GEMM launch list replayed as one GEMM-only hipGraph (HBM-cold operands) and every attention shape of the step replayed '
+                      'forward (+ backward) in a hipGraph, HIP events on the replay stream; dominant = the family with the larger replay time'}
+    dom = roof['attention' if dom_attn else 'gemm']
+    roof.update({'kernel': dom['kernel'], 'achieved': dom['achieved'], 'frac': dom['frac']})
+    ms_per_step = elapsed / args.steps * 1e3
+    out = {'metric': f'training samples/sec, one MI355X (pp=1), BASELINE config {dict(flux=3, wan=4, hv=5)[args.workload]}',
+           'value': round(value, 5), 'unit': 'samples/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 2),
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+           'config': {'workload': label + (', full fine-tune' if full_ft else f', LoRA rank {args.lora_rank} on every Linear of the blocks') +
+                      f', micro-batch 1, pp=1, GAS={gas}, AdamW, clip 1.0' + (' [tiny test config]' if args.config != 'full' else ''),
+                      'global_batch': gas, 'parallelism': 'pp1', 'gradient_accumulation_steps': gas, 'hip_graph': bool(graph), 'concurrent_micro_batch_lanes': lanes,
+                      'activation_checkpointing': ('host-offloaded (unsloth)' if args.workload == 'hv' else True) if full_ft else False,
+                      'parameters': n_params, 'trainable_parameters': n_train},
+           'loss': loss_v, 'grad_norm': gnorm, 'build_seconds': round(t_build, 1),
+           'sample_tflop_algorithmic': round(sample_flops / 1e12, 1), 'forward_tflop': {'gemm': round(fwd_gemm / 1e12, 2), 'attention': round(fwd_attn / 1e12, 2)},
+           'mfu_vs_bf16_mfma_peak': round(sample_flops * value / (peak * 1e12), 5),
+           'peak_hbm_gb': round(peak_hbm / 2 ** 30, 2), 'pinned_host_gb': round(pinned / 2 ** 30, 2), 'roofline': roof}
+    if not args.no_cpu_baseline:
+        from oracle.cpu_baseline import dit_block_cpu_baseline
+        out['cpu_baseline'] = dit_block_cpu_baseline(args.workload, sample_flops) if args.config == 'full' else None
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
     # watchdogs: (1) wall clock -- dump every thread's Python stack and exit; (2) progress (start_progress_monitor) -- exit as soon
@@ -131,6 +315,9 @@ def main():
     from diffusion_pipe_amd.workloads import sdxl
     hip.lib()
 
+    if args.workload != 'sdxl':
+        return run_dit_workload(args, device, world, rank)
+    args.lanes = args.lanes or 3
     cfg = sdxl.SDXLConfig() if args.config == 'full' else sdxl.tiny_config()
     latent = args.latent if args.config == 'full' else 32
     pp = world

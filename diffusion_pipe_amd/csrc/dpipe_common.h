@@ -19,6 +19,7 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA A/B fragme
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_mfma;
 typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;   // 16-byte payload of a raw buffer store
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 void set_last_error(const char* msg);

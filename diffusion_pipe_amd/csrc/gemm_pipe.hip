@@ -30,6 +30,7 @@ bool gemm_pipe_try(GemmParams& p, int transA, int transB, int batch, void* ws, l
     case 63: *rc_out = launch_pipe<T64S3>(p, a_mc, b_mc, batch, s); break;
     case 128: *rc_out = launch_pipe<T128>(p, a_mc, b_mc, batch, s); break;
     case 130: *rc_out = launch_pipe<T128S5>(p, a_mc, b_mc, batch, s); break;
+    case 1264: *rc_out = launch_pipe<T128N64>(p, a_mc, b_mc, batch, s); break;
     default: *rc_out = launch_pipe<T64>(p, a_mc, b_mc, batch, s); break;
     }
     return true;
@@ -52,14 +53,22 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
     // flight shorten the vmcnt wait: +5 .. +6 % (9216 x 5120 x 13824 NN: 996 vs 940 TFLOP/s).  A K-contiguous operand pays for half steps with 64-byte pieces
     // (half a cache line per row per step) and twice the barriers: NT is 8 % slower on T256K and stays on T256S (8192^3: 1 292 vs 1 184)
     if (force_tile == 0 && !a_mc && p.ksteps >= 64 && tiles256 >= 128) force_tile = b_mc ? 258 : 257;
-    const int bm = (force_tile == 256 || force_tile == 257 || force_tile == 258) ? 256 : big ? 128 : 64, bn = force_tile == 256 ? 128 : bm;
+    // skinny M (<= 128 rows: the 77-token linears of the text encoders / cross-attention K, V): one 128-row tile covers A, 64-wide N tiles, and the K
+    // range is cut into slices of ~4 K-steps (all of a slice's DMA in flight at once: one HBM round trip per workgroup instead of ksteps / 3)
+    // until about two workgroups per CU exist -- these GEMMs are pure weight streaming, bounded by the serial K walk of few workgroups
+    const bool skinny = force_tile == 1264 || (force_tile == 0 && p.M <= 128 && p.N >= 256 && p.ksteps >= 4 && option(DPIPE_OPT_GEMM_SKINNY, 1) != 0);
+    if (skinny) force_tile = 1264;
+    const int bm = (force_tile == 256 || force_tile == 257 || force_tile == 258) ? 256 : (big || skinny) ? 128 : 64,
+              bn = force_tile == 256 ? 128 : skinny ? 64 : bm;
     p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bn - 1) / bn;
     const long tiles = (long)p.tiles_m * p.tiles_n * batch;
     const long slab_bytes = ((long)bm * bn + bm) * 4;
     int S = 1;
     if (ws && ws_bytes > COUNTER_BYTES) {
         if (force_splitk > 0) S = force_splitk;
-        else if (!big && tiles <= 128 && p.ksteps >= 32) {   // every slice pays an agent-scope release: only few, long tiles split
+        else if (skinny) {
+            S = (int)(512 / tiles); const int cap = p.ksteps / 4; if (S > cap) S = cap; if (S > 16) S = 16;
+        } else if (!big && tiles <= 128 && p.ksteps >= 32) {   // every slice pays an agent-scope release: only few, long tiles split
             S = (int)(512 / tiles); const int cap = p.ksteps / 8; if (S > cap) S = cap; if (S > 4) S = 4;
         } else if (big && long_k && tiles <= 128) {
             S = (int)(256 / tiles); if (S > 3) S = 3; if (S < 2) S = 2;      // one round of workgroups: 80 tiles x 3, 120 x 2 (measured: tools/kernel_timing.py, tools/conv_timing.py)
@@ -86,7 +95,7 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
     if (c_ok && p.residual && reinterpret_cast<uintptr_t>(p.residual) % 8 == 0 && p.ldr % 4 == 0) p.vecA = 3;   // 8-byte residual loads too
     p.vecB = (p.bias && reinterpret_cast<uintptr_t>(p.bias) % 8 == 0) ? 2 : 0;
     if (force_tile == 258) { p.ksteps *= 2; p.ksteps_per_split *= 2; return 258; }      // T256K counts K in 32-wide half steps (slices keep their K ranges)
-    if (force_tile == 257 || force_tile == 256 || force_tile == 63 || force_tile == 130) return force_tile;
+    if (force_tile == 257 || force_tile == 256 || force_tile == 63 || force_tile == 130 || force_tile == 1264) return force_tile;
     if (force_tile == 129 || (force_tile == 0 && big && tiles128 >= 256 && (a_mc || b_mc || tiles128 >= 1024))) return 129;
     return big ? 128 : 64;
 }

@@ -30,6 +30,11 @@ namespace dpipe_pipe {   // named: a kernel template argument may not have inter
 
 constexpr int BK = 64;
 constexpr int COUNTER_BYTES = 4096;
+// Split-K slab publish: 1 = write-through (sc1) slab stores + ticket, no agent-scope release fence (the shipped form); 0 = plain stores + release
+// fence (round 2's form, kept for A/B: build a second library with -DDPIPE_SLAB_WT=0 and load it through DPIPE_HIP_LIB, tools/README.md)
+#ifndef DPIPE_SLAB_WT
+#define DPIPE_SLAB_WT 1
+#endif
 
 // Cycle stamps for tools/probes/gemm_timeline.hip (compiled only there): wave 0 of every workgroup writes s_memtime at the phase
 // boundaries of the kernel into timeline[blockIdx.x * 64 + slot].
@@ -67,6 +72,9 @@ using T128S5 = Tile<128, 128, 2, 4, 5>;     // 5-deep ring = all 160 KiB of LDS,
                                             // selectable (tile_hint 8000 + S), not chosen automatically: whole-kernel time is unchanged (52.9 vs 51.5 us on
                                             // [1024,1280] x [10240,1280]^T: 2.5 rounds of tiles at one workgroup per CU either way, longer prologue)
 using T64S3 = Tile<64, 64, 2, 2, 3>;         // selectable, not chosen automatically: 3-deep ring (3 workgroups per CU)
+using T128N64 = Tile<128, 64, 2, 2, 4>;     // skinny-M configuration (M <= 128: the 77-token text-encoder / cross-attention K,V linears): ONE tile row covers every
+                                            // row of A, so each weight panel is fetched by exactly one workgroup (the 64^2 tile reads it twice for M = 77), 4-deep ring
+                                            // of 24 KiB stages; meant to be combined with deeper split-K (a few K-steps per workgroup, all in flight at once)
 using T256 = Tile<256, 128, 4, 2, 3>;       // selectable, not chosen automatically: 256 x 128, 8 waves of 64 x 64, 144 KiB (T128R2 beats it)
 using T256K = Tile<256, 256, 2, 4, 4, 32>;  // the same 256 x 256 tile on a 4-deep ring of HALF K-steps (32 k, 32 KiB each; the same 128 KiB of LDS): three half steps in flight instead of
                                             // one whole step -- the 2-deep ring parks every wave ~1 100 cycles per K-step at vmcnt (timeline probe), its refill can only be issued
@@ -389,6 +397,32 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const GemmParams p) {
     if (p.splitk > 1) {
         float4* slab0 = reinterpret_cast<float4*>(p.slabs) + ((long)(z * nt + tile) * p.splitk) * TL::SLAB_F4;
         float4* mine = slab0 + (long)split * TL::SLAB_F4;
+#if DPIPE_SLAB_WT
+        // write-through publish (cdna_hip_programming.md section 6 Guideline 16, recipe R1): the slab goes out as 16-byte sc1 stores (they leave the XCD's L2 for
+        // memory as they retire), every storing wave drains its own vmcnt, then ONE lane draws the ticket -- no agent-scope release, i.e. no buffer_wbl2 scan of the
+        // L2 per slice (the price list's publish-large row: 3.0 vs 8.2 us for a 64 KB slab per workgroup)
+        const auto rsS = __builtin_amdgcn_make_buffer_rsrc(mine, (short)0, (int)(TL::SLAB_F4 * 16), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    u32x4_t v;
+                    v[0] = __float_as_uint(acc[i][j][4 * q]); v[1] = __float_as_uint(acc[i][j][4 * q + 1]);
+                    v[2] = __float_as_uint(acc[i][j][4 * q + 2]); v[3] = __float_as_uint(acc[i][j][4 * q + 3]);
+                    // per-lane part in voffset (one VGPR for all stores), the piece's constant offset in soffset (an SGPR: it exceeds the 12-bit immediate)
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsS, (int)threadIdx.x * 16, ((i * TN + j) * 4 + q) * TL::NT * 16, 16);      // aux 16 = sc1
+                }
+        if (do_colsum) {
+            float* crow = reinterpret_cast<float*>(mine + TL::SLAB_F4 - BM / 4);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float v = csum[i] + __shfl_xor(csum[i], 32, 64);
+                if (lane < 32) __hip_atomic_store(&crow[wm0 + i * 32 + lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // <= 8 bytes: an sc1 store
+            }
+        }
+#else
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -405,12 +439,15 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const GemmParams p) {
                 if (lane < 32) crow[wm0 + i * 32 + lane] = v;
             }
         }
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                       // all slab stores of this workgroup issued and waited for
         int* flag = reinterpret_cast<int*>(lds);               // the one LDS array doubles as the broadcast word
         if (threadIdx.x == 0) {
+#if !DPIPE_SLAB_WT
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             const int ticket = __hip_atomic_fetch_add(&p.counters[z * nt + tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *flag = (ticket == p.splitk - 1);
         }

@@ -994,7 +994,7 @@ def attention_packed(qkv_or_q, kv=None, heads=1, head_dim=64, kv_len=None, scale
         scale = 1.0 / math.sqrt(head_dim)
     if ATTN_TRACE is not None:
         Sk = qkv_or_q.shape[1] if kv is None else kv.shape[1]
-        ATTN_TRACE.append((qkv_or_q.shape[0], qkv_or_q.shape[1], Sk, heads, head_dim, int(causal)))
+        ATTN_TRACE.append((qkv_or_q.shape[0], qkv_or_q.shape[1], Sk, heads, head_dim, int(causal), int(torch.is_grad_enabled() and qkv_or_q.requires_grad)))
     if kv_len is not None and kv_len.dtype != torch.int32:
         kv_len = kv_len.to(torch.int32)
     return _FlashAttnPackedFn.apply(qkv_or_q, kv, heads, head_dim, kv_len, scale, causal)
@@ -1050,7 +1050,7 @@ class _UnfusedAttnFn(Function):
         return dq, dk, dv, None, None, None
 
 
-ATTN_TRACE = None     # like GEMM_TRACE: (B, Sq, Sk, H, D, causal) of every attention call of a step
+ATTN_TRACE = None     # like GEMM_TRACE: (B, Sq, Sk, H, D, causal, has_backward) of every attention call of a step
 
 
 def attention(q, k, v, kv_len=None, scale=None, impl='auto', causal=False):
@@ -1058,7 +1058,7 @@ def attention(q, k, v, kv_len=None, scale=None, impl='auto', causal=False):
     impl: 'flash' (bf16 MFMA flash kernel), 'unfused' (GEMM + softmax kernels), 'auto' = flash for bf16."""
     D = q.shape[-1]
     if ATTN_TRACE is not None:
-        ATTN_TRACE.append((q.shape[0], q.shape[1], k.shape[1], q.shape[2], D, int(causal)))
+        ATTN_TRACE.append((q.shape[0], q.shape[1], k.shape[1], q.shape[2], D, int(causal), int(torch.is_grad_enabled() and q.requires_grad)))
     if scale is None:
         scale = 1.0 / math.sqrt(D)
     if impl == 'auto':
@@ -1174,22 +1174,28 @@ _adam_tables = {}
 
 
 def _adam_table(params, exp_avgs, exp_avg_sqs, lane_grads, shifts=None):
-    """Device pointer / chunk tables of one (dtype, param group); cached on the buffer addresses (persistent in the graph path)."""
+    """Device pointer / chunk tables of one (dtype, param group); cached on the parameter / state addresses.  The gradient pointer table is
+    rebuilt whenever the gradient buffers moved (eager path: autograd allocates fresh .grad tensors every step; graph path: persistent) --
+    the cache keeps only the CURRENT gradient tensors alive, never those of earlier steps."""
     L = len(lane_grads)
-    key = tuple(t.data_ptr() for t in params) + tuple(t.data_ptr() for t in exp_avgs) + tuple(g.data_ptr() for lane in lane_grads for g in lane) \
-        + (tuple(t.data_ptr() for t in shifts) if shifts is not None else ())
+    key = (L,) + tuple(t.data_ptr() for t in params) + tuple(t.data_ptr() for t in exp_avgs) + (tuple(t.data_ptr() for t in shifts) if shifts is not None else ())
+    gkey = tuple(g.data_ptr() for lane in lane_grads for g in lane)
+    dev = params[0].device
+    i64 = lambda xs: torch.tensor(xs, dtype=torch.int64, device=dev)
     hit = _adam_tables.get(key)
     if hit is not None:
+        if hit['gkey'] != gkey:
+            hit['g'] = i64([lane_grads[l][i].data_ptr() for i in range(len(params)) for l in range(L)])
+            hit['gkey'] = gkey
+        hit['keep'] = (params, exp_avgs, exp_avg_sqs, lane_grads, shifts)
         return hit
-    dev = params[0].device
     ctens, coff, clen = [], [], []
     for i, t in enumerate(params):
         n = t.numel()
         for off in range(0, n, _CHUNK):
             ctens.append(i); coff.append(off); clen.append(min(_CHUNK, n - off))
-    i64 = lambda xs: torch.tensor(xs, dtype=torch.int64, device=dev)
     table = {'p': i64([t.data_ptr() for t in params]), 'm': i64([t.data_ptr() for t in exp_avgs]), 'v': i64([t.data_ptr() for t in exp_avg_sqs]),
-             'g': i64([lane_grads[l][i].data_ptr() for i in range(len(params)) for l in range(L)]),
+             'g': i64([lane_grads[l][i].data_ptr() for i in range(len(params)) for l in range(L)]), 'gkey': gkey,
              'ctens': torch.tensor(ctens, dtype=torch.int32, device=dev), 'coff': i64(coff),
              'clen': torch.tensor(clen, dtype=torch.int32, device=dev), 'n': len(ctens),
              'partials': torch.empty(max(len(ctens), 1), device=dev, dtype=torch.float32), 'keep': (params, exp_avgs, exp_avg_sqs, lane_grads, shifts),

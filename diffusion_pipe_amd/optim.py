@@ -67,7 +67,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self.kahan = bool(kahan)
 
     def _buckets(self, lane_grads_of):
-        """[(group, dtype, step, params, exp_avgs, exp_avg_sqs, lanes)] over parameters that have a gradient; parameters of one group are
+        """[(group, dtype, step, params, exp_avgs, exp_avg_sqs, lanes, Parameters)] over parameters that have a gradient; parameters of one group are
         bucketed by dtype AND by their own step count (torch.optim.AdamW keeps the bias correction per parameter: a parameter that first
         receives a gradient on a later step, or joins a group after a resume, must not borrow its neighbours' step)."""
         out = []
@@ -82,7 +82,7 @@ class FusedAdamW(torch.optim.Optimizer):
                     st['step'] = 0.0
                     st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)      # channels-last conv weights keep their layout
                     st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                b = by_dtype.setdefault((p.dtype, float(st['step'])), ([], [], [], [[] for _ in lanes]))
+                b = by_dtype.setdefault((p.dtype, float(st['step'])), ([], [], [], [[] for _ in lanes], []))
                 dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
                 if not dense:
                     raise RuntimeError('FusedAdamW needs dense (row-major or channels-last) parameters')
@@ -91,6 +91,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 b[2].append(st['exp_avg_sq'])
                 for lane_list, g in zip(b[3], lanes):
                     lane_list.append(g)
+                b[4].append(p)                    # the Parameter itself: optimizer state is looked up by it (never by data_ptr: empty / aliased storages collide)
             out += [(group, dt, step, *b) for (dt, step), b in by_dtype.items()]
         return out
 
@@ -118,7 +119,7 @@ class FusedAdamW(torch.optim.Optimizer):
             inner = of
             of = lambda p: inner(p) if only(p) else None
         total = None
-        for _, _, _, ps, ms, vs, lanes in self._buckets(of):
+        for _, _, _, ps, ms, vs, lanes, _ in self._buckets(of):
             if total is None:
                 total = torch.empty((), device=ps[0].device, dtype=torch.float32)
                 ops.adamw_grads_sumsq(ps, ms, vs, lanes, total, accumulate=False)
@@ -129,24 +130,22 @@ class FusedAdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def fused_update(self, lane_grads=None, total_sumsq=None, max_norm=0.0, zero_grads=True):
         from . import ops
-        by_data = {p.data_ptr(): p for group in self.param_groups for p in group['params']}
-        for group, dt, step, ps, ms, vs, lanes in self._buckets(self._lanes_from(lane_grads)):
+        updated = []
+        for group, dt, step, ps, ms, vs, lanes, owners in self._buckets(self._lanes_from(lane_grads)):
             beta1, beta2 = group['betas']
             shifts = None
             if self.kahan and dt == torch.bfloat16:
                 shifts = []
-                for pd in ps:
-                    st = self.state[by_data[pd.data_ptr()]]
+                for p, pd in zip(owners, ps):
+                    st = self.state[p]
                     if 'shift' not in st:
                         st['shift'] = torch.zeros_like(pd, memory_format=torch.preserve_format)
                     shifts.append(st['shift'])
+            updated += owners
             ops.adamw_step(ps, ms, vs, lanes, lr=group['lr'], beta1=beta1, beta2=beta2, eps=group['eps'], weight_decay=group['weight_decay'],
                            step=step + 1.0, total_sumsq=total_sumsq, max_norm=max_norm, zero_grads=zero_grads, shifts=shifts)
-        of = self._lanes_from(lane_grads)
-        for group in self.param_groups:
-            for p in group['params']:
-                if of(p) is not None:
-                    self.state[p]['step'] = float(self.state[p]['step']) + 1.0
+        for p in updated:
+            self.state[p]['step'] = float(self.state[p]['step']) + 1.0
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -333,9 +333,10 @@ class FluxWorkload:
         self.model_config.setdefault('guidance', 1.0)          # train.py:113
         state = torch.random.get_rng_state()
         torch.manual_seed(seed)
-        self.transformer = FluxTransformer2DModel(self.cfg)
+        with torch.device(device):               # a GPU workload is initialised in HBM (12 B parameters: seconds instead of minutes of host RNG); 'cpu' = the seeded host stream
+            self.transformer = FluxTransformer2DModel(self.cfg)
         torch.random.set_rng_state(state)
-        self.transformer.to(device=device, dtype=dtype)
+        self.transformer.to(dtype=dtype)
         for n, p in self.transformer.named_parameters():
             p.original_name = n
         self._image_tokens = None

@@ -251,9 +251,10 @@ class WanWorkload:
         self.model_config = model_config or {}
         state = torch.random.get_rng_state()
         torch.manual_seed(seed)
-        self.transformer = WanModel(config)
+        with torch.device(device):               # a GPU workload is initialised in HBM (14 B parameters); 'cpu' = the seeded host stream
+            self.transformer = WanModel(config)
         torch.random.set_rng_state(state)
-        self.transformer.to(device=device, dtype=dtype)
+        self.transformer.to(dtype=dtype)
         for n, p in self.transformer.named_parameters():
             p.original_name = n
         self.t_dist = get_t_distribution(self.model_config)

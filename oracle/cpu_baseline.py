@@ -42,3 +42,81 @@ def sdxl_cpu_baseline(cfg, latent_hw=128, threads=None, micro_batch=None, state=
             'build_seconds': round(t_build, 1), 'loss': float(loss), 'grad_norm': float(norm), 'weights': 'product state dict' if state is not None else 'oracle seed 0',
             'sample': f'oracle fp32 eager path (oracle/sdxl_ref.py + eager_step.py): ONE whole micro-batch = one {latent_hw * 8}x{latent_hw * 8} image '
                       f'through all 23 pipeline layers + loss + backward + clip (1 of the step\'s micro-batches, no optimizer step), {threads} threads'}
+
+
+def dit_block_cpu_baseline(kind, step_flops_per_sample, threads=None):
+    """cpu_baseline dict for the DiT workloads (BASELINE configs 3 - 5), where a whole fp32 step does not fit the bound of ~10 - 30 s of host work
+    (14 B / 13 B parameters in fp32 exceed the host memory of the build box, a HunyuanVideo step is ~11 PFLOP): ONE transformer
+    block of the oracle, forward + backward in fp32, at the workload's real width -- Wan / Flux at the real token count, HunyuanVideo at 1/8 of its
+    61 456 tokens -- gives the host's sustained FLOP rate on this arithmetic; samples/s = that rate / the step's algorithmic FLOPs per sample.  The
+    extrapolation is stated in `sample`."""
+    import torch.nn.functional as F
+    from . import blocks_ref as br, flux_ref
+    threads = threads or min(os.cpu_count() or 1, int(os.environ.get('DPIPE_CPU_BASELINE_THREADS', '32')))
+    prev = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(0)
+    try:
+        if kind == 'wan':
+            dim, ffn, heads, S, L = 5120, 13824, 40, 9216, 512
+            d = dim // heads
+            shapes = {'modulation': (1, 6, dim), 'norm3.weight': (dim,), 'norm3.bias': (dim,), 'ffn.0.weight': (ffn, dim), 'ffn.0.bias': (ffn,),
+                      'ffn.2.weight': (dim, ffn), 'ffn.2.bias': (dim,)}
+            for a in ('self_attn', 'cross_attn'):
+                for n in 'qkvo':
+                    shapes[f'{a}.{n}.weight'], shapes[f'{a}.{n}.bias'] = (dim, dim), (dim,)
+                shapes[f'{a}.norm_q.weight'], shapes[f'{a}.norm_k.weight'] = (dim,), (dim,)
+            p = {k: (torch.randn(s, generator=g) / (s[-1] ** 0.5 if len(s) > 1 else 4.0)).requires_grad_(True) for k, s in shapes.items()}
+            x = torch.randn(1, S, dim, generator=g).requires_grad_(True)
+            e, ctx = torch.randn(1, 1, 6, dim, generator=g) * 0.3, torch.randn(1, L, dim, generator=g)
+            ang = torch.rand(S, d // 2, generator=g) * 6.28
+            cos, sin = torch.cos(ang), torch.sin(ang)
+            fwd = 2 * S * dim * dim * 6 + 2 * 2 * L * dim * dim + 4 * S * S * dim + 4 * S * L * dim + 2 * 2 * S * dim * ffn
+            what = f'ONE Wan2.1-14B block (dim {dim}, ffn {ffn}, {heads} heads, {S} video + {L} text tokens = the real shape; 1 of 40 layers)'
+
+            def run():
+                br.wan_block(p, x, e, ctx, heads, cos, sin, 1e-6).square().mean().backward()
+        elif kind == 'flux':
+            dim, heads, hd, S, L = 3072, 24, 128, 4096, 512
+            blk = flux_ref.FluxTransformerBlock(dim, heads, hd)
+            x = torch.randn(1, S, dim, generator=g).requires_grad_(True)
+            c = torch.randn(1, L, dim, generator=g).requires_grad_(True)
+            temb = torch.randn(1, dim, generator=g)
+            ang = torch.rand(S + L, hd // 2, generator=g) * 6.28
+            rot = (torch.cos(ang).repeat_interleave(2, dim=1), torch.sin(ang).repeat_interleave(2, dim=1))
+            T = S + L
+            fwd = 2 * T * dim * dim * 4 + 4 * T * T * dim + 2 * 2 * T * dim * 4 * dim + 2 * 2 * 6 * dim * dim
+            what = f'ONE Flux.1-dev double-stream block (dim {dim}, {heads} x {hd}, {S} image + {L} text tokens = the real shape; 1 of 19 + 38 blocks)'
+
+            def run():
+                e_out, x_out = blk(x, c, temb, rot)
+                (x_out.square().mean() + e_out.square().mean()).backward()
+        elif kind == 'hv':
+            from . import hv_ref
+            dim, heads, S, L = 3072, 24, 7680, 256
+            blk = hv_ref.MMSingleStreamBlock(dim, heads, 4.0)
+            T = S + L
+            x = torch.randn(1, T, dim, generator=g).requires_grad_(True)
+            vec = torch.randn(1, dim, generator=g)
+            ang = torch.rand(S, dim // heads // 2, generator=g) * 6.28
+            cos, sin = torch.cos(ang), torch.sin(ang)
+            pd = blk.pdict()
+            fwd = 2 * T * dim * (3 * dim + 4 * dim) + 4 * T * T * dim + 2 * T * 5 * dim * dim + 2 * 3 * dim * dim
+            what = (f'ONE HunyuanVideo single-stream block (dim {dim}, {heads} x 128) at {S} video + {L} text tokens = 1/8 of the 61 456-token sequence '
+                    f'of config 5 (attention is 64 x smaller than at full length: the full-length block alone is ~180 TFLOP); 1 of 20 + 40 blocks')
+
+            def run():
+                br.mm_single_block(pd, x, vec, L, heads, cos, sin, None).square().mean().backward()
+        else:
+            raise ValueError(kind)
+        t0 = time.perf_counter()
+        run()
+        dt = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(prev)
+    sample_flops = 3.0 * fwd
+    rate = sample_flops / dt
+    return {'value': rate / step_flops_per_sample, 'unit': 'samples/s', 'cores': threads, 'kind': 'port', 'sample_seconds': round(dt, 3),
+            'host_tflops': round(rate / 1e12, 3), 'sample_tflop': round(sample_flops / 1e12, 2),
+            'sample': f'oracle fp32 eager path, {what}, forward + backward, {threads} threads; value = measured host FLOP rate / the step\'s '
+                      f'algorithmic FLOPs per sample ({step_flops_per_sample / 1e12:.1f} TFLOP) -- an extrapolation, the whole fp32 step does not fit the bound'}

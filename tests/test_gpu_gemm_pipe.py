@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 PIPE = 1000          # tile_hint: pipelined kernel, its own tile / split choice; PIPE + S forces S slices
 T64, T128 = 2000, 3000   # ... with the 64 x 64 / 128 x 128 tile forced (+ S)
 T256K = 9000         # the 256 x 256 tile on a 4-deep ring of 32-wide half K-steps
+T128N64 = 10000      # skinny-M configuration: 128 x 64 tile, 4-deep ring (M <= 128 linears, deeper split-K)
 T128S2, T256, T64S3, T256S = 4000, 5000, 6000, 7000  # further configurations: 128 x 128 with a 2-deep ring, 256 x 128, 64 x 64 with a 3-deep ring,
                                                       # 256 x 256 (the DiT-sized configuration: double-buffered fragments, DMA spread over the K-step)
 
@@ -46,7 +47,7 @@ SHAPES = [(128, 128, 64), (256, 384, 192), (77, 1280, 1280), (100, 72, 128), (10
 @pytest.mark.parametrize('trans', [(False, True), (False, False), (True, False), (True, True)])
 @pytest.mark.parametrize('shape', SHAPES)
 @pytest.mark.parametrize('split', [0, 1, 2, 5])
-@pytest.mark.parametrize('tile', [T64, T128, T128S2, T256, T64S3, T256S, T256K])
+@pytest.mark.parametrize('tile', [T64, T128, T128S2, T256, T64S3, T256S, T256K, T128N64])
 def test_pipe_gemm_matches_fp32_matmul(gpu, trans, shape, split, tile):
     from diffusion_pipe_amd import ops
     from diffusion_pipe_amd.hip import DpipeHipError
@@ -62,6 +63,31 @@ def test_pipe_gemm_matches_fp32_matmul(gpu, trans, shape, split, tile):
     assert out.shape == (M, N)
     assert _rel_err(out, ref) < 1.6e-2
     _assert_close_elementwise(out, ref)
+
+
+SKINNY = [(77, 768, 768), (77, 2304, 768), (77, 768, 3072), (77, 3840, 1280), (77, 1280, 5120), (77, 2560, 2048), (1, 1280, 1280), (128, 320, 256), (77, 264, 320)]
+
+
+@pytest.mark.parametrize('trans', [(False, True), (False, False)])
+@pytest.mark.parametrize('shape', SKINNY, ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('hint', [0, T128N64 + 1, T128N64 + 7, T128N64 + 16])
+def test_skinny_m_gemm_automatic_and_forced_split(gpu, trans, shape, hint):
+    """The 77-token linears of the text encoders / cross-attention K, V projections (forward NT, dgrad NN): the dispatcher's own choice (128 x 64 tile, K cut into
+    slices of >= 4 K-steps reduced by the last arriver over write-through slabs) and forced slice counts, with bias + residual riding the reducer's epilogue;
+    launched twice (ticket re-arm) and compared bit for bit (deterministic slice order)."""
+    from diffusion_pipe_amd import ops
+    ta, tb = trans
+    M, N, K = shape
+    a, b, ref = _operands(gpu, ta, tb, M, N, K, M + 3 * N + 5 * K)
+    g = torch.Generator(device='cpu').manual_seed(N)
+    bias = torch.randn(N, generator=g).to(gpu, torch.bfloat16)
+    res = torch.randn(M, N, generator=g).to(gpu, torch.bfloat16)
+    want = ref + bias.float() + res.float()
+    out = ops.mm(a, b, ta, tb, bias=bias, residual=res, tile_hint=hint)
+    out2 = ops.mm(a, b, ta, tb, bias=bias, residual=res, tile_hint=hint)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+    _assert_close_elementwise(out, want)
 
 
 @pytest.mark.parametrize('K', [77, 8, 200, 1024, 4100])
