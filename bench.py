@@ -26,10 +26,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-if int(os.environ.get('WORLD_SIZE', '1')) > 1:
-    # pp > 1 launches forward / backward stage graphs on two streams with P2P in between and cannot drain the queue per micro-batch:
-    # take the runtime's per-node dispatch path there instead of the AQL-packet-capture path that wedges under multi-stream run-ahead
-    # (engine.max_steps_in_flight).  Must be set before the HIP runtime initialises.
+def _argv_int(flag, default):
+    for i, a in enumerate(sys.argv):
+        if a == flag and i + 1 < len(sys.argv):
+            return int(sys.argv[i + 1])
+        if a.startswith(flag + '='):
+            return int(a.split('=', 1)[1])
+    return default
+
+
+if int(os.environ.get('WORLD_SIZE', '1')) > 1 and _argv_int('--pp', 0) != 1 and os.environ.get('DPIPE_PP_PACKET_CAPTURE', '0') != '1':
+    # pp > 1 launches forward / backward stage graphs on two streams with P2P in between: take the runtime's per-node dispatch path there instead of the
+    # AQL-packet-capture path that wedged under multi-stream run-ahead in round 2.  DPIPE_PP_PACKET_CAPTURE=1 keeps the packet-capture
+    # path (the engine drains the queue once per optimizer step at every pp: engine.max_steps_in_flight).  Must be set before the HIP runtime initialises.
+    # Pure data parallelism (--pp 1) runs the single-stage lane path of the N = 1 line and keeps packet capture.
     os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
 
 import torch
@@ -41,7 +51,9 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--gas', type=int, default=0, help='micro-batches per step (default 6 * gpus)')
+    ap.add_argument('--gas', type=int, default=0, help='micro-batches per step per replica (default 6 * pp)')
+    ap.add_argument('--pp', type=int, default=0, help='pipeline stages (default: = gpus, the BASELINE metric\'s pp = N line); gpus / pp data-parallel replicas of the pipeline')
+    ap.add_argument('--p2p', default='auto', choices=['auto', 'rccl', 'torch'], help='stage-to-stage link (engine p2p_backend)')
     ap.add_argument('--config', default='full', choices=['full', 'tiny'])
     ap.add_argument('--workload', default='sdxl', choices=['sdxl', 'flux', 'wan', 'hv'],
                     help='sdxl = BASELINE config 2 (the metric\'s configuration, the default); flux / wan / hv = BASELINE configs 3 / 4 / 5 as real steps on '
@@ -206,7 +218,8 @@ def run_dit_workload(args, device, world, rank):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     engine_mod.TRACE = None
-    peak_hbm = torch.cuda.max_memory_allocated(device)
+    free_b, total_b = torch.cuda.mem_get_info(device)
+    peak_hbm = max(torch.cuda.max_memory_reserved(device), total_b - free_b)      # the hipGraph pools hold the saved activations: reserved, not "allocated"
     gnorm = engine.get_global_grad_norm()
     gnorm = float(gnorm.item()) if gnorm is not None else float('nan')
     if not trace_in_timed:
@@ -320,8 +333,11 @@ def main():
     args.lanes = args.lanes or 3
     cfg = sdxl.SDXLConfig() if args.config == 'full' else sdxl.tiny_config()
     latent = args.latent if args.config == 'full' else 32
-    pp = world
-    gas = args.gas or 6 * world
+    pp = args.pp or world
+    if world % pp:
+        raise SystemExit(f'--pp {pp} does not divide {world} ranks')
+    dp = world // pp
+    gas = args.gas or 6 * pp
     work = sdxl.SDXLWorkload(cfg, dtype=torch.bfloat16, seed=0, device=device)
     layers = work.to_layers()
     kwargs = {}
@@ -333,7 +349,7 @@ def main():
                                   dynamic_shape=True, **kwargs)
     engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 1, 'gradient_accumulation_steps': gas,
                                                          'gradient_clipping': 1.0, 'steps_per_print': 1 << 30, 'hip_graph': not args.no_graph,
-                                                         'parallel_wgrad': args.parallel_wgrad, 'p2p_via_host': args.test_single_device, 'graph_lanes': args.lanes,
+                                                         'parallel_wgrad': args.parallel_wgrad, 'p2p_via_host': args.test_single_device, 'graph_lanes': args.lanes, 'p2p_backend': args.p2p,
                                                          'max_steps_in_flight': args.steps_in_flight}, device=device)
     params = [p for p in module.parameters() if p.requires_grad]
 
@@ -441,7 +457,9 @@ def main():
             'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': f'SDXL {latent * 8}x{latent * 8} full fine-tune (UNet + both CLIP text encoders trained), micro-batch 1 per stage, '
                                    f'pp={pp}, GAS={gas}, AdamW, clip 1.0' + (' [tiny test config]' if args.config != 'full' else ''),
-                       'global_batch': images, 'parallelism': f'pp{pp}', 'gradient_accumulation_steps': gas,
+                       'global_batch': images, 'parallelism': f'pp{pp}' + (f' x dp{dp}' if dp > 1 else ''), 'gradient_accumulation_steps': gas,
+                       'stage_link': type(engine.link).__name__ if engine.link is not None else None,
+                       'graph_packet_capture': os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '1') != '0',
                        'activation_checkpointing': bool(args.activation_checkpointing), 'partition': module.parts, 'hip_graph': bool(engine.use_graph or engine.use_stage_graphs),
                        'concurrent_micro_batch_lanes': engine.graph_lanes},
             'loss': float(loss.item()), 'grad_norm': float(gnorm),

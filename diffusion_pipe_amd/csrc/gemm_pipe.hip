@@ -31,6 +31,10 @@ bool gemm_pipe_try(GemmParams& p, int transA, int transB, int batch, void* ws, l
     case 128: *rc_out = launch_pipe<T128>(p, a_mc, b_mc, batch, s); break;
     case 130: *rc_out = launch_pipe<T128S5>(p, a_mc, b_mc, batch, s); break;
     case 1264: *rc_out = launch_pipe<T128N64>(p, a_mc, b_mc, batch, s); break;
+    case 1256: *rc_out = launch_pipe<T128x256W>(p, a_mc, b_mc, batch, s); break;
+    case 2561: *rc_out = launch_pipe<T256x128W>(p, a_mc, b_mc, batch, s); break;
+    case 1284: *rc_out = launch_pipe<T128W4>(p, a_mc, b_mc, batch, s); break;
+    case 1282: *rc_out = launch_pipe<T128W4R2>(p, a_mc, b_mc, batch, s); break;
     default: *rc_out = launch_pipe<T64>(p, a_mc, b_mc, batch, s); break;
     }
     return true;
@@ -53,13 +57,13 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
     // flight shorten the vmcnt wait: +5 .. +6 % (9216 x 5120 x 13824 NN: 996 vs 940 TFLOP/s).  A K-contiguous operand pays for half steps with 64-byte pieces
     // (half a cache line per row per step) and twice the barriers: NT is 8 % slower on T256K and stays on T256S (8192^3: 1 292 vs 1 184)
     if (force_tile == 0 && !a_mc && p.ksteps >= 64 && tiles256 >= 128) force_tile = b_mc ? 258 : 257;
-    // skinny M (<= 128 rows: the 77-token linears of the text encoders / cross-attention K, V): one 128-row tile covers A, 64-wide N tiles, and the K
-    // range is cut into slices of ~4 K-steps (all of a slice's DMA in flight at once: one HBM round trip per workgroup instead of ksteps / 3)
-    // until about two workgroups per CU exist -- these GEMMs are pure weight streaming, bounded by the serial K walk of few workgroups
-    const bool skinny = force_tile == 1264 || (force_tile == 0 && p.M <= 128 && p.N >= 256 && p.ksteps >= 4 && option(DPIPE_OPT_GEMM_SKINNY, 1) != 0);
+    // skinny M (<= 128 rows: the 77-token linears of the text encoders / cross-attention K, V): one 128-row tile covers A, 64-wide N tiles, K cut into
+    // slices of ~4 K-steps.  MEASURED SLOWER than the 64^2 tile on every such shape of the SDXL step (profiles/r3_gemm_desc_ledger.jsonl: 10.0 - 36 vs
+    // 7.9 - 27 us unsplit, 56 vs 39 ms per step over the M <= 128 launches): opt-in only (DPIPE_GEMM_SKINNY=1 / tile_hint 10000 + S)
+    const bool skinny = force_tile == 1264 || (force_tile == 0 && p.M <= 128 && p.N >= 256 && p.ksteps >= 4 && option(DPIPE_OPT_GEMM_SKINNY, 0) != 0);
     if (skinny) force_tile = 1264;
-    const int bm = (force_tile == 256 || force_tile == 257 || force_tile == 258) ? 256 : (big || skinny) ? 128 : 64,
-              bn = force_tile == 256 ? 128 : skinny ? 64 : bm;
+    const int bm = (force_tile == 256 || force_tile == 257 || force_tile == 258 || force_tile == 2561) ? 256 : (big || skinny) ? 128 : 64,
+              bn = (force_tile == 256 || force_tile == 2561) ? 128 : skinny ? 64 : force_tile == 1256 ? 256 : bm;
     p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bn - 1) / bn;
     const long tiles = (long)p.tiles_m * p.tiles_n * batch;
     const long slab_bytes = ((long)bm * bn + bm) * 4;
@@ -68,8 +72,12 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
         if (force_splitk > 0) S = force_splitk;
         else if (skinny) {
             S = (int)(512 / tiles); const int cap = p.ksteps / 4; if (S > cap) S = cap; if (S > 16) S = 16;
-        } else if (!big && tiles <= 128 && p.ksteps >= 32) {   // every slice pays an agent-scope release: only few, long tiles split
+        } else if (!big && tiles <= 128 && p.ksteps >= 32) {   // few, long tiles split
             S = (int)(512 / tiles); const int cap = p.ksteps / 8; if (S > cap) S = cap; if (S > 4) S = 4;
+        } else if (!big && tiles <= 64 && p.ksteps >= 16) {
+            // <= 64 tiles of 16 .. 31 K-steps (the 77-token and 1-token linears at K = 1 280 / 1 024): four slices of >= 4 K-steps -- with write-through
+            // slabs a slice no longer pays an L2 write-back scan (profiles/r3_gemm_desc_ledger.jsonl: NN 15.1 -> 9.2 us, NT 11.1 -> 10.4 us at [77, 1280, 1280])
+            S = 4; const int cap = p.ksteps / 4; if (S > cap) S = cap;
         } else if (big && long_k && tiles <= 128) {
             S = (int)(256 / tiles); if (S > 3) S = 3; if (S < 2) S = 2;      // one round of workgroups: 80 tiles x 3, 120 x 2 (measured: tools/kernel_timing.py, tools/conv_timing.py)
         } else if (big && long_k && tiles < 256) {
@@ -95,7 +103,7 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
     if (c_ok && p.residual && reinterpret_cast<uintptr_t>(p.residual) % 8 == 0 && p.ldr % 4 == 0) p.vecA = 3;   // 8-byte residual loads too
     p.vecB = (p.bias && reinterpret_cast<uintptr_t>(p.bias) % 8 == 0) ? 2 : 0;
     if (force_tile == 258) { p.ksteps *= 2; p.ksteps_per_split *= 2; return 258; }      // T256K counts K in 32-wide half steps (slices keep their K ranges)
-    if (force_tile == 257 || force_tile == 256 || force_tile == 63 || force_tile == 130 || force_tile == 1264) return force_tile;
+    if (force_tile == 257 || force_tile == 256 || force_tile == 63 || force_tile == 130 || force_tile == 1264 || force_tile == 1256 || force_tile == 2561 || force_tile == 1284 || force_tile == 1282) return force_tile;
     if (force_tile == 129 || (force_tile == 0 && big && tiles128 >= 256 && (a_mc || b_mc || tiles128 >= 1024))) return 129;
     return big ? 128 : 64;
 }

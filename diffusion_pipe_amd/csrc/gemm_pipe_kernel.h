@@ -79,6 +79,13 @@ using T256 = Tile<256, 128, 4, 2, 3>;       // selectable, not chosen automatica
 using T256K = Tile<256, 256, 2, 4, 4, 32>;  // the same 256 x 256 tile on a 4-deep ring of HALF K-steps (32 k, 32 KiB each; the same 128 KiB of LDS): three half steps in flight instead of
                                             // one whole step -- the 2-deep ring parks every wave ~1 100 cycles per K-step at vmcnt (timeline probe), its refill can only be issued
                                             // once the whole previous step has been consumed
+using T128x256W = Tile<128, 256, 1, 4, 3>;  // FOUR waves of 128 x 64 (8 MFMA tiles each, one wave per SIMD) on a 128 x 256 tile, 3 x 48 KiB: the LDS-traffic-lean configuration for
+using T256x128W = Tile<256, 128, 2, 2, 3>;  // SDXL's big linears (M = 1 024 tokens x N = 5 120 / 10 240, and the transposed wgrad shapes).  Why: per K-step an 8-wave 128^2 tile moves
+                                            // 32 KiB INTO the LDS and reads 96 KiB OUT of it (A fragments by 4 waves, B by 2) for 512 MFMA cycles per SIMD = 256 B/clk, the LDS peak --
+                                            // the reason every 128^2 / 256 x 128 eight-wave variant lands within 5 % of the others on these shapes (profiles/r3_gemm_desc_ledger.jsonl);
+                                            // 128 x 64 wave tiles read 96 KiB + write 48 KiB per 1 024 MFMA cycles = 140 B/clk and still give 320 tiles for [1024, 10240]
+using T128W4 = Tile<128, 128, 2, 2, 3>;     // the same idea on the 128^2 tile: FOUR waves of 64 x 64 (4 MFMA tiles each): 64 KiB of fragment reads per K-step instead of 96 (188 B/clk),
+using T128W4R2 = Tile<128, 128, 2, 2, 2>;   // 3-deep ring (1 workgroup per CU) / 2-deep ring (64 KiB: 2 workgroups per CU whose phases are independent)
 using T256S = Tile<256, 256, 2, 4, 2>;      // 256 x 256, 8 waves of 128 x 64 (128 accumulator VGPRs), 2 x 64 KiB: twice the MFMA work per DMA'd
                                             // byte of the 128^2 tile -- the large-GEMM configuration (DiT-sized linears: Flux / Wan / HunyuanVideo)
 
@@ -91,7 +98,16 @@ __device__ __forceinline__ float frag_sum(bf16x8_t f) {
 
 // counted wait for this wave's LDS-DMA: `ahead` later K-steps (NLOAD DMA instructions each) may stay in flight
 template <int NLOAD> __device__ __forceinline__ void wait_dma_ahead(int ahead) {
-    static_assert(NLOAD == 4 || NLOAD == 6 || NLOAD == 8, "DMA pieces per wave per K-step");
+    static_assert(NLOAD == 4 || NLOAD == 6 || NLOAD == 8 || NLOAD == 12, "DMA pieces per wave per K-step");
+    if constexpr (NLOAD == 12) {
+        switch (ahead) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
+        }
+        return;
+    }
     if constexpr (NLOAD == 8) {
         switch (ahead) {
         case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -124,7 +140,7 @@ template <int NLOAD> __device__ __forceinline__ void wait_dma_ahead(int ahead) {
 // zeros, so no im2col matrix and no padded copy ever exists.  CONV = 2: wgrad, one GEMM per tap (grid.y): the B operand's K-ROWS are
 // the gathered pixels (k = output pixel, n = input channel), A = dy read MN-contiguous.
 template <int BM_, int BN_, int WM_, int WN_, int STAGES_, bool A_MC, bool B_MC, int CONV = 0, int BKT = 64>
-__global__ void __launch_bounds__(512) gemm_pipe_kernel(const GemmParams p) {
+__global__ void __launch_bounds__(WM_ * WN_ * 64) gemm_pipe_kernel(const GemmParams p) {      // 4-wave configurations: one wave per SIMD may use the whole 512-register file
     using TL = Tile<BM_, BN_, WM_, WN_, STAGES_, BKT>;
     constexpr int BM = TL::BM, BN = TL::BN, STAGES = TL::STAGES, TM = TL::TM, TN = TL::TN, NLOAD = TL::NLOAD;
     constexpr int BK = BKT, KS = BKT / 16;          // (shadows the namespace default) k extent of a stage, 16-wide k-slices per stage

@@ -10,6 +10,7 @@
 // reductions by wavefront shuffles, statistics in fp32, 16-byte accesses.
 #include "dpipe_common.h"
 #include "../../include/dpipe_hip.h"
+#include <stdlib.h>
 
 using namespace dpipe;
 
@@ -181,6 +182,35 @@ __global__ void __launch_bounds__(NB) slabsum2_kernel(const float* __restrict__ 
     out0[i] = Elem<O>::from_f(a);
     if (out1) out1[i] = Elem<O>::from_f(b);
 }
+// the same over MANY slabs (the fused LayerNorm backward leaves rows / 16 partial rows): 32 columns x 8 slab lanes per block, each lane walks every 8th slab
+// with 8 loads in flight, the lanes combine through LDS -- deterministic (fixed lane / slab order)
+template <typename O>
+__global__ void __launch_bounds__(NB) slabsum2p_kernel(const float* __restrict__ p0, const float* __restrict__ p1, O* __restrict__ out0,
+                                                       O* __restrict__ out1, int cols, int slabs, int accumulate) {
+    __shared__ float red[2][8][32];
+    const int ct = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + ct;
+    const long g = blockIdx.y;
+    float a = 0.f, b = 0.f;
+    if (c < cols) {
+#pragma unroll 8
+        for (int s = sl; s < slabs; s += 8) {
+            a += p0[(g * slabs + s) * cols + c];
+            b += p1[(g * slabs + s) * cols + c];
+        }
+    }
+    red[0][sl][ct] = a; red[1][sl][ct] = b;
+    __syncthreads();
+    if (threadIdx.x < 32 && c < cols) {
+        float u = 0.f, v = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { u += red[0][r][ct]; v += red[1][r][ct]; }
+        const long i = g * cols + c;
+        if (accumulate) { u += Elem<O>::to_f(out0[i]); if (out1) v += Elem<O>::to_f(out1[i]); }
+        out0[i] = Elem<O>::from_f(u);
+        if (out1) out1[i] = Elem<O>::from_f(v);
+    }
+}
 template <typename O>
 __global__ void __launch_bounds__(NB) slabsum_kernel(const float* __restrict__ partial, O* __restrict__ out, long groups, int cols, int slabs, int accumulate) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -273,67 +303,117 @@ __global__ void __launch_bounds__(NB) lnmod_fwd_kernel(const T* __restrict__ x, 
 }
 // dxhat = gy * (1+scale) * gamma ;  dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)) (+ gadd: the gradient that reached x
 // through the residual branch around this norm, added here instead of by a separate elementwise kernel)
-template <typename T, typename W, typename M, int LPR>
+//
+// FUSE != 0 (rows that fit the register cache, cols <= 64 * V * RC): the per-column parameter-gradient sums ride this pass as well -- every lane keeps
+// fp32 accumulators for the columns it owns over the RW rows its wave walks, the block's waves combine through LDS and ONE partial row per block goes
+// to the workspace (p0 / p1, [groups][slabs][cols]); slabsum2 then finishes.  The separate column-reduction launch, which re-read x and gy, is gone:
+//   FUSE 1: (dgamma, dbeta):  p0 += dn * xhat, p1 += dn         with dn = gy * (1 + scale)
+//   FUSE 2: (dscale, dshift): p0 += gy * (xhat * gamma + beta), p1 += gy
+template <typename T, typename W, typename M, int LPR, int FUSE = 0, int RW = 1>
 __global__ void __launch_bounds__(NB) lnmod_bwd_dx_kernel(const T* __restrict__ x, const T* __restrict__ gy, const W* __restrict__ gamma,
                                                           const M* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                          T* __restrict__ gx, const T* __restrict__ gadd, long rows, int cols, long rows_per_mod) {
+                                                          T* __restrict__ gx, const T* __restrict__ gadd, long rows, int cols, long rows_per_mod,
+                                                          const W* __restrict__ beta = nullptr, float* __restrict__ p0 = nullptr, float* __restrict__ p1 = nullptr,
+                                                          int slabs = 1) {
     constexpr int V = Elem<T>::VEC;
     constexpr int RPB = NB / LPR;
-    const int sub = threadIdx.x % LPR;
-    const long row = (long)blockIdx.x * RPB + threadIdx.x / LPR;
-    const bool live = row < rows;
-    const long r = live ? row : 0;
-    const T* xr = x + r * (long)cols; const T* gr = gy + r * (long)cols;
-    const float mu = mean[r], rs = rstd[r];
-    const long b = r / rows_per_mod;
     constexpr int RC = 4;                         // see lnmod_fwd_kernel: rows that fit stay in registers between the two passes
-    const bool cached = cols <= LPR * V * RC;
-    Vec16<T> rx[RC], rg[RC];
-    float s1 = 0.f, s2 = 0.f;
-    auto pass1 = [&](int c, const Vec16<T>& vx, const Vec16<T>& vg) {
-        float fx[V], fg[V]; vx.unpack(fx); vg.unpack(fg);
+    const int sub = threadIdx.x % LPR;
+    const int wave = threadIdx.x / LPR;
+    const bool cached = FUSE != 0 || cols <= LPR * V * RC;
+    float a0[FUSE ? RC : 1][V], a1[FUSE ? RC : 1][V];
+    if (FUSE) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-            float d = fg[j] * (scale ? 1.f + Elem<M>::to_f(scale[b * cols + c + j]) : 1.f) * (gamma ? Elem<W>::to_f(gamma[c + j]) : 1.f);
-            s1 += d; s2 += d * (fx[j] - mu) * rs;
-        }
-    };
-    if (cached) {
+        for (int k = 0; k < RC; ++k)
 #pragma unroll
-        for (int k = 0; k < RC; ++k) {
-            const int c = (sub + k * LPR) * V;
-            if (c < cols) { rx[k].load(xr + c); rg[k].load(gr + c); pass1(c, rx[k], rg[k]); }
-        }
-    } else {
-        for (int c = sub * V; c < cols; c += LPR * V) { Vec16<T> vx, vg; vx.load(xr + c); vg.load(gr + c); pass1(c, vx, vg); }
+            for (int j = 0; j < V; ++j) { a0[k][j] = 0.f; a1[k][j] = 0.f; }
     }
-    s1 = group_sum<LPR>(s1) / (float)cols;
-    s2 = group_sum<LPR>(s2) / (float)cols;
-    if (!live) return;
-    T* o = gx + row * (long)cols;
-    auto pass2 = [&](int c, const Vec16<T>& vx, Vec16<T>& vg) {
-        float fx[V], fg[V]; vx.unpack(fx); vg.unpack(fg);
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-            float d = fg[j] * (scale ? 1.f + Elem<M>::to_f(scale[b * cols + c + j]) : 1.f) * (gamma ? Elem<W>::to_f(gamma[c + j]) : 1.f);
-            fg[j] = rs * (d - s1 - (fx[j] - mu) * rs * s2);
-        }
-        if (gadd) {
-            Vec16<T> va; va.load(gadd + row * (long)cols + c);
-            float fa[V]; va.unpack(fa);
+    for (int t = 0; t < RW; ++t) {
+        const long row = ((long)blockIdx.x * RW + t) * RPB + wave;
+        const bool live = row < rows;
+        const long r = live ? row : 0;
+        const T* xr = x + r * (long)cols; const T* gr = gy + r * (long)cols;
+        const float mu = mean[r], rs = rstd[r];
+        const long b = r / rows_per_mod;
+        Vec16<T> rx[RC], rg[RC];
+        float s1 = 0.f, s2 = 0.f;
+        auto pass1 = [&](int c, const Vec16<T>& vx, const Vec16<T>& vg) {
+            float fx[V], fg[V]; vx.unpack(fx); vg.unpack(fg);
 #pragma unroll
-            for (int j = 0; j < V; ++j) fg[j] += fa[j];
+            for (int j = 0; j < V; ++j) {
+                float d = fg[j] * (scale ? 1.f + Elem<M>::to_f(scale[b * cols + c + j]) : 1.f) * (gamma ? Elem<W>::to_f(gamma[c + j]) : 1.f);
+                s1 += d; s2 += d * (fx[j] - mu) * rs;
+            }
+        };
+        if (cached) {
+#pragma unroll
+            for (int k = 0; k < RC; ++k) {
+                const int c = (sub + k * LPR) * V;
+                if (c < cols) { rx[k].load(xr + c); rg[k].load(gr + c); pass1(c, rx[k], rg[k]); }
+            }
+        } else {
+            for (int c = sub * V; c < cols; c += LPR * V) { Vec16<T> vx, vg; vx.load(xr + c); vg.load(gr + c); pass1(c, vx, vg); }
         }
-        vg.pack(fg); vg.store(o + c);
-    };
-    if (cached) {
+        s1 = group_sum<LPR>(s1) / (float)cols;
+        s2 = group_sum<LPR>(s2) / (float)cols;
+        if (!live) continue;                       // (wave-uniform: a wave owns whole rows)
+        T* o = gx + row * (long)cols;
+        auto pass2 = [&](int c, int k, const Vec16<T>& vx, Vec16<T>& vg) {
+            float fx[V], fg[V]; vx.unpack(fx); vg.unpack(fg);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float sc = scale ? 1.f + Elem<M>::to_f(scale[b * cols + c + j]) : 1.f;
+                const float gm = gamma ? Elem<W>::to_f(gamma[c + j]) : 1.f;
+                const float xhat = (fx[j] - mu) * rs;
+                if (FUSE == 1) { const float dn = fg[j] * sc; a0[FUSE ? k : 0][j] += dn * xhat; a1[FUSE ? k : 0][j] += dn; }
+                if (FUSE == 2) { a0[FUSE ? k : 0][j] += fg[j] * (xhat * gm + (beta ? Elem<W>::to_f(beta[c + j]) : 0.f)); a1[FUSE ? k : 0][j] += fg[j]; }
+                const float d = fg[j] * sc * gm;
+                fg[j] = rs * (d - s1 - xhat * s2);
+            }
+            if (gadd) {
+                Vec16<T> va; va.load(gadd + row * (long)cols + c);
+                float fa[V]; va.unpack(fa);
+#pragma unroll
+                for (int j = 0; j < V; ++j) fg[j] += fa[j];
+            }
+            vg.pack(fg); vg.store(o + c);
+        };
+        if (cached) {
+#pragma unroll
+            for (int k = 0; k < RC; ++k) {
+                const int c = (sub + k * LPR) * V;
+                if (c < cols) pass2(c, k, rx[k], rg[k]);
+            }
+        } else {
+            for (int c = sub * V; c < cols; c += LPR * V) { Vec16<T> vx, vg; vx.load(xr + c); vg.load(gr + c); pass2(c, 0, vx, vg); }
+        }
+    }
+    if (FUSE) {
+        // block partial: the RPB waves' accumulators, one LPR * V column chunk at a time through LDS -> workspace row of this block's slab
+        __shared__ float red[2][RPB][LPR * V];
+        const long row0 = (long)blockIdx.x * RW * RPB;
+        const long grp = row0 / rows_per_mod;
+        const long slab = (row0 - grp * rows_per_mod) / (RW * RPB);
+        float* o0 = p0 + (grp * slabs + slab) * (long)cols;
+        float* o1 = p1 + (grp * slabs + slab) * (long)cols;
 #pragma unroll
         for (int k = 0; k < RC; ++k) {
-            const int c = (sub + k * LPR) * V;
-            if (c < cols) pass2(c, rx[k], rg[k]);
+            if (k * LPR * V >= cols) break;           // block-uniform
+            if (k) __syncthreads();
+#pragma unroll
+            for (int j = 0; j < V; ++j) { red[0][wave][sub * V + j] = a0[k][j]; red[1][wave][sub * V + j] = a1[k][j]; }
+            __syncthreads();
+            for (int cc = threadIdx.x; cc < LPR * V; cc += NB) {
+                const int c = k * LPR * V + cc;
+                if (c < cols) {
+                    float u0 = 0.f, u1 = 0.f;
+#pragma unroll
+                    for (int w = 0; w < RPB; ++w) { u0 += red[0][w][cc]; u1 += red[1][w][cc]; }
+                    o0[c] = u0; o1[c] = u1;
+                }
+            }
         }
-    } else {
-        for (int c = sub * V; c < cols; c += LPR * V) { Vec16<T> vx, vg; vx.load(xr + c); vg.load(gr + c); pass2(c, vx, vg); }
     }
 }
 
@@ -446,6 +526,8 @@ template <typename T> struct Tag { using type = T; };
 #define BAD(msg) do { set_last_error(msg); return DPIPE_ERR_ARG; } while (0)
 
 static inline int pick_lpr(int cols, int vec) { return (cols / vec) <= 16 ? 16 : 64; }
+// A/B switch (environment DPIPE_LNMOD_FUSE=0): LayerNorm backward with the separate column-reduction launch instead of the fused partials
+static inline bool lnmod_fuse_enabled() { static const int on = [] { const char* e = getenv("DPIPE_LNMOD_FUSE"); return e ? atoi(e) : 1; }(); return on != 0; }
 
 // dispatch helper over (T, W) where W in {T, float}
 #define DISPATCH_TW(dtype, wdtype, ...)                                         \
@@ -527,7 +609,22 @@ int dpipe_lnmod_bwd(const void* x, const void* gy, const void* gamma, const void
     const unsigned grid = (unsigned)cdiv(rows, NB / 64);
     const long groups = rows / rows_per_mod;
     const int slabs_all = dpipe_norm_slabs(rows), slabs_mod = dpipe_norm_slabs(rows_per_mod);
+    // fused parameter-gradient partials (see lnmod_bwd_dx_kernel): rows that fit the register cache, exactly one pair of column sums wanted, and modulation
+    // groups made of whole blocks.  RW = 4 rows per wave from 1 024 rows on (16 rows per block -> rows / 16 partial rows), else 1.
+    const int vec_cols = 64 * V * 4;
+    const int rw = rows_per_mod >= 1024 && rows_per_mod % 16 == 0 ? 4 : 1;
+    const bool fuse_ok = cols <= vec_cols && ((dgamma != nullptr) != (dscale != nullptr)) && (groups == 1 || rows_per_mod % (4 * rw) == 0) && lnmod_fuse_enabled();
+    const int fslabs = fuse_ok ? (int)cdiv(rows_per_mod, 4 * rw) : 0;
+#define LNBWD_FUSED(TT, WW, MM, FU, RWW) do { \
+    float* p0 = workspace; float* p1 = workspace + groups * fslabs * (long)cols; \
+    lnmod_bwd_dx_kernel<TT, WW, MM, 64, FU, RWW><<<(unsigned)cdiv(rows, 4 * RWW), NB, 0, s>>>((const TT*)x, (const TT*)gy, (const WW*)gamma, (const MM*)scale, mean, rstd, (TT*)gx, \
+        (const TT*)gx_add, rows, cols, rows_per_mod, (const WW*)beta, p0, p1, fslabs); \
+    if (FU == 1) slabsum2p_kernel<WW><<<dim3((unsigned)cdiv(cols, 32), 1), NB, 0, s>>>(p0, p1, (WW*)dgamma, (WW*)dbeta, cols, (int)(groups * fslabs), accumulate_params); \
+    else slabsum2p_kernel<MM><<<dim3((unsigned)cdiv(cols, 32), (unsigned)groups), NB, 0, s>>>(p0, p1, (MM*)dscale, (MM*)dshift, cols, fslabs, 0); \
+    } while (0)
 #define LNBWD(TT, WW, MM) do { \
+    if (fuse_ok && dgamma) { if (rw == 4) LNBWD_FUSED(TT, WW, MM, 1, 4); else LNBWD_FUSED(TT, WW, MM, 1, 1); break; } \
+    if (fuse_ok && dscale) { if (rw == 4) LNBWD_FUSED(TT, WW, MM, 2, 4); else LNBWD_FUSED(TT, WW, MM, 2, 1); break; } \
     lnmod_bwd_dx_kernel<TT, WW, MM, 64><<<grid, NB, 0, s>>>((const TT*)x, (const TT*)gy, (const WW*)gamma, (const MM*)scale, mean, rstd, (TT*)gx, (const TT*)gx_add, rows, cols, rows_per_mod); \
     if (dscale) { \
         float* p0 = workspace; float* p1 = workspace + groups * slabs_mod * (long)cols; \
@@ -551,12 +648,16 @@ int dpipe_lnmod_bwd(const void* x, const void* gy, const void* gamma, const void
     } else if (dtype == DPIPE_F32 && wdtype == DPIPE_F32 && mdtype == DPIPE_F32) LNBWD(float, float, float);
     else { set_last_error("dpipe_lnmod_bwd: dtype combination"); return DPIPE_ERR_UNSUPPORTED; }
 #undef LNBWD
+#undef LNBWD_FUSED
     return check_launch("dpipe_lnmod_bwd");
 }
 
 int dpipe_lnmod_workspace_floats(long rows, int cols, long rows_per_mod) {
     long groups = rows / rows_per_mod;
-    return (int)(2 * groups * dpipe_norm_slabs(rows_per_mod) * (long)cols);
+    long slabs = dpipe_norm_slabs(rows_per_mod);
+    const long fused = (rows_per_mod + 3) / 4;          // the fused backward writes one partial row per 4 (or 16) rows of a group (ragged tail block included)
+    if (cols <= 2048 && fused > slabs) slabs = fused;     // (the fused path exists for rows that fit the register cache only)
+    return (int)(2 * groups * slabs * (long)cols);
 }
 
 // out[c] (+)= sum_r x[r, c]: bias gradients of nn.Linear (db = column sums of dy).  workspace: dpipe_norm_slabs(rows) * cols floats.

@@ -48,6 +48,48 @@ def _as_list(x):
     return list(x) if isinstance(x, (tuple, list)) else [x]
 
 
+def flatten_grads(params, arenas=None):
+    """Re-home the existing `.grad` tensors of `params` into ONE flat buffer per dtype (a "gradient arena") and return {dtype: flat tensor}.
+
+    The data-parallel reduction and the lane summation then run on a handful of large contiguous views instead of thousands of tensors, with no
+    `torch.cat` staging copy and no copy back.  Gradients that share a storage -- the packed weight / bias gradients of a
+    fused QKV projection (ops.pack_parameters) -- move as one block, so their back-to-back layout survives.  Strides are preserved (channels-last
+    convolution weights keep channels-last gradients).  Gradients already inside `arenas` are left alone; gradients that appear later (a new tuple
+    layout reaching a parameter for the first time) simply stay outside and are handled one by one."""
+    arenas = dict(arenas or {})
+    inside = {dt: (a.untyped_storage().data_ptr()) for dt, a in arenas.items()}
+    blocks, sizes = {}, {}
+    for p in params:
+        g = p.grad
+        if g is None or inside.get(g.dtype) == g.untyped_storage().data_ptr():
+            continue
+        if g.dtype in arenas:
+            continue                                   # late arrival: an arena of this dtype exists already (its size is baked into captured graphs)
+        st = g.untyped_storage()
+        if st.data_ptr() not in blocks:
+            nel = st.nbytes() // g.element_size()
+            off = sizes.get(g.dtype, 0)
+            blocks[st.data_ptr()] = (g.dtype, off)
+            sizes[g.dtype] = off + (nel + 127) // 128 * 128
+    if not blocks:
+        return arenas
+    dev = next(p.grad.device for p in params if p.grad is not None)
+    for dt, n in sizes.items():
+        arenas[dt] = torch.zeros(n, dtype=dt, device=dev)
+    with torch.no_grad():
+        for p in params:
+            g = p.grad
+            if g is None:
+                continue
+            hit = blocks.get(g.untyped_storage().data_ptr())
+            if hit is None or hit[0] != g.dtype:
+                continue
+            view = torch.as_strided(arenas[g.dtype], g.shape, g.stride(), hit[1] + g.storage_offset())
+            view.copy_(g)
+            p.grad = view
+    return arenas
+
+
 class PipelineEngine:
     def __init__(self, module, config, args=None, optimizer=None, lr_scheduler=None, model_parameters=None, device=None):
         assert isinstance(module, PipelineModule), 'model must be a PipelineModule'
@@ -97,6 +139,11 @@ class PipelineEngine:
         self.clip_grad_fn = None           # optional whole-function override (the reference patches this, patches.py:429)
         self.grad_kernels = None           # provider of grads_sumsq / grads_clip_scale_; None = HIP kernels (ops.py)
         self.dp_bucket_bytes = int(self._config.get('dp_bucket_bytes', 512 << 20))
+        # flat gradient arenas (one buffer per dtype per lane / stage) whenever gradients are persistent (hipGraph paths) and replicas exist to
+        # reduce over; 'flat_grads': True forces them on a single replica as well (tests, lane summation in one launch per dtype)
+        self.flat_grads = bool(self._config.get('flat_grads', self.dp_world_size > 1))
+        self._stage_arena = {}
+        self._dp_stream = None
         self._last_grad_norm = None
 
         # hipGraph mode: one captured graph per micro-batch shape replaces ~10^4 per-op launches (static shapes only;
@@ -140,10 +187,7 @@ class PipelineEngine:
             from .. import ops as _ops
             _ops.FUSE_GRAD_ACCUM = True     # wgrad / bias / norm-weight kernels add straight into existing .grad buffers
             _ops.PARALLEL_WGRAD = self.use_graph and bool(self._config.get('parallel_wgrad', False))   # dgrad || wgrad as parallel graph branches (measured: no gain on MI355X, off)
-        link_cls = HostStagedLink if (self._config.get('p2p_via_host', False) and self.device.type == 'cuda') else StageLink
-        if link_cls is StageLink and self.device.type == 'cuda' and self._config.get('p2p_backend', 'torch') == 'rccl':
-            link_cls = RcclLink                 # csrc/comm.hip dpipe_send / dpipe_recv: grouped per tuple, receives straight into the slot buffers
-        self.link = link_cls(self.grid, self.device) if self.is_pipe_parallel else None
+        self.link = self._make_link() if self.is_pipe_parallel else None
         self.loss = None
         self.total_loss = None
         self.agg_train_loss = None
@@ -153,6 +197,29 @@ class PipelineEngine:
         self._force_grad_boundary = False
         if self.is_data_parallel:
             self._broadcast_model()
+
+    def _make_link(self):
+        """Stage-to-stage endpoint.  GPU default ('auto'): the C-ABI RCCL link (csrc/comm.hip dpipe_send / dpipe_recv: one grouped operation per tuple,
+        receives straight into the slot buffers) when EVERY rank of the world brings it up and passes its self-test, else torch.distributed's isend /
+        irecv on the same RCCL backend (the decision is a world all-reduce, so the two ends of a boundary can never pick different links)."""
+        if self._config.get('p2p_via_host', False) and self.device.type == 'cuda':
+            return HostStagedLink(self.grid, self.device)
+        backend = self._config.get('p2p_backend', 'auto' if self.device.type == 'cuda' else 'torch')
+        if self.device.type != 'cuda' or backend == 'torch':
+            return StageLink(self.grid, self.device)
+        if backend == 'rccl':
+            return RcclLink(self.grid, self.device)
+        link, ok = None, 1
+        try:
+            link = RcclLink(self.grid, self.device)
+        except Exception as e:                        # noqa: BLE001  (missing RCCL symbols, communicator failure, corrupted self-test pattern)
+            print(f'[dpipe] rank {self.global_rank}: RCCL link unavailable ({e}); stage exchange falls back to torch.distributed isend / irecv', flush=True)
+            ok = 0
+        flag = torch.tensor([ok], device=self.device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            return link
+        return StageLink(self.grid, self.device)
 
     # ------------------------------------------------------------------------------------------------ config
     def train_micro_batch_size_per_gpu(self):
@@ -311,7 +378,7 @@ class PipelineEngine:
         from .. import ops as _ops
         K = min(self.graph_lanes, self.micro_batches)
         while len(self._lanes) < K:
-            self._lanes.append({'id': len(self._lanes), 'stream': torch.cuda.Stream(self.device), 'graphs': {}, 'grads': {},
+            self._lanes.append({'id': len(self._lanes), 'stream': torch.cuda.Stream(self.device), 'graphs': {}, 'grads': {}, 'arena': {},
                                 'loss': torch.zeros((), device=self.device, dtype=torch.float32)})
         lanes = self._lanes[:K]
         params = list(self.module.parameters())
@@ -353,20 +420,34 @@ class PipelineEngine:
             _trace(('step_end', self.global_steps - 1), main)
             return
         # lane 0 owns the step's gradients; add the other lanes' accumulators and losses into it
+        flat_ok = bool(base['arena']) and all(set(l['arena']) == set(base['arena']) and all(l['arena'][d].numel() == base['arena'][d].numel() for d in base['arena'])
+                                              for l in lanes[1:])
+        covered = set()
+        if flat_ok:
+            covered = {dt: (a.untyped_storage().data_ptr()) for dt, a in base['arena'].items()}
         for lane in lanes[1:]:
-            dst = [base['grads'][k] for k in lane['grads'] if k in base['grads']]
-            src = [lane['grads'][k] for k in lane['grads'] if k in base['grads']]
-            if dst:
-                torch._foreach_add_(dst, src)
+            ks = [k for k in lane['grads'] if k in base['grads']]
+            if flat_ok:       # gradients outside the arenas (late arrivals) one by one; the arenas themselves in _reduce_flat (bucket-wise, overlapped with the all-reduce)
+                ks = [k for k in ks if covered.get(base['grads'][k].dtype) != base['grads'][k].untyped_storage().data_ptr()]
+            if ks:
+                torch._foreach_add_([base['grads'][k] for k in ks], [lane['grads'][k] for k in ks])
             base['loss'].add_(lane['loss'])
         for p in params:
             p.grad = base['grads'].get(id(p))
         self.total_loss = base['loss']
         self._exec_reduce_tied_grads()
-        self._exec_reduce_grads()
+        if flat_ok:
+            self._reduce_flat(base['arena'], [l['arena'] for l in lanes[1:]])
+        self._exec_reduce_grads(skip_storages=set(covered.values()) if flat_ok else None)
         self._exec_optimizer_step()                              # zeroes lane 0's buffers (p.grad)
         for lane in lanes[1:]:
-            if lane['grads']:
+            if flat_ok:
+                for a in lane['arena'].values():
+                    a.zero_()
+                rest = [g for g in lane['grads'].values() if covered.get(g.dtype) is None or g.untyped_storage().data_ptr() != lane['arena'][g.dtype].untyped_storage().data_ptr()]
+                if rest:
+                    torch._foreach_zero_(rest)
+            elif lane['grads']:
                 torch._foreach_zero_(list(lane['grads'].values()))
         _trace(('step_end', self.global_steps - 1), main)
 
@@ -405,6 +486,8 @@ class PipelineEngine:
                 body()
         cur.wait_stream(side)
         torch.cuda.synchronize(self.device)
+        if self.flat_grads:                          # the warm-up created this lane's .grad buffers: re-home them into one flat arena per dtype before
+            lane['arena'] = flatten_grads(params, lane['arena'])      # their addresses are baked into the graph
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode=_capture_mode()):
             body()
@@ -483,6 +566,8 @@ class PipelineEngine:
                 del xs, out
         cur.wait_stream(side)
         torch.cuda.synchronize(self.device)
+        if self.flat_grads:
+            self._stage_arena = flatten_grads(params, self._stage_arena)
 
         from .. import ops as _ops
         static_in = make_inputs()
@@ -647,14 +732,55 @@ class PipelineEngine:
     def _exec_reduce_tied_grads(self):
         pass   # the reference's adapters register no tied layers
 
-    def _exec_reduce_grads(self):
-        """Data-parallel gradient average in large flat buckets sized for xGMI / 288 GB HBM."""
+    def _dp_reduce_(self, chunk, group):
+        """in-place data-parallel AVERAGE of one contiguous bucket (RCCL: one all-reduce with the averaging folded in; gloo: sum, then scale)"""
+        if chunk.is_cuda:
+            dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=group)
+        else:
+            dist.all_reduce(chunk, group=group)
+            chunk.div_(self.dp_world_size)
+
+    def _reduce_flat(self, base, others):
+        """Lane summation + data-parallel average over flat gradient arenas, bucket by bucket: bucket k's lane sum runs on the compute
+        stream, its all-reduce on the communication stream behind an event -- so the all-reduce of bucket k overlaps the summation of bucket k + 1 and
+        the xGMI links start moving data as soon as the first bucket is summed.  No staging concatenation, no copy back: the buckets are views of the
+        arenas the wgrad kernels accumulated into.  base: {dtype: flat}; others: the other lanes' arenas (same layout)."""
+        group = self.grid.get_data_parallel_group() if self.is_data_parallel else None
+        cuda = self.device.type == 'cuda'
+        if cuda and group is not None and self._dp_stream is None:
+            self._dp_stream = torch.cuda.Stream(self.device)
+        cur = torch.cuda.current_stream(self.device) if cuda else None
+        for dt, flat in base.items():
+            step = max(1, self.dp_bucket_bytes // flat.element_size())
+            for off in range(0, flat.numel(), step):
+                chunk = flat[off:off + step]
+                for o in others:
+                    chunk.add_(o[dt][off:off + step])
+                if group is None:
+                    continue
+                if cuda:
+                    ev = cur.record_event()
+                    with torch.cuda.stream(self._dp_stream):
+                        self._dp_stream.wait_event(ev)
+                        self._dp_reduce_(chunk, group)
+                else:
+                    self._dp_reduce_(chunk, group)
+        if cuda and group is not None:
+            cur.wait_stream(self._dp_stream)
+
+    def _exec_reduce_grads(self, skip_storages=None):
+        """Data-parallel gradient average.  Persistent-gradient paths keep the gradients in flat arenas (flatten_grads) and reduce those in
+        place, in buckets sized for xGMI / 288 GB HBM; gradients outside an arena (eager path: autograd allocates them per step) are bucketed through a
+        staging concatenation."""
         if not self.is_data_parallel:
             return
         group = self.grid.get_data_parallel_group()
+        if skip_storages is None and self._stage_arena:
+            self._reduce_flat(self._stage_arena, [])
+            skip_storages = {a.untyped_storage().data_ptr() for a in self._stage_arena.values()}
         by_dtype = OrderedDict()
         for p in self._trainable_params():
-            if p.grad is not None:
+            if p.grad is not None and not (skip_storages and p.grad.untyped_storage().data_ptr() in skip_storages):
                 dt = self.communication_data_type or p.grad.dtype
                 by_dtype.setdefault((dt, p.grad.dtype), []).append(p.grad)
         for (comm_dt, _), grads in by_dtype.items():
@@ -664,8 +790,7 @@ class PipelineEngine:
                     bucket.append(g); size += g.numel() * g.element_size()
                 if bucket and (g is None or size >= self.dp_bucket_bytes):
                     flat = torch.cat([b.reshape(-1).to(comm_dt) for b in bucket])
-                    flat.div_(self.dp_world_size)
-                    dist.all_reduce(flat, group=group)
+                    self._dp_reduce_(flat, group)
                     off = 0
                     for b in bucket:
                         b.copy_(flat[off:off + b.numel()].view_as(b)); off += b.numel()

@@ -168,55 +168,82 @@ class RcclLink(StageLink):
     """P2P endpoint on the C-ABI RCCL wrappers (csrc/comm.hip: dpipe_send / dpipe_recv) instead of torch.distributed's
     isend / irecv: one 2-rank communicator per neighbour stage, every tuple leaves as ONE grouped RCCL operation on the communication stream
     (the `batch_isend_irecv` shape), and a receive lands directly in the buffers the caller names (`into=`: a stage graph's static inputs)
-    with no staging copy.  Communicator ids travel over the torch.distributed control plane (`dist.broadcast_object_list`) once.
-    Selected with engine config `p2p_backend: 'rccl'`."""
+    with no staging copy.  Communicator ids travel over the pipeline's torch.distributed group once, at construction.
+    Engine config `p2p_backend`: 'rccl' = this link, 'torch' = StageLink, 'auto' (default on GPU) = this link when its construction + self-test
+    succeed on every rank of the world, else StageLink."""
 
-    def __init__(self, grid, device):
+    def __init__(self, grid, device, self_test=True):
         super().__init__(grid, device)
         from .. import hip
         self._hip = hip
         self._comms = {}            # peer global rank -> (comm handle, peer's rank inside the pair communicator)
+        self._connect()
+        if self_test:
+            self._self_test()
+
+    def _connect(self):
+        """One 2-rank RCCL communicator per neighbour pair of THIS pipeline, created eagerly and in stage order by every rank of the pipeline: the
+        lower stage draws the ncclUniqueId and broadcasts it over the pipeline's existing process group (a collective every stage of the pipeline
+        takes part in, so no extra groups exist and ranks never reach a rendezvous at different points of the schedule); the two neighbours then
+        initialise their communicator.  With data parallelism the pipelines are disjoint rank sets (rank = stage * dp + replica), each does this
+        over its own pipe group."""
+        import ctypes
+        grid = self.grid
+        stages, me = grid.pipe_parallel_size, grid.global_rank
+        group = grid.get_pipe_parallel_group()
+        for s in range(stages - 1):
+            lo, hi = grid.stage_to_global(s), grid.stage_to_global(s + 1)
+            box = [None]
+            if me == lo:
+                buf = ctypes.create_string_buffer(128)
+                self._hip.check(self._hip.lib().dpipe_comm_unique_id(buf), 'comm_unique_id')
+                box[0] = buf.raw
+            dist.broadcast_object_list(box, src=lo, group=group)
+            if me in (lo, hi):
+                comm = ctypes.c_void_p()
+                with torch.cuda.device(self.device):
+                    self._hip.check(self._hip.lib().dpipe_comm_init(ctypes.byref(comm), 2, 0 if me == lo else 1, box[0]), 'comm_init')
+                self._comms[hi if me == lo else lo] = (comm, 1 if me == lo else 0)
+
+    def _self_test(self):
+        """A 4 KiB pattern travels down the pipeline and back over every communicator before the first real tuple does."""
+        grid = self.grid
+        s, S = grid.get_stage_id(), grid.pipe_parallel_size
+        want = torch.arange(1024, dtype=torch.int32, device=self.device)
+        buf = torch.empty_like(want)
+        if s > 0:
+            self._recv([buf], grid.stage_to_global(s - 1))
+            torch.cuda.current_stream(self.device).synchronize()
+            if not torch.equal(buf, want + (s - 1)):
+                raise RuntimeError(f'RcclLink self-test: stage {s} received a corrupted pattern from stage {s - 1}')
+        if s < S - 1:
+            self._isend([want + s], grid.stage_to_global(s + 1))
+            self._recv([buf], grid.stage_to_global(s + 1))
+            torch.cuda.current_stream(self.device).synchronize()
+            if not torch.equal(buf, want - (s + 1)):
+                raise RuntimeError(f'RcclLink self-test: stage {s} received a corrupted pattern from stage {s + 1}')
+        if s > 0:
+            self._isend([want - s], grid.stage_to_global(s - 1))
+        self.flush()
+        torch.cuda.current_stream(self.device).synchronize()
 
     def _comm(self, peer):
         hit = self._comms.get(peer)
-        if hit is not None:
-            return hit
-        import ctypes
-        me = self.grid.global_rank
-        lo, hi = min(me, peer), max(me, peer)
-        box = [None]
-        if me == lo:
-            buf = ctypes.create_string_buffer(128)
-            self._hip.check(self._hip.lib().dpipe_comm_unique_id(buf), 'comm_unique_id')
-            box[0] = buf.raw
-        group = self._pair_group(lo, hi)
-        dist.broadcast_object_list(box, src=lo, group=group)
-        comm = ctypes.c_void_p()
-        with torch.cuda.device(self.device):
-            self._hip.check(self._hip.lib().dpipe_comm_init(ctypes.byref(comm), 2, 0 if me == lo else 1, box[0]), 'comm_init')
-        self._comms[peer] = (comm, 1 if me == lo else 0)
-        return self._comms[peer]
-
-    _PAIR_GROUPS = {}
-
-    def _pair_group(self, lo, hi):
-        """control-plane group of a neighbour pair; new_group is collective over the world, so every rank creates every pair's group once, in order"""
-        if not RcclLink._PAIR_GROUPS:
-            world = dist.get_world_size()
-            for a in range(world - 1):
-                RcclLink._PAIR_GROUPS[(a, a + 1)] = dist.new_group([a, a + 1], backend='gloo')
-        if (lo, hi) not in RcclLink._PAIR_GROUPS:
-            raise RuntimeError(f'stages on ranks {lo} and {hi} are not neighbours')
-        return RcclLink._PAIR_GROUPS[(lo, hi)]
+        if hit is None:
+            raise RuntimeError(f'rank {self.grid.global_rank} has no RCCL communicator with rank {peer}: stages exchange tuples with their pipeline neighbours only')
+        return hit
 
     def _grouped(self, tensors, peer, op):
         comm, peer_rank = self._comm(peer)
         lib, st = self._hip.lib(), self.comm_stream.cuda_stream
         self._hip.check(lib.dpipe_group_start(), 'group_start')
-        for t in tensors:
-            w = _wire(t)
-            self._hip.check(op(lib)(comm, w.data_ptr(), w.numel() * w.element_size(), peer_rank, st), 'send / recv')
-        self._hip.check(lib.dpipe_group_end(), 'group_end')
+        try:
+            for t in tensors:
+                w = _wire(t)
+                self._hip.check(op(lib)(comm, w.data_ptr(), w.numel() * w.element_size(), peer_rank, st), 'send / recv')
+        finally:
+            rc = lib.dpipe_group_end()              # always close the group: an open RCCL group would swallow every later call of this thread
+        self._hip.check(rc, 'group_end')
 
     def _isend(self, tensors, peer):
         ev = torch.cuda.current_stream(self.device).record_event()

@@ -41,7 +41,7 @@ const char* dpipe_last_error(void);
 #define DPIPE_OPT_ATTN_BWD_DMA 1    /* 1 (default): LDS-DMA dQ / dK / dV kernels (delta fused into dQ); 0: register-staged kernels + attn_delta */
 #define DPIPE_OPT_ATTN_DQ8 2        /* register-staged path, head dim 128: 1 (default) 8-wave dQ kernel for long sequences */
 #define DPIPE_OPT_ATTN_DKV_SPLIT 3  /* head dim 128, long key sequences: 1 (default) dV and dK as two 8-wave kernels; 0: one pass */
-#define DPIPE_OPT_GEMM_SKINNY 4     /* M <= 128 GEMMs (77-token text-encoder / cross-attention linears): 1 = the 128 x 64 tile with deeper split-K; 0 = the 64 x 64 tile */
+#define DPIPE_OPT_GEMM_SKINNY 4     /* M <= 128 GEMMs (77-token text-encoder / cross-attention linears): 1 = the 128 x 64 tile with deeper split-K; 0 (default: measured faster) = the 64 x 64 tile */
 #define DPIPE_OPTION_COUNT 5
 int dpipe_set_option(int option, int value);
 int dpipe_get_option(int option);    /* the effective explicit / environment value, -1 if neither is set */

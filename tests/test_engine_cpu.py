@@ -141,6 +141,9 @@ def _worker(rank, world, port, mode, outdir):
         elif mode == 'pp2_loader':
             _loader_worker(rank, outdir)
             return
+        elif mode == 'flat_dp4':
+            _flat_reduce_worker(rank, world, outdir)
+            return
         else:  # dp2: each replica sees its own micro-batches
             batches = [make_batches(2 * gas, 2, 100 + s)[rank * gas:(rank + 1) * gas] for s in range(steps)]
             losses, params, engine = engine_run(steps, gas, 0.5, batches, num_stages=1)
@@ -180,6 +183,85 @@ def _loader_worker(rank, outdir):
         loader.sync_epoch()
         epochs.append(loader.epoch)
     torch.save({'losses': losses, 'seen': seen, 'epochs': epochs}, os.path.join(outdir, f'r{rank}.pt'))
+
+
+def _flat_case(rank, lane):
+    """gradients of replica `rank`, lane `lane`: seeded, different everywhere"""
+    torch.manual_seed(7)
+    layers = make_layers()
+    params = [p for l in layers for p in l.parameters()]
+    g = torch.Generator().manual_seed(1000 * rank + lane)
+    for p in params:
+        p.grad = torch.randn(p.shape, generator=g)
+    return layers, params
+
+
+def _flat_reduce_worker(rank, world, outdir):
+    """pp = 1, dp = world: two lanes of persistent gradients per replica in flat arenas -> engine._reduce_flat (lane sum + DP average, several buckets
+    per arena, in place) -> every parameter's .grad view holds the average over replicas of the sum over lanes."""
+    from diffusion_pipe_amd.engine.engine import flatten_grads
+    layers, params = _flat_case(rank, 0)
+    module = ManualPipelineModule(layers=layers, num_stages=1, partition_method='uniform', loss_fn=None)
+    engine, _, _, _ = initialize(model=module, config={'gradient_accumulation_steps': 2, 'dp_bucket_bytes': 256}, device='cpu')
+    assert engine.dp_world_size == world and engine.flat_grads
+    base = flatten_grads(params)
+    assert list(base) == [torch.float32] and base[torch.float32].numel() >= sum(p.numel() for p in params)
+    for p in params:
+        assert p.grad.untyped_storage().data_ptr() == base[torch.float32].untyped_storage().data_ptr()
+    _, lane1_params = _flat_case(rank, 1)
+    other = flatten_grads(lane1_params)
+    engine._reduce_flat(base, [other])
+    engine._exec_reduce_grads(skip_storages={base[torch.float32].untyped_storage().data_ptr()})     # nothing left outside the arena: a no-op
+    torch.save({'grads': [p.grad.clone() for p in params]}, os.path.join(outdir, f'r{rank}.pt'))
+
+
+def test_flat_gradient_arenas_lane_sum_and_dp_average_gloo_ws4():
+    world = 4
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), 'flat_dp4', d), nprocs=world, join=True)
+        res = [torch.load(os.path.join(d, f'r{r}.pt')) for r in range(world)]
+    want = None
+    for r in range(world):
+        tot = [a.grad + b.grad for a, b in zip(_flat_case(r, 0)[1], _flat_case(r, 1)[1])]
+        want = tot if want is None else [w + t for w, t in zip(want, tot)]
+    want = [w / world for w in want]
+    for r in res:
+        for a, b in zip(r['grads'], want):
+            assert torch.allclose(a, b, rtol=1e-6, atol=1e-6)
+
+
+def test_flatten_grads_keeps_packed_blocks_strides_and_values():
+    """engine.flatten_grads: gradients that share one storage (the packed Q / K / V weight gradients of a fused projection) stay back to back, a
+    channels-last convolution weight gradient keeps its strides, values survive, a second call is a no-op, late arrivals stay outside."""
+    from diffusion_pipe_amd.engine.engine import flatten_grads
+    from diffusion_pipe_amd import ops
+    q, k, v = (nn.Parameter(torch.randn(8, 16)) for _ in range(3))
+    conv = nn.Parameter(torch.randn(4, 6, 3, 3).contiguous(memory_format=torch.channels_last))
+    bias = nn.Parameter(torch.randn(5))
+    half = nn.Parameter(torch.randn(7, 3).to(torch.bfloat16))
+    packed = torch.randn(24, 16)
+    q.grad, k.grad, v.grad = packed[0:8], packed[8:16], packed[16:24]
+    conv.grad = torch.randn(4, 6, 3, 3).contiguous(memory_format=torch.channels_last)
+    bias.grad, half.grad = torch.randn(5), torch.randn(7, 3).to(torch.bfloat16)
+    params = [q, k, v, conv, bias, half]
+    before = [p.grad.clone() for p in params]
+    arenas = flatten_grads(params)
+    assert set(arenas) == {torch.float32, torch.bfloat16}
+    for p, b in zip(params, before):
+        assert torch.equal(p.grad, b) and p.grad.stride() == b.stride()
+        assert p.grad.untyped_storage().data_ptr() == arenas[p.grad.dtype].untyped_storage().data_ptr()
+        assert p.grad.data_ptr() % 16 == 0
+    assert ops.packed_view([q.grad, k.grad, v.grad]) is not None          # still one [24, 16] block
+    assert conv.grad.is_contiguous(memory_format=torch.channels_last)
+    again = flatten_grads(params, arenas)
+    assert all(again[dt] is arenas[dt] for dt in arenas)
+    late = nn.Parameter(torch.randn(3))
+    late.grad = torch.randn(3)
+    after = flatten_grads(params + [late], arenas)
+    assert after[torch.float32] is arenas[torch.float32]
+    assert late.grad.untyped_storage().data_ptr() != arenas[torch.float32].untyped_storage().data_ptr()
+    arenas[torch.float32].zero_()
+    assert all(float(p.grad.abs().sum()) == 0.0 for p in (q, k, v, conv, bias))
 
 
 def engine_dp_rank(rank):

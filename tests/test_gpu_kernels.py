@@ -212,6 +212,58 @@ def test_layernorm_modulate(gpu, dtype, wdtype, mdtype, affine, mod):
         assert _rel_err(shift.grad, hr.grad) < (3e-2 if mdtype == torch.bfloat16 else 2e-3)
 
 
+LN_FUSED_CASES = [  # (B, S, D, affine, mod): shapes that take the fused backward (parameter-gradient partials inside the dx pass) and its fall-backs
+    (1, 1024, 1280, True, False), (1, 4096, 640, True, False), (1, 77, 1280, True, False), (1, 77, 768, True, False), (2, 1024, 640, True, False),
+    (1, 1024, 1536, False, True), (2, 1024, 512, False, True), (2, 515, 384, False, True), (1, 1030, 2048, True, False), (1, 256, 3072, False, True)]
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('case', LN_FUSED_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_layernorm_backward_fused_parameter_gradients(gpu, dtype, case):
+    """LayerNorm backward at the SDXL / CLIP shapes: dx (+ the bypass gradient) and the column sums (dgamma, dbeta) or (dscale, dshift) from ONE pass over
+    x / dy plus the slab sum, per-element bound, twice in a row with fused accumulation into existing .grad buffers (the graph path's form)."""
+    from diffusion_pipe_amd import ops
+    B, S, D, affine, mod = case
+    if dtype == torch.float32 and D > 1024:
+        pytest.skip('fp32 rows beyond the register cache take the unfused path (covered by test_layernorm_modulate)')
+    g = torch.Generator().manual_seed(B * 31 + S + D)
+    x = torch.randn(B, S, D, generator=g).to(gpu, dtype).requires_grad_(True)
+    gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(gpu, dtype).requires_grad_(True) if affine else None
+    beta = (0.1 * torch.randn(D, generator=g)).to(gpu, dtype).requires_grad_(True) if affine else None
+    scale = (0.3 * torch.randn(B, 1, D, generator=g)).to(gpu, dtype).requires_grad_(True) if mod else None
+    shift = (0.3 * torch.randn(B, 1, D, generator=g)).to(gpu, dtype).requires_grad_(True) if mod else None
+    gy = torch.randn(B, S, D, generator=g).to(gpu, dtype)
+    gskip = torch.randn(B, S, D, generator=g).to(gpu, dtype)
+    f = lambda t: None if t is None else t.detach().float().requires_grad_(True)
+    xr, gr, br, sr, hr = f(x), f(gamma), f(beta), f(scale), f(shift)
+    n = F.layer_norm(xr, (D,), gr, br, 1e-5)
+    yr = n * (1 + sr) + hr if mod else n
+    (yr * gy.float()).sum().backward()
+    old = ops.FUSE_GRAD_ACCUM
+    try:
+        ops.FUSE_GRAD_ACCUM = True
+        for _ in range(2):       # the second pass adds into the .grad buffers the first one created
+            y, xs = ops.layer_norm_modulate(x, gamma, beta, scale, shift, 1e-5, with_skip=True)
+            torch.autograd.backward([y, xs], [gy, gskip])
+    finally:
+        ops.FUSE_GRAD_ACCUM = old
+    rt = 2.0 ** -7 if dtype == torch.bfloat16 else 1e-4
+
+    def close(got, want, what, k=1.0):
+        got, want = got.float(), want.float()
+        tol = k * rt * (want.pow(2).mean().sqrt().clamp_min(1e-6) + want.abs())
+        bad = (got - want).abs() > tol
+        assert not bad.any(), f'{what}: {int(bad.sum())} / {bad.numel()} off, worst {(got - want).abs().max().item():.4g}'
+    close(x.grad, 2 * (xr.grad + gskip.float()), 'dx')
+    # column sums over up to 4 096 rows of bf16-rounded terms, accumulated twice in the parameter dtype: 4 x the per-element bound
+    if affine:
+        close(gamma.grad, 2 * gr.grad, 'dgamma', 4.0)
+        close(beta.grad, 2 * br.grad, 'dbeta', 4.0)
+    if mod:
+        close(scale.grad, 2 * sr.grad, 'dscale', 4.0)
+        close(shift.grad, 2 * hr.grad, 'dshift', 4.0)
+
+
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize('interleaved', [True, False])
 def test_rope(gpu, dtype, interleaved):

@@ -29,11 +29,14 @@ dev = torch.device('cuda', 0)
 if world > 1:
     dist.init_process_group('gloo', rank=rank, world_size=world)
 cfg = sdxl.tiny_config()
-gas = 4
+dp_mode = len(sys.argv) > 4 and sys.argv[4] == 'dp'          # every rank a whole replica (pp = 1, dp = world) instead of a pipeline stage
+total_mb = int(sys.argv[5]) if len(sys.argv) > 5 else 4      # micro-batches per optimizer step over all replicas
+gas = total_mb // world if dp_mode else total_mb
 work = sdxl.SDXLWorkload(cfg, model_config={'min_snr_gamma': 5.0}, dtype=torch.bfloat16, seed=2, device=dev)
-module = ManualPipelineModule(layers=work.to_layers(), num_stages=world, partition_method='parameters', loss_fn=work.get_loss_fn(), dynamic_shape=True)
+module = ManualPipelineModule(layers=work.to_layers(), num_stages=1 if dp_mode else world, partition_method='parameters', loss_fn=work.get_loss_fn(), dynamic_shape=True)
+extra = {'graph_lanes': 2, 'flat_grads': True, 'dp_bucket_bytes': 1 << 20} if (dp_mode or (len(sys.argv) > 4 and sys.argv[4] == 'flat')) else {}
 engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 1, 'gradient_accumulation_steps': gas, 'gradient_clipping': 1.0,
-                                                     'hip_graph': mode != 'eager', 'p2p_via_host': True, 'clip_norm_scope': 'global'}, device=dev)
+                                                     'hip_graph': mode != 'eager', 'p2p_via_host': True, 'clip_norm_scope': 'global', **extra}, device=dev)
 params = [p for p in module.parameters() if p.requires_grad]
 if len(sys.argv) > 3 and sys.argv[3] == 'fused_adamw':     # the fused HIP step end: norm of the local grads -> cross-stage all-reduce -> clip + AdamW + zero
     from diffusion_pipe_amd import optim
@@ -45,8 +48,10 @@ else:
 res = []
 for step in range(3):
     torch.manual_seed(100 + step)
-    feats, label = work.prepare_inputs(sdxl.synthetic_batch(cfg, batch_size=gas, latent_hw=32, seed=10 + step))
-    micro = split_batch((feats, label), gas)
+    feats, label = work.prepare_inputs(sdxl.synthetic_batch(cfg, batch_size=total_mb, latent_hw=32, seed=10 + step))
+    micro = split_batch((feats, label), total_mb)
+    if dp_mode:
+        micro = micro[rank * gas:(rank + 1) * gas]            # replica r trains on its slice of the global batch
     need = engine.is_first_stage() or engine.is_last_stage()
     engine.reset_activation_shape()
     loss = engine.train_batch(iter(micro) if need else None)
@@ -65,17 +70,17 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(tmp_path, mode, world, opt='sgd'):
+def _run(tmp_path, mode, world, opt='sgd', par='pp', total_mb=4):
     script = tmp_path / 'worker.py'
     script.write_text(WORKER)
-    out = tmp_path / f'{mode}_{world}_{opt}.json'
+    out = tmp_path / f'{mode}_{world}_{opt}_{par}.json'
     env = dict(os.environ, DPIPE_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0')
     if world == 1:
         env.update(RANK='0', WORLD_SIZE='1')
-        cmd = [sys.executable, str(script), mode, str(out), opt]
+        cmd = [sys.executable, str(script), mode, str(out), opt, par, str(total_mb)]
     else:
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}', '--master-addr', '127.0.0.1',
-               '--master-port', str(_free_port()), str(script), mode, str(out), opt]
+               '--master-port', str(_free_port()), str(script), mode, str(out), opt, par, str(total_mb)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return json.loads(out.read_text())
@@ -106,6 +111,22 @@ def test_pp2_fused_step_end_matches_single_stage_engine(gpu, tmp_path):
     for (l0, n0), (l1, n1), (l2, n2) in zip(base['res'], eager2['res'], graph2['res']):
         assert abs(l1 - l0) / abs(l0) < 2e-2 and abs(l2 - l0) / abs(l0) < 2e-2, (l0, l1, l2)
         assert abs(n1 - n0) / n0 < 3e-2 and abs(n2 - n0) / n0 < 3e-2, (n0, n1, n2)
+
+
+@pytest.mark.parametrize('opt', ['sgd', 'fused_adamw'])
+def test_dp2_flat_gradient_arenas_match_one_replica(gpu, tmp_path, opt):
+    """Two data-parallel replicas (two processes on cuda:0, gloo), each replaying its half of the global batch on 2 lanes: the lanes' gradients live in flat
+    per-dtype arenas (engine.flatten_grads), are summed and averaged over the replicas bucket by bucket (1 MiB buckets here: several per arena) with no staging
+    concatenation -- against ONE replica that accumulates the whole global batch (flat arenas too, and the plain per-tensor path)."""
+    one_flat = _run(tmp_path, 'graph', 1, opt, 'flat', 8)
+    one_plain = _run(tmp_path, 'graph', 1, opt, 'pp', 8)
+    two = _run(tmp_path, 'graph', 2, opt, 'dp', 8)
+    for (l0, n0), (l1, n1), (l2, n2) in zip(one_plain['res'], one_flat['res'], two['res']):
+        assert abs(l1 - l0) / abs(l0) < 2e-2 and abs(l2 - l0) / abs(l0) < 2e-2, (l0, l1, l2)
+        assert abs(n1 - n0) / n0 < 3e-2 and abs(n2 - n0) / n0 < 3e-2, (n0, n1, n2)
+    # first step: identical weights everywhere, the same micro-batches -> tight
+    assert abs(two['res'][0][0] - one_flat['res'][0][0]) / abs(one_flat['res'][0][0]) < 3e-3
+    assert abs(two['res'][0][1] - one_flat['res'][0][1]) / one_flat['res'][0][1] < 1e-2
 
 
 def test_bench_multi_rank_path_runs_end_to_end_on_one_shared_gpu(gpu, tmp_path):

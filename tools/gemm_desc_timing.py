@@ -17,7 +17,9 @@ from tools import gemm_replay  # noqa: E402
 
 DEFAULT_HINTS = {'auto': 0, 't64': 2001, 't64k2': 2002, 't64k4': 2004, 't128': 3001, 't128k2': 3002, 't128k3': 3003, 't128r2': 4001, 't128r2k2': 4002,
                  't256x128': 5001, 't256': 7001, 't256k2': 7002, 't256h': 9001,
-                 'sk1': 10001, 'sk2': 10002, 'sk4': 10004, 'sk8': 10008, 'sk16': 10016}      # 128 x 64 skinny tile (M <= 128 only)
+                 'sk1': 10001, 'sk2': 10002, 'sk4': 10004, 'sk8': 10008, 'sk16': 10016,      # 128 x 64 skinny tile (M <= 128 only)
+                 'w128x256': 11001, 'w128x256k2': 11002, 'w256x128': 12001, 'w256x128k2': 12002,      # four 128 x 64 waves per workgroup
+                 'w128': 13001, 'w128k3': 13003, 'w128r2': 14001, 'w128r2k2': 14002}       # four 64 x 64 waves on the 128^2 tile (3-deep / 2-deep ring)
 
 
 def time_desc(d, hint, device, arena, ops, budget_bytes=600 << 20):
@@ -97,8 +99,11 @@ def main():
     out = open(args[1], 'w') if len(args) > 1 else None
     hints = DEFAULT_HINTS
     if 'hints' in opts:
-        hints = {('auto' if h in ('0', 'auto') else f'h{h}'): (0 if h in ('0', 'auto') else int(h)) for h in opts['hints'].split(',')}
+        named = {v: k for k, v in DEFAULT_HINTS.items()}
+        hints = {('auto' if h in ('0', 'auto') else named.get(int(h), f'h{h}')): (0 if h in ('0', 'auto') else int(h)) for h in opts['hints'].split(',')}
     skip_torch = 'no-torch' in opts
+    min_gflop = float(opts.get('min-gflop', 0))
+    uniq = [d for d in uniq if gemm_replay.flops({k: (tuple(v) if isinstance(v, list) else v) for k, v in d.items()}) / 1e9 >= min_gflop]
     dev = torch.device('cuda:0')
     arena = gemm_replay.Arena(dev, 3 << 30)
     ops.WS_LANE = 'desc-timing'
@@ -108,7 +113,7 @@ def main():
         rec = {'ta': d['ta'], 'tb': d['tb'], 'M': d['M'], 'N': d['N'], 'K': d['K'], 'batch': d['bo'] * d['bi'], 'count': d['count'], 'acc': int(d['acc']),
                'colsum': int(d['colsum']), 'bias': int(d['bias']), 'res': int(d['res']), 'gflop': round(gemm_replay.flops(d) / 1e9, 3), 'us': {}}
         for name, hint in hints.items():
-            if (hint >= 10000 and d['M'] > 128) or (7000 <= hint < 8000 or hint >= 9000 and hint < 10000) and (d['M'] < 512 or d['N'] < 512):
+            if (10000 <= hint < 11000 and d['M'] > 128) or (7000 <= hint < 8000 or 9000 <= hint < 10000 or 11000 <= hint < 13000) and (d['M'] < 512 or d['N'] < 512) or (hint >= 13000 and d['M'] <= 128):
                 continue                     # skinny tile: M <= 128 only; 256^2 tiles: not for slivers
             try:
                 rec['us'][name] = round(time_desc(d, hint, dev, arena, ops), 2)
