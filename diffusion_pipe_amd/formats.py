@@ -231,8 +231,10 @@ def sdxl_openclip_to_ldm(text_enc_dict):
     return out
 
 
-def sdxl_diffusers_to_ldm(diffusers_sd, vae_state_dict=None):
-    """{'unet.*', 'text_encoder.*', 'text_encoder_2.*'} (parameters' original_name keys) -> single-file SDXL state dict (models/sdxl.py:489-523)."""
+def sdxl_diffusers_to_ldm(diffusers_sd, vae_state_dict=None, ldm_vae=None):
+    """{'unet.*', 'text_encoder.*', 'text_encoder_2.*'} (parameters' original_name keys) -> single-file SDXL state dict (models/sdxl.py:489-523).
+    vae_state_dict: diffusers AutoencoderKL names (converted like the reference does); ldm_vae: tensors already named `first_stage_model.*` (taken verbatim
+    from the base single-file checkpoint), inserted at the same position so the key order equals the reference writer's."""
     unet, te1, te2 = {}, {}, {}
     for name, p in diffusers_sd.items():
         if name.startswith('unet.'):
@@ -246,6 +248,8 @@ def sdxl_diffusers_to_ldm(diffusers_sd, vae_state_dict=None):
     out = {'model.diffusion_model.' + sdxl_unet_key_to_ldm(k): v for k, v in unet.items()}
     if vae_state_dict is not None:
         out.update({'first_stage_model.' + k: v for k, v in sdxl_vae_to_ldm(vae_state_dict).items()})
+    elif ldm_vae is not None:
+        out.update(ldm_vae)
     out.update({'conditioner.embedders.0.transformer.' + k: v for k, v in te1.items()})
     te2 = {'conditioner.embedders.1.model.' + k: v for k, v in sdxl_openclip_to_ldm(te2).items()}
     proj = 'conditioner.embedders.1.model.text_projection'
@@ -255,10 +259,10 @@ def sdxl_diffusers_to_ldm(diffusers_sd, vae_state_dict=None):
     return out
 
 
-def save_sdxl_ldm(save_dir, diffusers_sd, vae_state_dict=None):
+def save_sdxl_ldm(save_dir, diffusers_sd, vae_state_dict=None, ldm_vae=None):
     save_dir = Path(save_dir)
     os.makedirs(save_dir, exist_ok=True)
-    save_file({k: v.contiguous() for k, v in sdxl_diffusers_to_ldm(diffusers_sd, vae_state_dict).items()}, save_dir / 'model.safetensors', metadata={'format': 'pt'})
+    save_file({k: v.contiguous() for k, v in sdxl_diffusers_to_ldm(diffusers_sd, vae_state_dict, ldm_vae).items()}, save_dir / 'model.safetensors', metadata={'format': 'pt'})
 
 
 # ------------------------------------------------------------------------------------------------ SDXL LoRA -> kohya file, Flux LoRA -> diffusers file

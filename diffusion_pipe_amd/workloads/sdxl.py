@@ -12,6 +12,8 @@ checkpoints map 1:1.  No checkpoints exist offline: weights are random-initialis
 from dataclasses import dataclass, field
 from typing import Optional, Tuple
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -526,10 +528,39 @@ class SDXLWorkload:
         from ..formats import save_sdxl_kohya_lora
         save_sdxl_kohya_lora(save_dir, peft_state_dict)
 
-    def save_model(self, save_dir, diffusers_sd, vae_state_dict=None):
-        """Full fine-tune -> single-file SDXL checkpoint (UNet, both text encoders; the VAE -- not part of the training step here -- when given)."""
+    def set_vae_state_dict(self, vae_state_dict):
+        """The base checkpoint's VAE weights (diffusers AutoencoderKL names): not part of the training step, but part of every single-file checkpoint
+        the reference writes (models/sdxl.py:503-522 always converts and embeds self.vae.state_dict())."""
+        self.vae_state_dict = dict(vae_state_dict)
+
+    def _vae_for_save(self):
+        """-> (diffusers-named VAE state dict or None, already-LDM-named `first_stage_model.*` tensors or None).  Sources, in order: set_vae_state_dict();
+        the `first_stage_model.*` tensors of the single-file checkpoint the run was configured with (`[model] checkpoint_path`, models/sdxl.py:386),
+        read lazily at the first save."""
+        if getattr(self, 'vae_state_dict', None) is not None:
+            return self.vae_state_dict, None
+        path = self.model_config.get('checkpoint_path')
+        if path and os.path.isfile(path) and str(path).endswith('.safetensors'):
+            from safetensors import safe_open
+            with safe_open(path, framework='pt', device='cpu') as f:
+                ldm = {k: f.get_tensor(k) for k in f.keys() if k.startswith('first_stage_model.')}
+            if ldm:
+                return None, ldm
+        return None, None
+
+    def save_model(self, save_dir, diffusers_sd, vae_state_dict=None, allow_missing_vae=False):
+        """Full fine-tune -> single-file SDXL checkpoint: UNet, both text encoders AND the VAE, like the reference's (models/sdxl.py:487-525; ComfyUI, Forge and
+        diffusers' from_single_file expect the complete ldm file).  The saver passes two arguments (utils/saver.py:106), so the VAE comes from the workload
+        (_vae_for_save); a checkpoint without `first_stage_model.*` keys is only written when the caller asks for it explicitly."""
         from ..formats import save_sdxl_ldm
-        save_sdxl_ldm(save_dir, diffusers_sd, vae_state_dict)
+        ldm_vae = None
+        if vae_state_dict is None:
+            vae_state_dict, ldm_vae = self._vae_for_save()
+        if vae_state_dict is None and ldm_vae is None and not allow_missing_vae:
+            raise RuntimeError('SDXL save_model: no VAE weights to embed -- the reference always writes first_stage_model.* into model.safetensors.  Give the workload the '
+                               "base checkpoint's VAE (set_vae_state_dict(...) or [model] checkpoint_path = a single-file .safetensors), or pass allow_missing_vae=True "
+                               'to write a UNet + text-encoder-only file on purpose.')
+        save_sdxl_ldm(save_dir, diffusers_sd, vae_state_dict, ldm_vae)
 
     def to_layers(self):
         unet = self.unet

@@ -95,6 +95,36 @@ def test_sdxl_full_model_is_written_in_the_single_file_ldm_layout(tmp_path):
         formats.sdxl_diffusers_to_ldm({'vae.x': torch.zeros(1)})
 
 
+def test_sdxl_save_model_as_the_saver_calls_it_embeds_the_vae(tmp_path):
+    """utils/saver.py:106 calls model.save_model(save_dir, state_dict) with TWO arguments; the reference's SDXLPipeline.save_model then embeds
+    self.vae.state_dict() (models/sdxl.py:503-522).  The workload must produce the same complete key set from the VAE it holds (set_vae_state_dict), or
+    from the base single-file checkpoint's first_stage_model.* tensors, and refuse to write a VAE-less file silently."""
+    from oracle.make_golden_formats import fake_vae_state_dict, sdxl_state_dict
+    from diffusion_pipe_amd.workloads import sdxl
+    sd, vae = sdxl_state_dict(), fake_vae_state_dict()
+    # 1. VAE held by the workload: two-argument call == the golden's three-argument file
+    work = sdxl.SDXLWorkload(sdxl.tiny_config(), dtype=torch.float32, seed=21)
+    work.set_vae_state_dict(vae)
+    work.save_model(tmp_path / 'a', sd)
+    got = load_file(tmp_path / 'a' / 'model.safetensors')
+    assert {k: list(v.shape) for k, v in sorted(got.items())} == G['sdxl_ldm']['keys']
+    if same_build:
+        assert _sha(tmp_path / 'a' / 'model.safetensors') == G['sdxl_ldm']['sha256']
+    # 2. VAE read lazily from the configured base checkpoint (already in ldm naming): same key set, tensors verbatim
+    work2 = sdxl.SDXLWorkload(sdxl.tiny_config(), model_config={'checkpoint_path': str(tmp_path / 'a' / 'model.safetensors')}, dtype=torch.float32, seed=21)
+    work2.save_model(tmp_path / 'b', sd)
+    got2 = load_file(tmp_path / 'b' / 'model.safetensors')
+    assert sorted(got2) == sorted(got)
+    assert all(torch.equal(got2[k], got[k]) for k in got if k.startswith('first_stage_model.'))
+    assert list(load_file(tmp_path / 'b' / 'model.safetensors').keys()) == list(got.keys())
+    # 3. nothing to embed: loud failure, unless the caller opts in to a UNet + text-encoder-only file
+    work3 = sdxl.SDXLWorkload(sdxl.tiny_config(), dtype=torch.float32, seed=21)
+    with pytest.raises(RuntimeError, match='no VAE weights'):
+        work3.save_model(tmp_path / 'c', sd)
+    work3.save_model(tmp_path / 'c', sd, allow_missing_vae=True)
+    assert not any(k.startswith('first_stage_model.') for k in load_file(tmp_path / 'c' / 'model.safetensors'))
+
+
 def test_sdxl_and_flux_adapter_files(tmp_path):
     """kohya LoRA naming (restated from diffusers' published convert_state_dict_to_kohya; diffusers absent -> parity unpinned): structure checks."""
     from oracle.make_golden_formats import sdxl_peft_state_dict
