@@ -438,7 +438,7 @@ def main():
         dist.all_reduce(rl)
     g_flops, g_ms, launches, g_bytes = rl.tolist()
     traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'r2_pmc_gemm_traffic.json')      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this launch list
+    tpath = os.path.join(ROOT, 'profiles', 'r3_pmc_gemm_traffic.json')      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this launch list
     if os.path.isfile(tpath):
         with open(tpath) as f:
             traffic = json.load(f)

@@ -1,4 +1,5 @@
 // gemm_pipe.hip -- dispatch of the plain bf16 GEMM onto the LDS-DMA pipelined kernel (gemm_pipe_kernel.h): eligibility, tile / split-K choice.
+#include <stdlib.h>
 #include "gemm_pipe_kernel.h"
 #include "../../include/dpipe_hip.h"
 
@@ -31,10 +32,6 @@ bool gemm_pipe_try(GemmParams& p, int transA, int transB, int batch, void* ws, l
     case 128: *rc_out = launch_pipe<T128>(p, a_mc, b_mc, batch, s); break;
     case 130: *rc_out = launch_pipe<T128S5>(p, a_mc, b_mc, batch, s); break;
     case 1264: *rc_out = launch_pipe<T128N64>(p, a_mc, b_mc, batch, s); break;
-    case 1256: *rc_out = launch_pipe<T128x256W>(p, a_mc, b_mc, batch, s); break;
-    case 2561: *rc_out = launch_pipe<T256x128W>(p, a_mc, b_mc, batch, s); break;
-    case 1284: *rc_out = launch_pipe<T128W4>(p, a_mc, b_mc, batch, s); break;
-    case 1282: *rc_out = launch_pipe<T128W4R2>(p, a_mc, b_mc, batch, s); break;
     default: *rc_out = launch_pipe<T64>(p, a_mc, b_mc, batch, s); break;
     }
     return true;
@@ -62,8 +59,8 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
     // 7.9 - 27 us unsplit, 56 vs 39 ms per step over the M <= 128 launches): opt-in only (DPIPE_GEMM_SKINNY=1 / tile_hint 10000 + S)
     const bool skinny = force_tile == 1264 || (force_tile == 0 && p.M <= 128 && p.N >= 256 && p.ksteps >= 4 && option(DPIPE_OPT_GEMM_SKINNY, 0) != 0);
     if (skinny) force_tile = 1264;
-    const int bm = (force_tile == 256 || force_tile == 257 || force_tile == 258 || force_tile == 2561) ? 256 : (big || skinny) ? 128 : 64,
-              bn = (force_tile == 256 || force_tile == 2561) ? 128 : skinny ? 64 : force_tile == 1256 ? 256 : bm;
+    const int bm = (force_tile == 256 || force_tile == 257 || force_tile == 258) ? 256 : (big || skinny) ? 128 : 64,
+              bn = force_tile == 256 ? 128 : skinny ? 64 : bm;
     p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bn - 1) / bn;
     const long tiles = (long)p.tiles_m * p.tiles_n * batch;
     const long slab_bytes = ((long)bm * bn + bm) * 4;
@@ -103,8 +100,12 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
     if (c_ok && p.residual && reinterpret_cast<uintptr_t>(p.residual) % 8 == 0 && p.ldr % 4 == 0) p.vecA = 3;   // 8-byte residual loads too
     p.vecB = (p.bias && reinterpret_cast<uintptr_t>(p.bias) % 8 == 0) ? 2 : 0;
     if (force_tile == 258) { p.ksteps *= 2; p.ksteps_per_split *= 2; return 258; }      // T256K counts K in 32-wide half steps (slices keep their K ranges)
-    if (force_tile == 257 || force_tile == 256 || force_tile == 63 || force_tile == 130 || force_tile == 1264 || force_tile == 1256 || force_tile == 2561 || force_tile == 1284 || force_tile == 1282) return force_tile;
+    if (force_tile == 257 || force_tile == 256 || force_tile == 63 || force_tile == 130 || force_tile == 1264) return force_tile;
     if (force_tile == 129 || (force_tile == 0 && big && tiles128 >= 256 && (a_mc || b_mc || tiles128 >= 1024))) return 129;
+    // experiment switch (environment DPIPE_GEMM_SHALLOW=1): the shallow rings everywhere (128^2 on 2 x 32 KiB, 64^2 on 3 x 16 KiB) -- slower launches in
+    // isolation, but a smaller LDS footprint lets workgroups of the OTHER micro-batch lanes share the CU
+    static const int shallow = [] { const char* e = getenv("DPIPE_GEMM_SHALLOW"); return e ? atoi(e) : 0; }();
+    if (shallow && force_tile == 0) return big ? 129 : 63;
     return big ? 128 : 64;
 }
 

@@ -79,13 +79,9 @@ using T256 = Tile<256, 128, 4, 2, 3>;       // selectable, not chosen automatica
 using T256K = Tile<256, 256, 2, 4, 4, 32>;  // the same 256 x 256 tile on a 4-deep ring of HALF K-steps (32 k, 32 KiB each; the same 128 KiB of LDS): three half steps in flight instead of
                                             // one whole step -- the 2-deep ring parks every wave ~1 100 cycles per K-step at vmcnt (timeline probe), its refill can only be issued
                                             // once the whole previous step has been consumed
-using T128x256W = Tile<128, 256, 1, 4, 3>;  // FOUR waves of 128 x 64 (8 MFMA tiles each, one wave per SIMD) on a 128 x 256 tile, 3 x 48 KiB: the LDS-traffic-lean configuration for
-using T256x128W = Tile<256, 128, 2, 2, 3>;  // SDXL's big linears (M = 1 024 tokens x N = 5 120 / 10 240, and the transposed wgrad shapes).  Why: per K-step an 8-wave 128^2 tile moves
-                                            // 32 KiB INTO the LDS and reads 96 KiB OUT of it (A fragments by 4 waves, B by 2) for 512 MFMA cycles per SIMD = 256 B/clk, the LDS peak --
-                                            // the reason every 128^2 / 256 x 128 eight-wave variant lands within 5 % of the others on these shapes (profiles/r3_gemm_desc_ledger.jsonl);
-                                            // 128 x 64 wave tiles read 96 KiB + write 48 KiB per 1 024 MFMA cycles = 140 B/clk and still give 320 tiles for [1024, 10240]
-using T128W4 = Tile<128, 128, 2, 2, 3>;     // the same idea on the 128^2 tile: FOUR waves of 64 x 64 (4 MFMA tiles each): 64 KiB of fragment reads per K-step instead of 96 (188 B/clk),
-using T128W4R2 = Tile<128, 128, 2, 2, 2>;   // 3-deep ring (1 workgroup per CU) / 2-deep ring (64 KiB: 2 workgroups per CU whose phases are independent)
+// (Round 3 negative result, profiles/r3_gemm_desc_ledger_4wave_tiles_negative.jsonl: FOUR-wave workgroups -- 128 x 64 wave tiles on 128 x 256 / 256 x 128, 64 x 64 wave tiles
+//  on 128 x 128, one wave per SIMD -- read a third less from the LDS per MFMA but run 15 .. 55 % SLOWER than the eight-wave tiles on every SDXL shape >= 9 GFLOP
+//  ([1024, 10240, 1280]: 90 / 69 us vs 59): with one wave per SIMD nothing covers the wave's own DMA issue, fragment reads and barrier waits.  Removed again.)
 using T256S = Tile<256, 256, 2, 4, 2>;      // 256 x 256, 8 waves of 128 x 64 (128 accumulator VGPRs), 2 x 64 KiB: twice the MFMA work per DMA'd
                                             // byte of the 128^2 tile -- the large-GEMM configuration (DiT-sized linears: Flux / Wan / HunyuanVideo)
 

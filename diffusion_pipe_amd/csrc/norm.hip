@@ -610,9 +610,12 @@ int dpipe_lnmod_bwd(const void* x, const void* gy, const void* gamma, const void
     const long groups = rows / rows_per_mod;
     const int slabs_all = dpipe_norm_slabs(rows), slabs_mod = dpipe_norm_slabs(rows_per_mod);
     // fused parameter-gradient partials (see lnmod_bwd_dx_kernel): rows that fit the register cache, exactly one pair of column sums wanted, and modulation
-    // groups made of whole blocks.  RW = 4 rows per wave from 1 024 rows on (16 rows per block -> rows / 16 partial rows), else 1.
+    // groups made of whole blocks.
     const int vec_cols = 64 * V * 4;
-    const int rw = rows_per_mod >= 1024 && rows_per_mod % 16 == 0 ? 4 : 1;
+    // rows per wave: 1 (4 rows per block) up to 2 048 rows -- the kernel is latency-bound and wants the blocks; 4 beyond (measured on MI355X, tools/norm_timing.py:
+    // [1024, 1280] backward 35.8 us at 4 rows per wave vs 24.4 us unfused; [4096, 640] 33.3 vs 34.3).  DPIPE_LNMOD_RW = 1 / 4 forces one for A/B.
+    static const int rw_env = [] { const char* e = getenv("DPIPE_LNMOD_RW"); return e ? atoi(e) : 0; }();
+    const int rw = rw_env == 1 || rw_env == 4 ? rw_env : (rows_per_mod > 2048 ? 4 : 1);
     const bool fuse_ok = cols <= vec_cols && ((dgamma != nullptr) != (dscale != nullptr)) && (groups == 1 || rows_per_mod % (4 * rw) == 0) && lnmod_fuse_enabled();
     const int fslabs = fuse_ok ? (int)cdiv(rows_per_mod, 4 * rw) : 0;
 #define LNBWD_FUSED(TT, WW, MM, FU, RWW) do { \

@@ -67,10 +67,14 @@ def test_full_size_sdxl_three_lanes_twelve_unsynchronised_steps_match_one_lane(g
 # bf16 path loss 1.7e-4, norm 2.2e-4, per-parameter max abs_sum 0.083, l2 0.092, proj 0.84 -- all three on the self-attention to_q / to_k weights of the
 # deepest transformer blocks, whose gradient is a small difference of bf16-rounded softmax terms (dS = P o (dP - delta)); bounds ~3 x observed.
 FP32_BOUNDS = dict(loss=1e-3, norm=1e-3, abs_sum=5e-3, signed_sum=5e-3, proj=1.5e-2, l2=5e-3, agg=5e-3)
-BF16_BOUNDS = dict(loss=6e-4, norm=1e-3, abs_sum=0.25, signed_sum=1.5e-2, proj=2.5, l2=0.28, agg=0.1)
+BF16_BOUNDS = dict(loss=6e-4, norm=2e-3, abs_sum=0.25, signed_sum=1.5e-2, proj=2.5, l2=0.28, agg=0.026)
+# 99th percentile over the parameters (observed bf16: abs_sum 0.035, signed_sum 0.002, proj 0.18, l2 0.032; fp32: 2.6e-6, 1.4e-6, 3.6e-5, 2.7e-6; whole-gradient L2 error
+# estimate 0.0086 / 5.3e-6)
+FP32_Q99 = dict(abs_sum=1e-4, signed_sum=1e-4, proj=1e-3, l2=1e-4)
+BF16_Q99 = dict(abs_sum=0.1, signed_sum=6e-3, proj=0.55, l2=0.1)
 
 
-def _compare_grad_rows(rows, meta, bounds, what):
+def _compare_grad_rows(rows, meta, bounds, what, q99=None):
     """rows: {name: checksum4 row} of this run.  Returns the observed error statistics; asserts the bounds (+ an absolute floor of 1e-8 of the model's
     total sum |g| for parameters whose gradient is analytically zero -- attention key biases: softmax is invariant to them -- and therefore rounding noise)."""
     from oracle.checksums import relative_errors
@@ -105,6 +109,8 @@ def _compare_grad_rows(rows, meta, bounds, what):
                                                         for k in kinds) + f'; whole-gradient relative L2 error estimate {stats["agg"]:.3g}')
     assert not bad, f'{what}: {len(bad)} parameter checks beyond the bounds, e.g. {bad[:5]}'
     assert stats['agg'] <= bounds['agg'], (what, stats['agg'])
+    for k, b in (q99 or {}).items():
+        assert stats[k]['q99'] <= b, (what, k, 'q99', stats[k]['q99'], b)
     return stats
 
 
@@ -157,7 +163,7 @@ def test_full_size_sdxl_micro_batch_matches_the_cpu_oracle_golden(gpu, record_pr
     print(f'fp32 kernel path vs oracle: loss rel. error {e_loss:.3g}, gradient-norm rel. error {e_norm:.3g}')
     assert e_loss < FP32_BOUNDS['loss'], (loss.item(), meta['loss'])
     assert e_norm < FP32_BOUNDS['norm'], (sq ** 0.5, meta['grad_norm'])
-    w32 = _compare_grad_rows(rows, meta, FP32_BOUNDS, 'fp32 kernel path')
+    w32 = _compare_grad_rows(rows, meta, FP32_BOUNDS, 'fp32 kernel path', FP32_Q99)
     # ---- the timed path: bf16, hipGraph, 3 lanes (the same micro-batch on every lane: same mean loss, same averaged gradient)
     names = {}
     for k, m in work.modules().items():
@@ -176,7 +182,7 @@ def test_full_size_sdxl_micro_batch_matches_the_cpu_oracle_golden(gpu, record_pr
     print(f'timed path (bf16, hipGraph, 3 lanes) vs oracle: loss rel. error {e_loss16:.3g}, gradient-norm rel. error {e_norm16:.3g}')
     assert e_loss16 < BF16_BOUNDS['loss'], (loss, meta['loss'])
     assert e_norm16 < BF16_BOUNDS['norm'], (norm, meta['grad_norm'])
-    w16 = _compare_grad_rows(opt.rows, meta, BF16_BOUNDS, 'timed bf16 path')
+    w16 = _compare_grad_rows(opt.rows, meta, BF16_BOUNDS, 'timed bf16 path', BF16_Q99)
     for k, v in (('fp32_loss', e_loss), ('fp32_norm', e_norm), ('bf16_loss', e_loss16), ('bf16_norm', e_norm16)):
         record_property(k, v)
     for tag, w in (('fp32', w32), ('bf16', w16)):

@@ -17,9 +17,8 @@ from tools import gemm_replay  # noqa: E402
 
 DEFAULT_HINTS = {'auto': 0, 't64': 2001, 't64k2': 2002, 't64k4': 2004, 't128': 3001, 't128k2': 3002, 't128k3': 3003, 't128r2': 4001, 't128r2k2': 4002,
                  't256x128': 5001, 't256': 7001, 't256k2': 7002, 't256h': 9001,
-                 'sk1': 10001, 'sk2': 10002, 'sk4': 10004, 'sk8': 10008, 'sk16': 10016,      # 128 x 64 skinny tile (M <= 128 only)
-                 'w128x256': 11001, 'w128x256k2': 11002, 'w256x128': 12001, 'w256x128k2': 12002,      # four 128 x 64 waves per workgroup
-                 'w128': 13001, 'w128k3': 13003, 'w128r2': 14001, 'w128r2k2': 14002}       # four 64 x 64 waves on the 128^2 tile (3-deep / 2-deep ring)
+                 'sk1': 10001, 'sk2': 10002, 'sk4': 10004, 'sk8': 10008, 'sk16': 10016}      # 128 x 64 skinny tile (M <= 128 only)
+# (round 3 also timed four-wave tiles under hints 11000 - 14000: profiles/r3_gemm_desc_ledger_4wave_tiles_negative.jsonl; removed from the library)
 
 
 def time_desc(d, hint, device, arena, ops, budget_bytes=600 << 20):
