@@ -350,6 +350,7 @@ def main():
     engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 1, 'gradient_accumulation_steps': gas,
                                                          'gradient_clipping': 1.0, 'steps_per_print': 1 << 30, 'hip_graph': not args.no_graph,
                                                          'parallel_wgrad': args.parallel_wgrad, 'p2p_via_host': args.test_single_device, 'graph_lanes': args.lanes, 'p2p_backend': args.p2p,
+                                                         'stage_fwd_streams': int(os.environ.get('DPIPE_STAGE_FWD_STREAMS', '2')),
                                                          'max_steps_in_flight': args.steps_in_flight}, device=device)
     params = [p for p in module.parameters() if p.requires_grad]
 

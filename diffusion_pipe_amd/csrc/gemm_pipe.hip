@@ -105,7 +105,7 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
     // experiment switch (environment DPIPE_GEMM_SHALLOW=1): the shallow rings everywhere (128^2 on 2 x 32 KiB, 64^2 on 3 x 16 KiB) -- slower launches in
     // isolation, but a smaller LDS footprint lets workgroups of the OTHER micro-batch lanes share the CU
     static const int shallow = [] { const char* e = getenv("DPIPE_GEMM_SHALLOW"); return e ? atoi(e) : 0; }();
-    if (shallow && force_tile == 0) return big ? 129 : 63;
+    if (shallow && force_tile == 0) { if (big && shallow != 3) return 129; if (!big && shallow != 2) return 63; }     // 1: both, 2: 128^2 only, 3: 64^2 only
     return big ? 128 : 64;
 }
 

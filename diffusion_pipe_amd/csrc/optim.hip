@@ -233,6 +233,135 @@ __global__ void __launch_bounds__(256) adamw8bit_kernel(T* __restrict__ p, const
     }
 }
 
+
+// The same update as adamw8bit_kernel for MANY tensors in one launch, 8 consecutive elements per thread: a 256-element quantisation block is 32 lanes x 8
+// elements (16-byte parameter / gradient / shift accesses, 8-byte code accesses), its absmax a 5-step shuffle inside the half-wave -- no LDS round trip, no
+// barrier in the loop.  One workgroup = one 2 048-element chunk (8 quantisation blocks) of one tensor; chunk table as in adamw_step_kernel.  Element-wise
+// arithmetic identical to adamw8bit_kernel (same order, same roundings), so the two produce the same codes and parameters.
+template <typename T>
+__global__ void __launch_bounds__(256) adamw8bit_multi_kernel(void* const* __restrict__ p_ptrs, void* const* __restrict__ g_ptrs, void* const* __restrict__ c1_ptrs,
+                                                              void* const* __restrict__ c2_ptrs, void* const* __restrict__ a1_ptrs, void* const* __restrict__ a2_ptrs,
+                                                              void* const* __restrict__ s_ptrs, const long* __restrict__ sizes, const int* __restrict__ chunk_tensor,
+                                                              const long* __restrict__ chunk_off, const float* __restrict__ qmap1, const float* __restrict__ qmap2,
+                                                              float beta1, float beta2, float eps, float lr, float weight_decay, float step_size, float correction2,
+                                                              float gnorm_scale) {
+    __shared__ float q1[256], q2[256];
+    q1[threadIdx.x] = qmap1[threadIdx.x]; q2[threadIdx.x] = qmap2[threadIdx.x];
+    __syncthreads();
+    constexpr int E = 8;
+    const int ti = chunk_tensor[blockIdx.x];
+    const long off = chunk_off[blockIdx.x], n = sizes[ti];
+    T* p = reinterpret_cast<T*>(p_ptrs[ti]);
+    const T* g = reinterpret_cast<const T*>(g_ptrs[ti]);
+    uint8_t* c1 = reinterpret_cast<uint8_t*>(c1_ptrs[ti]);
+    uint8_t* c2 = reinterpret_cast<uint8_t*>(c2_ptrs[ti]);
+    float* absmax1 = reinterpret_cast<float*>(a1_ptrs[ti]);
+    float* absmax2 = reinterpret_cast<float*>(a2_ptrs[ti]);
+    T* shift = s_ptrs ? reinterpret_cast<T*>(s_ptrs[ti]) : nullptr;
+    const long i0 = off + (long)threadIdx.x * E;
+    const bool any = i0 < n;                                  // lanes past the tensor's end stay in the half-wave shuffles with neutral values
+    const long blk = (any ? i0 : n - 1) >> 8;
+    const bool full = i0 + E <= n && (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (reinterpret_cast<uintptr_t>(g) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(c1) & 7) == 0 && (reinterpret_cast<uintptr_t>(c2) & 7) == 0 && (!shift || (reinterpret_cast<uintptr_t>(shift) & 15) == 0);
+    float gv[E], tv[E], pv[E];
+    uint8_t k1[E], k2[E];
+    bool live[E];
+    if (full) {
+        if constexpr (sizeof(T) == 2) {
+            Vec16<T> vg; vg.load(g + i0); vg.unpack(gv);
+            Vec16<T> vt; vt.load((shift ? shift : p) + i0); vt.unpack(tv);
+            if (shift) { Vec16<T> vp; vp.load(p + i0); vp.unpack(pv); }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                Vec16<T> vg; vg.load(g + i0 + 4 * h); vg.unpack(gv + 4 * h);
+                Vec16<T> vt; vt.load((shift ? shift : p) + i0 + 4 * h); vt.unpack(tv + 4 * h);
+                if (shift) { Vec16<T> vp; vp.load(p + i0 + 4 * h); vp.unpack(pv + 4 * h); }
+            }
+        }
+        const uint2 u1 = *reinterpret_cast<const uint2*>(c1 + i0), u2 = *reinterpret_cast<const uint2*>(c2 + i0);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            k1[e] = (uint8_t)(((e < 4 ? u1.x : u1.y) >> (8 * (e & 3))) & 0xff);
+            k2[e] = (uint8_t)(((e < 4 ? u2.x : u2.y) >> (8 * (e & 3))) & 0xff);
+            live[e] = true;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            live[e] = any && i0 + e < n;
+            const long i = live[e] ? i0 + e : n - 1;
+            gv[e] = live[e] ? Elem<T>::to_f(g[i]) : 0.f;
+            tv[e] = Elem<T>::to_f((shift ? shift : p)[i]);
+            pv[e] = shift ? Elem<T>::to_f(p[i]) : 0.f;
+            k1[e] = c1[i]; k2[e] = c2[i];
+        }
+    }
+    const float am1 = absmax1[blk], am2 = absmax2[blk];
+    float m[E], v[E];
+    bool fin[E];
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        fin[e] = isfinite(gv[e]);
+        m[e] = 0.f; v[e] = 0.f;
+        if (live[e] && fin[e]) {
+            const float gs = gv[e] * gnorm_scale;
+            m[e] = q1[k1[e]] * am1; v[e] = q2[k2[e]] * am2;
+            m[e] = m[e] * beta1 + (1.f - beta1) * gs;
+            v[e] = v[e] * beta2 + (1.f - beta2) * gs * gs;
+        }
+        a1 = fmaxf(a1, fabsf(m[e])); a2 = fmaxf(a2, v[e]);
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { a1 = fmaxf(a1, __shfl_xor(a1, o, 64)); a2 = fmaxf(a2, __shfl_xor(a2, o, 64)); }   // the 32 lanes of one quantisation block
+    if ((threadIdx.x & 31) == 0 && any) { absmax1[blk] = a1; absmax2[blk] = a2; }
+    float outp[E], outs[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        float t = tv[e];
+        if (fin[e]) {
+            t = Elem<T>::to_f(Elem<T>::from_f(t + step_size * (m[e] / (sqrtf(v[e]) + correction2 * eps))));
+            if (weight_decay > 0.f) t = Elem<T>::to_f(Elem<T>::from_f(t * (1.f - lr * weight_decay)));
+        }
+        if (shift) {
+            const float pn = Elem<T>::to_f(Elem<T>::from_f(pv[e] + t));
+            const float diff = Elem<T>::to_f(Elem<T>::from_f(pv[e] - pn));
+            outp[e] = pn; outs[e] = t + diff;
+        } else {
+            outp[e] = t; outs[e] = 0.f;
+        }
+        int n1 = nearest_code(q1, a1 > 0.f ? m[e] / a1 : 0.f);
+        const int n2 = nearest_code(q2, a2 > 0.f ? v[e] / a2 : 0.f);
+        if (signbit(q1[n1]) != signbit(m[e])) n1 = m[e] > 0.f ? min(n1 + 1, 255) : max(n1 - 1, 0);
+        k1[e] = (uint8_t)n1; k2[e] = (uint8_t)n2;
+    }
+    if (full) {
+        if constexpr (sizeof(T) == 2) {
+            Vec16<T> vo; vo.pack(outp); vo.store(p + i0);
+            if (shift) { Vec16<T> vs; vs.pack(outs); vs.store(shift + i0); }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                Vec16<T> vo; vo.pack(outp + 4 * h); vo.store(p + i0 + 4 * h);
+                if (shift) { Vec16<T> vs; vs.pack(outs + 4 * h); vs.store(shift + i0 + 4 * h); }
+            }
+        }
+        uint2 u1, u2;
+        u1.x = k1[0] | (k1[1] << 8) | (k1[2] << 16) | ((unsigned)k1[3] << 24); u1.y = k1[4] | (k1[5] << 8) | (k1[6] << 16) | ((unsigned)k1[7] << 24);
+        u2.x = k2[0] | (k2[1] << 8) | (k2[2] << 16) | ((unsigned)k2[3] << 24); u2.y = k2[4] | (k2[5] << 8) | (k2[6] << 16) | ((unsigned)k2[7] << 24);
+        *reinterpret_cast<uint2*>(c1 + i0) = u1; *reinterpret_cast<uint2*>(c2 + i0) = u2;
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (!live[e]) continue;
+            p[i0 + e] = Elem<T>::from_f(outp[e]);
+            if (shift) shift[i0 + e] = Elem<T>::from_f(outs[e]);
+            c1[i0 + e] = k1[e]; c2[i0 + e] = k2[e];
+        }
+    }
+}
+
 }  // namespace
 
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
@@ -306,6 +435,27 @@ int dpipe_adamw8bit_step(void* p, const void* g, void* state1, void* state2, flo
                                                      beta1, beta2, eps, lr, weight_decay, step_size, correction2, gnorm_scale);
     else { set_last_error("dpipe_adamw8bit_step: dtype"); return DPIPE_ERR_UNSUPPORTED; }
     return check_launch("dpipe_adamw8bit_step");
+}
+
+int dpipe_adamw8bit_multi(void* const* p_ptrs, void* const* g_ptrs, void* const* state1_ptrs, void* const* state2_ptrs, void* const* absmax1_ptrs,
+                          void* const* absmax2_ptrs, void* const* shift_ptrs, const long* sizes, const int* chunk_tensor, const long* chunk_off, int nchunks,
+                          const float* qmap1, const float* qmap2, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float gnorm_scale,
+                          int dtype, void* stream) {
+    if (nchunks <= 0) return DPIPE_OK;
+    if (!p_ptrs || !g_ptrs || !state1_ptrs || !state2_ptrs || !absmax1_ptrs || !absmax2_ptrs || !sizes || !chunk_tensor || !chunk_off || !qmap1 || !qmap2 || step < 1) {
+        set_last_error("dpipe_adamw8bit_multi: bad argument"); return DPIPE_ERR_ARG;
+    }
+    const float correction1 = 1.f - powf(beta1, (float)step), correction2 = sqrtf(1.f - powf(beta2, (float)step));
+    const float step_size = -lr * correction2 / correction1;
+    hipStream_t s = STREAM(stream);
+    if (dtype == DPIPE_BF16)
+        adamw8bit_multi_kernel<bf16_t><<<nchunks, 256, 0, s>>>(p_ptrs, g_ptrs, state1_ptrs, state2_ptrs, absmax1_ptrs, absmax2_ptrs, shift_ptrs, sizes, chunk_tensor, chunk_off,
+                                                               qmap1, qmap2, beta1, beta2, eps, lr, weight_decay, step_size, correction2, gnorm_scale);
+    else if (dtype == DPIPE_F32)
+        adamw8bit_multi_kernel<float><<<nchunks, 256, 0, s>>>(p_ptrs, g_ptrs, state1_ptrs, state2_ptrs, absmax1_ptrs, absmax2_ptrs, shift_ptrs, sizes, chunk_tensor, chunk_off,
+                                                              qmap1, qmap2, beta1, beta2, eps, lr, weight_decay, step_size, correction2, gnorm_scale);
+    else { set_last_error("dpipe_adamw8bit_multi: dtype"); return DPIPE_ERR_UNSUPPORTED; }
+    return check_launch("dpipe_adamw8bit_multi");
 }
 
 }  // extern "C"

@@ -144,6 +144,7 @@ class PipelineEngine:
         self.flat_grads = bool(self._config.get('flat_grads', self.dp_world_size > 1))
         self._stage_arena = {}
         self._dp_stream = None
+        self._capturing_buffer = 0
         self._last_grad_norm = None
 
         # hipGraph mode: one captured graph per micro-batch shape replaces ~10^4 per-op launches (static shapes only;
@@ -162,7 +163,13 @@ class PipelineEngine:
         # its pending backward belong to different micro-batches, so their graphs overlap on the GPU (same effect as the
         # concurrent lanes of the single-stage path).  Per-slot events order a slot's forward before its backward and its
         # backward before the slot is reused.
-        self._fwd_stream = torch.cuda.Stream(self.device) if self.use_stage_graphs else None
+        # `stage_fwd_streams` (default 2; not on the last stage, whose forward feeds its own backward at once and accumulates the loss): forwards of
+        # consecutive micro-batches alternate between two streams (pipe buffer id parity), so in the fill phase and whenever the previous stage runs
+        # ahead TWO forward graphs and one backward graph share the GPU -- the concurrency the three micro-batch lanes give the single-stage path.
+        # Backwards stay on ONE stream: their wgrad kernels accumulate into the same .grad buffers.
+        n_fwd = max(1, int(self._config.get('stage_fwd_streams', 2))) if (self.use_stage_graphs and self.stage_id != self.num_stages - 1) else 1
+        self._fwd_streams = [torch.cuda.Stream(self.device) for _ in range(n_fwd)] if self.use_stage_graphs else []
+        self._fwd_stream = self._fwd_streams[0] if self._fwd_streams else None
         self._bwd_stream = torch.cuda.Stream(self.device) if self.use_stage_graphs else None
         self._streams_forked = False
         self._g_total_loss = None
@@ -344,7 +351,8 @@ class PipelineEngine:
         two_streams = self.use_stage_graphs and not self._eval_mode
         if two_streams:
             main = torch.cuda.current_stream(self.device)
-            self._fwd_stream.wait_stream(main)          # previous optimizer step / data preparation
+            for st in self._fwd_streams:
+                st.wait_stream(main)                    # previous optimizer step / data preparation
             self._bwd_stream.wait_stream(main)
             self._streams_forked = True
         for step_cmds in pipe_schedule:
@@ -353,7 +361,7 @@ class PipelineEngine:
                 if handler is None:
                     raise RuntimeError(f'{self.__class__.__name__} does not understand instruction {cmd!r}')
                 if two_streams and isinstance(cmd, self._FWD_INSTR):
-                    with torch.cuda.stream(self._fwd_stream):
+                    with torch.cuda.stream(self._fwd_streams[cmd.kwargs.get('buffer_id', 0) % len(self._fwd_streams)]):
                         handler(self, **cmd.kwargs)
                 elif two_streams and isinstance(cmd, self._BWD_INSTR):
                     with torch.cuda.stream(self._bwd_stream):
@@ -366,7 +374,8 @@ class PipelineEngine:
     def _join_streams(self):
         if self._streams_forked:
             main = torch.cuda.current_stream(self.device)
-            main.wait_stream(self._fwd_stream)
+            for st in self._fwd_streams:
+                main.wait_stream(st)
             main.wait_stream(self._bwd_stream)
             self._streams_forked = False
 
@@ -513,6 +522,7 @@ class PipelineEngine:
         sig = (buffer_id, torch.is_tensor(inputs), torch.is_tensor(labels), tuple((tuple(t.shape), t.dtype) for t in ins + labs))
         slot = self._stage_slots.get(sig)
         if slot is None:
+            self._capturing_buffer = buffer_id
             slot = self._capture_stage_slot(ins, labs, torch.is_tensor(inputs), torch.is_tensor(labels))
             self._stage_slots[sig] = slot
         return slot
@@ -572,7 +582,7 @@ class PipelineEngine:
         from .. import ops as _ops
         static_in = make_inputs()
         fwd_graph, bwd_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        _ops.WS_LANE = 'stage-fwd'                  # forward and backward graphs replay on different streams at the same time:
+        _ops.WS_LANE = ('stage-fwd', self._capturing_buffer % max(1, len(self._fwd_streams)))   # forward graphs of the two forward streams and the backward graph replay at the same time:
         with torch.cuda.graph(fwd_graph, capture_error_mode=_capture_mode()):   # they must not share split-K ticket counters / slabs
             out = forward(static_in)
         static_gout = None if last else grads_like(out)

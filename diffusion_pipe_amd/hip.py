@@ -16,7 +16,7 @@ import os
 LIB_PATH = Path(os.environ.get('DPIPE_HIP_LIB') or Path(__file__).resolve().parent / 'libdpipe_hip.so')
 
 BF16, F32 = 0, 1
-ABI_VERSION = 3                      # DPIPE_ABI_VERSION of include/dpipe_hip.h this binding was written against
+ABI_VERSION = 4                      # DPIPE_ABI_VERSION of include/dpipe_hip.h this binding was written against
 CONV_OUT_F32, CONV_ACCUMULATE = 1, 2  # dpipe_conv2d_fwd / _dgrad `flags`
 OPT_ATTN_FWD_DMA, OPT_ATTN_BWD_DMA, OPT_ATTN_DQ8, OPT_ATTN_DKV_SPLIT, OPT_GEMM_SKINNY = 0, 1, 2, 3, 4     # dpipe_set_option ids (include/dpipe_hip.h)
 ACT = {None: 0, 'none': 0, 'gelu_tanh': 1, 'gelu': 2, 'gelu_erf': 2, 'silu': 3, 'quick_gelu': 4}
@@ -56,6 +56,7 @@ _SIGNATURES = {
     'dpipe_adamw_step': (I, [P, P, P, P, I, P, P, P, I, I, F, F, F, F, F, F, F, P, F, I, P]),
     'dpipe_adamw_step_kahan': (I, [P, P, P, P, P, I, P, P, P, I, I, F, F, F, F, F, F, F, P, F, I, P]),
     'dpipe_adamw8bit_step': (I, [P, P, P, P, P, P, P, P, P, L, F, F, F, F, F, I, F, I, P]),
+    'dpipe_adamw8bit_multi': (I, [P, P, P, P, P, P, P, P, P, P, I, P, P, F, F, F, F, F, I, F, I, P]),
     'dpipe_rmsnorm_fwd': (I, [P, P, P, P, L, I, F, I, I, P]),
     'dpipe_norm_slabs': (I, [L]),
     'dpipe_rmsnorm_bwd': (I, [P, P, P, P, P, P, P, L, I, I, I, I, P]),

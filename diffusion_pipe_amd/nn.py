@@ -274,9 +274,17 @@ class Attention(nn.Module):
         self.attn_impl = 'auto'
         self.fuse_projections = True      # fused QKV / KV GEMMs + packed flash attention in bf16 (fp32 parity mode: separate)
 
-    def forward(self, hidden_states, encoder_hidden_states=None, residual=None):
+    def kv_batchable(self):
+        """True when this (cross-) attention's K / V projections may be computed outside, batched with other blocks' (Transformer2DModel)."""
+        return (type(self.to_k) is Linear and type(self.to_v) is Linear and self.to_k.bias is None and self.to_v.bias is None and self.fuse_projections
+                and self.attn_impl == 'auto' and ops.flash_eligible(self.to_q.weight.dtype, self.dim_head))
+
+    def forward(self, hidden_states, encoder_hidden_states=None, residual=None, kv=None):
+        """kv: this block's packed [B, Sk, 2 H D] key / value projection of the context, computed by the caller for several blocks at once."""
         B, S, _ = hidden_states.shape
         H, D = self.heads, self.dim_head
+        if kv is not None:
+            return self.to_out[0](ops.attention_packed(self.to_q(hidden_states), kv, H, D), residual)
         plain = type(self.to_q) is Linear and type(self.to_k) is Linear and type(self.to_v) is Linear     # no adapter wrapped around them
         fused = plain and self.fuse_projections and self.attn_impl == 'auto' and ops.flash_eligible(self.to_q.weight.dtype, D)
         if fused and encoder_hidden_states is None:         # self attention: one QKV GEMM, packed attention

@@ -334,6 +334,33 @@ def fused_linear(x, weights, biases=None):
     return _FusedLinearFn.apply(x, len(weights), *weights, *biases)
 
 
+class _SplitColumnsFn(Function):
+    """[..., sum w_i] -> column-block views (w_i wide each) with ONE concatenation as the backward -- torch's own slicing would give every consumer a
+    zero-filled full-width gradient plus an add (3 launches per slice).  Used to hand the per-block K / V slices of one batched context projection
+    (nn.Transformer cross attention: every block of a Transformer2DModel projects the same 77 text tokens) to their blocks."""
+
+    @staticmethod
+    def forward(ctx, x, widths):
+        ctx.widths, ctx.shape, ctx.dtype = widths, x.shape, x.dtype
+        ctx.set_materialize_grads(False)
+        outs, off = [], 0
+        for w in widths:
+            outs.append(x[..., off:off + w])
+            off += w
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        parts = []
+        for g, w in zip(grads, ctx.widths):
+            parts.append(g if g is not None else torch.zeros(*ctx.shape[:-1], w, device=next(t for t in grads if t is not None).device, dtype=ctx.dtype))
+        return torch.cat(parts, dim=-1), None
+
+
+def split_columns(x, widths):
+    return _SplitColumnsFn.apply(x, tuple(int(w) for w in widths))
+
+
 def column_sum(x2, out=None, out_dtype=None):
     """sum over the rows of a [rows, cols] matrix (fp32 accumulate, two-stage slab reduction).  `out` given: out += sum
     (the fused gradient-accumulation form); else a new [cols] tensor in x2's dtype (or out_dtype)."""
@@ -946,7 +973,7 @@ class _FlashAttnFn(Function):
 def _split_heads(packed, parts, H, D):
     """[B, S, parts * H * D] -> `parts` strided views [B, S, H, D] (no copies: the kernels take strides)."""
     B, S, _ = packed.shape
-    return [packed[..., i * H * D:(i + 1) * H * D].view(B, S, H, D) for i in range(parts)]
+    return [torch.as_strided(packed, (B, S, H, D), (packed.stride(0), packed.stride(1), D, 1), packed.storage_offset() + i * H * D) for i in range(parts)]
 
 
 class _FlashAttnPackedFn(Function):
@@ -961,7 +988,9 @@ class _FlashAttnPackedFn(Function):
         if b is None:
             q, k, v = _split_heads(a, 3, H, D)
         else:
-            b = _contig(b)
+            # a column block of a wider projection output (split_columns) is consumed in place: the kernels take the token stride
+            if not (b.dim() == 3 and b.stride(2) == 1 and b.stride(1) % 8 == 0 and (b.shape[0] == 1 or b.stride(0) == b.shape[1] * b.stride(1))):
+                b = _contig(b)
             q = a.view(a.shape[0], a.shape[1], H, D)
             k, v = _split_heads(b, 2, H, D)
         o, lse = _flash_fwd(q, k, v, kv_len, scale, causal)

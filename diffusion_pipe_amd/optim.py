@@ -201,6 +201,7 @@ class AdamW8bit(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self.kahan, self.min_8bit_size = bool(kahan), int(min_8bit_size)
         self._qmaps = {}
+        self._tables = {}
 
     def _maps(self, device):
         if device not in self._qmaps:
@@ -286,7 +287,7 @@ class AdamW8bit(torch.optim.Optimizer):
         loss = closure() if closure is not None else None
         for group in self.param_groups:
             lr, (b1, b2), eps, wd = group['lr'], group['betas'], group['eps'], group['weight_decay']
-            small = []                                          # tensors below min_8bit_size: fp32 moments, updated together by multi-tensor ops
+            small, big = [], {}                                 # tensors below min_8bit_size: fp32 moments, updated together by multi-tensor ops
             for p in group['params']:
                 if p.grad is None:
                     continue
@@ -302,15 +303,43 @@ class AdamW8bit(torch.optim.Optimizer):
                 t = st['step']
                 shift = st.get('shift')
                 if st['state1'].dtype == torch.uint8:
-                    hip.check(hip.lib().dpipe_adamw8bit_step(hip.ptr(p), hip.ptr(grad), hip.ptr(st['state1']), hip.ptr(st['state2']), hip.ptr(st['absmax1']),
-                                                             hip.ptr(st['absmax2']), hip.ptr(st['qmap1']), hip.ptr(st['qmap2']), hip.ptr(shift), p.numel(),
-                                                             float(lr), float(b1), float(b2), float(eps), float(wd), int(t), 1.0, hip.dtype_code(p.dtype),
-                                                             hip.stream()), 'adamw8bit_step')
+                    big.setdefault((p.dtype, int(t)), []).append((p, grad, st))
                     continue
                 small.append((p, grad, st))
+            for (dt, t), items in big.items():                  # one multi-tensor launch per (dtype, step count) of the group
+                self._step_8bit(items, dt, t, lr, b1, b2, eps, wd)
             if small:
                 self._step_fp32_moments(small, lr, b1, b2, eps, wd)
         return loss
+
+    CHUNK = 2048                                                # elements per workgroup of dpipe_adamw8bit_multi: 8 quantisation blocks
+
+    def _step_8bit(self, items, dt, t, lr, b1, b2, eps, wd):
+        """Every 8-bit tensor of a group in ONE launch (dpipe_adamw8bit_multi).  Pointer / chunk tables live on the device and are cached on the buffer
+        addresses: with the engine's persistent gradient buffers nothing is rebuilt after the first step."""
+        from . import hip
+        dev = items[0][0].device
+        key = (dt, self.kahan) + tuple(x.data_ptr() for p, g, st in items for x in (p, g, st['state1']))
+        tab = self._tables.get(key)
+        if tab is None:
+            i64 = lambda xs: torch.tensor(xs, dtype=torch.int64, device=dev)
+            ctens, coff = [], []
+            for i, (p, _, _) in enumerate(items):
+                for off in range(0, p.numel(), self.CHUNK):
+                    ctens.append(i); coff.append(off)
+            tab = {'p': i64([p.data_ptr() for p, _, _ in items]), 'g': i64([g.data_ptr() for _, g, _ in items]),
+                   'c1': i64([st['state1'].data_ptr() for *_, st in items]), 'c2': i64([st['state2'].data_ptr() for *_, st in items]),
+                   'a1': i64([st['absmax1'].data_ptr() for *_, st in items]), 'a2': i64([st['absmax2'].data_ptr() for *_, st in items]),
+                   's': i64([st['shift'].data_ptr() for *_, st in items]) if self.kahan else None,
+                   'n': i64([p.numel() for p, _, _ in items]), 'ctens': torch.tensor(ctens, dtype=torch.int32, device=dev), 'coff': i64(coff),
+                   'nchunks': len(ctens), 'keep': items}
+            if len(self._tables) > 16:
+                self._tables.clear()
+            self._tables[key] = tab
+        q1, q2 = self._maps(dev)
+        hip.check(hip.lib().dpipe_adamw8bit_multi(hip.ptr(tab['p']), hip.ptr(tab['g']), hip.ptr(tab['c1']), hip.ptr(tab['c2']), hip.ptr(tab['a1']), hip.ptr(tab['a2']),
+                                                  hip.ptr(tab['s']), hip.ptr(tab['n']), hip.ptr(tab['ctens']), hip.ptr(tab['coff']), tab['nchunks'], hip.ptr(q1), hip.ptr(q2),
+                                                  float(lr), float(b1), float(b2), float(eps), float(wd), int(t), 1.0, hip.dtype_code(dt), hip.stream()), 'adamw8bit_multi')
 
 
 def computed_beta2(global_batch_size, beta2_half_life):

@@ -215,14 +215,17 @@ class BasicTransformerBlock(nn.Module):
         self.norm2, self.attn2 = dnn.LayerNorm(dim), dnn.Attention(dim, cross_dim, heads, head_dim)
         self.norm3, self.ff = dnn.LayerNorm(dim), dnn.FeedForward(dim)
 
-    def forward(self, x, encoder_hidden_states):
+    def forward(self, x, encoder_hidden_states, kv=None):
         # the three "x + f(norm(x))" adds ride the epilogue of f's output projection (GEMM `residual`)
         h, x = self.norm1(x, with_skip=True)            # (and their gradients ride the LayerNorm backward kernels)
         x = self.attn1(h, residual=x)
         h, x = self.norm2(x, with_skip=True)
-        x = self.attn2(h, encoder_hidden_states, residual=x)
+        x = self.attn2(h, encoder_hidden_states, residual=x, kv=kv)
         h, x = self.norm3(x, with_skip=True)
         return self.ff(h, residual=x)
+
+
+BATCH_CONTEXT_KV = os.environ.get('DPIPE_BATCH_CONTEXT_KV', '1') == '1'     # A/B switch: per-block K / V projections of the text context
 
 
 class Transformer2DModel(nn.Module):
@@ -244,8 +247,14 @@ class Transformer2DModel(nn.Module):
         h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
         h = self.proj_in(h)
         ctx = encoder_hidden_states.to(h.dtype)
-        for blk in self.transformer_blocks:
-            h = blk(h, ctx)
+        kvs = [None] * len(self.transformer_blocks)
+        if BATCH_CONTEXT_KV and len(self.transformer_blocks) > 1 and all(b.attn2.kv_batchable() for b in self.transformer_blocks):
+            # every block projects the SAME 77 text tokens to its keys / values: one GEMM for all of them (forward, and one dgrad + one wgrad in the
+            # backward) instead of one tiny M = 77 launch per block -- 70 -> 11 launches per pass over the UNet; the blocks consume column slices in place
+            ws = [w for b in self.transformer_blocks for w in (b.attn2.to_k.weight, b.attn2.to_v.weight)]
+            kvs = ops.split_columns(ops.fused_linear(ctx, ws, None), [2 * b.attn2.heads * b.attn2.dim_head for b in self.transformer_blocks])
+        for blk, kv in zip(self.transformer_blocks, kvs):
+            h = blk(h, ctx, kv)
         h = self.proj_out(h, residual)                               # "+ residual" in the projection's epilogue
         return h.reshape(B, H, W, C).permute(0, 3, 1, 2)
 

@@ -32,7 +32,7 @@ extern "C" {
 #define DPIPE_LOSS_SMOOTH_L1 2
 
 /* ABI version: bumped whenever a signature of this header changes; the host binding refuses a library of another version. */
-#define DPIPE_ABI_VERSION 3
+#define DPIPE_ABI_VERSION 4
 int dpipe_version(void);
 const char* dpipe_last_error(void);
 /* Kernel-selection options (process-wide; for A/B timing and for testing the fallback kernels -- every default is the measured-faster choice).
@@ -143,6 +143,13 @@ int dpipe_adamw_step_kahan(void* const* p_ptrs, void* const* m_ptrs, void* const
 int dpipe_adamw8bit_step(void* p, const void* g, void* state1, void* state2, float* absmax1, float* absmax2, const float* qmap1, const float* qmap2,
                          void* shift, long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float gnorm_scale, int dtype,
                          void* stream);
+/* The same update for MANY tensors in one launch (the step of a whole parameter group): device tables of per-tensor pointers (`shift_ptrs` NULL = no Kahan
+ * buffers) and element counts `sizes`, and a chunk table (chunk c covers elements [chunk_off[c], chunk_off[c] + 2048) of tensor chunk_tensor[c]; offsets are
+ * multiples of 2 048 = 8 quantisation blocks).  8 elements per thread with 16-byte accesses; HBM-bound: 10 B per parameter (14 with Kahan). */
+int dpipe_adamw8bit_multi(void* const* p_ptrs, void* const* g_ptrs, void* const* state1_ptrs, void* const* state2_ptrs, void* const* absmax1_ptrs,
+                          void* const* absmax2_ptrs, void* const* shift_ptrs, const long* sizes, const int* chunk_tensor, const long* chunk_off, int nchunks,
+                          const float* qmap1, const float* qmap2, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float gnorm_scale,
+                          int dtype, void* stream);
 
 /* ---- K2 RMSNorm (models/wan/model.py:70-86; per-head form models/hunyuan_image_modeling.py:98-103) ------------
  * y = cast(x * rsqrt(mean(x^2) + eps)) * w ; w may be NULL; rstd [rows] saved for backward (may be NULL). */

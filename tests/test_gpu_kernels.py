@@ -212,6 +212,42 @@ def test_layernorm_modulate(gpu, dtype, wdtype, mdtype, affine, mod):
         assert _rel_err(shift.grad, hr.grad) < (3e-2 if mdtype == torch.bfloat16 else 2e-3)
 
 
+def test_batched_context_kv_projection_matches_per_block_projections(gpu):
+    """Cross attention of several transformer blocks over the same text context: ONE K / V projection GEMM for all blocks + column slices consumed in
+    place by the packed flash attention (ops.split_columns, strided K / V views) vs one projection per block -- outputs and every gradient (context,
+    all projection weights, queries) agree to bf16 rounding."""
+    from diffusion_pipe_amd import nn as dnn, ops
+    torch.manual_seed(4)
+    B, S, L, C, H, D, NB = 2, 300, 77, 256, 4, 64, 3
+    attns = [dnn.Attention(H * D, C, H, D).to(gpu, torch.bfloat16) for _ in range(NB)]
+    assert all(a.kv_batchable() for a in attns)
+    x = torch.randn(B, S, H * D, device=gpu).to(torch.bfloat16)
+    ctx = torch.randn(B, L, C, device=gpu).to(torch.bfloat16)
+    gy = torch.randn(B, S, H * D, device=gpu).to(torch.bfloat16)
+
+    def run(batched):
+        for a in attns:
+            for p in a.parameters():
+                p.grad = None
+        xi, ci = x.clone().requires_grad_(True), ctx.clone().requires_grad_(True)
+        kvs = [None] * NB
+        if batched:
+            ws = [w for a in attns for w in (a.to_k.weight, a.to_v.weight)]
+            kvs = ops.split_columns(ops.fused_linear(ci, ws, None), [2 * H * D] * NB)
+            assert kvs[1].stride(1) == NB * 2 * H * D and kvs[1].data_ptr() != kvs[0].data_ptr()
+        h = xi
+        for a, kv in zip(attns, kvs):
+            h = a(h, ci, residual=h, kv=kv)
+        h.backward(gy)
+        return h.detach(), xi.grad, ci.grad, [p.grad.clone() for a in attns for p in a.parameters()]
+
+    o0, gx0, gc0, gp0 = run(False)
+    o1, gx1, gc1, gp1 = run(True)
+    assert _rel_err(o1, o0) < 1.6e-2 and _rel_err(gx1, gx0) < 2e-2 and _rel_err(gc1, gc0) < 2e-2
+    for a, b in zip(gp1, gp0):
+        assert _rel_err(a, b) < 2e-2
+
+
 LN_FUSED_CASES = [  # (B, S, D, affine, mod): shapes that take the fused backward (parameter-gradient partials inside the dx pass) and its fall-backs
     (1, 1024, 1280, True, False), (1, 4096, 640, True, False), (1, 77, 1280, True, False), (1, 77, 768, True, False), (2, 1024, 640, True, False),
     (1, 1024, 1536, False, True), (2, 1024, 512, False, True), (2, 515, 384, False, True), (1, 1030, 2048, True, False), (1, 256, 3072, False, True)]

@@ -233,6 +233,51 @@ def test_adamw8bit_kernel_matches_the_restated_library_algorithm(gpu, dtype, kah
             sr['shift'] = st['shift'].float().cpu().numpy().copy()
 
 
+@pytest.mark.parametrize('kahan', [False, True])
+def test_adamw8bit_multi_tensor_launch_equals_the_single_tensor_kernel(gpu, kahan):
+    """optim.AdamW8bit.step() = ONE dpipe_adamw8bit_multi launch over every 8-bit tensor of a group (8 elements per thread, half-wave absmax) vs the
+    one-tensor kernel dpipe_adamw8bit_step on copies of the same state: ragged sizes (tail lanes, partial quantisation blocks), a channels-last 4-D tensor,
+    three steps -- identical up to rare fused-multiply-add rounding flips (>= 99.9 % of codes / parameters bit-equal, the rest one code / one ulp)."""
+    from diffusion_pipe_amd import hip, optim
+    g = torch.Generator().manual_seed(3)
+    shapes = [(8192,), (5000,), (4096 + 77,), (300, 41), (64, 33, 3, 3), (2048 * 5 + 8,)]
+    ps = []
+    for sh in shapes:
+        t = torch.randn(*sh, generator=g).to(torch.bfloat16).to(gpu)
+        if len(sh) == 4:
+            t = t.contiguous(memory_format=torch.channels_last)
+        ps.append(torch.nn.Parameter(t))
+    kw = dict(lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01)
+    opt = optim.AdamW8bit(ps, kahan=kahan, **kw)
+    q1, q2 = opt._maps(gpu)
+    ref = [{'p': p.detach().clone(), 'c1': torch.zeros(p.numel(), dtype=torch.uint8, device=gpu), 'c2': torch.zeros(p.numel(), dtype=torch.uint8, device=gpu),
+            'a1': torch.zeros(-(-p.numel() // 256), device=gpu), 'a2': torch.zeros(-(-p.numel() // 256), device=gpu),
+            's': torch.zeros_like(p) if kahan else None} for p in ps]
+    for step in range(1, 4):
+        for p, r in zip(ps, ref):
+            gr = (torch.randn(p.shape, generator=g) * step).to(torch.bfloat16).to(gpu)
+            if p.dim() == 4:
+                gr = gr.contiguous(memory_format=torch.channels_last)
+            p.grad = gr
+            hip.check(hip.lib().dpipe_adamw8bit_step(hip.ptr(r['p']), hip.ptr(gr), hip.ptr(r['c1']), hip.ptr(r['c2']), hip.ptr(r['a1']), hip.ptr(r['a2']), hip.ptr(q1), hip.ptr(q2),
+                                                     hip.ptr(r['s']), p.numel(), kw['lr'], 0.9, 0.99, kw['eps'], kw['weight_decay'], step, 1.0, hip.BF16, hip.stream()), 'single')
+        opt.step()
+        torch.cuda.synchronize()
+        assert len(opt._tables) == 1
+        for p, r in zip(ps, ref):
+            st = opt.state[p]
+            assert st['state1'].dtype == torch.uint8
+            same_p = (p.detach().view(torch.int16) == r['p'].view(torch.int16)).float().mean().item()
+            d1 = (st['state1'].int() - r['c1'].int()).abs()
+            d2 = (st['state2'].int() - r['c2'].int()).abs()
+            assert same_p > 0.999 and d1.max().item() <= 1 and d2.max().item() <= 1 and (d1 == 0).float().mean().item() > 0.999, (step, tuple(p.shape), same_p)
+            assert torch.allclose(st['absmax1'], r['a1'], rtol=2e-6, atol=0) and torch.allclose(st['absmax2'], r['a2'], rtol=2e-6, atol=0)
+            # keep the two trajectories on identical state (a one-code flip would otherwise propagate)
+            r['p'].copy_(p.detach()); r['c1'].copy_(st['state1']); r['c2'].copy_(st['state2']); r['a1'].copy_(st['absmax1']); r['a2'].copy_(st['absmax2'])
+            if kahan:
+                r['s'].copy_(st['shift'])
+
+
 def test_adamw8bit_trains_like_fp32_adamw(gpu):
     """60 steps on a quadratic with raw bf16 parameters: the 8-bit (Kahan) optimizer reaches the fp32 AdamW trajectory's error level, with 2.03 bytes of
     moment state per parameter."""
