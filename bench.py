@@ -350,7 +350,7 @@ def main():
     engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 1, 'gradient_accumulation_steps': gas,
                                                          'gradient_clipping': 1.0, 'steps_per_print': 1 << 30, 'hip_graph': not args.no_graph,
                                                          'parallel_wgrad': args.parallel_wgrad, 'p2p_via_host': args.test_single_device, 'graph_lanes': args.lanes, 'p2p_backend': args.p2p,
-                                                         'stage_fwd_streams': int(os.environ.get('DPIPE_STAGE_FWD_STREAMS', '2')),
+                                                         'stage_fwd_streams': int(os.environ.get('DPIPE_STAGE_FWD_STREAMS', '1' if args.test_single_device else '2')),
                                                          'max_steps_in_flight': args.steps_in_flight}, device=device)
     params = [p for p in module.parameters() if p.requires_grad]
 
@@ -434,6 +434,12 @@ def main():
         with open(args.save_gemm_trace, 'w') as f:
             json.dump(gemm_replay.unique_with_counts(trace), f)
     rt = gemm_replay.time_in_graph(trace, device, reps=3) if trace else {'ms': 0.0, 'launches': 0, 'flops': 0.0, 'read_bytes': 0, 'write_bytes': 0}
+    # ... and the same list the way the step runs it: one graph per micro-batch lane, all lanes replaying at once (the lanes exist because a single list leaves
+    # CUs idle; this is the dominant kernel's sustained rate in the product's execution mode, reported NEXT TO the single-stream figure, never instead of it)
+    rc = None
+    if trace and world == 1 and engine.graph_lanes > 1:
+        per_lane = trace[:len(trace) // gas * max(1, gas // engine.graph_lanes)]      # a lane's share of the step: GAS / lanes micro-batches
+        rc = gemm_replay.time_concurrent(per_lane, device, engine.graph_lanes)
     rl = torch.tensor([rt['flops'], rt['ms'], rt['launches'], rt['read_bytes'] + rt['write_bytes']], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(rl)
@@ -474,8 +480,15 @@ def main():
                          'algorithmic_bytes_per_launch': round(g_bytes / max(launches, 1)),
                          'gemm_gpu_ms_per_step': round(g_ms / world, 2),
                          'traffic_detail': traffic,
+                         'gemm_shallow_rings': getattr(engine, 'gemm_shallow_rings', None),
                          'method': 'GEMM-only hipGraph of the step\'s recorded launch list, HIP events on the replay stream, HBM-cold operands'},
         }
+        if rc:
+            c_ach = rc['flops'] / (rc['ms'] * 1e-3) / 1e12
+            out['roofline']['concurrent_lanes'] = {'lanes': rc['lanes'], 'achieved': round(c_ach, 2), 'frac': round(c_ach / peak, 5), 'ms': round(rc['ms'], 2),
+                                                   'launches': rc['launches'],
+                                                   'method': 'the same launch list split over the engine\'s micro-batch lanes: one GEMM-only hipGraph per lane, all '
+                                                             'lanes replayed at once on their own streams (how the timed step runs them)'}
         if world == 1 and not args.no_cpu_baseline:
             # parity of the TIMED path, in every run: the product's current weights go to the host as fp32, the GPU engine (bf16 kernels,
             # hipGraph, lanes -- exactly what was timed) evaluates ONE step whose micro-batches are all `cpu_sample`, and the oracle's fp32

@@ -102,9 +102,10 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
     if (force_tile == 258) { p.ksteps *= 2; p.ksteps_per_split *= 2; return 258; }      // T256K counts K in 32-wide half steps (slices keep their K ranges)
     if (force_tile == 257 || force_tile == 256 || force_tile == 63 || force_tile == 130 || force_tile == 1264) return force_tile;
     if (force_tile == 129 || (force_tile == 0 && big && tiles128 >= 256 && (a_mc || b_mc || tiles128 >= 1024))) return 129;
-    // experiment switch (environment DPIPE_GEMM_SHALLOW=1): the shallow rings everywhere (128^2 on 2 x 32 KiB, 64^2 on 3 x 16 KiB) -- slower launches in
-    // isolation, but a smaller LDS footprint lets workgroups of the OTHER micro-batch lanes share the CU
-    static const int shallow = [] { const char* e = getenv("DPIPE_GEMM_SHALLOW"); return e ? atoi(e) : 0; }();
+    // DPIPE_OPT_GEMM_SHALLOW: the shallow rings everywhere (128^2 on 2 x 32 KiB, 64^2 on 3 x 16 KiB) -- slower launches in isolation (step list: 23.5 vs 22.0 us
+    // average), but a 64 KiB footprint lets a workgroup of ANOTHER micro-batch lane share the CU: 19.34 vs 18.93 images/s with 3 lanes
+    // (profiles/r3e_bench_variants.jsonl).  The engine sets 2 (128^2 only) when it replays >= 2 lanes
+    const int shallow = option(DPIPE_OPT_GEMM_SHALLOW, 0);
     if (shallow && force_tile == 0) { if (big && shallow != 3) return 129; if (!big && shallow != 2) return 63; }     // 1: both, 2: 128^2 only, 3: 64^2 only
     return big ? 128 : 64;
 }

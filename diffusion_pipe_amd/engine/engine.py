@@ -90,6 +90,8 @@ def flatten_grads(params, arenas=None):
     return arenas
 
 
+_SHALLOW_SET_BY_ENGINE = False      # the process-wide GEMM ring option currently holds an engine's 'auto' choice (a later engine may replace it)
+
 class PipelineEngine:
     def __init__(self, module, config, args=None, optimizer=None, lr_scheduler=None, model_parameters=None, device=None):
         assert isinstance(module, PipelineModule), 'model must be a PipelineModule'
@@ -179,6 +181,22 @@ class PipelineEngine:
         # once before ReduceGrads / clip / optimizer.  Same math as sequential accumulation up to fp summation order.
         self.graph_lanes = max(1, int(self._config.get('graph_lanes', 1))) if self.use_graph else 1     # bench: 3 (best of 1..4 on MI355X)
         self._lanes = []
+        # GEMM ring-depth policy (C-ABI option DPIPE_OPT_GEMM_SHALLOW): with >= 2 graphs replaying concurrently (micro-batch lanes, or forward + backward stage
+        # graphs) the 128^2 GEMM tile runs on its 2-deep 64 KiB ring, so a workgroup of another lane fits the same CU -- each launch is ~7 % slower alone, the
+        # step 2 % faster (MI355X, 3 lanes: 19.34 vs 18.93 images/s).  `gemm_shallow_rings`: 'auto' (default) | 0 | 1 | 2 | 3; an explicit DPIPE_GEMM_SHALLOW /
+        # dpipe_set_option wins over 'auto'.
+        if self.device.type == 'cuda':
+            from .. import hip as _hip
+            want = self._config.get('gemm_shallow_rings', 'auto')
+            concurrent = self.graph_lanes if self.use_graph else ((len(self._fwd_streams) + 1) if self.use_stage_graphs else 1)
+            if want == 'auto':
+                global _SHALLOW_SET_BY_ENGINE
+                if _SHALLOW_SET_BY_ENGINE or _hip.lib().dpipe_get_option(_hip.OPT_GEMM_SHALLOW) < 0:      # never override the user's explicit choice
+                    _hip.check(_hip.lib().dpipe_set_option(_hip.OPT_GEMM_SHALLOW, 2 if concurrent >= 2 else 0), 'set_option')
+                    _SHALLOW_SET_BY_ENGINE = True
+            else:
+                _hip.check(_hip.lib().dpipe_set_option(_hip.OPT_GEMM_SHALLOW, int(want)), 'set_option')
+            self.gemm_shallow_rings = _hip.lib().dpipe_get_option(_hip.OPT_GEMM_SHALLOW)
         # Bounded host run-ahead.  train_batch returns a device scalar, so a tight loop could queue optimizer steps without limit.
         # Before enqueuing step n the host waits for the end of step n - max_steps_in_flight.  Default 1: measured on MI355X /
         # ROCm 7.2 (round 2, tools/hang_repro.sh, 20+ runs): with hipGraph launches of >= 2 lanes' graphs queued ACROSS a step

@@ -315,11 +315,12 @@ class AdamW8bit(torch.optim.Optimizer):
     CHUNK = 2048                                                # elements per workgroup of dpipe_adamw8bit_multi: 8 quantisation blocks
 
     def _step_8bit(self, items, dt, t, lr, b1, b2, eps, wd):
-        """Every 8-bit tensor of a group in ONE launch (dpipe_adamw8bit_multi).  Pointer / chunk tables live on the device and are cached on the buffer
-        addresses: with the engine's persistent gradient buffers nothing is rebuilt after the first step."""
+        """Every 8-bit tensor of a group in ONE launch (dpipe_adamw8bit_multi).  Pointer / chunk tables live on the device, cached on the parameter / state
+        addresses; the gradient pointer row is re-uploaded only when a gradient buffer moved (never, with the engine's persistent gradient buffers)."""
         from . import hip
         dev = items[0][0].device
-        key = (dt, self.kahan) + tuple(x.data_ptr() for p, g, st in items for x in (p, g, st['state1']))
+        key = (dt, self.kahan) + tuple(x.data_ptr() for p, g, st in items for x in (p, st['state1']))
+        gkey = tuple(g.data_ptr() for _, g, _ in items)
         tab = self._tables.get(key)
         if tab is None:
             i64 = lambda xs: torch.tensor(xs, dtype=torch.int64, device=dev)
@@ -327,15 +328,17 @@ class AdamW8bit(torch.optim.Optimizer):
             for i, (p, _, _) in enumerate(items):
                 for off in range(0, p.numel(), self.CHUNK):
                     ctens.append(i); coff.append(off)
-            tab = {'p': i64([p.data_ptr() for p, _, _ in items]), 'g': i64([g.data_ptr() for _, g, _ in items]),
+            tab = {'p': i64([p.data_ptr() for p, _, _ in items]), 'g': None, 'gkey': None,
                    'c1': i64([st['state1'].data_ptr() for *_, st in items]), 'c2': i64([st['state2'].data_ptr() for *_, st in items]),
                    'a1': i64([st['absmax1'].data_ptr() for *_, st in items]), 'a2': i64([st['absmax2'].data_ptr() for *_, st in items]),
                    's': i64([st['shift'].data_ptr() for *_, st in items]) if self.kahan else None,
                    'n': i64([p.numel() for p, _, _ in items]), 'ctens': torch.tensor(ctens, dtype=torch.int32, device=dev), 'coff': i64(coff),
-                   'nchunks': len(ctens), 'keep': items}
+                   'nchunks': len(ctens), 'keep': [(p, st) for p, _, st in items]}     # parameters and states only: a table never pins a gradient buffer
             if len(self._tables) > 16:
                 self._tables.clear()
             self._tables[key] = tab
+        if tab['gkey'] != gkey:                                 # gradient buffers moved (no persistent arena): one small pointer upload, the rest stays
+            tab['g'], tab['gkey'] = torch.tensor(gkey, dtype=torch.int64, device=dev), gkey
         q1, q2 = self._maps(dev)
         hip.check(hip.lib().dpipe_adamw8bit_multi(hip.ptr(tab['p']), hip.ptr(tab['g']), hip.ptr(tab['c1']), hip.ptr(tab['c2']), hip.ptr(tab['a1']), hip.ptr(tab['a2']),
                                                   hip.ptr(tab['s']), hip.ptr(tab['n']), hip.ptr(tab['ctens']), hip.ptr(tab['coff']), tab['nchunks'], hip.ptr(q1), hip.ptr(q2),

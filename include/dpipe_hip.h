@@ -42,7 +42,10 @@ const char* dpipe_last_error(void);
 #define DPIPE_OPT_ATTN_DQ8 2        /* register-staged path, head dim 128: 1 (default) 8-wave dQ kernel for long sequences */
 #define DPIPE_OPT_ATTN_DKV_SPLIT 3  /* head dim 128, long key sequences: 1 (default) dV and dK as two 8-wave kernels; 0: one pass */
 #define DPIPE_OPT_GEMM_SKINNY 4     /* M <= 128 GEMMs (77-token text-encoder / cross-attention linears): 1 = the 128 x 64 tile with deeper split-K; 0 (default: measured faster) = the 64 x 64 tile */
-#define DPIPE_OPTION_COUNT 5
+#define DPIPE_OPT_GEMM_SHALLOW 5    /* ring depth of the plain GEMM's tiles.  0 (default): 128^2 on the 3-deep 96 KiB ring, 64^2 on the 4-deep 64 KiB ring -- the fastest launch
+                                      in isolation; 2: 128^2 on the 2-deep 64 KiB ring (two workgroups per CU) -- slower alone, faster when concurrent streams share the
+                                      chip: the engine selects it for >= 2 micro-batch lanes; 3: 64^2 on the 3-deep 48 KiB ring; 1: both */
+#define DPIPE_OPTION_COUNT 6
 int dpipe_set_option(int option, int value);
 int dpipe_get_option(int option);    /* the effective explicit / environment value, -1 if neither is set */
 /* Number of compute units / name of device `dev`; used by the host to sanity-check it runs on gfx950. */

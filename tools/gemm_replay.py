@@ -108,6 +108,46 @@ def time_in_graph(trace, device, reps=3, arena_bytes=3 << 30):
     return {'ms': e0.elapsed_time(e1) / reps, 'launches': len(trace), 'flops': sum(flops(d) for d in trace), 'read_bytes': rd, 'write_bytes': wr}
 
 
+def time_concurrent(trace, device, lanes, reps=2, arena_bytes=2 << 30):
+    """The same launch list as `lanes` hipGraphs replayed AT THE SAME TIME on `lanes` HIP streams (each its own operand arena and split-K workspace) -- the
+    way the engine's micro-batch lanes run it.  -> dict(ms for all lanes' lists, launches, flops) of ONE round (every lane replays its list once)."""
+    from diffusion_pipe_amd import ops
+    main = torch.cuda.current_stream(device)
+    streams = [torch.cuda.Stream(device) for _ in range(lanes)]
+    graphs = []
+    for li, st in enumerate(streams):
+        arena = Arena(device, arena_bytes)
+        ops.WS_LANE = ('roofline-lane', li)
+        st.wait_stream(main)
+        with torch.cuda.stream(st):
+            issue(trace[:64], arena, ops)
+        main.wait_stream(st)
+        torch.cuda.synchronize(device)
+        arena.off = 0
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st, capture_error_mode='thread_local'):
+            issue(trace, arena, ops)
+        graphs.append((g, arena))
+    ops.WS_LANE = None
+
+    def round_():
+        for st, (g, _) in zip(streams, graphs):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                g.replay()
+        for st in streams:
+            main.wait_stream(st)
+    round_()
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(main)
+    for _ in range(reps):
+        round_()
+    e1.record(main)
+    torch.cuda.synchronize(device)
+    return {'ms': e0.elapsed_time(e1) / reps, 'launches': len(trace) * lanes, 'flops': sum(flops(d) for d in trace) * lanes, 'lanes': lanes}
+
+
 def unique_with_counts(trace):
     u = OrderedDict()
     for d in trace:

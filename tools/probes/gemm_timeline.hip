@@ -9,6 +9,7 @@
 
 namespace dpipe {
 void set_last_error(const char* msg) { fprintf(stderr, "error: %s\n", msg); }
+int option(int, int dflt) { return dflt; }
 int check_launch(const char* what) { hipError_t e = hipGetLastError(); if (e != hipSuccess) fprintf(stderr, "%s: %s\n", what, hipGetErrorString(e)); return (int)e; }
 }
 
@@ -16,7 +17,7 @@ int main(int argc, char** argv) {
     struct Case { int ta, tb, M, N, K, tile, sk; };
     std::vector<Case> cases = {{0, 1, 1024, 1280, 1280, 64, 1}, {0, 1, 1024, 1280, 1280, 65, 1}, {0, 1, 1024, 10240, 1280, 128, 1}, {0, 1, 1024, 10240, 1280, 130, 1},
                                {0, 0, 1024, 1280, 1280, 64, 1}, {0, 0, 1024, 1280, 1280, 65, 1}, {1, 0, 1280, 1280, 1024, 65, 1}, {1, 0, 10240, 1280, 1024, 129, 1},
-                               {1, 0, 10240, 1280, 1024, 130, 1}, {0, 0, 1024, 5120, 1280, 130, 1}};
+                               {1, 0, 10240, 1280, 1024, 130, 1}, {0, 0, 1024, 5120, 1280, 130, 1}, {0, 1, 1024, 10240, 1280, 257, 1}, {0, 1, 1024, 10240, 1280, 129, 1}, {0, 1, 8192, 8192, 8192, 257, 1}};
     const size_t arena_bytes = 2ul << 30;
     char* arena; hipMalloc(&arena, arena_bytes); hipMemset(arena, 0x11, arena_bytes);
     void* ws; hipMalloc(&ws, 4096 + 640 * 65536); hipMemset(ws, 0, 4096 + 640 * 65536);
