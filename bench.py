@@ -66,7 +66,7 @@ def parse():
     ap.add_argument('--activation-checkpointing', action='store_true')
     ap.add_argument('--partition', default='parameters')
     ap.add_argument('--no-graph', action='store_true', help='disable hipGraph capture of the micro-batch fwd+bwd')
-    ap.add_argument('--lanes', type=int, default=0, help='concurrent micro-batch lanes of the single-stage hipGraph path (default: 3 for sdxl, 1 for the DiT workloads)')
+    ap.add_argument('--lanes', type=int, default=0, help='concurrent micro-batch lanes of the single-stage hipGraph path (default: 3 for sdxl, 2 for flux / wan, 1 for hv)')
     ap.add_argument('--test-single-device', action='store_true',
                     help='TEST ONLY: all ranks share cuda:0, collectives over gloo, stage payloads staged through the host')
     ap.add_argument('--torch-adamw', action='store_true', help='A/B switch: torch.optim.AdamW(fused=True) + separate lane-sum / clip / zero passes')
@@ -86,6 +86,7 @@ def start_progress_monitor(engine_mod, stall_s):
     import subprocess
     import threading
     engine_mod.TRACE = []
+    engine_mod.TRACE_TIMING = bool(os.environ.get('DPIPE_STEP_TIMELINE', ''))
     verbose = os.environ.get('DPIPE_TRACE_STEPS', '0') == '1'
 
     def run():
@@ -181,7 +182,7 @@ def run_dit_workload(args, device, world, rank):
     work, label, make, kwargs, full_ft, gas_default, graph = build_dit_workload(args, device)
     graph = graph and not args.no_graph
     gas = args.gas or gas_default
-    lanes = args.lanes or 1
+    lanes = args.lanes or (2 if (graph and args.workload in ('flux', 'wan') and gas >= 2) else 1)      # measured: Flux 2.49 / 3.09 / 2.89 samples/s at 1 / 2 / 3 lanes, Wan-14B 0.85 / 0.94 at 1 / 2
     n_params = sum(p.numel() for p in work.transformer.parameters())
     n_train = sum(p.numel() for p in work.transformer.parameters() if p.requires_grad)
     module = ManualPipelineModule(layers=work.to_layers(), num_stages=1, partition_method=args.partition, loss_fn=work.get_loss_fn(), dynamic_shape=True, **kwargs)
@@ -403,8 +404,25 @@ def main():
         if trace_steps:
             print(f'[trace] timed step {i} enqueued at {time.monotonic():.2f}', file=sys.stderr, flush=True)
     fence()
-    engine_mod.TRACE = None
     elapsed = time.perf_counter() - t0
+    timeline_path = os.environ.get('DPIPE_STEP_TIMELINE', '')
+    if timeline_path and engine_mod.TRACE_TIMING and rank == 0:
+        # per-step timeline of the timed steps: GPU time (ms, relative to the step's first event) at which every lane's replay started / ended, the lanes
+        # joined and the step end retired, plus the host clock at which each launch was issued
+        tr = [e for e in engine_mod.TRACE if len(e) == 3]
+        steps_ = {}
+        for label, ev, host in tr:
+            steps_.setdefault(label[1] if label[0] != 'step_end' else label[1], []).append((label, ev, host))
+        rows = []
+        for st in sorted(steps_)[-min(6, len(steps_)):]:
+            evs = steps_[st]
+            ev0, h0 = evs[0][1], evs[0][2]
+            rows.append({'step': st, 'events': [{'label': list(l), 'gpu_ms': round(ev0.elapsed_time(e), 3), 'host_ms': round((h - h0) * 1e3, 3)} for l, e, h in evs]})
+        for r in rows:
+            r['gpu_ms_total'] = r['events'][-1]['gpu_ms']
+        with open(timeline_path, 'w') as f:
+            json.dump(rows, f, indent=1)
+    engine_mod.TRACE = None
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -27,11 +27,18 @@ from .p2p import HostStagedLink, RcclLink, StageLink
 # step end -- recorded on the launch stream, never waited on here, so tracing does not change the execution order.  A monitor
 # thread polls event.query() to report which replay a wedged queue stopped at.
 TRACE = None
+TRACE_TIMING = False        # True (bench.py DPIPE_STEP_TIMELINE): timing events + the host clock of the launch, for a per-step timeline of the lanes
 
 
 def _trace(label, stream):
     if TRACE is not None:
-        TRACE.append((label, stream.record_event()))
+        if TRACE_TIMING:
+            import time
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream)
+            TRACE.append((label, ev, time.perf_counter()))
+        else:
+            TRACE.append((label, stream.record_event()))
 
 
 def _capture_mode():
@@ -429,10 +436,14 @@ class PipelineEngine:
                 for dst, src in zip(entry['inputs'] + entry['labels'], feats + labels):
                     if src.numel() > 0:
                         dst.copy_(src, non_blocking=True)
+                if TRACE_TIMING:
+                    _trace(('launch', self.global_steps, i, lane['id']), lane['stream'])
                 entry['graph'].replay()
                 _trace(('replay', self.global_steps, i, lane['id']), lane['stream'])
         for lane in lanes:
             main.wait_stream(lane['stream'])
+        if TRACE_TIMING:
+            _trace(('lanes_joined', self.global_steps), main)
         base = lanes[0]
         _ops.WS_LANE = None
         if self._fused_step_end() and not self.is_data_parallel:
