@@ -82,6 +82,12 @@ using T256K = Tile<256, 256, 2, 4, 4, 32>;  // the same 256 x 256 tile on a 4-de
 // (Round 3 negative result, profiles/r3_gemm_desc_ledger_4wave_tiles_negative.jsonl: FOUR-wave workgroups -- 128 x 64 wave tiles on 128 x 256 / 256 x 128, 64 x 64 wave tiles
 //  on 128 x 128, one wave per SIMD -- read a third less from the LDS per MFMA but run 15 .. 55 % SLOWER than the eight-wave tiles on every SDXL shape >= 9 GFLOP
 //  ([1024, 10240, 1280]: 90 / 69 us vs 59): with one wave per SIMD nothing covers the wave's own DMA issue, fragment reads and barrier waits.  Removed again.)
+using T128Q3 = Tile<128, 128, 2, 2, 3, 32>;  // OCCUPANCY-style 128^2 tile: 4 waves of 64 x 64 on a 3-deep ring of HALF K-steps (3 x 16 KiB = 48 KiB) -> THREE workgroups per CU, one wave of
+                                             // each per SIMD: a workgroup's vmcnt wait / barrier / fragment-read latency is covered by the other two (the deep-ring tiles rely on one
+                                             // workgroup's own look-ahead instead).  tile_hint 11000 + S.  Measured (profiles/r3k_gemm_desc_ledger_halfstep_4wave_tiles.jsonl):
+                                             // -11 % on [1024,1280] x [10240,1280]^T (52.2 vs 58.8 us) and -17 % on [4096,640] x [640,2560], +5 .. +15 % on the wgrad (TN) shapes and far
+                                             // behind wherever split-K is what fills the chip; forced for every 128^2 launch of the step: 19.06 vs 19.44 images/s.  Selectable, not dispatched.
+using T128Q4 = Tile<128, 128, 2, 2, 4, 32>;  // the same on a 4-deep ring (64 KiB, two workgroups per CU, three half steps in flight): never ahead of T128Q3.  tile_hint 12000 + S
 using T256S = Tile<256, 256, 2, 4, 2>;      // 256 x 256, 8 waves of 128 x 64 (128 accumulator VGPRs), 2 x 64 KiB: twice the MFMA work per DMA'd
                                             // byte of the 128^2 tile -- the large-GEMM configuration (DiT-sized linears: Flux / Wan / HunyuanVideo)
 
@@ -136,7 +142,7 @@ template <int NLOAD> __device__ __forceinline__ void wait_dma_ahead(int ahead) {
 // zeros, so no im2col matrix and no padded copy ever exists.  CONV = 2: wgrad, one GEMM per tap (grid.y): the B operand's K-ROWS are
 // the gathered pixels (k = output pixel, n = input channel), A = dy read MN-contiguous.
 template <int BM_, int BN_, int WM_, int WN_, int STAGES_, bool A_MC, bool B_MC, int CONV = 0, int BKT = 64>
-__global__ void __launch_bounds__(WM_ * WN_ * 64) gemm_pipe_kernel(const GemmParams p) {      // 4-wave configurations: one wave per SIMD may use the whole 512-register file
+__global__ void __launch_bounds__(WM_ * WN_ * 64, (WM_ * WN_ == 4 && BKT == 32) ? 3 : 1) gemm_pipe_kernel(const GemmParams p) {     // half-step 4-wave tiles: three waves per SIMD (<= 168 VGPRs)      // 4-wave configurations: one wave per SIMD may use the whole 512-register file
     using TL = Tile<BM_, BN_, WM_, WN_, STAGES_, BKT>;
     constexpr int BM = TL::BM, BN = TL::BN, STAGES = TL::STAGES, TM = TL::TM, TN = TL::TN, NLOAD = TL::NLOAD;
     constexpr int BK = BKT, KS = BKT / 16;          // (shadows the namespace default) k extent of a stage, 16-wide k-slices per stage

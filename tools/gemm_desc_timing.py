@@ -17,7 +17,8 @@ from tools import gemm_replay  # noqa: E402
 
 DEFAULT_HINTS = {'auto': 0, 't64': 2001, 't64k2': 2002, 't64k4': 2004, 't128': 3001, 't128k2': 3002, 't128k3': 3003, 't128r2': 4001, 't128r2k2': 4002,
                  't256x128': 5001, 't256': 7001, 't256k2': 7002, 't256h': 9001,
-                 'sk1': 10001, 'sk2': 10002, 'sk4': 10004, 'sk8': 10008, 'sk16': 10016}      # 128 x 64 skinny tile (M <= 128 only)
+                 'sk1': 10001, 'sk2': 10002, 'sk4': 10004, 'sk8': 10008, 'sk16': 10016,      # 128 x 64 skinny tile (M <= 128 only)
+                 'q3': 11001, 'q3k2': 11002, 'q3k3': 11003, 'q4': 12001, 'q4k2': 12002}     # 4-wave 128^2 on 3- / 4-deep rings of half K-steps (3 / 2 workgroups per CU)
 # (round 3 also timed four-wave tiles under hints 11000 - 14000: profiles/r3_gemm_desc_ledger_4wave_tiles_negative.jsonl; removed from the library)
 
 
