@@ -37,14 +37,18 @@ _SPLITK_WS_BYTES = 4096 + 640 * 65536
 # Set by the engine while it captures / runs one of several concurrent micro-batch lanes: graphs captured on the same
 # capture stream but replayed on different streams must not share ticket counters, so the lane id replaces the stream key.
 WS_LANE = None
+# Streams on which a model forks a parallel branch inside a lane (workloads/sdxl.py: CLIP-L next to CLIP-G): stream handle -> branch tag.  A branch's
+# launches -- forward AND backward: autograd runs a node on the stream of its forward -- take their own workspace.
+BRANCH_TAGS = {}
 
 
 def _splitk_workspace(device):
     cur = torch.cuda.current_stream(device)
     if WS_LANE is not None:
-        # a lane's graph may fork wgrad onto the side stream (PARALLEL_WGRAD): the two parallel branches need separate ticket counters
+        # a lane's graph may fork wgrad onto the side stream (PARALLEL_WGRAD) or a model branch onto a tagged stream: parallel branches need separate ticket counters
         side = _SIDE_STREAMS.get(device.index)
-        key = (device.index, ('lane', WS_LANE, 'side' if (side is not None and cur == side) else 'main'))
+        tag = BRANCH_TAGS.get(cur.cuda_stream) or ('side' if (side is not None and cur == side) else 'main')
+        key = (device.index, ('lane', WS_LANE, tag))
     else:
         key = (device.index, cur.cuda_stream)
     ws = _SPLITK_WS.get(key)
