@@ -116,6 +116,8 @@ def test_concurrent_micro_batch_lanes_match_sequential_graph_path(gpu):
     """graph_lanes = 2 / 4: micro-batches replay concurrently on separate streams into per-lane gradient accumulators that
     are summed before clip / step -- loss and global gradient norm must agree with the one-lane path on every step
     (a lane sharing scratch memory with another lane would show up here as run-to-run noise)."""
+    import os
+    from diffusion_pipe_amd import hip
     from diffusion_pipe_amd.data import split_batch
     from diffusion_pipe_amd.engine import ManualPipelineModule, initialize
     from diffusion_pipe_amd.workloads import sdxl
@@ -128,6 +130,11 @@ def test_concurrent_micro_batch_lanes_match_sequential_graph_path(gpu):
         engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 1, 'gradient_accumulation_steps': gas, 'gradient_clipping': 1.0,
                                                              'hip_graph': True, 'graph_lanes': lanes}, device=gpu)
         engine._configure_optimizer(lambda ps: torch.optim.SGD(ps, lr=1e-3), [p for p in module.parameters()])
+        if os.environ.get('DPIPE_GEMM_SHALLOW') is None:
+            # the engine picks the GEMM ring depth from the number of graphs it replays concurrently (C-ABI option DPIPE_OPT_GEMM_SHALLOW): deep rings for one
+            # lane, the two-workgroups-per-CU ring of the 128^2 tile from two lanes on -- and a later engine in the same process may change an earlier one's choice
+            assert engine.gemm_shallow_rings == (2 if lanes > 1 else 0)
+            assert hip.lib().dpipe_get_option(hip.OPT_GEMM_SHALLOW) == engine.gemm_shallow_rings
         res = []
         for step in range(4):
             torch.manual_seed(100 + step)
