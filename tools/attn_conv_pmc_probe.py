@@ -7,7 +7,8 @@ import sys
 
 import torch
 
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diffusion_pipe_amd import nn as dnn, ops  # noqa: E402
 
 dev = torch.device('cuda:0')
