@@ -142,7 +142,7 @@ template <int NLOAD> __device__ __forceinline__ void wait_dma_ahead(int ahead) {
 // zeros, so no im2col matrix and no padded copy ever exists.  CONV = 2: wgrad, one GEMM per tap (grid.y): the B operand's K-ROWS are
 // the gathered pixels (k = output pixel, n = input channel), A = dy read MN-contiguous.
 template <int BM_, int BN_, int WM_, int WN_, int STAGES_, bool A_MC, bool B_MC, int CONV = 0, int BKT = 64>
-__global__ void __launch_bounds__(WM_ * WN_ * 64, (WM_ * WN_ == 4 && BKT == 32) ? 3 : 1) gemm_pipe_kernel(const GemmParams p) {     // half-step 4-wave tiles: three waves per SIMD (<= 168 VGPRs)      // 4-wave configurations: one wave per SIMD may use the whole 512-register file
+__global__ void __launch_bounds__(WM_ * WN_ * 64, (WM_ * WN_ == 4 && BKT == 32) ? (STAGES_ == 3 ? 3 : 2) : 1) gemm_pipe_kernel(const GemmParams p) {     // half-step 4-wave tiles: three waves per SIMD (<= 168 VGPRs)      // 4-wave configurations: one wave per SIMD may use the whole 512-register file
     using TL = Tile<BM_, BN_, WM_, WN_, STAGES_, BKT>;
     constexpr int BM = TL::BM, BN = TL::BN, STAGES = TL::STAGES, TM = TL::TM, TN = TL::TN, NLOAD = TL::NLOAD;
     constexpr int BK = BKT, KS = BKT / 16;          // (shadows the namespace default) k extent of a stage, 16-wide k-slices per stage

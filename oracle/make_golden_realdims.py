@@ -6,6 +6,9 @@
   * Flux.1-dev width (3072 = 24 heads of 128, rotary axes (16, 56, 56), 4096-wide text states): one double-stream + one single-stream block inside the
     reference's pipeline layers, 4 096 image + 512 text tokens, through oracle/flux_ref.py (diffusers restated: parity unpinned) -- output, loss, gradients.
 
+  * HunyuanVideo width (BASELINE config 5: 3072 = 24 x 128, rope (16, 56, 56), token refiner over 4096-wide LLM states): one double + one single stream
+    block between the real embedders / refiner / final layer, 2 880 video + 256 text tokens (66 padded), through oracle/hv_ref.py (parity unpinned).
+
 Nothing large is stored: weights and inputs are rebuilt from seeds by `wan_case()` / `flux_case()` (shared with the GPU test), the JSON holds the loss and
 (sum |t|, sum t, seeded projection <t, r>, ||t||_2) checksums (oracle/checksums.py) of the outputs and of every gradient.  ~15 GB of host memory, a few minutes of CPU.
 
@@ -70,7 +73,62 @@ def flux_case():
     return cfg, work, feats, target
 
 
+HV = dict(latent_thw=(5, 48, 48), text_tokens=256, valid_text=(190,), seed=41)
+
+
+def hv_case():
+    """-> (HunyuanVideoConfig, oracle transformer, product workload on CPU fp32 with the same weights, prepared features, label): HunyuanVideo's real width
+    (3072 = 24 heads of 128, rope (16, 56, 56), 4096-wide LLM states, 768-wide pooled CLIP vector), 1 double + 1 single stream block, 2 880 video tokens +
+    256 text tokens of which 66 are padding."""
+    from diffusion_pipe_amd.workloads import hunyuan_video as hv
+    from oracle import hv_ref
+    cfg = hv.HunyuanVideoConfig(mm_double_blocks_depth=1, mm_single_blocks_depth=1)
+    tr = hv_ref.HYVideoDiffusionTransformer(cfg, seed=HV['seed'])
+    work = hv.HunyuanVideoWorkload(cfg, model_config={}, dtype=torch.float32, seed=HV['seed'] + 1)
+    work.transformer.load_state_dict(tr.state_dict())
+    torch.manual_seed(HV['seed'] + 2)
+    feats, label = work.prepare_inputs(hv.synthetic_hv_batch(cfg, batch_size=1, latent_thw=HV['latent_thw'], text_tokens=HV['text_tokens'], valid_text=HV['valid_text'],
+                                                             seed=HV['seed'] + 3))
+    return cfg, tr, work, feats, label
+
+
+def hv_reference_forward(tr, cfg, f):
+    """the reference's layer sequence (models/hunyuan_video.py:483-680) over the oracle transformer, as tests/test_gpu_hv.py spells it"""
+    from oracle import hv_ref
+    x_t, t, pe1, m1, pe2, fc, fs, gd = f
+    vec = tr.time_in(t) + tr.vector_in(pe2) + tr.guidance_in(gd)
+    img, txt = tr.img_in(x_t), tr.txt_in(pe1, t, m1)
+    cu = hv_ref.get_cu_seqlens(m1, img.shape[1])
+    mx = img.shape[1] + txt.shape[1]
+    for b in tr.double_blocks:
+        img, txt = b(img, txt, vec, cu, cu, mx, mx, (fc[0], fs[0]))
+    x = torch.cat([img, txt], 1)
+    for b in tr.single_blocks:
+        x = b(x, vec, txt.shape[1], cu, cu, mx, mx, (fc[0], fs[0]))
+    out = tr.final_layer(x[:, :img.shape[1]], vec)
+    _, _, T, H, W = x_t.shape
+    return tr.unpatchify(out, T // cfg.patch_size[0], H // cfg.patch_size[1], W // cfg.patch_size[2])
+
+
+def hv_section():
+    cfg, tr, work, feats, label = hv_case()
+    out = hv_reference_forward(tr, cfg, feats)
+    loss = ((out - label[0]) ** 2).mean()
+    loss.backward()
+    print('hunyuan-video blocks: loss', float(loss), flush=True)
+    return {'case': HV, 'source': 'oracle/hv_ref.py + oracle/blocks_ref.py (hyvideo transformer restated; block dataflow pinned by models/hunyuan_image_modeling.py, wrappers by '
+                                  'models/hunyuan_video.py:413-492)', 'loss': float(loss), 'out': checksum(out, 'out'),
+            'param_grads': {n: checksum(p.grad, n) for n, p in tr.named_parameters() if p.grad is not None},
+            'state_checksum': float(sum(v.double().abs().sum() for v in tr.state_dict().values()))}
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'hv':         # add / refresh the HunyuanVideo section only (the Wan / Flux sections take ~15 GB and minutes)
+        gold = json.load(open(OUT))
+        gold['hv_blocks'] = hv_section()
+        with open(OUT, 'w') as fh:
+            json.dump(gold, fh)
+        return
     gold = {'torch': torch.__version__}
     # ---- Wan-14B-width block: the reference's own class
     from oracle.make_golden import import_reference_wan
@@ -106,6 +164,8 @@ def main():
                            'param_grads': {n: checksum(p.grad, n) for n, p in ref.transformer.named_parameters() if p.grad is not None},
                            'state_checksum': float(sum(v.double().abs().sum() for v in work.transformer.state_dict().values()))}
     print('flux blocks: loss', float(loss), flush=True)
+    del ref, work, xx
+    gold['hv_blocks'] = hv_section()
     with open(OUT, 'w') as fh:
         json.dump(gold, fh)
 

@@ -1,6 +1,7 @@
 """GPU: block arithmetic at the REAL widths of BASELINE configs 3 and 4 (head_dim 128) against tests/golden/realdims.json
 (oracle/make_golden_realdims.py): the Wan2.1-14B DiT block (dim 5120, ffn 13824, 40 heads, 4 608 tokens, 512 text tokens) vs the reference's OWN
-`WanAttentionBlock` run on CPU; one Flux double + one single stream block at 3072 = 24 x 128 (4 096 image + 512 text tokens) vs the oracle's restatement.
+`WanAttentionBlock` run on CPU; one Flux double + one single stream block at 3072 = 24 x 128 (4 096 image + 512 text tokens) vs the oracle's restatement;
+HunyuanVideo's width (BASELINE config 5: embedders, token refiner, one double + one single stream block, final layer; 2 880 video + 256 text tokens, 66 padded).
 Weights and inputs are rebuilt from the generator's seeds; compared: loss, and the (sum |t|, sum t, seeded projection, L2 norm) rows of the output and of every gradient.
 
 Tolerances: exact-fp32 kernel mode 1e-3 on the loss (north_star's bound) and 5e-3 on each checksum; bf16 mode (the flash-attention / LDS-DMA GEMM path that
@@ -26,8 +27,9 @@ def _check(got, want, tol, floor, what, tag=''):
     row = checksum4(got, what)
     e_abs, e_sum, e_proj, e_l2 = relative_errors(row, want)
     w = WORST.setdefault(tag, [0.0, 0.0, 0.0, 0.0])
-    for i, e in enumerate((e_abs, e_sum, e_proj, e_l2)):
-        w[i] = max(w[i], e)
+    if want[0] > 1e3 * floor:            # the printed worst case skips gradients that are analytically ~0 (held to the absolute floor below instead)
+        for i, e in enumerate((e_abs, e_sum, e_proj, e_l2)):
+            w[i] = max(w[i], e)
     assert abs(row[0] - want[0]) <= tol * want[0] + floor, (what, 'sum |t|', row[0], want[0])
     assert abs(row[1] - want[1]) <= tol * want[0] + floor, (what, 'sum t', row[1], want[1])
     assert abs(row[3] - want[3]) <= tol * want[3] + floor, (what, 'L2 norm', row[3], want[3])
@@ -89,3 +91,33 @@ def test_flux_width_double_and_single_block_match_the_oracle(gpu, dtype, ltol, c
         if n in ref['param_grads']:
             _check(p.grad, ref['param_grads'][n], ctol, floor, n, tag)
     print(f'{tag}: worst (abs-sum, signed-sum, projection, L2) errors {[round(v, 5) for v in WORST[tag]]}')
+
+
+@pytest.mark.parametrize('dtype,ltol,ctol', [(torch.float32, 1e-3, 5e-3), (torch.bfloat16, 3e-2, 5e-2)])
+def test_hunyuan_video_width_blocks_match_the_oracle(gpu, dtype, ltol, ctol):
+    """BASELINE config 5's widths through the product's pipeline layers (`to_layers()`: 1 + 1 + concatenate + 1 + 1) -- the real-width HunyuanVideo case
+    round 2's review found missing: head dim 128 attention over [video ; text] with a padded-text key count, the token refiner, modulated double / single blocks."""
+    from oracle.make_golden_realdims import hv_case
+    ref = G['hv_blocks']
+    cfg, tr, work, feats, label = hv_case()
+    assert abs(float(sum(v.double().abs().sum() for v in tr.state_dict().values())) - ref['state_checksum']) <= 1e-9 * ref['state_checksum']
+    del tr
+    work.transformer.to(gpu, dtype)
+    x = tuple(t.to(gpu) for t in feats)
+    for layer in work.to_layers():
+        x = layer(x)
+    loss = ((x.float() - label[0].to(gpu)) ** 2).mean()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - ref['loss']) <= ltol * ref['loss'], (loss.item(), ref['loss'])
+    tag = f'hunyuan-video {dtype}'
+    print(f'hunyuan-video blocks {dtype}: loss rel. error {abs(loss.item() - ref["loss"]) / ref["loss"]:.3g}')
+    _check(x, ref['out'], ctol, 0.0, 'out', tag)
+    floor = 1e-6 * max(v[0] for v in ref['param_grads'].values())
+    n_checked = 0
+    for n, p in work.transformer.named_parameters():
+        if n in ref['param_grads'] and p.grad is not None:
+            _check(p.grad, ref['param_grads'][n], ctol, floor, n, tag)
+            n_checked += 1
+    assert n_checked >= 0.9 * len(ref['param_grads']), (n_checked, len(ref['param_grads']))
+    print(f'{tag}: {n_checked} parameter gradients, worst (abs-sum, signed-sum, projection, L2) errors {[round(v, 5) for v in WORST[tag]]}')
