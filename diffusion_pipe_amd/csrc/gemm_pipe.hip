@@ -33,7 +33,6 @@ bool gemm_pipe_try(GemmParams& p, int transA, int transB, int batch, void* ws, l
     case 130: *rc_out = launch_pipe<T128S5>(p, a_mc, b_mc, batch, s); break;
     case 1264: *rc_out = launch_pipe<T128N64>(p, a_mc, b_mc, batch, s); break;
     case 1283: *rc_out = launch_pipe<T128Q3>(p, a_mc, b_mc, batch, s); break;
-    case 1284: *rc_out = launch_pipe<T128Q4>(p, a_mc, b_mc, batch, s); break;
     default: *rc_out = launch_pipe<T64>(p, a_mc, b_mc, batch, s); break;
     }
     return true;
@@ -101,7 +100,7 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
     p.vecA = c_ok ? 2 : 0;
     if (c_ok && p.residual && reinterpret_cast<uintptr_t>(p.residual) % 8 == 0 && p.ldr % 4 == 0) p.vecA = 3;   // 8-byte residual loads too
     p.vecB = (p.bias && reinterpret_cast<uintptr_t>(p.bias) % 8 == 0) ? 2 : 0;
-    if (force_tile == 258 || force_tile == 1283 || force_tile == 1284) { p.ksteps *= 2; p.ksteps_per_split *= 2; return force_tile; }      // T256K counts K in 32-wide half steps (slices keep their K ranges)
+    if (force_tile == 258 || force_tile == 1283) { p.ksteps *= 2; p.ksteps_per_split *= 2; return force_tile; }      // T256K counts K in 32-wide half steps (slices keep their K ranges)
     if (force_tile == 257 || force_tile == 256 || force_tile == 63 || force_tile == 130 || force_tile == 1264) return force_tile;
     if (force_tile == 129 || (force_tile == 0 && big && tiles128 >= 256 && (a_mc || b_mc || tiles128 >= 1024))) return 129;
     // DPIPE_OPT_GEMM_SHALLOW: the shallow rings everywhere (128^2 on 2 x 32 KiB, 64^2 on 3 x 16 KiB) -- slower launches in isolation (step list: 23.5 vs 22.0 us

@@ -87,7 +87,10 @@ using T128Q3 = Tile<128, 128, 2, 2, 3, 32>;  // OCCUPANCY-style 128^2 tile: 4 wa
                                              // workgroup's own look-ahead instead).  tile_hint 11000 + S.  Measured (profiles/r3k_gemm_desc_ledger_halfstep_4wave_tiles.jsonl):
                                              // -11 % on [1024,1280] x [10240,1280]^T (52.2 vs 58.8 us) and -17 % on [4096,640] x [640,2560], +5 .. +15 % on the wgrad (TN) shapes and far
                                              // behind wherever split-K is what fills the chip; forced for every 128^2 launch of the step: 19.06 vs 19.44 images/s.  Selectable, not dispatched.
-using T128Q4 = Tile<128, 128, 2, 2, 4, 32>;  // the same on a 4-deep ring (64 KiB, two workgroups per CU, three half steps in flight): never ahead of T128Q3.  tile_hint 12000 + S
+// (T128Q4, the same on a 4-deep ring = 64 KiB, two workgroups per CU, was never ahead of T128Q3: removed.)
+// (Round 3 negative result, profiles/r3q_gemm_desc_ledger_halfstep_8wave_tiles_negative.jsonl: the 8-wave 128^2 tile on 5- / 4-deep rings of half K-steps -- 80 / 64 KiB, two
+//  workgroups per CU WITH two / one and a half K-steps of look-ahead -- lands within +-5 % of the better of T128 / T128R2 on every shape and never ahead in the step
+//  (18.35 / 18.45 vs 18.74 images/s): look-ahead and co-residency buy the same thing.  Removed again.)
 using T256S = Tile<256, 256, 2, 4, 2>;      // 256 x 256, 8 waves of 128 x 64 (128 accumulator VGPRs), 2 x 64 KiB: twice the MFMA work per DMA'd
                                             // byte of the 128^2 tile -- the large-GEMM configuration (DiT-sized linears: Flux / Wan / HunyuanVideo)
 
@@ -142,7 +145,7 @@ template <int NLOAD> __device__ __forceinline__ void wait_dma_ahead(int ahead) {
 // zeros, so no im2col matrix and no padded copy ever exists.  CONV = 2: wgrad, one GEMM per tap (grid.y): the B operand's K-ROWS are
 // the gathered pixels (k = output pixel, n = input channel), A = dy read MN-contiguous.
 template <int BM_, int BN_, int WM_, int WN_, int STAGES_, bool A_MC, bool B_MC, int CONV = 0, int BKT = 64>
-__global__ void __launch_bounds__(WM_ * WN_ * 64, (WM_ * WN_ == 4 && BKT == 32) ? (STAGES_ == 3 ? 3 : 2) : 1) gemm_pipe_kernel(const GemmParams p) {     // half-step 4-wave tiles: three waves per SIMD (<= 168 VGPRs)      // 4-wave configurations: one wave per SIMD may use the whole 512-register file
+__global__ void __launch_bounds__(WM_ * WN_ * 64, (WM_ * WN_ == 4 && BKT == 32) ? 3 : 1) gemm_pipe_kernel(const GemmParams p) {     // half-step 4-wave tiles: three waves per SIMD (<= 168 VGPRs)      // 4-wave configurations: one wave per SIMD may use the whole 512-register file
     using TL = Tile<BM_, BN_, WM_, WN_, STAGES_, BKT>;
     constexpr int BM = TL::BM, BN = TL::BN, STAGES = TL::STAGES, TM = TL::TM, TN = TL::TN, NLOAD = TL::NLOAD;
     constexpr int BK = BKT, KS = BKT / 16;          // (shadows the namespace default) k extent of a stage, 16-wide k-slices per stage
