@@ -71,7 +71,8 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
         else if (skinny) {
             S = (int)(512 / tiles); const int cap = p.ksteps / 4; if (S > cap) S = cap; if (S > 16) S = 16;
         } else if (!big && tiles <= 128 && p.ksteps >= 32) {   // few, long tiles split
-            S = (int)(512 / tiles); const int cap = p.ksteps / 8; if (S > cap) S = cap; if (S > 4) S = 4;
+            // up to 4 slices; 8 once a slice would still walk >= 32 K-steps (the batched context K / V dgrad [77, 2048] <- [77, 25600]: 69.8 -> 44.9 us)
+            S = (int)(512 / tiles); const int cap = p.ksteps / 8; if (S > cap) S = cap; const int smax = p.ksteps >= 256 ? 8 : 4; if (S > smax) S = smax;
         } else if (!big && tiles <= 64 && p.ksteps >= 16) {
             // <= 64 tiles of 16 .. 31 K-steps (the 77-token and 1-token linears at K = 1 280 / 1 024): four slices of >= 4 K-steps -- with write-through
             // slabs a slice no longer pays an L2 write-back scan (profiles/r3_gemm_desc_ledger.jsonl: NN 15.1 -> 9.2 us, NT 11.1 -> 10.4 us at [77, 1280, 1280])
