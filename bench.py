@@ -7,8 +7,8 @@
 A "step" is one optimizer step of the hot path (`engine.train_batch`): GAS micro-batches of one 1024x1024 image each
 (latents [1,4,128,128], 75-token prompts through both trained CLIP text encoders) through the SDXL UNet split over N
 pipeline stages, 1F1B schedule, fused loss, gradient clip, AdamW -- full fine-tune, bf16, synthetic data resident in HBM before the
-timed region, random weights.  GAS = 6 * N so per-GPU work is constant as N grows ("weak"); at N = 1 the six micro-batches of a step
-run on three concurrent hipGraph lanes.  The host waits for the end of step n - 1 before it enqueues step n (engine
+timed region, random weights.  GAS = 8 * N so per-GPU work is constant as N grows ("weak"); at N = 1 the eight micro-batches of a step
+run on four concurrent hipGraph lanes (rounds 1 - 2 and most of round 3: GAS 6 on three lanes; `--lanes 3 --gas 6` reproduces that line).  The host waits for the end of step n - 1 before it enqueues step n (engine
 `max_steps_in_flight = 1`).  Prints ONE JSON line on rank 0.
 
 Extra objects: `roofline` (dominant kernel = the hand-written MFMA GEMM: the step's recorded GEMM launch list replayed as one
@@ -51,7 +51,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--gas', type=int, default=0, help='micro-batches per step per replica (default 6 * pp)')
+    ap.add_argument('--gas', type=int, default=0, help='micro-batches per step per replica (default 8 * pp)')
     ap.add_argument('--pp', type=int, default=0, help='pipeline stages (default: = gpus, the BASELINE metric\'s pp = N line); gpus / pp data-parallel replicas of the pipeline')
     ap.add_argument('--p2p', default='auto', choices=['auto', 'rccl', 'torch'], help='stage-to-stage link (engine p2p_backend)')
     ap.add_argument('--config', default='full', choices=['full', 'tiny'])
@@ -66,7 +66,7 @@ def parse():
     ap.add_argument('--activation-checkpointing', action='store_true')
     ap.add_argument('--partition', default='parameters')
     ap.add_argument('--no-graph', action='store_true', help='disable hipGraph capture of the micro-batch fwd+bwd')
-    ap.add_argument('--lanes', type=int, default=0, help='concurrent micro-batch lanes of the single-stage hipGraph path (default: 3 for sdxl, 2 for flux / wan, 1 for hv)')
+    ap.add_argument('--lanes', type=int, default=0, help='concurrent micro-batch lanes of the single-stage hipGraph path (default: 4 for sdxl, 2 for flux / wan, 1 for hv)')
     ap.add_argument('--test-single-device', action='store_true',
                     help='TEST ONLY: all ranks share cuda:0, collectives over gloo, stage payloads staged through the host')
     ap.add_argument('--torch-adamw', action='store_true', help='A/B switch: torch.optim.AdamW(fused=True) + separate lane-sum / clip / zero passes')
@@ -331,14 +331,14 @@ def main():
 
     if args.workload != 'sdxl':
         return run_dit_workload(args, device, world, rank)
-    args.lanes = args.lanes or 3
+    args.lanes = args.lanes or 4           # 4 lanes with lane 0 on the caller's stream = the 4 hardware queues HIP streams map onto (engine._train_batch_graphed)
     cfg = sdxl.SDXLConfig() if args.config == 'full' else sdxl.tiny_config()
     latent = args.latent if args.config == 'full' else 32
     pp = args.pp or world
     if world % pp:
         raise SystemExit(f'--pp {pp} does not divide {world} ranks')
     dp = world // pp
-    gas = args.gas or 6 * pp
+    gas = args.gas or 8 * pp               # two micro-batches per lane and step
     work = sdxl.SDXLWorkload(cfg, dtype=torch.bfloat16, seed=0, device=device)
     layers = work.to_layers()
     kwargs = {}

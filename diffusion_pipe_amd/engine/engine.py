@@ -179,7 +179,9 @@ class PipelineEngine:
         n_fwd = max(1, int(self._config.get('stage_fwd_streams', 2))) if (self.use_stage_graphs and self.stage_id != self.num_stages - 1) else 1
         self._fwd_streams = [torch.cuda.Stream(self.device) for _ in range(n_fwd)] if self.use_stage_graphs else []
         self._fwd_stream = self._fwd_streams[0] if self._fwd_streams else None
-        self._bwd_stream = torch.cuda.Stream(self.device) if self.use_stage_graphs else None
+        # the backward half runs on the caller's stream unless `stage_bwd_own_stream` is set: with two forward streams and the link's communication stream a
+        # stage then uses exactly the 4 hardware queues HIP streams are multiplexed onto (see the lane path: a 5th stream shares a queue and serialises)
+        self._bwd_stream = torch.cuda.Stream(self.device) if (self.use_stage_graphs and self._config.get('stage_bwd_own_stream', False)) else None
         self._streams_forked = False
         self._g_total_loss = None
         # Concurrent micro-batch lanes (single-stage graph path): at micro-batch 1 most kernels of the step fill well under
@@ -378,7 +380,8 @@ class PipelineEngine:
             main = torch.cuda.current_stream(self.device)
             for st in self._fwd_streams:
                 st.wait_stream(main)                    # previous optimizer step / data preparation
-            self._bwd_stream.wait_stream(main)
+            if self._bwd_stream is not None:
+                self._bwd_stream.wait_stream(main)
             self._streams_forked = True
         for step_cmds in pipe_schedule:
             for cmd in step_cmds:
@@ -388,9 +391,11 @@ class PipelineEngine:
                 if two_streams and isinstance(cmd, self._FWD_INSTR):
                     with torch.cuda.stream(self._fwd_streams[cmd.kwargs.get('buffer_id', 0) % len(self._fwd_streams)]):
                         handler(self, **cmd.kwargs)
-                elif two_streams and isinstance(cmd, self._BWD_INSTR):
+                elif two_streams and isinstance(cmd, self._BWD_INSTR) and self._bwd_stream is not None:
                     with torch.cuda.stream(self._bwd_stream):
                         handler(self, **cmd.kwargs)
+                elif two_streams and isinstance(cmd, self._BWD_INSTR):
+                    handler(self, **cmd.kwargs)             # backward half on the caller's stream
                 else:
                     self._join_streams()                # step end (reduce / clip / optimizer) sees both halves finished
                     handler(self, **cmd.kwargs)
@@ -401,7 +406,8 @@ class PipelineEngine:
             main = torch.cuda.current_stream(self.device)
             for st in self._fwd_streams:
                 main.wait_stream(st)
-            main.wait_stream(self._bwd_stream)
+            if self._bwd_stream is not None:
+                main.wait_stream(self._bwd_stream)
             self._streams_forked = False
 
     # ------------------------------------------------------------------------------------------- hipGraph path
@@ -411,12 +417,17 @@ class PipelineEngine:
         lane i % K (own stream, own static buffers, own gradient accumulators); lanes are joined and summed at the end."""
         from .. import ops as _ops
         K = min(self.graph_lanes, self.micro_batches)
+        main = torch.cuda.current_stream(self.device)
         while len(self._lanes) < K:
-            self._lanes.append({'id': len(self._lanes), 'stream': torch.cuda.Stream(self.device), 'graphs': {}, 'grads': {}, 'arena': {},
+            # Lane 0 replays on the CALLER'S stream, lanes 1 .. K - 1 on streams of their own.  The runtime multiplexes HIP streams onto 4 hardware queues
+            # (GPU_MAX_HW_QUEUES = 8 / 16 changes nothing measurable): with K lane streams NEXT TO an idle caller's stream, the 4th lane shares a queue with
+            # another one and the two serialise -- 4 lanes on own streams 16.4 images/s, the same 4 lanes with lane 0 on the caller's stream 20.6 (MI355X,
+            # round 3, profiles/r3t_*, r3u_*); 5 lanes fall back to 17.8.  DPIPE_LANE0_MAIN=0 restores a separate stream for lane 0 (A/B).
+            st = main if (len(self._lanes) == 0 and os.environ.get('DPIPE_LANE0_MAIN', '1') != '0') else torch.cuda.Stream(self.device)
+            self._lanes.append({'id': len(self._lanes), 'stream': st, 'graphs': {}, 'grads': {}, 'arena': {},
                                 'loss': torch.zeros((), device=self.device, dtype=torch.float32)})
         lanes = self._lanes[:K]
         params = list(self.module.parameters())
-        main = torch.cuda.current_stream(self.device)
         for lane in lanes:
             lane['loss'].zero_()
             lane['stream'].wait_stream(main)

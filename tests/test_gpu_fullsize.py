@@ -1,7 +1,7 @@
-"""BASELINE config 2 at FULL size on the MI355X: SDXL 1024x1024 (latent 128), the full `SDXLConfig()`, micro-batch 1, GAS 6, AdamW, clip 1.0 --
-the configuration `bench.py` times.  Regression test for the round-1 driver-bench hang (hipGraph replays of 3 concurrent lanes queued
+"""BASELINE config 2 at FULL size on the MI355X: SDXL 1024x1024 (latent 128), the full `SDXLConfig()`, micro-batch 1, GAS 8 on 4 lanes, AdamW, clip 1.0 --
+the configuration `bench.py` times.  Regression test for the round-1 driver-bench hang (hipGraph replays of concurrent lanes queued
 across step boundaries wedged the queue): >= 12 optimizer steps are enqueued back to back with NO host synchronisation by the caller,
-the 3-lane graph path must finish, stay finite and follow the 1-lane path's trajectory (same math up to the summation order of the
+the 4-lane graph path (lane 0 on the caller's stream, the engine's default) must finish, stay finite and follow the 1-lane path's trajectory (same math up to the summation order of the
 lanes' bf16 gradient accumulators)."""
 import math
 
@@ -11,7 +11,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 STEPS = 12
-GAS = 6
+GAS = 8
+LANES = 4
 
 
 def _engine(gpu, lanes, pool_seed=100):
@@ -48,19 +49,19 @@ def _trajectory(gpu, lanes):
     return out
 
 
-def test_full_size_sdxl_three_lanes_twelve_unsynchronised_steps_match_one_lane(gpu):
-    loss3, norm3 = _trajectory(gpu, 3)
+def test_full_size_sdxl_four_lanes_twelve_unsynchronised_steps_match_one_lane(gpu):
+    loss3, norm3 = _trajectory(gpu, LANES)
     assert all(math.isfinite(v) for v in loss3 + norm3), (loss3, norm3)
     loss1, norm1 = _trajectory(gpu, 1)
     assert all(math.isfinite(v) for v in loss1 + norm1), (loss1, norm1)
     for i, (a, b) in enumerate(zip(loss3, loss1)):
-        assert abs(a - b) <= 2e-2 * abs(b) + 1e-4, f'step {i}: loss {a} (3 lanes) vs {b} (1 lane)'
+        assert abs(a - b) <= 2e-2 * abs(b) + 1e-4, f'step {i}: loss {a} ({LANES} lanes) vs {b} (1 lane)'
     for i, (a, b) in enumerate(zip(norm3, norm1)):
-        assert abs(a - b) <= 5e-2 * abs(b) + 1e-4, f'step {i}: grad norm {a} (3 lanes) vs {b} (1 lane)'
+        assert abs(a - b) <= 5e-2 * abs(b) + 1e-4, f'step {i}: grad norm {a} ({LANES} lanes) vs {b} (1 lane)'
 
 
 # Bounds of the golden comparison.  fp32 = the exact-parity kernel mode (north_star: 1e-3 on loss and gradient norm); bf16 = the TIMED path (bf16 kernels,
-# hipGraph, 3 lanes).  Per parameter, against the golden's [sum |g|, sum g, <g, r>, ||g||_2] rows (oracle/checksums.py): abs-sum and L2 norm relative,
+# hipGraph, 4 lanes).  Per parameter, against the golden's [sum |g|, sum g, <g, r>, ||g||_2] rows (oracle/checksums.py): abs-sum and L2 norm relative,
 # signed sum relative to sum |g|, projection error in units of ||g_ref|| / sqrt(12) (a sample of the tensor's relative L2 error, sign / placement included).
 # Three levels per kind: `max` over all 2 375 parameters, the 99th percentile `q99`, and for the projection the AGGREGATE sqrt(12 sum_p dproj_p^2) / ||g||
 # = an estimate of the relative L2 error of the whole gradient vector.  Observed on MI355X (round 3): fp32 path loss 0 / norm 8.3e-5 / proj max 5.9e-5;
@@ -134,7 +135,7 @@ def test_full_size_sdxl_micro_batch_matches_the_cpu_oracle_golden(gpu, record_pr
     eager path on the host, same seeded weights and prepared input) -- loss, global gradient norm and, for every one of the 2 375 parameters with a
     gradient, sum |g|, sum g, a seeded projection <g, r> and ||g||_2:
       * exact-fp32 kernel mode (fp32 MFMA GEMM, unfused attention, the implicit-GEMM convolution as bf16 hi / lo split launches): FP32_BOUNDS;
-      * the timed path (bf16, hipGraph, 3 lanes replaying the micro-batch): BF16_BOUNDS."""
+      * the timed path (bf16, hipGraph, 4 lanes replaying the micro-batch): BF16_BOUNDS."""
     import json
     import os
     from diffusion_pipe_amd.engine import ManualPipelineModule, initialize
@@ -164,7 +165,7 @@ def test_full_size_sdxl_micro_batch_matches_the_cpu_oracle_golden(gpu, record_pr
     assert e_loss < FP32_BOUNDS['loss'], (loss.item(), meta['loss'])
     assert e_norm < FP32_BOUNDS['norm'], (sq ** 0.5, meta['grad_norm'])
     w32 = _compare_grad_rows(rows, meta, FP32_BOUNDS, 'fp32 kernel path', FP32_Q99)
-    # ---- the timed path: bf16, hipGraph, 3 lanes (the same micro-batch on every lane: same mean loss, same averaged gradient)
+    # ---- the timed path: bf16, hipGraph, 4 lanes (the same micro-batch on every lane: same mean loss, same averaged gradient)
     names = {}
     for k, m in work.modules().items():
         for p in m.parameters():
@@ -173,13 +174,13 @@ def test_full_size_sdxl_micro_batch_matches_the_cpu_oracle_golden(gpu, record_pr
         for n, p in m.named_parameters():
             names[id(p)] = f'{k}.{n}'
     module = ManualPipelineModule(layers=work.to_layers(), num_stages=1, partition_method='parameters', loss_fn=work.get_loss_fn(), dynamic_shape=True)
-    engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 1, 'gradient_accumulation_steps': 3, 'gradient_clipping': 1e9,
-                                                         'hip_graph': True, 'graph_lanes': 3}, device=gpu)
+    engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 1, 'gradient_accumulation_steps': LANES, 'gradient_clipping': 1e9,
+                                                         'hip_graph': True, 'graph_lanes': LANES}, device=gpu)
     opt = engine._configure_optimizer(lambda ps: _ChecksumOptimizer(ps, names), [p for p in module.parameters() if p.requires_grad])
-    loss = engine.train_batch(iter([micro[0]] * 3)).item()
+    loss = engine.train_batch(iter([micro[0]] * LANES)).item()
     norm = engine.get_global_grad_norm().item()
     e_loss16, e_norm16 = abs(loss - meta['loss']) / meta['loss'], abs(norm - meta['grad_norm']) / meta['grad_norm']
-    print(f'timed path (bf16, hipGraph, 3 lanes) vs oracle: loss rel. error {e_loss16:.3g}, gradient-norm rel. error {e_norm16:.3g}')
+    print(f'timed path (bf16, hipGraph, {LANES} lanes) vs oracle: loss rel. error {e_loss16:.3g}, gradient-norm rel. error {e_norm16:.3g}')
     assert e_loss16 < BF16_BOUNDS['loss'], (loss, meta['loss'])
     assert e_norm16 < BF16_BOUNDS['norm'], (norm, meta['grad_norm'])
     w16 = _compare_grad_rows(opt.rows, meta, BF16_BOUNDS, 'timed bf16 path', BF16_Q99)

@@ -141,5 +141,5 @@ def test_bench_multi_rank_path_runs_end_to_end_on_one_shared_gpu(gpu, tmp_path):
     line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(line) == 1, r.stdout[-2000:]
     out = json.loads(line[0])
-    assert out['n_gpus'] == 2 and out['config']['parallelism'] == 'pp2' and out['config']['gradient_accumulation_steps'] == 12
+    assert out['n_gpus'] == 2 and out['config']['parallelism'] == 'pp2' and out['config']['gradient_accumulation_steps'] == 16
     assert out['value'] > 0 and out['loss'] == out['loss'] and out['roofline']['launches_per_step'] > 0

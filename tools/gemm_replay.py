@@ -113,29 +113,31 @@ def time_concurrent(trace, device, lanes, reps=2, arena_bytes=2 << 30):
     way the engine's micro-batch lanes run it.  -> dict(ms for all lanes' lists, launches, flops) of ONE round (every lane replays its list once)."""
     from diffusion_pipe_amd import ops
     main = torch.cuda.current_stream(device)
-    streams = [torch.cuda.Stream(device) for _ in range(lanes)]
+    streams = [main] + [torch.cuda.Stream(device) for _ in range(lanes - 1)]        # lane 0 on the caller's stream, as the engine runs it (4 hardware queues)
     graphs = []
     for li, st in enumerate(streams):
         arena = Arena(device, arena_bytes)
         ops.WS_LANE = ('roofline-lane', li)
-        st.wait_stream(main)
-        with torch.cuda.stream(st):
+        side = torch.cuda.Stream(device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
             issue(trace[:64], arena, ops)
-        main.wait_stream(st)
+        main.wait_stream(side)
         torch.cuda.synchronize(device)
         arena.off = 0
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=st, capture_error_mode='thread_local'):
+        with torch.cuda.graph(g, capture_error_mode='thread_local'):       # captured on torch's capture stream; a graph replays on whatever stream launches it
             issue(trace, arena, ops)
         graphs.append((g, arena))
     ops.WS_LANE = None
 
     def round_():
+        for st in streams[1:]:
+            st.wait_stream(main)            # fork BEFORE the caller's stream receives lane 0's graph
         for st, (g, _) in zip(streams, graphs):
-            st.wait_stream(main)
             with torch.cuda.stream(st):
                 g.replay()
-        for st in streams:
+        for st in streams[1:]:
             main.wait_stream(st)
     round_()
     torch.cuda.synchronize(device)
