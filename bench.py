@@ -339,6 +339,10 @@ def main():
         raise SystemExit(f'--pp {pp} does not divide {world} ranks')
     dp = world // pp
     gas = args.gas or 8 * pp               # two micro-batches per lane and step
+    _extra_streams = [torch.cuda.Stream(device) for _ in range(int(os.environ.get('DPIPE_BENCH_EXTRA_STREAMS', '0')))]     # A/B knob for engine.concurrent_streams:
+    for _st in _extra_streams:                                                                                                  # shifts which hardware queue later streams get
+        with torch.cuda.stream(_st):
+            torch.zeros(1, device=device)
     work = sdxl.SDXLWorkload(cfg, dtype=torch.bfloat16, seed=0, device=device)
     layers = work.to_layers()
     kwargs = {}

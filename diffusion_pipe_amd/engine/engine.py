@@ -55,6 +55,48 @@ def _as_list(x):
     return list(x) if isinstance(x, (tuple, list)) else [x]
 
 
+def concurrent_streams(device, n, main=None, candidates=12):
+    """-> n HIP streams whose work overlaps with `main`'s (default: the current stream) and with each other's.
+
+    The runtime multiplexes HIP streams onto a handful of hardware queues (4 on MI355X / ROCm 7.2 whatever GPU_MAX_HW_QUEUES says): two streams that land on
+    the same queue run their kernels one after the other, and which queue a new stream gets depends on how many streams the process created before.  Each
+    candidate is therefore PROBED: a spin kernel (torch.cuda._sleep) on the candidate next to one on every stream already chosen must take about as long as one
+    alone; candidates that double the time share a queue with a chosen stream and are dropped.  Falls back to fresh streams when the probe is unavailable or no
+    candidate passes (fewer queues than lanes: the caller still works, two lanes serialise)."""
+    import time
+    main = main or torch.cuda.current_stream(device)
+    fresh = lambda: [torch.cuda.Stream(device) for _ in range(n)]
+    if n <= 0:
+        return []
+    try:
+        def spin(streams, cycles):
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for st in streams:
+                with torch.cuda.stream(st):
+                    torch.cuda._sleep(cycles)
+            torch.cuda.synchronize(device)
+            return time.perf_counter() - t0
+        cycles = 200_000
+        spin([main], cycles)                                    # warm-up (module load)
+        t1 = min(spin([main], cycles) for _ in range(3))
+        while t1 < 1.5e-3 and cycles < (1 << 30):               # ~2 ms per spin: far above launch / synchronize jitter
+            cycles *= 2
+            t1 = min(spin([main], cycles) for _ in range(2))
+        chosen = []
+        for _ in range(candidates):
+            if len(chosen) == n:
+                break
+            cand = torch.cuda.Stream(device)
+            group = [main] + chosen + [cand]
+            t = min(spin(group, cycles) for _ in range(2))
+            if t < 1.5 * t1:                                    # all of them overlapped; a shared queue gives >= 2 x
+                chosen.append(cand)
+        return chosen if len(chosen) == n else chosen + [torch.cuda.Stream(device) for _ in range(n - len(chosen))]
+    except Exception:                                           # noqa: BLE001 -- a probe must never stop training
+        return fresh()
+
+
 def flatten_grads(params, arenas=None):
     """Re-home the existing `.grad` tensors of `params` into ONE flat buffer per dtype (a "gradient arena") and return {dtype: flat tensor}.
 
@@ -190,6 +232,7 @@ class PipelineEngine:
         # once before ReduceGrads / clip / optimizer.  Same math as sequential accumulation up to fp summation order.
         self.graph_lanes = max(1, int(self._config.get('graph_lanes', 1))) if self.use_graph else 1     # bench: 3 (best of 1..4 on MI355X)
         self._lanes = []
+        self._lane_streams = None
         # GEMM ring-depth policy (C-ABI option DPIPE_OPT_GEMM_SHALLOW): with >= 2 graphs replaying concurrently (micro-batch lanes, or forward + backward stage
         # graphs) the 128^2 GEMM tile runs on its 2-deep 64 KiB ring, so a workgroup of another lane fits the same CU -- each launch is ~7 % slower alone, the
         # step 2 % faster (MI355X, 3 lanes: 19.34 vs 18.93 images/s).  `gemm_shallow_rings`: 'auto' (default) | 0 | 1 | 2 | 3; an explicit DPIPE_GEMM_SHALLOW /
@@ -222,6 +265,13 @@ class PipelineEngine:
             _ops.FUSE_GRAD_ACCUM = True     # wgrad / bias / norm-weight kernels add straight into existing .grad buffers
             _ops.PARALLEL_WGRAD = self.use_graph and bool(self._config.get('parallel_wgrad', False))   # dgrad || wgrad as parallel graph branches (measured: no gain on MI355X, off)
         self.link = self._make_link() if self.is_pipe_parallel else None
+        if self.use_stage_graphs and self.device.type == 'cuda' and os.environ.get('DPIPE_LANE_STREAM_PROBE', '1') != '0':
+            # forward streams + the link's communication stream next to the caller's stream (backward half): streams probed to sit on distinct hardware queues
+            sts = concurrent_streams(self.device, len(self._fwd_streams) + (1 if getattr(self.link, 'comm_stream', None) is not None else 0))
+            self._fwd_streams = sts[:len(self._fwd_streams)]
+            self._fwd_stream = self._fwd_streams[0]
+            if len(sts) > len(self._fwd_streams):
+                self.link.comm_stream = sts[-1]
         self.loss = None
         self.total_loss = None
         self.agg_train_loss = None
@@ -418,12 +468,18 @@ class PipelineEngine:
         from .. import ops as _ops
         K = min(self.graph_lanes, self.micro_batches)
         main = torch.cuda.current_stream(self.device)
+        if len(self._lanes) < K and self._lane_streams is None:
+            self._lane_streams = concurrent_streams(self.device, self.graph_lanes - 1, main) if os.environ.get('DPIPE_LANE_STREAM_PROBE', '1') != '0' else []
         while len(self._lanes) < K:
-            # Lane 0 replays on the CALLER'S stream, lanes 1 .. K - 1 on streams of their own.  The runtime multiplexes HIP streams onto 4 hardware queues
+            # Lane 0 replays on the CALLER'S stream, lanes 1 .. K - 1 on streams of their own (probed to be concurrent: concurrent_streams).  The runtime multiplexes HIP streams onto 4 hardware queues
             # (GPU_MAX_HW_QUEUES = 8 / 16 changes nothing measurable): with K lane streams NEXT TO an idle caller's stream, the 4th lane shares a queue with
             # another one and the two serialise -- 4 lanes on own streams 16.4 images/s, the same 4 lanes with lane 0 on the caller's stream 20.6 (MI355X,
             # round 3, profiles/r3t_*, r3u_*); 5 lanes fall back to 17.8.  DPIPE_LANE0_MAIN=0 restores a separate stream for lane 0 (A/B).
-            st = main if (len(self._lanes) == 0 and os.environ.get('DPIPE_LANE0_MAIN', '1') != '0') else torch.cuda.Stream(self.device)
+            li = len(self._lanes)
+            if li == 0 and os.environ.get('DPIPE_LANE0_MAIN', '1') != '0':
+                st = main
+            else:
+                st = self._lane_streams[li - 1] if 0 < li <= len(self._lane_streams) else torch.cuda.Stream(self.device)
             self._lanes.append({'id': len(self._lanes), 'stream': st, 'graphs': {}, 'grads': {}, 'arena': {},
                                 'loss': torch.zeros((), device=self.device, dtype=torch.float32)})
         lanes = self._lanes[:K]

@@ -222,3 +222,29 @@ def test_host_offloaded_checkpointing_runs_inside_the_hipgraph_path(gpu):
     assert any(k[0] == ('lane', 0) for k in offload._FREE) and any(k[0] == ('lane', 1) for k in offload._FREE)      # per-lane pinned pools were used
     for (l0, n0), (l1, n1) in zip(base, got):
         assert abs(l1 - l0) / abs(l0) < 2e-3 and abs(n1 - n0) / n0 < 5e-3, (base, got)
+
+
+def test_lane_streams_are_probed_to_run_concurrently(gpu):
+    """engine.concurrent_streams: HIP streams share 4 hardware queues, and which queue a new stream lands on depends on how many streams the process created
+    before -- two lanes on one queue serialise (16.4 instead of 20.6 images/s on the full-size step).  The engine therefore PROBES its lane streams: spin
+    kernels on the caller's stream and on every returned stream together must take about as long as one alone, whatever was created beforehand."""
+    import time
+    from diffusion_pipe_amd.engine.engine import concurrent_streams
+    junk = [torch.cuda.Stream(gpu) for _ in range(3)]                  # shift the round-robin the way an application's own streams would
+    main = torch.cuda.current_stream(gpu)
+    picked = concurrent_streams(gpu, 3, main)
+    assert len(picked) == 3 and len({s.cuda_stream for s in picked} | {main.cuda_stream}) == 4
+
+    def spin(streams, cycles=3_000_000):
+        torch.cuda.synchronize(gpu)
+        t0 = time.perf_counter()
+        for st in streams:
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(cycles)
+        torch.cuda.synchronize(gpu)
+        return time.perf_counter() - t0
+    spin([main])
+    one = min(spin([main]) for _ in range(3))
+    four = min(spin([main] + picked) for _ in range(3))
+    assert four < 1.6 * one, (one, four)
+    del junk
