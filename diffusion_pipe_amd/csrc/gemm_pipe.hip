@@ -55,6 +55,14 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
     // flight shorten the vmcnt wait: +5 .. +6 % (9216 x 5120 x 13824 NN: 996 vs 940 TFLOP/s).  A K-contiguous operand pays for half steps with 64-byte pieces
     // (half a cache line per row per step) and twice the barriers: NT is 8 % slower on T256K and stays on T256S (8192^3: 1 292 vs 1 184)
     if (force_tile == 0 && !a_mc && p.ksteps >= 64 && tiles256 >= 128) force_tile = b_mc ? 258 : 257;
+    // many tiles of a SHORT K with a K-contiguous A (>= 2 rounds of 128^2 tiles, <= 24 K-steps: the GEGLU / up-projection forwards [1024, 10240] <- 1280 and
+    // [4096, 2560] <- 640): the occupancy-style tile (three 4-wave workgroups per CU on 48 KiB rings of half K-steps) -- a workgroup spends most of such a tile in
+    // prologue / epilogue, which its two neighbours cover: 58.8 -> 52.2 us and 33.2 -> 27.4 us (profiles/r3k_gemm_desc_ledger_halfstep_4wave_tiles.jsonl); wgrad
+    // (A MN-contiguous) and long-K shapes lose on it and stay where they are.  In the four-lane step the rule LOSES (20.25 / 20.40 vs 20.51 / 20.49 images/s, same box:
+    // the lanes already cover those gaps, and three 4-wave workgroups per CU crowd out the other lanes' workgroups) while the single-stream list gains 0.7 % --
+    // so it is opt-in: DPIPE_GEMM_Q3=1 (a workload without lanes)
+    static const bool q3_rule = [] { const char* e = getenv("DPIPE_GEMM_Q3"); return e && atoi(e) != 0; }();
+    if (q3_rule && force_tile == 0 && !a_mc && force_splitk <= 1 && p.ksteps <= 24 && p.ksteps >= 8 && tiles128 >= 512 && p.M >= 512 && p.N >= 512) force_tile = 1283;
     // skinny M (<= 128 rows: the 77-token linears of the text encoders / cross-attention K, V): one 128-row tile covers A, 64-wide N tiles, K cut into
     // slices of ~4 K-steps.  MEASURED SLOWER than the 64^2 tile on every such shape of the SDXL step (profiles/r3_gemm_desc_ledger.jsonl: 10.0 - 36 vs
     // 7.9 - 27 us unsplit, 56 vs 39 ms per step over the M <= 128 launches): opt-in only (DPIPE_GEMM_SKINNY=1 / tile_hint 10000 + S)
