@@ -28,6 +28,25 @@ def test_library_exports_every_declared_symbol():
     assert lib.dpipe_version() >= 1
 
 
+def test_header_constants_match_the_python_binding():
+    """ABI version, option ids and flag bits are #defines in the header and plain ints in hip.py: a drift between the two is a silent wrong call."""
+    from diffusion_pipe_amd import hip
+    text = open(os.path.join(ROOT, 'include', 'dpipe_hip.h')).read()
+    defs = {k: int(v) for k, v in re.findall(r'^#define\s+(DPIPE_\w+)\s+(-?\d+)\b', text, flags=re.M)}
+    assert defs['DPIPE_ABI_VERSION'] == hip.ABI_VERSION == hip.lib().dpipe_version()
+    opts = {'DPIPE_OPT_ATTN_FWD_DMA': hip.OPT_ATTN_FWD_DMA, 'DPIPE_OPT_ATTN_BWD_DMA': hip.OPT_ATTN_BWD_DMA, 'DPIPE_OPT_ATTN_DQ8': hip.OPT_ATTN_DQ8,
+            'DPIPE_OPT_ATTN_DKV_SPLIT': hip.OPT_ATTN_DKV_SPLIT, 'DPIPE_OPT_GEMM_SKINNY': hip.OPT_GEMM_SKINNY, 'DPIPE_OPT_GEMM_SHALLOW': hip.OPT_GEMM_SHALLOW}
+    for name, val in opts.items():
+        assert defs[name] == val, name
+    assert sorted(opts.values()) == list(range(defs['DPIPE_OPTION_COUNT'])), 'an option id of the header has no binding in hip.py'
+    assert defs['DPIPE_CONV_OUT_F32'] == hip.CONV_OUT_F32 and defs['DPIPE_CONV_ACCUMULATE'] == hip.CONV_ACCUMULATE
+    # options are process-wide state reachable without a GPU: set / get / unset round-trips, unknown ids are refused
+    lib = hip.lib()
+    assert lib.dpipe_set_option(hip.OPT_GEMM_SHALLOW, 2) == 0 and lib.dpipe_get_option(hip.OPT_GEMM_SHALLOW) == 2
+    assert lib.dpipe_set_option(hip.OPT_GEMM_SHALLOW, -1) == 0 and lib.dpipe_get_option(hip.OPT_GEMM_SHALLOW) == int(os.environ.get('DPIPE_GEMM_SHALLOW', '-1'))
+    assert lib.dpipe_set_option(defs['DPIPE_OPTION_COUNT'], 1) != 0
+
+
 def test_argument_errors_are_reported_without_a_gpu():
     from diffusion_pipe_amd import hip
     lib = hip.lib()
