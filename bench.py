@@ -2,7 +2,8 @@
 """bench.py -- BASELINE.json metric: training images/sec (whole node), SDXL 1024x1024, bs=1 per stage, pp = N.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+    (N > 1: either that bare command -- it re-execs itself under torch.distributed.run, one rank per GPU -- or the launcher form
+     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
 
 A "step" is one optimizer step of the hot path (`engine.train_batch`): GAS micro-batches of one 1024x1024 image each
 (latents [1,4,128,128], 75-token prompts through both trained CLIP text encoders) through the SDXL UNet split over N
@@ -26,6 +27,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+PARITY_BOUND = 1e-3       # north_star: loss and grad-norm of the timed path within 1e-3 relative of the oracle's fp32 eager path (asserted after the line is printed)
+
+
 def _argv_int(flag, default):
     for i, a in enumerate(sys.argv):
         if a == flag and i + 1 < len(sys.argv):
@@ -34,6 +38,28 @@ def _argv_int(flag, default):
             return int(a.split('=', 1)[1])
     return default
 
+
+def _self_launch():
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): re-exec this very command line under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port>` -- one rank per GPU; every rank
+    re-enters this file with RANK / LOCAL_RANK / WORLD_SIZE set, so what follows (the graph-dispatch choice below included, which must precede HIP
+    initialisation) runs exactly as under an external launcher.  Done before `import torch`: nothing of this process survives the exec."""
+    n = _argv_int('--gpus', 1)
+    if n <= 1 or 'WORLD_SIZE' in os.environ or 'RANK' in os.environ:
+        return
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC only on this driver (RCCL / tensor sharing across ranks)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
+if __name__ == '__main__':
+    _self_launch()
 
 if int(os.environ.get('WORLD_SIZE', '1')) > 1 and _argv_int('--pp', 0) != 1 and os.environ.get('DPIPE_PP_PACKET_CAPTURE', '0') != '1':
     # pp > 1 launches forward / backward stage graphs on two streams with P2P in between: take the runtime's per-node dispatch path there instead of the
@@ -308,8 +334,8 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run for --gpus > 1')
+        # (a bare `python bench.py --gpus N` never gets here: _self_launch() re-execs it under torch.distributed.run before torch is imported)
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch `python bench.py --gpus N` (self-launching) or torch.distributed.run --nproc-per-node N')
     if args.test_single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -321,8 +347,6 @@ def main():
         else:
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
-    if os.environ.get('DPIPE_MIOPEN_BENCHMARK', '0') == '1':
-        torch.backends.cudnn.benchmark = True          # MIOpen exhaustive solver search per convolution shape (A/B switch)
     from diffusion_pipe_amd import hip, ops
     from diffusion_pipe_amd.data import split_batch
     from diffusion_pipe_amd.engine import ManualPipelineModule, initialize
@@ -428,8 +452,12 @@ def main():
             json.dump(rows, f, indent=1)
     engine_mod.TRACE = None
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    comm_ranks, comm_backend = 1, None
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ones = torch.ones(1, device=device, dtype=torch.float32)       # rank count as the communicator itself sees it (one contribution per rank)
+        dist.all_reduce(ones)
+        comm_ranks, comm_backend = int(ones.item()), dist.get_backend()
     elapsed = t.item()
     gnorm = engine.get_global_grad_norm()
     gnorm = float(gnorm.item()) if gnorm is not None else float('nan')
@@ -472,6 +500,7 @@ def main():
         with open(tpath) as f:
             traffic = json.load(f)
 
+    parity_failed = False
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         images = gas * 1 * engine.dp_world_size
@@ -488,6 +517,7 @@ def main():
                                    f'pp={pp}, GAS={gas}, AdamW, clip 1.0' + (' [tiny test config]' if args.config != 'full' else ''),
                        'global_batch': images, 'parallelism': f'pp{pp}' + (f' x dp{dp}' if dp > 1 else ''), 'gradient_accumulation_steps': gas,
                        'stage_link': type(engine.link).__name__ if engine.link is not None else None,
+                       'rccl_ranks': comm_ranks if comm_backend == 'nccl' else 0, 'process_group': comm_backend,
                        'graph_packet_capture': os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '1') != '0',
                        'activation_checkpointing': bool(args.activation_checkpointing), 'partition': module.parts, 'hip_graph': bool(engine.use_graph or engine.use_stage_graphs),
                        'concurrent_micro_batch_lanes': engine.graph_lanes},
@@ -529,10 +559,21 @@ def main():
                              'what': 'timed path (bf16 kernels, hipGraph, lanes) vs the oracle fp32 eager path: same weights (the product state dict after the '
                                      'timed steps), same micro-batch; pre-clip global gradient norm'}
         print(json.dumps(out), flush=True)
+        par = out.get('parity')
+        if par and args.config == 'full':
+            # north_star's bound on the timed path: loss and pre-clip gradient norm within 1e-3 (relative) of the oracle's fp32 eager path.  The line above is
+            # printed either way; a run that misses the bound exits non-zero so a parity regression cannot ship behind a good throughput number.
+            bad = [k for k in ('loss_rel', 'grad_norm_rel') if not (par[k] <= PARITY_BOUND)]
+            if bad:
+                print(f'[bench] PARITY FAILURE: {", ".join(f"{k} = {par[k]:.3e}" for k in bad)} exceeds {PARITY_BOUND:g} (timed path vs oracle fp32 eager path)',
+                      file=sys.stderr, flush=True)
+                parity_failed = True
     faulthandler.cancel_dump_traceback_later()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if parity_failed:
+        sys.exit(4)
 
 
 if __name__ == '__main__':

@@ -152,8 +152,8 @@ class Conv2d(nn.Conv2d):
     forward / backward run as implicit GEMM on the MFMA tile kernel (csrc/conv_pipe.hip) over channels-last activations.  Returns a
     channels-last [B, Cout, Ho, Wo] tensor.  `upsample=2` folds diffusers' nearest 2x Upsample2D into the convolution's gather;
     `residual` / `extra_bias` ride the epilogue.  fp32 tensors (exact-parity mode) take the same kernels as three bf16 hi / lo split launches
-    accumulated in fp32 (ops._Conv2dNHWCFn); the UNet's 4-channel conv_in / conv_out run as a tiny im2col GEMM / a Cout-padded tile.  What is
-    left for torch's convolution: grouped / dilated / non-square-padded convolutions, none of which the reference's models have on this path."""
+    accumulated in fp32 (ops._Conv2dNHWCFn); the UNet's 4-channel conv_in / conv_out run as a tiny im2col GEMM / a Cout-padded tile.  Grouped /
+    dilated / non-square-padded convolutions (none of which the reference's models have on this path) raise: there is no library fallback."""
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
@@ -193,11 +193,11 @@ class Conv2d(nn.Conv2d):
             Ho = (H + 2 * self.padding[0] - kh) // self.stride[0] + 1
             y = ops.linear(col, w2, bias).view(B, Ho, -1, Cout).permute(0, 3, 1, 2)                                     # channels-last [B, Cout, Ho, Wo]
             return y if residual is None else y + residual
-        if upsample > 1:
-            x = torch.nn.functional.interpolate(x, scale_factor=float(upsample), mode='nearest')
-        y = self._conv_forward(x.contiguous(memory_format=torch.channels_last), self.weight, bias)
-        y = y.contiguous(memory_format=torch.channels_last)
-        return y if residual is None else y + residual
+        # no library fallback on the product path: a convolution none of this repo's kernels takes (grouped, dilated, non-square padding / stride,
+        # a CPU tensor) is an error, never a silent MIOpen call (the reference's models have none of these on the hot path)
+        from .hip import DpipeHipError
+        raise DpipeHipError(f'Conv2d({Cin}, {Cout}, kernel {kh}x{kw}, stride {tuple(self.stride)}, padding {self.padding}, dilation {tuple(self.dilation)}, '
+                            f'groups {self.groups}, {x.dtype} on {x.device}): no HIP kernel of libdpipe_hip takes this convolution')
 
 
 class RMSNorm(nn.Module):

@@ -143,3 +143,19 @@ def test_bench_multi_rank_path_runs_end_to_end_on_one_shared_gpu(gpu, tmp_path):
     out = json.loads(line[0])
     assert out['n_gpus'] == 2 and out['config']['parallelism'] == 'pp2' and out['config']['gradient_accumulation_steps'] == 16
     assert out['value'] > 0 and out['loss'] == out['loss'] and out['roofline']['launches_per_step'] > 0
+
+
+def test_bare_bench_command_self_launches_its_ranks(gpu, tmp_path):
+    """`python bench.py --gpus 2 ...` with NO launcher around it -- the shape of the driver's command -- re-execs itself under torch.distributed.run
+    (one rank per stage; WORLD_SIZE / RANK / MASTER_* come from that launcher) and rank 0 prints the one JSON line, including the rank count the
+    process group's own all-reduce reports and the stage link in use."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY='0', DPIPE_BENCH_WATCHDOG_S='500')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '2', '--config', 'tiny', '--test-single-device', '--no-cpu-baseline']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=560, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(line) == 1, r.stdout[-2000:]
+    out = json.loads(line[0])
+    assert out['n_gpus'] == 2 and out['config']['parallelism'] == 'pp2' and out['value'] > 0
+    assert out['config']['process_group'] == 'gloo' and out['config']['rccl_ranks'] == 0 and out['config']['stage_link'] == 'HostStagedLink'
