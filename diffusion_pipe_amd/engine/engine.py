@@ -55,16 +55,22 @@ def _as_list(x):
     return list(x) if isinstance(x, (tuple, list)) else [x]
 
 
-def concurrent_streams(device, n, main=None, candidates=12):
+def concurrent_streams(device, n, main=None, candidates=12, report=None):
     """-> n HIP streams whose work overlaps with `main`'s (default: the current stream) and with each other's.
 
     The runtime multiplexes HIP streams onto a handful of hardware queues (4 on MI355X / ROCm 7.2 whatever GPU_MAX_HW_QUEUES says): two streams that land on
     the same queue run their kernels one after the other, and which queue a new stream gets depends on how many streams the process created before.  Each
     candidate is therefore PROBED: a spin kernel (torch.cuda._sleep) on the candidate next to one on every stream already chosen must take about as long as one
-    alone; candidates that double the time share a queue with a chosen stream and are dropped.  Falls back to fresh streams when the probe is unavailable or no
-    candidate passes (fewer queues than lanes: the caller still works, two lanes serialise)."""
+    alone (median of 3 samples < 1.5 x); candidates that double the time share a queue with a chosen stream and are dropped.  Falls back to fresh streams when
+    the probe is unavailable or no candidate passes (fewer queues than lanes: the caller still works, two lanes serialise).
+
+    `report` (a dict, filled in place; the engine keeps it as `engine.stream_probe` and bench.py prints it): how many streams were wanted / passed the probe /
+    were padded with unprobed fresh streams, the spin time alone and every candidate's ratio -- so a run whose lanes share a queue says so."""
+    import statistics
     import time
     main = main or torch.cuda.current_stream(device)
+    report = report if report is not None else {}
+    report.update({'wanted': n, 'probed_ok': 0, 'unprobed_fallback': 0, 'candidates_tried': 0, 'ratios': [], 'spin_ms': None, 'error': None})
     fresh = lambda: [torch.cuda.Stream(device) for _ in range(n)]
     if n <= 0:
         return []
@@ -79,21 +85,30 @@ def concurrent_streams(device, n, main=None, candidates=12):
             return time.perf_counter() - t0
         cycles = 200_000
         spin([main], cycles)                                    # warm-up (module load)
-        t1 = min(spin([main], cycles) for _ in range(3))
+        t1 = statistics.median(spin([main], cycles) for _ in range(3))
         while t1 < 1.5e-3 and cycles < (1 << 30):               # ~2 ms per spin: far above launch / synchronize jitter
             cycles *= 2
-            t1 = min(spin([main], cycles) for _ in range(2))
+            t1 = statistics.median(spin([main], cycles) for _ in range(3))
+        report['spin_ms'] = round(t1 * 1e3, 3)
         chosen = []
         for _ in range(candidates):
             if len(chosen) == n:
                 break
             cand = torch.cuda.Stream(device)
             group = [main] + chosen + [cand]
-            t = min(spin(group, cycles) for _ in range(2))
+            t = statistics.median(spin(group, cycles) for _ in range(3))
+            report['candidates_tried'] += 1
+            report['ratios'].append(round(t / t1, 2))
             if t < 1.5 * t1:                                    # all of them overlapped; a shared queue gives >= 2 x
                 chosen.append(cand)
+        report['probed_ok'] = len(chosen)
+        report['unprobed_fallback'] = n - len(chosen)
+        if len(chosen) < n and int(os.environ.get('RANK', '0')) == 0:
+            print(f'[dpipe] stream probe: only {len(chosen)} of {n} extra streams overlap with the caller\'s (ratios {report["ratios"]}); '
+                  f'{n - len(chosen)} unprobed stream(s) may share a hardware queue and serialise', flush=True)
         return chosen if len(chosen) == n else chosen + [torch.cuda.Stream(device) for _ in range(n - len(chosen))]
-    except Exception:                                           # noqa: BLE001 -- a probe must never stop training
+    except Exception as e:                                      # noqa: BLE001 -- a probe must never stop training
+        report.update({'error': repr(e), 'unprobed_fallback': n})
         return fresh()
 
 
@@ -195,6 +210,8 @@ class PipelineEngine:
         self.flat_grads = bool(self._config.get('flat_grads', self.dp_world_size > 1))
         self._stage_arena = {}
         self._dp_stream = None
+        self._dp_avg_ok = None             # ReduceOp.AVG capability of the data-parallel backend (probed on first use)
+        self._probe_report = {}            # engine.concurrent_streams fills it: how many lane / stage streams passed the hardware-queue probe
         self._capturing_buffer = 0
         self._last_grad_norm = None
 
@@ -264,14 +281,17 @@ class PipelineEngine:
             from .. import ops as _ops
             _ops.FUSE_GRAD_ACCUM = True     # wgrad / bias / norm-weight kernels add straight into existing .grad buffers
             _ops.PARALLEL_WGRAD = self.use_graph and bool(self._config.get('parallel_wgrad', False))   # dgrad || wgrad as parallel graph branches (measured: no gain on MI355X, off)
-        self.link = self._make_link() if self.is_pipe_parallel else None
+        comm_stream = None
         if self.use_stage_graphs and self.device.type == 'cuda' and os.environ.get('DPIPE_LANE_STREAM_PROBE', '1') != '0':
-            # forward streams + the link's communication stream next to the caller's stream (backward half): streams probed to sit on distinct hardware queues
-            sts = concurrent_streams(self.device, len(self._fwd_streams) + (1 if getattr(self.link, 'comm_stream', None) is not None else 0))
+            # forward streams + the link's communication stream next to the caller's stream (backward half): streams probed to sit on distinct hardware
+            # queues -- chosen BEFORE the link is built, so its self-test and every later transfer run on the stream it keeps
+            want_comm = not self._config.get('p2p_via_host', False)
+            sts = concurrent_streams(self.device, len(self._fwd_streams) + (1 if want_comm else 0), report=self._probe_report)
             self._fwd_streams = sts[:len(self._fwd_streams)]
             self._fwd_stream = self._fwd_streams[0]
-            if len(sts) > len(self._fwd_streams):
-                self.link.comm_stream = sts[-1]
+            if want_comm:
+                comm_stream = sts[-1]
+        self.link = self._make_link(comm_stream) if self.is_pipe_parallel else None
         self.loss = None
         self.total_loss = None
         self.agg_train_loss = None
@@ -282,28 +302,21 @@ class PipelineEngine:
         if self.is_data_parallel:
             self._broadcast_model()
 
-    def _make_link(self):
+    def _make_link(self, comm_stream=None):
         """Stage-to-stage endpoint.  GPU default ('auto'): the C-ABI RCCL link (csrc/comm.hip dpipe_send / dpipe_recv: one grouped operation per tuple,
         receives straight into the slot buffers) when EVERY rank of the world brings it up and passes its self-test, else torch.distributed's isend /
-        irecv on the same RCCL backend (the decision is a world all-reduce, so the two ends of a boundary can never pick different links)."""
+        irecv on the same RCCL backend.  The decision is `RcclLink.negotiate`: phased (local probe, connect, self-test), each phase closed by a world
+        all-reduce(MIN) that every rank reaches -- so the two ends of a boundary can never pick different links and an asymmetric failure cannot strand
+        a neighbour inside a collective.  `comm_stream`: the link's communication stream, chosen (probed) by the caller before the link uses it."""
         if self._config.get('p2p_via_host', False) and self.device.type == 'cuda':
             return HostStagedLink(self.grid, self.device)
         backend = self._config.get('p2p_backend', 'auto' if self.device.type == 'cuda' else 'torch')
         if self.device.type != 'cuda' or backend == 'torch':
-            return StageLink(self.grid, self.device)
+            return StageLink(self.grid, self.device, comm_stream=comm_stream)
         if backend == 'rccl':
-            return RcclLink(self.grid, self.device)
-        link, ok = None, 1
-        try:
-            link = RcclLink(self.grid, self.device)
-        except Exception as e:                        # noqa: BLE001  (missing RCCL symbols, communicator failure, corrupted self-test pattern)
-            print(f'[dpipe] rank {self.global_rank}: RCCL link unavailable ({e}); stage exchange falls back to torch.distributed isend / irecv', flush=True)
-            ok = 0
-        flag = torch.tensor([ok], device=self.device, dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
-            return link
-        return StageLink(self.grid, self.device)
+            return RcclLink(self.grid, self.device, comm_stream=comm_stream)
+        link = RcclLink.negotiate(self.grid, self.device, comm_stream=comm_stream)
+        return link if link is not None else StageLink(self.grid, self.device, comm_stream=comm_stream)
 
     # ------------------------------------------------------------------------------------------------ config
     def train_micro_batch_size_per_gpu(self):
@@ -345,6 +358,11 @@ class PipelineEngine:
 
     def get_global_grad_norm(self):
         return self._last_grad_norm
+
+    @property
+    def stream_probe(self):
+        """Outcome of the hardware-queue probe for this engine's lane / stage streams (engine.concurrent_streams `report`); {} before the probe ran."""
+        return dict(self._probe_report)
 
     # -------------------------------------------------------------------------------------------- optimizer
     def _configure_optimizer(self, client_optimizer, model_parameters):
@@ -469,7 +487,7 @@ class PipelineEngine:
         K = min(self.graph_lanes, self.micro_batches)
         main = torch.cuda.current_stream(self.device)
         if len(self._lanes) < K and self._lane_streams is None:
-            self._lane_streams = concurrent_streams(self.device, self.graph_lanes - 1, main) if os.environ.get('DPIPE_LANE_STREAM_PROBE', '1') != '0' else []
+            self._lane_streams = concurrent_streams(self.device, self.graph_lanes - 1, main, report=self._probe_report) if os.environ.get('DPIPE_LANE_STREAM_PROBE', '1') != '0' else []
         while len(self._lanes) < K:
             # Lane 0 replays on the CALLER'S stream, lanes 1 .. K - 1 on streams of their own (probed to be concurrent: concurrent_streams).  The runtime multiplexes HIP streams onto 4 hardware queues
             # (GPU_MAX_HW_QUEUES = 8 / 16 changes nothing measurable): with K lane streams NEXT TO an idle caller's stream, the 4th lane shares a queue with
@@ -484,12 +502,16 @@ class PipelineEngine:
                                 'loss': torch.zeros((), device=self.device, dtype=torch.float32)})
         lanes = self._lanes[:K]
         params = list(self.module.parameters())
+        # every micro-batch of the step is pulled BEFORE the first replay is enqueued (the reference's loader pre-pulls a step the same way, train.py:164-173):
+        # lane 0 replays on the caller's stream, so an iterator that produces device tensors lazily on that stream (device-side prepare_inputs, H2D from
+        # pinned memory) would otherwise be queued BEHIND lane 0's whole graph while lanes 1 .. K - 1 copy from its outputs right away
+        batches = [self._next_batch() for _ in range(self.micro_batches)]
         for lane in lanes:
             lane['loss'].zero_()
-            lane['stream'].wait_stream(main)
+            lane['stream'].wait_stream(main)          # ordered after the previous step end AND after whatever the iterator enqueued on the caller's stream
         for i in range(self.micro_batches):
             lane = lanes[i % K]
-            feats, labels = self._next_batch()
+            feats, labels = batches[i]
             feats = (feats,) if torch.is_tensor(feats) else tuple(feats)
             labels = (labels,) if torch.is_tensor(labels) else tuple(labels)
             sig = tuple((tuple(t.shape), t.dtype) for t in feats + labels)
@@ -839,12 +861,24 @@ class PipelineEngine:
         pass   # the reference's adapters register no tied layers
 
     def _dp_reduce_(self, chunk, group):
-        """in-place data-parallel AVERAGE of one contiguous bucket (RCCL: one all-reduce with the averaging folded in; gloo: sum, then scale)"""
-        if chunk.is_cuda:
-            dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=group)
-        else:
-            dist.all_reduce(chunk, group=group)
-            chunk.div_(self.dp_world_size)
+        """in-place data-parallel AVERAGE of one contiguous bucket.  One all-reduce with the averaging folded in (ReduceOp.AVG) where the backend has it (RCCL;
+        the gloo of this torch build), else sum + scale; `communication_data_type` (DeepSpeed's knob, honoured by the bucketed path too) reduces a cast copy
+        of the bucket and writes the result back."""
+        comm_dt = self.communication_data_type
+        buf = chunk if (comm_dt is None or comm_dt == chunk.dtype) else chunk.to(comm_dt)
+        if self._dp_avg_ok is None or self._dp_avg_ok:
+            try:
+                dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=group)
+                self._dp_avg_ok = True
+            except (RuntimeError, ValueError):
+                if self._dp_avg_ok:                # it worked before: a real failure, not a missing capability
+                    raise
+                self._dp_avg_ok = False
+        if self._dp_avg_ok is False:
+            dist.all_reduce(buf, group=group)
+            buf.div_(self.dp_world_size)
+        if buf is not chunk:
+            chunk.copy_(buf)
 
     def _reduce_flat(self, base, others):
         """Lane summation + data-parallel average over flat gradient arenas, bucket by bucket: bucket k's lane sum runs on the compute

@@ -52,11 +52,12 @@ def _wire(t):
 class StageLink:
     """P2P endpoint of one pipeline stage."""
 
-    def __init__(self, grid, device):
+    def __init__(self, grid, device, comm_stream=None):
         self.grid = grid
         self.device = torch.device(device)
         self.on_gpu = self.device.type == 'cuda'
-        self.comm_stream = torch.cuda.Stream(self.device) if self.on_gpu else None
+        # `comm_stream`: the engine hands over a stream probed to sit on a hardware queue of its own (engine.concurrent_streams) BEFORE the link runs anything on it
+        self.comm_stream = comm_stream if comm_stream is not None else (torch.cuda.Stream(self.device) if self.on_gpu else None)
         self._pending = []          # (work, tensors) of sends not yet waited for
         self.reset()
 
@@ -172,60 +173,140 @@ class RcclLink(StageLink):
     Engine config `p2p_backend`: 'rccl' = this link, 'torch' = StageLink, 'auto' (default on GPU) = this link when its construction + self-test
     succeed on every rank of the world, else StageLink."""
 
-    def __init__(self, grid, device, self_test=True):
-        super().__init__(grid, device)
+    def __init__(self, grid, device, self_test=True, comm_stream=None, connect=True):
+        super().__init__(grid, device, comm_stream=comm_stream)
         from .. import hip
         self._hip = hip
         self._comms = {}            # peer global rank -> (comm handle, peer's rank inside the pair communicator)
-        self._connect()
-        if self_test:
-            self._self_test()
+        if connect:
+            err = self._connect()
+            if err is not None:
+                raise err
+            if self_test:
+                err = self._self_test()
+                if err is not None:
+                    raise err
+
+    @classmethod
+    def negotiate(cls, grid, device, comm_stream=None, agree=None, log=print):
+        """All-ranks-agree construction for `p2p_backend: 'auto'`: returns a connected, self-tested link on EVERY rank of the world or None on every rank.
+
+        The decision is taken in phases, each closed by a world all-reduce(MIN) of a local ok flag, and no rank ever leaves a phase early (ADVICE round 3:
+        a rank that raised out of `_connect` went straight to the agreement while its neighbours still sat in the pipe-group broadcast / ncclCommInitRank /
+        a self-test receive -- a deadlock instead of the documented fallback):
+          0. local probe, no collectives: the library loads, RCCL resolves and a ncclUniqueId can be drawn;
+          1. `_connect`: every stage takes part in every broadcast of its pipe group (a lower stage that cannot draw an id broadcasts None and the pair
+             skips its rendezvous together); communicator errors are recorded, not raised;
+          2. `_self_test`: a corrupted pattern is recorded and the chain of sends still completes, so no neighbour is left in a receive."""
+        import ctypes
+        device = torch.device(device)
+        if agree is None:
+            def agree(ok):
+                flag = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                return int(flag.item()) == 1
+        rank = grid.global_rank
+
+        def phase(name, err):
+            if err is not None:
+                log(f'[dpipe] rank {rank}: RCCL link unavailable at {name} ({err}); stage exchange falls back to torch.distributed isend / irecv', flush=True)
+            return agree(err is None)
+
+        err, link = None, None
+        try:
+            from .. import hip
+            buf = ctypes.create_string_buffer(128)
+            hip.check(hip.lib().dpipe_comm_unique_id(buf), 'comm_unique_id')
+        except Exception as e:                            # noqa: BLE001  (library / RCCL symbols missing, id not drawable)
+            err = e
+        if not phase('probe', err):
+            return None
+        try:
+            link = cls(grid, device, comm_stream=comm_stream, connect=False)
+            err = link._connect()
+        except Exception as e:                            # noqa: BLE001
+            err = e
+        if not phase('connect', err):
+            if link is not None:
+                link.close()
+            return None
+        try:
+            err = link._self_test()
+        except Exception as e:                            # noqa: BLE001
+            err = e
+        if not phase('self-test', err):
+            link.close()
+            return None
+        return link
+
+    def close(self):
+        """Destroy this endpoint's communicators (a link the ranks agreed not to use)."""
+        for comm, _ in self._comms.values():
+            try:
+                self._hip.lib().dpipe_comm_destroy(comm)
+            except Exception:                             # noqa: BLE001
+                pass
+        self._comms = {}
 
     def _connect(self):
         """One 2-rank RCCL communicator per neighbour pair of THIS pipeline, created eagerly and in stage order by every rank of the pipeline: the
         lower stage draws the ncclUniqueId and broadcasts it over the pipeline's existing process group (a collective every stage of the pipeline
         takes part in, so no extra groups exist and ranks never reach a rendezvous at different points of the schedule); the two neighbours then
         initialise their communicator.  With data parallelism the pipelines are disjoint rank sets (rank = stage * dp + replica), each does this
-        over its own pipe group."""
+        over its own pipe group.  Never raises and never skips a broadcast: returns the first error (or None) once every pair has been visited."""
         import ctypes
         grid = self.grid
         stages, me = grid.pipe_parallel_size, grid.global_rank
         group = grid.get_pipe_parallel_group()
+        first_err = None
         for s in range(stages - 1):
             lo, hi = grid.stage_to_global(s), grid.stage_to_global(s + 1)
             box = [None]
             if me == lo:
-                buf = ctypes.create_string_buffer(128)
-                self._hip.check(self._hip.lib().dpipe_comm_unique_id(buf), 'comm_unique_id')
-                box[0] = buf.raw
+                try:
+                    buf = ctypes.create_string_buffer(128)
+                    self._hip.check(self._hip.lib().dpipe_comm_unique_id(buf), 'comm_unique_id')
+                    box[0] = buf.raw
+                except Exception as e:                    # noqa: BLE001 -- broadcast the sentinel instead: both ends skip the rendezvous together
+                    first_err = first_err or e
             dist.broadcast_object_list(box, src=lo, group=group)
             if me in (lo, hi):
-                comm = ctypes.c_void_p()
-                with torch.cuda.device(self.device):
-                    self._hip.check(self._hip.lib().dpipe_comm_init(ctypes.byref(comm), 2, 0 if me == lo else 1, box[0]), 'comm_init')
-                self._comms[hi if me == lo else lo] = (comm, 1 if me == lo else 0)
+                if box[0] is None:
+                    first_err = first_err or RuntimeError(f'stage {s} could not draw a ncclUniqueId for the pair ({s}, {s + 1})')
+                    continue
+                try:
+                    comm = ctypes.c_void_p()
+                    with torch.cuda.device(self.device):
+                        self._hip.check(self._hip.lib().dpipe_comm_init(ctypes.byref(comm), 2, 0 if me == lo else 1, box[0]), 'comm_init')
+                    self._comms[hi if me == lo else lo] = (comm, 1 if me == lo else 0)
+                except Exception as e:                    # noqa: BLE001
+                    first_err = first_err or e
+        return first_err
 
     def _self_test(self):
-        """A 4 KiB pattern travels down the pipeline and back over every communicator before the first real tuple does."""
+        """A 4 KiB pattern travels down the pipeline and back over every communicator before the first real tuple does.  A corrupted pattern is RECORDED and
+        the chain goes on (the next stage still gets its send), so a failure never strands a neighbour in a receive; returns the first error or None."""
         grid = self.grid
         s, S = grid.get_stage_id(), grid.pipe_parallel_size
         want = torch.arange(1024, dtype=torch.int32, device=self.device)
         buf = torch.empty_like(want)
+        err = None
         if s > 0:
             self._recv([buf], grid.stage_to_global(s - 1))
             torch.cuda.current_stream(self.device).synchronize()
             if not torch.equal(buf, want + (s - 1)):
-                raise RuntimeError(f'RcclLink self-test: stage {s} received a corrupted pattern from stage {s - 1}')
+                err = err or RuntimeError(f'RcclLink self-test: stage {s} received a corrupted pattern from stage {s - 1}')
         if s < S - 1:
             self._isend([want + s], grid.stage_to_global(s + 1))
             self._recv([buf], grid.stage_to_global(s + 1))
             torch.cuda.current_stream(self.device).synchronize()
             if not torch.equal(buf, want - (s + 1)):
-                raise RuntimeError(f'RcclLink self-test: stage {s} received a corrupted pattern from stage {s + 1}')
+                err = err or RuntimeError(f'RcclLink self-test: stage {s} received a corrupted pattern from stage {s + 1}')
         if s > 0:
             self._isend([want - s], grid.stage_to_global(s - 1))
         self.flush()
         torch.cuda.current_stream(self.device).synchronize()
+        return err
 
     def _comm(self, peer):
         hit = self._comms.get(peer)

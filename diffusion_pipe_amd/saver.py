@@ -34,6 +34,11 @@ class Saver:
         need = 'save_adapter' if is_adapter else 'save_model'
         if not callable(getattr(model, need, None)):
             raise NotImplementedError(f'{type(model).__name__} has no {need}(save_dir, state_dict): the run could not save its weights')
+        # ... and anything else the adapter needs at save time (SDXL full fine-tune: the base checkpoint's VAE to embed) is checked NOW, not at the first
+        # checkpoint hours into the run
+        check = getattr(model, 'check_save_sources', None)
+        if callable(check):
+            check(is_adapter)
 
     # ------------------------------------------------------------------------------------------------ model files
     def _gather_and_save(self, name, select, finish):

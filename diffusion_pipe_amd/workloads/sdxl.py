@@ -583,6 +583,19 @@ class SDXLWorkload:
                 return None, ldm
         return None, None
 
+    _NO_VAE = ('SDXL save_model: no VAE weights to embed -- the reference always writes first_stage_model.* into model.safetensors.  Give the workload the '
+               "base checkpoint's VAE (set_vae_state_dict(...) or [model] checkpoint_path = a single-file .safetensors), or pass allow_missing_vae=True "
+               'to write a UNet + text-encoder-only file on purpose.')
+
+    def check_save_sources(self, is_adapter=False):
+        """Called by saver.Saver at construction: a full fine-tune that could not write its single-file checkpoint fails before the first step, not at the
+        first save.  Honours model_config['allow_missing_vae']."""
+        if is_adapter or self.model_config.get('allow_missing_vae', False):
+            return
+        vae, ldm = self._vae_for_save()
+        if vae is None and ldm is None:
+            raise RuntimeError(self._NO_VAE)
+
     def save_model(self, save_dir, diffusers_sd, vae_state_dict=None, allow_missing_vae=False):
         """Full fine-tune -> single-file SDXL checkpoint: UNet, both text encoders AND the VAE, like the reference's (models/sdxl.py:487-525; ComfyUI, Forge and
         diffusers' from_single_file expect the complete ldm file).  The saver passes two arguments (utils/saver.py:106), so the VAE comes from the workload
@@ -591,10 +604,8 @@ class SDXLWorkload:
         ldm_vae = None
         if vae_state_dict is None:
             vae_state_dict, ldm_vae = self._vae_for_save()
-        if vae_state_dict is None and ldm_vae is None and not allow_missing_vae:
-            raise RuntimeError('SDXL save_model: no VAE weights to embed -- the reference always writes first_stage_model.* into model.safetensors.  Give the workload the '
-                               "base checkpoint's VAE (set_vae_state_dict(...) or [model] checkpoint_path = a single-file .safetensors), or pass allow_missing_vae=True "
-                               'to write a UNet + text-encoder-only file on purpose.')
+        if vae_state_dict is None and ldm_vae is None and not (allow_missing_vae or self.model_config.get('allow_missing_vae', False)):
+            raise RuntimeError(self._NO_VAE)
         save_sdxl_ldm(save_dir, diffusers_sd, vae_state_dict, ldm_vae)
 
     def to_layers(self):

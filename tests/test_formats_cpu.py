@@ -153,3 +153,18 @@ def test_saver_rejects_an_adapter_without_save_methods_before_training(tmp_path)
     from diffusion_pipe_amd.saver import Saver
     with pytest.raises(NotImplementedError):
         Saver(None, {}, True, tmp_path, object(), None, None, None)
+
+
+def test_saver_checks_the_sdxl_vae_source_before_training(tmp_path):
+    """a full fine-tune with nothing to embed as `first_stage_model.*` must fail when the Saver is built, not at the first checkpoint."""
+    from diffusion_pipe_amd.saver import Saver
+    from diffusion_pipe_amd.workloads import sdxl
+    from oracle.make_golden_formats import fake_vae_state_dict
+    work = sdxl.SDXLWorkload(sdxl.tiny_config(), dtype=torch.float32, seed=21)
+    with pytest.raises(RuntimeError, match='no VAE weights'):
+        Saver(None, {}, False, tmp_path, work, None, None, None)
+    Saver(None, {}, True, tmp_path, work, None, None, None)                  # LoRA runs write no VAE
+    work.set_vae_state_dict(fake_vae_state_dict())
+    Saver(None, {}, False, tmp_path, work, None, None, None)
+    opt_in = sdxl.SDXLWorkload(sdxl.tiny_config(), model_config={'allow_missing_vae': True}, dtype=torch.float32, seed=21)
+    Saver(None, {}, False, tmp_path, opt_in, None, None, None)

@@ -88,3 +88,82 @@ def test_tuple_protocol_over_gloo():
     assert send['headers_sent'] == 4 and 'shapes changed' in send['shape_change']
     assert recv['after_reset'].shape == (3, 3)
     assert torch.equal(send['grads'][0], torch.full((2, 5), 7.0)) and send['grads'][1].dtype == torch.bfloat16
+
+
+def _negotiate_worker(rank, port, outdir, world, fail_rank, fail_phase):
+    """RcclLink.negotiate over gloo with the native calls stubbed: one rank fails at one phase, every rank must still reach every agreement."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import datetime
+        group = dist.new_group(list(range(world)), timeout=datetime.timedelta(seconds=60))
+        grid = type('G', (), {'stage_to_global': staticmethod(lambda s: s), 'pipe_parallel_size': world, 'global_rank': rank,
+                              'get_pipe_parallel_group': staticmethod(lambda: group), 'get_stage_id': staticmethod(lambda: rank)})
+        calls = []
+
+        class FakeLib:
+            def dpipe_comm_unique_id(self, buf):
+                calls.append('id')
+                return -1 if (rank == fail_rank and fail_phase in ('probe', 'connect-id') and (fail_phase == 'probe' or len([c for c in calls if c == 'id']) > 1)) else 0
+
+            def dpipe_comm_init(self, comm, world_, r, id_):
+                calls.append('init')
+                return -1 if (rank == fail_rank and fail_phase == 'connect-init') else 0
+
+            def dpipe_comm_destroy(self, comm):
+                calls.append('destroy')
+                return 0
+
+        class FakeHip:
+            @staticmethod
+            def lib():
+                return FakeLib()
+
+            @staticmethod
+            def check(rc, what):
+                if rc != 0:
+                    raise RuntimeError(f'{what} failed')
+
+        import sys
+        import types
+        import diffusion_pipe_amd
+        fake = types.ModuleType('diffusion_pipe_amd.hip')
+        fake.lib, fake.check = FakeHip.lib, FakeHip.check
+        sys.modules['diffusion_pipe_amd.hip'] = fake
+        diffusion_pipe_amd.hip = fake
+
+        class Link(p2p.RcclLink):
+            def _self_test(self):            # the data path needs a GPU; the phase protocol does not
+                calls.append('selftest')
+                return RuntimeError('corrupted pattern') if (rank == fail_rank and fail_phase == 'self-test') else None
+
+        class Dev:
+            def __enter__(self): return self
+            def __exit__(self, *a): return False
+        orig = torch.cuda.device
+        torch.cuda.device = lambda d: Dev()
+        try:
+            link = Link.negotiate(grid, 'cpu', log=lambda *a, **k: None)
+        finally:
+            torch.cuda.device = orig
+        torch.save({'link': link is not None, 'calls': calls}, os.path.join(outdir, f'n{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('fail_phase', ['none', 'probe', 'connect-id', 'connect-init', 'self-test'])
+def test_rccl_link_negotiation_never_strands_a_rank(fail_phase):
+    """with p2p_backend 'auto' an ASYMMETRIC failure (one rank cannot draw an id / initialise its communicator / sees a corrupted
+    self-test pattern) must end with every rank agreeing on the fallback -- not with its neighbours blocked in a broadcast or a rendezvous."""
+    world = 3
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_negotiate_worker, args=(_free_port(), d, world, 1, fail_phase), nprocs=world, join=True)
+        res = [torch.load(os.path.join(d, f'n{r}.pt'), weights_only=False) for r in range(world)]
+    assert [r['link'] for r in res] == [fail_phase == 'none'] * world
+    if fail_phase == 'probe':
+        assert all('init' not in r['calls'] for r in res)                      # nobody started connecting
+    if fail_phase in ('connect-id', 'connect-init'):
+        assert all('selftest' not in r['calls'] for r in res)                  # nobody started the self-test
+        assert 'destroy' in res[0]['calls'] or 'destroy' in res[2]['calls'] or fail_phase == 'connect-id'
+    if fail_phase == 'connect-id':
+        assert 'init' in res[0]['calls'] and res[2]['calls'].count('init') == 0      # pair (0, 1) connected; pair (1, 2) skipped its rendezvous on BOTH ends
