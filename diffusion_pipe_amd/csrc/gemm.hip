@@ -280,7 +280,7 @@ int dpipe_gemm_ex(int dtype, int transA, int transB, int M, int N, int K,
     // 64 x 64 / 128 x 128 tile forced -- an error when the problem is not eligible.
     if (dtype == DPIPE_BF16 && (tile_hint == 0 || tile_hint >= 1000)) {
         int rc = 0;
-        const int force_tile = tile_hint >= 11000 ? 1283 : tile_hint >= 10000 ? 1264 : tile_hint >= 9000 ? 258 : tile_hint >= 8000 ? 130 : tile_hint >= 7000 ? 257 : tile_hint >= 6000 ? 63 : tile_hint >= 5000 ? 256 : tile_hint >= 4000 ? 129 : tile_hint >= 3000 ? 128 : tile_hint >= 2000 ? 64 : 0;   // 4000: 128^2 4-deep ring, 5000: 256 x 128 (experiments)
+        const int force_tile = tile_hint >= 13000 ? 646 : tile_hint >= 12000 ? 648 : tile_hint >= 11000 ? 1283 : tile_hint >= 10000 ? 1264 : tile_hint >= 9000 ? 258 : tile_hint >= 8000 ? 130 : tile_hint >= 7000 ? 257 : tile_hint >= 6000 ? 63 : tile_hint >= 5000 ? 256 : tile_hint >= 4000 ? 129 : tile_hint >= 3000 ? 128 : tile_hint >= 2000 ? 64 : 0;   // 4000: 128^2 4-deep ring, 5000: 256 x 128 (experiments)
         const int force_s = tile_hint >= 1000 ? tile_hint % 1000 : 0;
         if (gemm_pipe_try(p, transA, transB, batch, splitk_ws, splitk_ws_bytes, force_s, force_tile, s, &rc)) return rc;
         if (tile_hint >= 1000) { set_last_error("dpipe_gemm: problem not eligible for the pipelined kernel"); return DPIPE_ERR_UNSUPPORTED; }
@@ -298,6 +298,44 @@ int dpipe_gemm_ex(int dtype, int transA, int transB, int M, int N, int K,
     bool big = tile_hint == 128 || (tile_hint == 0 && t128 >= 192);
     if (dtype == DPIPE_BF16) return big ? launch_cfg<bf16_t, 128, 128>(p, transA, transB, batch, s) : launch_cfg<bf16_t, 64, 64>(p, transA, transB, batch, s);
     return big ? launch_cfg<float, 128, 128>(p, transA, transB, batch, s) : launch_cfg<float, 64, 64>(p, transA, transB, batch, s);
+}
+
+int dpipe_gemm_group(const dpipe_gemm_desc* descs, int n, void* splitk_ws, long splitk_ws_bytes, int* launches_out, void* stream) {
+    if (!descs || n <= 0 || n > 16) { set_last_error("dpipe_gemm_group: 1 <= n <= 16 descriptors"); return DPIPE_ERR_ARG; }
+    GemmParams ps[16];
+    int ta[16], tb[16];
+    bool pipe[16];
+    int npipe = 0;
+    for (int i = 0; i < n; ++i) {
+        const dpipe_gemm_desc& d = descs[i];
+        if (!d.A || !d.B || !d.C || d.M <= 0 || d.N <= 0 || d.K <= 0) { set_last_error("dpipe_gemm_group: bad argument"); return DPIPE_ERR_ARG; }
+        if (d.dtype != DPIPE_BF16 && d.dtype != DPIPE_F32) { set_last_error("dpipe_gemm_group: dtype"); return DPIPE_ERR_UNSUPPORTED; }
+        if (d.residual && d.residual == d.C && !d.accumulate) { set_last_error("dpipe_gemm_group: residual may not alias C"); return DPIPE_ERR_ARG; }
+        GemmParams p;
+        p.A = d.A; p.B = d.B; p.C = d.C; p.bias = d.bias; p.M = d.M; p.N = d.N; p.K = d.K; p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc;
+        p.sAo = p.sAi = p.sBo = p.sBi = p.sCo = p.sCi = 0;
+        p.batch_inner = 1; p.alpha = d.alpha; p.act = d.act; p.accumulate = d.accumulate; p.out_f32 = d.out_f32;
+        p.splitk = 1; p.ksteps = 0; p.ksteps_per_split = 0; p.slabs = nullptr; p.counters = nullptr;
+        p.residual = d.residual; p.ldr = d.ldr; p.colsum = d.colsum; p.colsum_acc = d.colsum_accumulate;
+        pipe[i] = d.dtype == DPIPE_BF16 && gemm_pipe_eligible(p, d.transA, d.transB);
+        if (d.colsum && !pipe[i]) { set_last_error("dpipe_gemm_group: fused column sum needs the pipelined kernel with a K-major A operand (transA = 1)"); return DPIPE_ERR_UNSUPPORTED; }
+        if (pipe[i]) { ps[npipe] = p; ta[npipe] = d.transA; tb[npipe] = d.transB; ++npipe; }
+    }
+    int launches = 0;
+    if (npipe > 0) {
+        const int rc = gemm_pipe_group(ps, ta, tb, npipe, splitk_ws, splitk_ws_bytes, reinterpret_cast<hipStream_t>(stream), &launches);
+        if (rc != DPIPE_OK) return rc;
+    }
+    for (int i = 0; i < n; ++i) {          // fp32 / unaligned / ragged-K problems: the generic kernel, one launch each
+        if (pipe[i]) continue;
+        const dpipe_gemm_desc& d = descs[i];
+        const int rc = dpipe_gemm_ex(d.dtype, d.transA, d.transB, d.M, d.N, d.K, d.A, d.lda, d.B, d.ldb, d.C, d.ldc, 1, 1, 0, 0, 0, 0, 0, 0, d.bias, d.act, d.alpha,
+                                     d.accumulate, d.out_f32, 0, nullptr, 0, d.residual, d.ldr, nullptr, 0, stream);
+        if (rc != DPIPE_OK) return rc;
+        ++launches;
+    }
+    if (launches_out) *launches_out = launches;
+    return DPIPE_OK;
 }
 
 int dpipe_gemm(int dtype, int transA, int transB, int M, int N, int K,

@@ -8,11 +8,9 @@ using namespace dpipe_pipe;
 
 namespace dpipe {
 
-bool gemm_pipe_try(GemmParams& p, int transA, int transB, int batch, void* ws, long ws_bytes, int force_splitk, int force_tile,
-                   hipStream_t s, int* rc_out) {
-    const bool a_mc = transA != 0, b_mc = transB == 0;
+// eligibility for the LDS-DMA kernel: 16-byte DMA pieces, K-contiguous operands need whole K-steps, 32-bit buffer offsets
+static bool pipe_eligible(const GemmParams& p, bool a_mc, bool b_mc) {
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    // eligibility: 16-byte DMA pieces, K-contiguous operands need whole K-steps, 32-bit offsets
     if (!al16(p.A) || !al16(p.B)) return false;
     if (p.lda % 8 || p.ldb % 8 || p.sAo % 8 || p.sAi % 8 || p.sBo % 8 || p.sBi % 8) return false;
     if ((!a_mc || !b_mc) && (p.K % BK) != 0) return false;
@@ -20,25 +18,105 @@ bool gemm_pipe_try(GemmParams& p, int transA, int transB, int batch, void* ws, l
     const long kpad = (long)((p.K + BK - 1) / BK) * BK, mpad = (long)((p.M + 255) / 256) * 256, npad = (long)((p.N + 255) / 256) * 256;
     const long ext_a = a_mc ? kpad * p.lda + mpad : mpad * p.lda + kpad;
     const long ext_b = b_mc ? kpad * p.ldb + npad : npad * p.ldb + kpad;
-    if (ext_a * 2 >= (1L << 31) || ext_b * 2 >= (1L << 31)) return false;
+    return ext_a * 2 < (1L << 31) && ext_b * 2 < (1L << 31);
+}
 
-    const int tile = gemm_pipe_plan(p, a_mc, b_mc, batch, ws, ws_bytes, force_splitk, force_tile);
+static int launch_by_tile(int tile, const GemmParams& p, bool a_mc, bool b_mc, int batch, hipStream_t s) {
     switch (tile) {
-    case 257: *rc_out = launch_pipe<T256S>(p, a_mc, b_mc, batch, s); break;
-    case 258: *rc_out = launch_pipe<T256K>(p, a_mc, b_mc, batch, s); break;
-    case 256: *rc_out = launch_pipe<T256>(p, a_mc, b_mc, batch, s); break;
-    case 129: *rc_out = launch_pipe<T128R2>(p, a_mc, b_mc, batch, s); break;
-    case 63: *rc_out = launch_pipe<T64S3>(p, a_mc, b_mc, batch, s); break;
-    case 128: *rc_out = launch_pipe<T128>(p, a_mc, b_mc, batch, s); break;
-    case 130: *rc_out = launch_pipe<T128S5>(p, a_mc, b_mc, batch, s); break;
-    case 1264: *rc_out = launch_pipe<T128N64>(p, a_mc, b_mc, batch, s); break;
-    case 1283: *rc_out = launch_pipe<T128Q3>(p, a_mc, b_mc, batch, s); break;
-    default: *rc_out = launch_pipe<T64>(p, a_mc, b_mc, batch, s); break;
+    case 257: return launch_pipe<T256S>(p, a_mc, b_mc, batch, s);
+    case 258: return launch_pipe<T256K>(p, a_mc, b_mc, batch, s);
+    case 256: return launch_pipe<T256>(p, a_mc, b_mc, batch, s);
+    case 129: return launch_pipe<T128R2>(p, a_mc, b_mc, batch, s);
+    case 63: return launch_pipe<T64S3>(p, a_mc, b_mc, batch, s);
+    case 648: return launch_pipe<T64D8>(p, a_mc, b_mc, batch, s);
+    case 646: return launch_pipe<T64D6>(p, a_mc, b_mc, batch, s);
+    case 128: return launch_pipe<T128>(p, a_mc, b_mc, batch, s);
+    case 130: return launch_pipe<T128S5>(p, a_mc, b_mc, batch, s);
+    case 1264: return launch_pipe<T128N64>(p, a_mc, b_mc, batch, s);
+    case 1283: return launch_pipe<T128Q3>(p, a_mc, b_mc, batch, s);
+    default: return launch_pipe<T64>(p, a_mc, b_mc, batch, s);
     }
+}
+
+bool gemm_pipe_eligible(const GemmParams& p, int transA, int transB) { return pipe_eligible(p, transA != 0, transB == 0); }
+
+bool gemm_pipe_try(GemmParams& p, int transA, int transB, int batch, void* ws, long ws_bytes, int force_splitk, int force_tile,
+                   hipStream_t s, int* rc_out) {
+    const bool a_mc = transA != 0, b_mc = transB == 0;
+    if (!pipe_eligible(p, a_mc, b_mc)) return false;
+    const int tile = gemm_pipe_plan(p, a_mc, b_mc, batch, ws, ws_bytes, force_splitk, force_tile);
+    *rc_out = launch_by_tile(tile, p, a_mc, b_mc, batch, s);
     return true;
 }
 
-int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, long ws_bytes, int force_splitk, int force_tile) {
+// Grouped launch of n independent plain GEMMs (dpipe_gemm_group).  Each problem is planned exactly as a single launch would plan it (same tile, same split-K:
+// bit-identical results), on a private share of the split-K workspace; problems that land on the same groupable tile geometry (64^2 4-deep, 128^2 2-deep,
+// 128^2 3-deep) leave as ONE launch of up to GROUP_MAX problems, the workgroups of the problem with the longest K walk first; a dgrad / wgrad pair whose
+// geometries differ is re-planned onto the 64^2 tile when that keeps it one launch (`pair_unify`).  Everything else goes out as single launches.
+int gemm_pipe_group(GemmParams* ps, const int* transA, const int* transB, int n, void* ws, long ws_bytes, hipStream_t s, int* launches_out) {
+    struct Plan { int tile; bool a_mc, b_mc; long tiles; int counter_base; long slab_base; };
+    Plan pl[16];
+    if (n > 16) { set_last_error("dpipe_gemm_group: at most 16 problems"); return DPIPE_ERR_ARG; }
+    auto slab_bytes_of = [](int tile) { const long bm = (tile == 128 || tile == 129) ? 128 : 64; return (bm * bm + bm) * 4L; };
+    auto plan_all = [&](int force) {
+        int cbase = 0; long sbase = 0;
+        for (int i = 0; i < n; ++i) {
+            GemmParams& p = ps[i];
+            p.splitk = 1; p.ksteps = 0; p.ksteps_per_split = 0; p.slabs = nullptr; p.counters = nullptr;
+            pl[i].a_mc = transA[i] != 0; pl[i].b_mc = transB[i] == 0;
+            pl[i].counter_base = cbase; pl[i].slab_base = sbase;
+            pl[i].tile = gemm_pipe_plan(p, pl[i].a_mc, pl[i].b_mc, 1, ws, ws_bytes, 0, force, cbase, sbase);
+            pl[i].tiles = (long)p.tiles_m * p.tiles_n;
+            if (p.splitk > 1) {
+                cbase += (int)pl[i].tiles;
+                sbase += pl[i].tiles * p.splitk * slab_bytes_of(pl[i].tile);
+                sbase = (sbase + 255) & ~255L;
+            }
+        }
+    };
+    plan_all(0);
+    auto groupable = [](int tile) { return tile == 64 || tile == 129 || tile == 128 || tile == 648 || tile == 646; };
+    static const bool pair_unify = [] { const char* e = getenv("DPIPE_GEMM_GROUP_UNIFY"); return !e || atoi(e) != 0; }();
+    if (pair_unify && n == 2 && pl[0].tile != pl[1].tile && groupable(pl[0].tile) && groupable(pl[1].tile)) plan_all(64);
+    bool done[16] = {};
+    int launches = 0, rc = DPIPE_OK;
+    for (int i = 0; i < n && rc == DPIPE_OK; ++i) {
+        if (done[i]) continue;
+        int members[GROUP_MAX], m = 0;
+        members[m++] = i;
+        if (groupable(pl[i].tile))
+            for (int j = i + 1; j < n && m < GROUP_MAX; ++j)
+                if (!done[j] && pl[j].tile == pl[i].tile) members[m++] = j;
+        for (int k = 0; k < m; ++k) done[members[k]] = true;
+        ++launches;
+        if (m == 1) { rc = launch_by_tile(pl[i].tile, ps[i], pl[i].a_mc, pl[i].b_mc, 1, s); continue; }
+        // longest K walk first: its workgroups start in the first round, the short ones fill the tail
+        for (int a = 1; a < m; ++a)
+            for (int b = a; b > 0 && ps[members[b]].ksteps_per_split > ps[members[b - 1]].ksteps_per_split; --b) { const int t = members[b]; members[b] = members[b - 1]; members[b - 1] = t; }
+        GemmGroup g;
+        g.n = m;
+        int at = 0;
+        for (int k = 0; k < GROUP_MAX; ++k) {
+            if (k < m) {
+                const int id = members[k];
+                g.p[k] = ps[id]; g.mode[k] = 2 * (int)pl[id].a_mc + (int)pl[id].b_mc;
+                g.start[k] = at; g.nwg[k] = (int)(pl[id].tiles * ps[id].splitk);
+                at += (g.nwg[k] + 7) & ~7;
+            } else { g.p[k] = ps[members[0]]; g.mode[k] = 0; g.start[k] = at; g.nwg[k] = 0; }
+        }
+        switch (pl[i].tile) {
+        case 648: rc = launch_pipe_group<T64D8>(g, at, s); break;
+        case 646: rc = launch_pipe_group<T64D6>(g, at, s); break;
+        case 129: rc = launch_pipe_group<T128R2>(g, at, s); break;
+        case 128: rc = launch_pipe_group<T128>(g, at, s); break;
+        default: rc = launch_pipe_group<T64>(g, at, s); break;
+        }
+    }
+    if (launches_out) *launches_out = launches;
+    return rc;
+}
+
+int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, long ws_bytes, int force_splitk, int force_tile, int counter_base, long slab_base) {
     p.ksteps = (p.K + BK - 1) / BK;
     const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
     const long tiles64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64) * batch;
@@ -94,14 +172,15 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
         }
         if (S < 1) S = 1;
         if (S > p.ksteps) S = p.ksteps;
-        const long max_slabs = (ws_bytes - COUNTER_BYTES) / slab_bytes;
+        // (counter_base, slab_base: the share of the workspace problems planned earlier into the same grouped launch already own)
+        const long max_slabs = (ws_bytes - COUNTER_BYTES - slab_base) / slab_bytes;
         if (tiles * S > max_slabs) S = (int)(max_slabs / tiles);
-        if (tiles > COUNTER_BYTES / 4 || S < 1) S = 1;
+        if (counter_base + tiles > COUNTER_BYTES / 4 || S < 1) S = 1;
     }
     p.ksteps_per_split = (p.ksteps + S - 1) / S;
     p.splitk = (p.ksteps + p.ksteps_per_split - 1) / p.ksteps_per_split;
-    p.counters = reinterpret_cast<int*>(ws);
-    p.slabs = ws ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + COUNTER_BYTES) : nullptr;
+    p.counters = ws ? reinterpret_cast<int*>(ws) + counter_base : nullptr;
+    p.slabs = ws ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + COUNTER_BYTES + slab_base) : nullptr;
     // vector epilogue flags (re-using the generic kernel's fields): vecA >= 2 -> C rows allow 4-element vector accesses,
     // vecB >= 2 -> bias allows 8-byte loads
     const int celt = p.out_f32 ? 4 : 2;
@@ -110,7 +189,13 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
     if (c_ok && p.residual && reinterpret_cast<uintptr_t>(p.residual) % 8 == 0 && p.ldr % 4 == 0) p.vecA = 3;   // 8-byte residual loads too
     p.vecB = (p.bias && reinterpret_cast<uintptr_t>(p.bias) % 8 == 0) ? 2 : 0;
     if (force_tile == 258 || force_tile == 1283) { p.ksteps *= 2; p.ksteps_per_split *= 2; return force_tile; }      // T256K counts K in 32-wide half steps (slices keep their K ranges)
-    if (force_tile == 257 || force_tile == 256 || force_tile == 63 || force_tile == 130 || force_tile == 1264) return force_tile;
+    if (force_tile == 257 || force_tile == 256 || force_tile == 63 || force_tile == 130 || force_tile == 1264 || force_tile == 648 || force_tile == 646) return force_tile;
+    // DPIPE_OPT_GEMM_DEEP64 = 6 / 8: launches of at most ONE 64^2 workgroup per CU with a K walk of >= 6 steps (the 77-token linears, the slices of few-tile split
+    // problems) run on the 6- / 8-deep ring -- their time is the HBM round trips of the K walk, which a deeper ring overlaps; nothing else is resident to use the LDS
+    {
+        const int deep = option(DPIPE_OPT_GEMM_DEEP64, 0);
+        if (deep && force_tile == 0 && !big && tiles * p.splitk <= 256 && p.ksteps_per_split >= 6) return deep >= 8 ? 648 : 646;
+    }
     if (force_tile == 129 || (force_tile == 0 && big && tiles128 >= 256 && (a_mc || b_mc || tiles128 >= 1024))) return 129;
     // DPIPE_OPT_GEMM_SHALLOW: the shallow rings everywhere (128^2 on 2 x 32 KiB, 64^2 on 3 x 16 KiB) -- slower launches in isolation (step list: 23.5 vs 22.0 us
     // average), but a 64 KiB footprint lets a workgroup of ANOTHER micro-batch lane share the CU: 19.34 vs 18.93 images/s with 3 lanes

@@ -71,6 +71,10 @@ using T128S5 = Tile<128, 128, 2, 4, 5>;     // 5-deep ring = all 160 KiB of LDS,
                                             // HBM-cold DMA pieces landing ~4 500 cycles after issue -- a 3-deep ring parks every wave ~900 cycles per K-step at vmcnt, this one ~460;
                                             // selectable (tile_hint 8000 + S), not chosen automatically: whole-kernel time is unchanged (52.9 vs 51.5 us on
                                             // [1024,1280] x [10240,1280]^T: 2.5 rounds of tiles at one workgroup per CU either way, longer prologue)
+using T64D8 = Tile<64, 64, 2, 2, 8>;         // DEEP ring for launches of <= one workgroup per CU (the 77-token linears, split slices of few-tile problems): 8 x 16 KiB = 128 KiB, seven K-steps
+                                            // (28 DMA pieces per wave) in flight -- such a launch is bound by the HBM round trip of its K walk (a 12-step tile: 8 us = launch + 12 exposed
+                                            // latencies on the 4-deep ring), not by occupancy: nothing else would use the CU's LDS.  tile_hint 12000 + S
+using T64D6 = Tile<64, 64, 2, 2, 6>;         // the same at 96 KiB (five K-steps in flight): leaves 64 KiB of the CU's LDS to a workgroup of another micro-batch lane.  tile_hint 13000 + S
 using T64S3 = Tile<64, 64, 2, 2, 3>;         // selectable, not chosen automatically: 3-deep ring (3 workgroups per CU)
 using T128N64 = Tile<128, 64, 2, 2, 4>;     // skinny-M configuration (M <= 128: the 77-token text-encoder / cross-attention K,V linears): ONE tile row covers every
                                             // row of A, so each weight panel is fetched by exactly one workgroup (the 64^2 tile reads it twice for M = 77), 4-deep ring
@@ -102,40 +106,22 @@ __device__ __forceinline__ float frag_sum(bf16x8_t f) {
 }
 
 // counted wait for this wave's LDS-DMA: `ahead` later K-steps (NLOAD DMA instructions each) may stay in flight
-template <int NLOAD> __device__ __forceinline__ void wait_dma_ahead(int ahead) {
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int NLOAD, int MAXAHEAD> __device__ __forceinline__ void wait_dma_ahead(int ahead) {
     static_assert(NLOAD == 4 || NLOAD == 6 || NLOAD == 8 || NLOAD == 12, "DMA pieces per wave per K-step");
-    if constexpr (NLOAD == 12) {
-        switch (ahead) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
-        }
-        return;
-    }
-    if constexpr (NLOAD == 8) {
-        switch (ahead) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-        }
-        return;
-    }
-    if constexpr (NLOAD == 4) {
-        switch (ahead) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-        }
-    } else {
-        switch (ahead) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
-        }
+    static_assert(MAXAHEAD >= 1 && MAXAHEAD <= 7 && NLOAD * MAXAHEAD <= 63, "look-ahead of the ring vs the vmcnt field");
+    switch (ahead) {       // (ahead <= MAXAHEAD = STAGES - 2 by construction; the unreachable cases fold away)
+    case 0: wait_vmcnt<0>(); break;
+    case 1: wait_vmcnt<NLOAD>(); break;
+    case 2: if constexpr (MAXAHEAD >= 2) { wait_vmcnt<NLOAD * 2>(); break; }
+    case 3: if constexpr (MAXAHEAD >= 3) { wait_vmcnt<NLOAD * 3>(); break; }
+    case 4: if constexpr (MAXAHEAD >= 4) { wait_vmcnt<NLOAD * 4>(); break; }
+    case 5: if constexpr (MAXAHEAD >= 5) { wait_vmcnt<NLOAD * 5>(); break; }
+    case 6: if constexpr (MAXAHEAD >= 6) { wait_vmcnt<NLOAD * 6>(); break; }
+    default: wait_vmcnt<NLOAD * MAXAHEAD>(); break;
     }
 }
 
@@ -144,21 +130,22 @@ template <int NLOAD> __device__ __forceinline__ void wait_dma_ahead(int ahead) {
 // a row that falls into the zero padding gets a DMA source offset beyond the buffer extent, which the buffer bounds check turns into
 // zeros, so no im2col matrix and no padded copy ever exists.  CONV = 2: wgrad, one GEMM per tap (grid.y): the B operand's K-ROWS are
 // the gathered pixels (k = output pixel, n = input channel), A = dy read MN-contiguous.
+// The body of one workgroup: `orig` = its index among the problem's tiles_m * tiles_n * splitk workgroups (the launch's blockIdx.x, or the workgroup's index
+// inside its problem's share of a GROUPED launch), `bz` = batch index / CONV 2 tap (blockIdx.y), `lds` = the launch's one LDS array (STAGES * STAGE_BYTES, 1 KiB
+// aligned).  Always inlined: the array's address space reaches the ds_read / DMA instructions through the inliner.
 template <int BM_, int BN_, int WM_, int WN_, int STAGES_, bool A_MC, bool B_MC, int CONV = 0, int BKT = 64>
-__global__ void __launch_bounds__(WM_ * WN_ * 64, (WM_ * WN_ == 4 && BKT == 32) ? 3 : 1) gemm_pipe_kernel(const GemmParams p) {     // half-step 4-wave tiles: three waves per SIMD (<= 168 VGPRs)      // 4-wave configurations: one wave per SIMD may use the whole 512-register file
+__device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, char* const lds, const int orig, const int bz) {
     using TL = Tile<BM_, BN_, WM_, WN_, STAGES_, BKT>;
     constexpr int BM = TL::BM, BN = TL::BN, STAGES = TL::STAGES, TM = TL::TM, TN = TL::TN, NLOAD = TL::NLOAD;
     constexpr int BK = BKT, KS = BKT / 16;          // (shadows the namespace default) k extent of a stage, 16-wide k-slices per stage
     static_assert(CONV == 0 || BKT == 64, "the convolution gathers are written for 64-channel K-steps");
-    static_assert(STAGES >= 2 && STAGES <= 5, "ring depth (the vmcnt ladder covers <= 3 K-steps ahead)");
-    __shared__ __attribute__((aligned(1024))) char lds[STAGES * TL::STAGE_BYTES];
+    static_assert(STAGES >= 2 && STAGES <= 8, "ring depth");
     TL_STAMP(0);
 
     // XCD-aware bijective remap (consecutive ids round-robin over the 8 XCDs): each XCD owns a contiguous run of
     // (tile, slice) pairs; slices of one tile are adjacent, so a tile's slabs stay in one L2.
     const int nt = p.tiles_m * p.tiles_n;
     const int nwg = nt * p.splitk;
-    const int orig = blockIdx.x;
     const int xq = nwg / 8, xr = nwg % 8, xcd = orig % 8;
     const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + orig / 8;
     const int split = wg % p.splitk, tile = wg / p.splitk;
@@ -172,7 +159,7 @@ __global__ void __launch_bounds__(WM_ * WN_ * 64, (WM_ * WN_ == 4 && BKT == 32) 
     const int tile_m = first_m + (tile - grp * gsz) % rows_in, tile_n = (tile - grp * gsz) / rows_in;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    const int z = blockIdx.y;
+    const int z = bz;
     const long zo = z / p.batch_inner, zi = z % p.batch_inner;
     const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + zo * p.sAo + zi * p.sAi;
     const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B) + zo * p.sBo + zi * p.sBi;
@@ -233,7 +220,7 @@ __global__ void __launch_bounds__(WM_ * WN_ * 64, (WM_ * WN_ == 4 && BKT == 32) 
         }
     }
     if constexpr (CONV == 2) {
-        const int t = cg.tap0 + (int)blockIdx.y;
+        const int t = cg.tap0 + bz;
         c_ky = t / cg.kw; c_kx = t - c_ky * cg.kw;
         adv_y = BK / cg.rows_w; adv_x = BK - adv_y * cg.rows_w;
         const int plane = cg.rows_h * cg.rows_w;
@@ -324,7 +311,7 @@ __global__ void __launch_bounds__(WM_ * WN_ * 64, (WM_ * WN_ == 4 && BKT == 32) 
     float csum[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) csum[i] = 0.f;
-    const bool colsum_here = A_MC && p.colsum != nullptr && tile_n == 0 && (CONV != 2 || blockIdx.y == 0);   // CONV 2: every tap sees the same dy
+    const bool colsum_here = A_MC && p.colsum != nullptr && tile_n == 0 && (CONV != 2 || bz == 0);   // CONV 2: every tap sees the same dy
     const bool do_colsum = colsum_here && (wid % TL::WN) == 0;
 
     // ---- prologue: STAGES - 1 K-steps in flight
@@ -337,7 +324,7 @@ __global__ void __launch_bounds__(WM_ * WN_ * 64, (WM_ * WN_ == 4 && BKT == 32) 
     for (int it = 0; it < nk; ++it) {
         // retire this wave's DMA of K-step `it` (later steps stay in flight), then one barrier: every wave's share of
         // step `it` has landed AND every wave has finished reading buffer `nxt` (it computed step it-1 from it).
-        wait_dma_ahead<NLOAD>(min(nk - it - 1, STAGES - 2));
+        wait_dma_ahead<NLOAD, (STAGES > 2 ? STAGES - 2 : 1)>(min(nk - it - 1, STAGES - 2));
         TL_STAMP(4 + 4 * it);
         __builtin_amdgcn_s_barrier();
         TL_STAMP(5 + 4 * it);
@@ -606,6 +593,52 @@ __global__ void __launch_bounds__(WM_ * WN_ * 64, (WM_ * WN_ == 4 && BKT == 32) 
             }
     }
     TL_STAMP(3);
+}
+
+template <int BM_, int BN_, int WM_, int WN_, int STAGES_, bool A_MC, bool B_MC, int CONV = 0, int BKT = 64>
+__global__ void __launch_bounds__(WM_ * WN_ * 64, (WM_ * WN_ == 4 && BKT == 32) ? 3 : 1) gemm_pipe_kernel(const GemmParams p) {     // half-step 4-wave tiles: three waves per SIMD (<= 168 VGPRs)
+    using TL = Tile<BM_, BN_, WM_, WN_, STAGES_, BKT>;
+    __shared__ __attribute__((aligned(1024))) char lds[TL::STAGES * TL::STAGE_BYTES];
+    gemm_pipe_body<BM_, BN_, WM_, WN_, STAGES_, A_MC, B_MC, CONV, BKT>(p, lds, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// ---- grouped launch: up to GROUP_MAX INDEPENDENT plain GEMMs (batch 1, one tile geometry, any mix of operand layouts) as ONE kernel launch.  Each workgroup
+// finds its problem from the table of first-workgroup indices (a problem's share starts at a multiple of 8, so its workgroups keep the XCD round-robin the body's
+// remap assumes; the padding workgroups exit at once) and runs the ordinary body on it.  What it buys: the dgrad and wgrad of a Linear (same dy, nothing else
+// in common) fill the chip together instead of as two half-empty launches with a kernel boundary in between; the launch list of a micro-batch shrinks by a third.
+constexpr int GROUP_MAX = 4;
+struct GemmGroup {
+    GemmParams p[GROUP_MAX];
+    int start[GROUP_MAX];        // first workgroup of problem i (multiple of 8)
+    int nwg[GROUP_MAX];          // its workgroups: tiles_m * tiles_n * splitk
+    int mode[GROUP_MAX];         // 2 * a_mc + b_mc
+    int n;
+};
+
+template <int BM_, int BN_, int WM_, int WN_, int STAGES_>
+__global__ void __launch_bounds__(WM_ * WN_ * 64, 1) gemm_pipe_group_kernel(const GemmGroup g) {
+    using TL = Tile<BM_, BN_, WM_, WN_, STAGES_, 64>;
+    __shared__ __attribute__((aligned(1024))) char lds[TL::STAGES * TL::STAGE_BYTES];
+    const int b = (int)blockIdx.x;
+    int i = 0;
+#pragma unroll
+    for (int j = 1; j < GROUP_MAX; ++j)
+        if (j < g.n && b >= g.start[j]) i = j;
+    const int local = b - g.start[i];
+    if (local >= g.nwg[i]) return;
+    const GemmParams& p = g.p[i];
+    switch (g.mode[i]) {
+    case 0: gemm_pipe_body<BM_, BN_, WM_, WN_, STAGES_, false, false>(p, lds, local, 0); break;
+    case 1: gemm_pipe_body<BM_, BN_, WM_, WN_, STAGES_, false, true>(p, lds, local, 0); break;
+    case 2: gemm_pipe_body<BM_, BN_, WM_, WN_, STAGES_, true, false>(p, lds, local, 0); break;
+    default: gemm_pipe_body<BM_, BN_, WM_, WN_, STAGES_, true, true>(p, lds, local, 0); break;
+    }
+}
+
+template <typename TL>
+int launch_pipe_group(const GemmGroup& g, int total_wg, hipStream_t s) {
+    gemm_pipe_group_kernel<TL::BM, TL::BN, TL::WM, TL::WN, TL::STAGES><<<dim3((unsigned)total_wg), TL::NT, 0, s>>>(g);
+    return check_launch("dpipe_gemm_group");
 }
 
 template <typename TL, int CONV = 0>

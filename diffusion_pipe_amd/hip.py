@@ -16,13 +16,22 @@ import os
 LIB_PATH = Path(os.environ.get('DPIPE_HIP_LIB') or Path(__file__).resolve().parent / 'libdpipe_hip.so')
 
 BF16, F32 = 0, 1
-ABI_VERSION = 4                      # DPIPE_ABI_VERSION of include/dpipe_hip.h this binding was written against
+ABI_VERSION = 5                      # DPIPE_ABI_VERSION of include/dpipe_hip.h this binding was written against
 CONV_OUT_F32, CONV_ACCUMULATE = 1, 2  # dpipe_conv2d_fwd / _dgrad `flags`
-OPT_ATTN_FWD_DMA, OPT_ATTN_BWD_DMA, OPT_ATTN_DQ8, OPT_ATTN_DKV_SPLIT, OPT_GEMM_SKINNY, OPT_GEMM_SHALLOW = 0, 1, 2, 3, 4, 5     # dpipe_set_option ids (include/dpipe_hip.h)
+OPT_ATTN_FWD_DMA, OPT_ATTN_BWD_DMA, OPT_ATTN_DQ8, OPT_ATTN_DKV_SPLIT, OPT_GEMM_SKINNY, OPT_GEMM_SHALLOW, OPT_GEMM_DEEP64 = 0, 1, 2, 3, 4, 5, 6     # dpipe_set_option ids (include/dpipe_hip.h)
 ACT = {None: 0, 'none': 0, 'gelu_tanh': 1, 'gelu': 2, 'gelu_erf': 2, 'silu': 3, 'quick_gelu': 4}
 LOSS_KIND = {'mse': 0, 'huber': 1, 'smooth_l1': 2}
 
 P, I, L, F = c_void_p, c_int, c_long, c_float
+
+
+class GemmDesc(ctypes.Structure):
+    """dpipe_gemm_desc of include/dpipe_hip.h (one problem of dpipe_gemm_group), field for field."""
+    _fields_ = [('dtype', I), ('transA', I), ('transB', I), ('M', I), ('N', I), ('K', I),
+                ('A', P), ('lda', L), ('B', P), ('ldb', L), ('C', P), ('ldc', L),
+                ('bias', P), ('act', I), ('alpha', F), ('accumulate', I), ('out_f32', I),
+                ('residual', P), ('ldr', L), ('colsum', P), ('colsum_accumulate', I)]
+
 
 # name -> (restype, argtypes); mirrors include/dpipe_hip.h one to one.
 _SIGNATURES = {
@@ -79,6 +88,7 @@ _SIGNATURES = {
     'dpipe_transpose': (I, [P, P, I, I, L, L, L, L, I, I, P]),
     'dpipe_gemm': (I, [I, I, I, I, I, I, P, L, P, L, P, L, I, I, L, L, L, L, L, L, P, I, F, I, I, I, P]),
     'dpipe_gemm_ex': (I, [I, I, I, I, I, I, P, L, P, L, P, L, I, I, L, L, L, L, L, L, P, I, F, I, I, I, P, L, P, L, P, I, P]),
+    'dpipe_gemm_group': (I, [POINTER(GemmDesc), I, P, L, POINTER(c_int), P]),
     'dpipe_tr16_probe': (I, [P, P, P]),
     'dpipe_attn_fwd': (I, [P, P, P, P, P, P, I, I, I, I, I] + [L] * 12 + [F, I, P]),
     'dpipe_attn_bwd_partial_floats': (L, [I, I, I, I, I]),

@@ -4,6 +4,7 @@ Every function here launches gfx950 kernels from libdpipe_hip.so on the current 
 CPU fallback (a CPU tensor or a missing library raises `DpipeHipError`).  Reference semantics are cited per op.
 """
 import math
+import os as _os_mod
 
 import torch
 from torch.autograd import Function
@@ -110,6 +111,83 @@ def mm(a, b, trans_a=False, trans_b=False, bias=None, act=None, out=None, out_dt
                 ldr=residual.stride(0) if residual is not None else 0, colsum=colsum, colsum_accumulate=colsum_accumulate)
 
 
+def mm_problem(a, b, trans_a=False, trans_b=False, out=None, bias=None, act=None, accumulate=False, residual=None, colsum=None, colsum_accumulate=False,
+               out_dtype=None):
+    """One problem of `gemm_group`: the arguments of `mm` (2-D row-major operands, last dim contiguous), resolved to the descriptor fields."""
+    assert a.dim() == 2 and b.dim() == 2
+    if a.stride(1) != 1:
+        a = a.contiguous()
+    if b.stride(1) != 1:
+        b = b.contiguous()
+    M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    Kb, N = (b.shape[1], b.shape[0]) if trans_b else b.shape
+    if K != Kb:
+        raise DpipeHipError(f'mm shape mismatch: K={K} vs {Kb}')
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=out_dtype or a.dtype)
+    return {'a': a, 'b': b, 'ta': int(trans_a), 'tb': int(trans_b), 'M': M, 'N': N, 'K': K, 'out': out, 'lda': a.stride(0), 'ldb': b.stride(0), 'ldc': out.stride(0),
+            'bias': bias, 'act': act, 'alpha': 1.0, 'acc': bool(accumulate), 'res': residual, 'ldr': residual.stride(0) if residual is not None else 0,
+            'colsum': colsum, 'colsum_acc': bool(colsum_accumulate)}
+
+
+# A/B switch (bench / tests): 0 = every problem of a group as its own dpipe_gemm_ex launch (the round-3 launch list)
+GROUP_GEMM = _os_mod.environ.get('DPIPE_GROUP_GEMM', '1') == '1'
+
+
+def gemm_group(problems):
+    """INDEPENDENT 2-D GEMMs (`mm_problem` dicts; none reads what another writes) as few kernel launches as possible: dpipe_gemm_group puts the problems that
+    share a tile geometry into ONE launch of the LDS-DMA kernel (the dgrad and the wgrad of a Linear fill the chip together).  Results are bit-identical to
+    issuing the problems one by one.  -> the list of outputs, or None (nothing launched) when a problem asking for a fused column sum cannot take the
+    pipelined kernel (the caller then takes the separate-launch route, as with `mm(..., colsum=...)` returning None)."""
+    if not GROUP_GEMM:
+        outs = []
+        for q in problems:
+            r = gemm(q['a'], q['b'], q['ta'], q['tb'], q['M'], q['N'], q['K'], q['out'], lda=q['lda'], ldb=q['ldb'], ldc=q['ldc'], bias=q['bias'], act=q['act'],
+                     alpha=q['alpha'], accumulate=q['acc'], residual=q['res'], ldr=q['ldr'], colsum=q['colsum'], colsum_accumulate=q['colsum_acc'])
+            if r is None:
+                if outs:
+                    raise DpipeHipError('gemm_group (ungrouped A/B path): a fused column sum turned out ineligible after earlier problems were launched')
+                return None
+            outs.append(r)
+        return outs
+    n = len(problems)
+    descs = (hip.GemmDesc * n)()
+    any_bf16 = False
+    for d, q in zip(descs, problems):
+        a, b, out, bias, res = q['a'], q['b'], q['out'], q['bias'], q['res']
+        require_cuda(a, b, out, bias, res, q['colsum'])
+        if a.dtype != b.dtype:
+            raise DpipeHipError(f'gemm operand dtypes differ: {a.dtype} vs {b.dtype}')
+        dt = dtype_code(a.dtype)
+        out_f32 = int(out.dtype == torch.float32 and a.dtype == torch.bfloat16)
+        if not out_f32 and out.dtype != a.dtype:
+            raise DpipeHipError('gemm output dtype must be the operand dtype or fp32')
+        if bias is not None and bias.dtype != a.dtype:
+            bias = q['bias'] = bias.to(a.dtype)
+        if res is not None and (res.dtype != out.dtype or res.stride(-1) != 1):
+            raise DpipeHipError('gemm residual must have the output dtype and a contiguous last dim')
+        any_bf16 = any_bf16 or dt == hip.BF16
+        d.dtype, d.transA, d.transB, d.M, d.N, d.K = dt, q['ta'], q['tb'], q['M'], q['N'], q['K']
+        d.A, d.lda, d.B, d.ldb, d.C, d.ldc = a.data_ptr(), q['lda'], b.data_ptr(), q['ldb'], out.data_ptr(), q['ldc']
+        d.bias, d.act, d.alpha, d.accumulate, d.out_f32 = (bias.data_ptr() if bias is not None else None), ACT[q['act']], float(q['alpha']), int(q['acc']), out_f32
+        d.residual, d.ldr = (res.data_ptr() if res is not None else None), q['ldr']
+        d.colsum, d.colsum_accumulate = (q['colsum'].data_ptr() if q['colsum'] is not None else None), int(q['colsum_acc'])
+        q['_dt'], q['_out_f32'] = dt, out_f32
+    ws = _splitk_workspace(problems[0]['a'].device) if any_bf16 else None
+    launches = hip.c_int(0)
+    rc = lib().dpipe_gemm_group(descs, n, ptr(ws), ws.numel() if ws is not None else 0, hip.ctypes.byref(launches), stream())
+    if rc == -2 and any(q['colsum'] is not None for q in problems):
+        return None
+    check(rc, 'dpipe_gemm_group')
+    if GEMM_TRACE is not None:
+        for i, q in enumerate(problems):
+            GEMM_TRACE.append({'dt': q['_dt'], 'ta': q['ta'], 'tb': q['tb'], 'M': q['M'], 'N': q['N'], 'K': q['K'], 'lda': q['lda'], 'ldb': q['ldb'], 'ldc': q['ldc'],
+                               'bo': 1, 'bi': 1, 'sa': (0, 0), 'sb': (0, 0), 'sc': (0, 0), 'bias': q['bias'] is not None, 'act': q['act'], 'alpha': float(q['alpha']),
+                               'acc': q['acc'], 'out_f32': q['_out_f32'], 'tile': 0, 'res': q['res'] is not None, 'ldr': q['ldr'], 'colsum': q['colsum'] is not None,
+                               'colsum_acc': q['colsum_acc'], 'grp': i, 'grp_n': n, 'grp_l': int(launches.value)})
+    return [q['out'] for q in problems]
+
+
 # Gradient-accumulation fusion (set by the engine): when a parameter already owns a .grad buffer (micro-batch > 0 of a
 # step, or the persistent buffers of the hipGraph path) the parameter-gradient kernels add into it in their epilogue
 # (wgrad GEMM `accumulate`, column-sum / slab-sum `accumulate`) and autograd receives None -- this removes one
@@ -203,6 +281,31 @@ class _LinearFn(Function):
             return gw_, gb_
 
         fork = PARALLEL_WGRAD and ctx.needs_input_grad[0] and (need_w or need_b)
+        if not fork and ctx.needs_input_grad[0] and need_w and gy2.dtype == torch.bfloat16:
+            # dgrad and wgrad (+ the bias column sums inside it) as ONE grouped launch: dx = dy . W next to dW (+)= dy^T . x -- independent problems that share
+            # dy, each filling well under half of the chip at micro-batch 1
+            tw = _accum_target(weight)
+            w_out = tw if tw is not None else torch.empty(weight.shape, device=weight.device, dtype=weight.dtype)
+            fuse_b = FUSE_BIAS_GRAD and need_b
+            tb = _accum_target(bias) if fuse_b else None
+            b_out = (tb if tb is not None else torch.empty(bias.shape, device=bias.device, dtype=bias.dtype)) if fuse_b else None
+            gx2 = torch.empty((gy2.shape[0], weight.shape[1]), device=gy2.device, dtype=gy2.dtype)
+            done = gemm_group([mm_problem(gy2, weight, False, False, out=gx2),
+                               mm_problem(gy2, x2, True, False, out=w_out, accumulate=tw is not None, colsum=b_out, colsum_accumulate=tb is not None)])
+            if done is not None:
+                gx = gx2.view(ctx.x_shape)
+                if gx.dtype != ctx.x_dtype:
+                    gx = gx.to(ctx.x_dtype)
+                gw = None if tw is not None else w_out
+                if fuse_b:
+                    gb = None if tb is not None else b_out
+                elif need_b:
+                    tgt = _accum_target(bias)
+                    gb = column_sum(gy2, out=tgt)
+                    if tgt is not None:
+                        gb = None
+                gres = gy if (ctx.has_res and ctx.needs_input_grad[3]) else None
+                return gx, gw, gb, gres
         if fork:
             main, side = torch.cuda.current_stream(gy2.device), _side_stream(gy2.device)
             side.wait_stream(main)
@@ -290,40 +393,73 @@ class _FusedLinearFn(Function):
         if gy2.dtype != ws[0].dtype:
             gy2 = gy2.to(ws[0].dtype)
         wcat = packed_view(ws)
-        gx = None
-        if ctx.needs_input_grad[0]:
-            gx = mm(gy2, wcat, False, False).view(ctx.x_shape)                 # dx = dy . [W_1; ...; W_n], K = sum N_i
-            if gx.dtype != ctx.x_dtype:
-                gx = gx.to(ctx.x_dtype)
+        need_dx = ctx.needs_input_grad[0]
+        state = {'gx2': None}
 
-        def grads_for(group, compute):
-            """`compute(out, accumulate)` writes the packed gradient of the group.  Returns the per-parameter gradients
-            autograd should see: None after a fused accumulation / direct .grad installation, else row-block views."""
-            if not any(ctx.needs_input_grad[2 + (0 if group is ws else n) + i] for i in range(n)):
-                return [None] * n
+        def dgrad():
+            return mm(gy2, wcat, False, False)                                     # dx = dy . [W_1; ...; W_n], K = sum N_i
+
+        def plan(group, first):
+            """Where the packed gradient of a parameter group goes: -> (mode, out, accumulate).  'skip': nobody needs it; 'install': first micro-batch under
+            fused accumulation, a fresh packed buffer becomes the parameters' .grad; 'accum': accumulate into the packed .grad in the epilogue; 'return':
+            hand row-block views to autograd."""
+            if not any(ctx.needs_input_grad[2 + first + i] for i in range(n)):
+                return 'skip', None, False
             if FUSE_GRAD_ACCUM:
                 grads = [p.grad for p in group]
                 if all(g is None for g in grads):
-                    gcat = compute(None, False)                                   # first micro-batch: the packed buffer becomes .grad
-                    off = 0
-                    for p in group:
-                        p.grad = gcat[off:off + p.shape[0]]
-                        off += p.shape[0]
-                    return [None] * n
+                    return 'install', None, False
                 if all(g is not None for g in grads):
                     gv = packed_view(grads)
                     if gv is not None:
-                        compute(gv, True)                                          # later micro-batches: accumulate in the epilogue
-                        return [None] * n
-            gcat = compute(None, False)
+                        return 'accum', gv, True
+            return 'return', None, False
+
+        def finish(group, mode, gcat):
+            if mode in ('skip', 'accum'):
+                return [None] * n
             out, off = [], 0
             for p in group:
-                out.append(gcat[off:off + p.shape[0]])
+                blk = gcat[off:off + p.shape[0]]
                 off += p.shape[0]
-            return out
+                if mode == 'install':
+                    p.grad = blk
+                else:
+                    out.append(blk)
+            return out if mode == 'return' else [None] * n
 
-        gws = grads_for(ws, lambda out, acc: mm(gy2, x2, True, False, out=out, accumulate=acc))
-        gbs = grads_for(bs, lambda out, acc: column_sum(gy2, out=out)) if ctx.has_bias else [None] * n
+        wmode, w_out, w_acc = plan(ws, 0)
+        bmode, b_out, b_acc = plan(bs, n) if ctx.has_bias else ('skip', None, False)
+        gwcat = gbcat = None
+        if wmode != 'skip' and gy2.dtype == torch.bfloat16 and (need_dx or bmode != 'skip'):
+            # ONE grouped launch: dgrad next to the packed wgrad, the packed bias gradient as column sums inside the wgrad
+            if w_out is None:
+                w_out = torch.empty(wcat.shape, device=wcat.device, dtype=wcat.dtype)
+            fuse_b = FUSE_BIAS_GRAD and bmode != 'skip'
+            if fuse_b and b_out is None:
+                b_out = torch.empty((wcat.shape[0],), device=wcat.device, dtype=bs[0].dtype)
+            probs = [mm_problem(gy2, x2, True, False, out=w_out, accumulate=w_acc, colsum=b_out if fuse_b else None, colsum_accumulate=b_acc)]
+            if need_dx:
+                state['gx2'] = torch.empty((gy2.shape[0], wcat.shape[1]), device=gy2.device, dtype=gy2.dtype)
+                probs.insert(0, mm_problem(gy2, wcat, False, False, out=state['gx2']))
+            if gemm_group(probs) is not None:
+                gwcat = w_out
+                gbcat = b_out if fuse_b else None
+            else:
+                state['gx2'] = None
+        if need_dx and state['gx2'] is None:
+            state['gx2'] = dgrad()
+        gx = None
+        if need_dx:
+            gx = state['gx2'].view(ctx.x_shape)
+            if gx.dtype != ctx.x_dtype:
+                gx = gx.to(ctx.x_dtype)
+        if wmode != 'skip' and gwcat is None:
+            gwcat = mm(gy2, x2, True, False, out=w_out, accumulate=w_acc)
+        if bmode != 'skip' and gbcat is None:
+            gbcat = column_sum(gy2, out=b_out if b_acc else None)      # `out` given = accumulate into it
+        gws = finish(ws, wmode, gwcat)
+        gbs = finish(bs, bmode, gbcat) if ctx.has_bias else [None] * n
         return (gx, None, *gws, *gbs)
 
 

@@ -32,7 +32,7 @@ extern "C" {
 #define DPIPE_LOSS_SMOOTH_L1 2
 
 /* ABI version: bumped whenever a signature of this header changes; the host binding refuses a library of another version. */
-#define DPIPE_ABI_VERSION 4
+#define DPIPE_ABI_VERSION 5
 int dpipe_version(void);
 const char* dpipe_last_error(void);
 /* Kernel-selection options (process-wide; for A/B timing and for testing the fallback kernels -- every default is the measured-faster choice).
@@ -45,7 +45,9 @@ const char* dpipe_last_error(void);
 #define DPIPE_OPT_GEMM_SHALLOW 5    /* ring depth of the plain GEMM's tiles.  0 (default): 128^2 on the 3-deep 96 KiB ring, 64^2 on the 4-deep 64 KiB ring -- the fastest launch
                                       in isolation; 2: 128^2 on the 2-deep 64 KiB ring (two workgroups per CU) -- slower alone, faster when concurrent streams share the
                                       chip: the engine selects it for >= 2 micro-batch lanes; 3: 64^2 on the 3-deep 48 KiB ring; 1: both */
-#define DPIPE_OPTION_COUNT 6
+#define DPIPE_OPT_GEMM_DEEP64 6     /* 64^2 launches of at most one workgroup per CU (77-token linears, split slices): 0 (default) the 4-deep 64 KiB ring; 6 / 8: the 6- / 8-deep
+                                      ring (96 / 128 KiB, five / seven K-steps of DMA in flight) */
+#define DPIPE_OPTION_COUNT 7
 int dpipe_set_option(int option, int value);
 int dpipe_get_option(int option);    /* the effective explicit / environment value, -1 if neither is set */
 /* Number of compute units / name of device `dev`; used by the host to sanity-check it runs on gfx950. */
@@ -274,6 +276,24 @@ int dpipe_gemm_ex(int dtype, int transA, int transB, int M, int N, int K, const 
                   long strideA_inner, long strideB_outer, long strideB_inner, long strideC_outer, long strideC_inner,
                   const void* bias, int act, float alpha, int accumulate, int out_f32, int tile_hint, void* splitk_ws,
                   long splitk_ws_bytes, const void* residual, long ldr, void* colsum, int colsum_accumulate, void* stream);
+/* Grouped launch: n INDEPENDENT plain GEMMs (batch 1; no problem reads what another writes) as few kernel launches as possible -- the dgrad
+ * (dx = dy W) and wgrad (dW += dy^T x, db += column sums of dy) of one nn.Linear backward (models/wan/model.py:120-122 under autograd), or
+ * the same-shaped linears of two sibling branches.  Every problem is computed exactly as dpipe_gemm_ex(tile_hint = 0) would compute it alone
+ * (same tile, same split-K: bit-identical results); bf16 problems of one tile geometry leave as ONE launch of the LDS-DMA kernel whose
+ * workgroups are divided between them (csrc/gemm_pipe_kernel.h: gemm_pipe_group_kernel), the rest as single launches.  `splitk_ws` as
+ * dpipe_gemm_ex (the problems of a group get disjoint shares).  Returns DPIPE_ERR_UNSUPPORTED (-2) with NOTHING launched when a problem that
+ * asks for `colsum` cannot take the pipelined kernel (the caller then uses dpipe_colsum, as with dpipe_gemm_ex).  *launches_out (may be NULL)
+ * = kernel launches issued.  n <= 16. */
+typedef struct dpipe_gemm_desc {
+    int dtype, transA, transB, M, N, K;
+    const void* A; long lda;
+    const void* B; long ldb;
+    void* C; long ldc;
+    const void* bias; int act; float alpha; int accumulate; int out_f32;
+    const void* residual; long ldr;
+    void* colsum; int colsum_accumulate;
+} dpipe_gemm_desc;
+int dpipe_gemm_group(const dpipe_gemm_desc* descs, int n, void* splitk_ws, long splitk_ws_bytes, int* launches_out, void* stream);
 /* Test probe: runs ds_read_b64_tr_b16 over a 256-element i16 LDS image so the GPU tests can pin the lane mapping
  * the transposed-operand paths rely on. */
 int dpipe_tr16_probe(const void* in256_i16, void* out256_i16, void* stream);

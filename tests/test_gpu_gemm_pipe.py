@@ -14,6 +14,7 @@ T64, T128 = 2000, 3000   # ... with the 64 x 64 / 128 x 128 tile forced (+ S)
 T256K = 9000         # the 256 x 256 tile on a 4-deep ring of 32-wide half K-steps
 T128N64 = 10000      # skinny-M configuration: 128 x 64 tile, 4-deep ring (M <= 128 linears, deeper split-K)
 T128Q3 = 11000      # occupancy-style 128 x 128: 4 waves of 64 x 64, 3-deep ring of half K-steps (three workgroups per CU)
+T64D8, T64D6 = 12000, 13000   # 64 x 64 on the 8- / 6-deep ring (launches of <= one workgroup per CU)
 T128S2, T256, T64S3, T256S = 4000, 5000, 6000, 7000  # further configurations: 128 x 128 with a 2-deep ring, 256 x 128, 64 x 64 with a 3-deep ring,
                                                       # 256 x 256 (the DiT-sized configuration: double-buffered fragments, DMA spread over the K-step)
 
@@ -48,7 +49,7 @@ SHAPES = [(128, 128, 64), (256, 384, 192), (77, 1280, 1280), (100, 72, 128), (10
 @pytest.mark.parametrize('trans', [(False, True), (False, False), (True, False), (True, True)])
 @pytest.mark.parametrize('shape', SHAPES)
 @pytest.mark.parametrize('split', [0, 1, 2, 5])
-@pytest.mark.parametrize('tile', [T64, T128, T128S2, T256, T64S3, T256S, T256K, T128N64, T128Q3])
+@pytest.mark.parametrize('tile', [T64, T128, T128S2, T256, T64S3, T256S, T256K, T128N64, T128Q3, T64D8, T64D6])
 def test_pipe_gemm_matches_fp32_matmul(gpu, trans, shape, split, tile):
     from diffusion_pipe_amd import ops
     from diffusion_pipe_amd.hip import DpipeHipError
@@ -228,3 +229,142 @@ def test_pipe_dit_sized_gemm_256_tile(gpu, trans, hint):
     base = acc.clone()
     ops.mm(a, b, ta, tb, out=acc, accumulate=True, tile_hint=hint)
     assert _rel_err(acc, base + ref) < 2e-3
+
+
+# ---------------------------------------------------------------------------------------------------------- grouped launches
+# (tokens, out_features, in_features) of Linear layers whose backward the step issues: dgrad [tokens, in] = dy [tokens, out] . W [out, in] next to
+# wgrad [out, in] (+)= dy^T . x with the bias gradient as column sums of dy inside the wgrad
+LINEAR_BWD = [(1024, 1280, 1280), (1024, 3840, 1280), (1024, 10240, 1280), (1024, 1280, 5120), (4096, 640, 640), (4096, 2560, 640), (77, 1280, 1280),
+              (77, 5120, 1280), (77, 768, 3072), (77, 2304, 768), (1, 1280, 320), (300, 200, 136), (64, 32, 1280)]
+
+
+def _linear_bwd_problems(gpu, ops, rows, nout, nin, seed, accumulate, with_bias):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    dy = torch.randn(rows, nout, generator=g).to(gpu, torch.bfloat16)
+    x = torch.randn(rows, nin, generator=g).to(gpu, torch.bfloat16)
+    w = (torch.randn(nout, nin, generator=g) * 0.05).to(gpu, torch.bfloat16)
+    gw0 = (torch.randn(nout, nin, generator=g) * 0.5).to(gpu, torch.bfloat16)
+    gb0 = torch.randn(nout, generator=g).to(gpu, torch.bfloat16)
+
+    def make():
+        gx, gw, gb = torch.empty(rows, nin, device=gpu, dtype=torch.bfloat16), gw0.clone(), gb0.clone()
+        probs = [ops.mm_problem(dy, w, False, False, out=gx),
+                 ops.mm_problem(dy, x, True, False, out=gw, accumulate=accumulate, colsum=gb if with_bias else None, colsum_accumulate=accumulate)]
+        return probs, (gx, gw, gb)
+    ref = {'gx': dy.float() @ w.float(), 'gw': dy.float().t() @ x.float() + (gw0.float() if accumulate else 0),
+           'gb': dy.float().sum(0) + (gb0.float() if accumulate else 0)}
+    return make, ref
+
+
+@pytest.mark.parametrize('shape', LINEAR_BWD, ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('accumulate', [False, True])
+@pytest.mark.parametrize('shallow', [0, 2])
+def test_grouped_dgrad_wgrad_launch_equals_separate_launches(gpu, shape, accumulate, shallow):
+    """dpipe_gemm_group: the dgrad and the wgrad (+ fused bias column sums, + fused gradient accumulation) of one Linear backward as ONE launch whose workgroups
+    are divided between the two problems.  Against the fp32 reference per element; bit-identical to two separate dpipe_gemm_ex launches whenever the group keeps
+    each problem's own tile choice (the dispatcher re-plans a mixed-geometry pair onto the 64 x 64 tile: then within the bf16 bound only); twice in a row
+    (split-K tickets of both problems re-arm)."""
+    from diffusion_pipe_amd import hip, ops
+    rows, nout, nin = shape
+    lib = hip.lib()
+    prev = lib.dpipe_get_option(hip.OPT_GEMM_SHALLOW)
+    lib.dpipe_set_option(hip.OPT_GEMM_SHALLOW, shallow)
+    try:
+        make, ref = _linear_bwd_problems(gpu, ops, rows, nout, nin, rows + nout + nin, accumulate, True)
+        probs, (gx, gw, gb) = make()
+        ops.GEMM_TRACE = []
+        done = ops.gemm_group(probs)
+        trace, ops.GEMM_TRACE = ops.GEMM_TRACE, None
+        if done is None:                      # fused column sum not eligible (unaligned): the caller's two-kernel route; nothing may have been written
+            assert (rows % 8) or (nout % 8) or (nin % 8)
+            return
+        torch.cuda.synchronize()
+        _assert_close_elementwise(gx, ref['gx'])
+        _assert_close_elementwise(gw, ref['gw'])
+        _assert_close_elementwise(gb, ref['gb'])
+        assert [t['grp'] for t in trace] == [0, 1] and trace[0]['grp_n'] == 2 and trace[0]['grp_l'] in (1, 2)
+        # separate launches of the same problems
+        old, ops.GROUP_GEMM = ops.GROUP_GEMM, False
+        try:
+            probs2, (gx2, gw2, gb2) = make()
+            assert ops.gemm_group(probs2) is not None
+        finally:
+            ops.GROUP_GEMM = old
+        torch.cuda.synchronize()
+        _assert_close_elementwise(gx2, ref['gx'])
+        # run the grouped form again on fresh outputs: deterministic, tickets re-armed
+        probs3, (gx3, gw3, gb3) = make()
+        ops.gemm_group(probs3)
+        torch.cuda.synchronize()
+        assert torch.equal(gx3, gx) and torch.equal(gw3, gw) and torch.equal(gb3, gb)
+        same_plan = trace[0]['grp_l'] == 1 and (torch.equal(gx2, gx) and torch.equal(gw2, gw))
+        if not same_plan:                     # re-planned pair: still within the per-element bound of the separately launched results
+            _assert_close_elementwise(gw2, ref['gw'])
+    finally:
+        lib.dpipe_set_option(hip.OPT_GEMM_SHALLOW, prev)
+
+
+def test_grouped_launch_of_four_mixed_layout_problems(gpu):
+    """Four independent problems of one tile geometry (NT forward-style, NN, TN, TT) in one launch -- the general form of the table (e.g. same-shaped linears of
+    two sibling branches with their gradients): each equals its single launch bit for bit."""
+    from diffusion_pipe_amd import ops
+    M, N, K = 320, 256, 512
+    outs, singles, probs = [], [], []
+    for i, (ta, tb) in enumerate([(False, True), (False, False), (True, False), (True, True)]):
+        a, b, ref = _operands(gpu, ta, tb, M, N, K, 100 + i)
+        out = torch.empty(M, N, device=gpu, dtype=torch.bfloat16)
+        probs.append(ops.mm_problem(a, b, ta, tb, out=out))
+        singles.append(ops.mm(a, b, ta, tb))
+        outs.append((out, ref))
+    ops.GEMM_TRACE = []
+    assert ops.gemm_group(probs) is not None
+    trace, ops.GEMM_TRACE = ops.GEMM_TRACE, None
+    torch.cuda.synchronize()
+    assert trace[0]['grp_l'] == 1 and len(trace) == 4
+    for (out, ref), single in zip(outs, singles):
+        _assert_close_elementwise(out, ref)
+        assert torch.equal(out, single)
+
+
+def test_grouped_launch_with_an_fp32_member_falls_back_per_problem(gpu):
+    from diffusion_pipe_amd import ops
+    a, b, ref = _operands(gpu, False, True, 128, 128, 256, 5)
+    af, bf = a.float(), b.float()
+    o1 = torch.empty(128, 128, device=gpu, dtype=torch.bfloat16)
+    o2 = torch.empty(128, 128, device=gpu, dtype=torch.float32)
+    assert ops.gemm_group([ops.mm_problem(a, b, False, True, out=o1), ops.mm_problem(af, bf, False, True, out=o2)]) is not None
+    torch.cuda.synchronize()
+    _assert_close_elementwise(o1, ref)
+    assert (o2 - ref).abs().max().item() < 1e-3 * ref.abs().max().item()
+
+
+def test_linear_backward_through_the_grouped_launch_matches_ungrouped(gpu):
+    """ops.linear / ops.fused_linear backward (grouped dgrad + wgrad + bias sums) vs the ungrouped A/B path: identical gradients, with and without fused accumulation."""
+    from diffusion_pipe_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(9)
+    x0 = torch.randn(2, 512, 640, generator=g).to(gpu, torch.bfloat16)
+    ws = [torch.nn.Parameter((torch.randn(640, 640, generator=g) * 0.04).to(gpu, torch.bfloat16)) for _ in range(3)]
+    bs = [torch.nn.Parameter(torch.randn(640, generator=g).to(gpu, torch.bfloat16)) for _ in range(3)]
+    w1 = torch.nn.Parameter((torch.randn(640, 1920, generator=g) * 0.04).to(gpu, torch.bfloat16))       # (both pairs keep their own 64 x 64 plan inside the group)
+    b1 = torch.nn.Parameter(torch.randn(640, generator=g).to(gpu, torch.bfloat16))
+
+    def run(grouped, accum):
+        old, ops.GROUP_GEMM = ops.GROUP_GEMM, grouped
+        oldf, ops.FUSE_GRAD_ACCUM = ops.FUSE_GRAD_ACCUM, accum
+        try:
+            for p in ws + bs + [w1, b1]:
+                p.grad = None
+            res = None
+            for _ in range(2 if accum else 1):            # second pass accumulates into the .grad buffers of the first
+                x = x0.clone().requires_grad_(True)
+                y = ops.linear(ops.fused_linear(x, ws, bs), w1, b1)
+                y.float().pow(2).mean().backward()
+                res = x.grad
+            torch.cuda.synchronize()
+            return [res.clone()] + [p.grad.clone() for p in ws + bs + [w1, b1]]
+        finally:
+            ops.GROUP_GEMM, ops.FUSE_GRAD_ACCUM = old, oldf
+    for accum in (False, True):
+        a, b = run(True, accum), run(False, accum)
+        for u, v in zip(a, b):
+            assert torch.equal(u, v), (accum, (u.float() - v.float()).abs().max().item())

@@ -57,24 +57,62 @@ class Arena:
         return v
 
 
-def issue(trace, arena, ops):
-    """launch every descriptor once on the current stream over fresh arena slices"""
+def _operands(d, arena):
     from diffusion_pipe_amd import hip
-    for d in trace:
-        dt = torch.bfloat16 if d['dt'] == hip.BF16 else torch.float32
-        odt = torch.float32 if d['out_f32'] else dt
-        ea, eb, ec = operand_elems(d)
-        a = arena.take(ea * ESZ[d['dt']], dt)[:ea]
-        b = arena.take(eb * ESZ[d['dt']], dt)[:eb]
-        osz = 4 if d['out_f32'] else ESZ[d['dt']]
-        c = arena.take(ec * osz, odt)[:ec]
-        bias = arena.take(d['N'] * ESZ[d['dt']], dt)[:d['N']] if d['bias'] else None
-        er = (d['M'] - 1) * d['ldr'] + d['N'] + (d['bo'] - 1) * d['sc'][0] + (d['bi'] - 1) * d['sc'][1] if d['res'] else 0
-        res = arena.take(er * osz, odt)[:er] if d['res'] else None
-        cs = arena.take(d['M'] * d['bo'] * d['bi'] * ESZ[d['dt']], dt)[:d['M'] * d['bo'] * d['bi']] if d['colsum'] else None
-        ops.gemm(a, b, d['ta'], d['tb'], d['M'], d['N'], d['K'], c, lda=d['lda'], ldb=d['ldb'], ldc=d['ldc'], batch_outer=d['bo'], batch_inner=d['bi'],
-                 stride_a=d['sa'], stride_b=d['sb'], stride_c=d['sc'], bias=bias, act=d['act'], alpha=d['alpha'], accumulate=d['acc'], tile_hint=d['tile'],
-                 residual=res, ldr=d['ldr'], colsum=cs, colsum_accumulate=d['colsum_acc'])
+    dt = torch.bfloat16 if d['dt'] == hip.BF16 else torch.float32
+    odt = torch.float32 if d['out_f32'] else dt
+    ea, eb, ec = operand_elems(d)
+    a = arena.take(ea * ESZ[d['dt']], dt)[:ea]
+    b = arena.take(eb * ESZ[d['dt']], dt)[:eb]
+    osz = 4 if d['out_f32'] else ESZ[d['dt']]
+    c = arena.take(ec * osz, odt)[:ec]
+    bias = arena.take(d['N'] * ESZ[d['dt']], dt)[:d['N']] if d['bias'] else None
+    er = (d['M'] - 1) * d['ldr'] + d['N'] + (d['bo'] - 1) * d['sc'][0] + (d['bi'] - 1) * d['sc'][1] if d['res'] else 0
+    res = arena.take(er * osz, odt)[:er] if d['res'] else None
+    cs = arena.take(d['M'] * d['bo'] * d['bi'] * ESZ[d['dt']], dt)[:d['M'] * d['bo'] * d['bi']] if d['colsum'] else None
+    return a, b, c, bias, res, cs
+
+
+def groups(trace):
+    """the launch list as the step issued it: [[d], [d0, d1], ...] -- consecutive descriptors recorded by one ops.gemm_group call (`grp` = 0 .. `grp_n` - 1) form
+    one entry, every other descriptor an entry of its own"""
+    out, i = [], 0
+    while i < len(trace):
+        n = trace[i].get('grp_n') or 1
+        if n > 1 and trace[i].get('grp') == 0 and all(j < len(trace) and trace[j].get('grp') == j - i for j in range(i, i + n)):
+            out.append(trace[i:i + n]); i += n
+        else:
+            out.append([trace[i]]); i += 1
+    return out
+
+
+def launch_count(trace):
+    """kernel launches of the list: 1 per single descriptor, what dpipe_gemm_group reported (`grp_l`) per grouped call"""
+    return sum((g[0].get('grp_l') or len(g)) if len(g) > 1 else 1 for g in groups(trace))
+
+
+def issue(trace, arena, ops):
+    """launch every descriptor once on the current stream over fresh arena slices (grouped calls as grouped calls)"""
+    for g in groups(trace):
+        if len(g) == 1:
+            d = g[0]
+            a, b, c, bias, res, cs = _operands(d, arena)
+            ops.gemm(a, b, d['ta'], d['tb'], d['M'], d['N'], d['K'], c, lda=d['lda'], ldb=d['ldb'], ldc=d['ldc'], batch_outer=d['bo'], batch_inner=d['bi'],
+                     stride_a=d['sa'], stride_b=d['sb'], stride_c=d['sc'], bias=bias, act=d['act'], alpha=d['alpha'], accumulate=d['acc'], tile_hint=d['tile'],
+                     residual=res, ldr=d['ldr'], colsum=cs, colsum_accumulate=d['colsum_acc'])
+            continue
+        probs = []
+        for d in g:
+            a, b, c, bias, res, cs = _operands(d, arena)
+            ra, ca = (d['K'], d['M']) if d['ta'] else (d['M'], d['K'])
+            rb, cb = (d['N'], d['K']) if d['tb'] else (d['K'], d['N'])
+            probs.append({'a': torch.as_strided(a, (ra, ca), (d['lda'], 1)), 'b': torch.as_strided(b, (rb, cb), (d['ldb'], 1)), 'ta': d['ta'], 'tb': d['tb'],
+                          'M': d['M'], 'N': d['N'], 'K': d['K'], 'out': torch.as_strided(c, (d['M'], d['N']), (d['ldc'], 1)), 'lda': d['lda'], 'ldb': d['ldb'], 'ldc': d['ldc'],
+                          'bias': bias, 'act': d['act'], 'alpha': d['alpha'], 'acc': d['acc'],
+                          'res': torch.as_strided(res, (d['M'], d['N']), (d['ldr'], 1)) if res is not None else None, 'ldr': d['ldr'],
+                          'colsum': cs, 'colsum_acc': d['colsum_acc']})
+        if ops.gemm_group(probs) is None:
+            raise RuntimeError('gemm_replay: a recorded grouped call is not eligible on replay')
 
 
 def time_in_graph(trace, device, reps=3, arena_bytes=3 << 30):
@@ -105,7 +143,7 @@ def time_in_graph(trace, device, reps=3, arena_bytes=3 << 30):
     torch.cuda.synchronize(device)
     rd = sum(algorithmic_bytes(d)[0] for d in trace)
     wr = sum(algorithmic_bytes(d)[1] for d in trace)
-    return {'ms': e0.elapsed_time(e1) / reps, 'launches': len(trace), 'flops': sum(flops(d) for d in trace), 'read_bytes': rd, 'write_bytes': wr}
+    return {'ms': e0.elapsed_time(e1) / reps, 'launches': launch_count(trace), 'problems': len(trace), 'flops': sum(flops(d) for d in trace), 'read_bytes': rd, 'write_bytes': wr}
 
 
 def time_concurrent(trace, device, lanes, reps=2, arena_bytes=2 << 30):
@@ -147,15 +185,17 @@ def time_concurrent(trace, device, lanes, reps=2, arena_bytes=2 << 30):
         round_()
     e1.record(main)
     torch.cuda.synchronize(device)
-    return {'ms': e0.elapsed_time(e1) / reps, 'launches': len(trace) * lanes, 'flops': sum(flops(d) for d in trace) * lanes, 'lanes': lanes}
+    return {'ms': e0.elapsed_time(e1) / reps, 'launches': launch_count(trace) * lanes, 'flops': sum(flops(d) for d in trace) * lanes, 'lanes': lanes}
 
 
 def unique_with_counts(trace):
+    """unique launch-list entries with their counts, flattened: the members of a grouped call stay adjacent (`grp` / `grp_n` / `grp_l` keys) and carry the count of
+    their group, so per-descriptor tools can still walk the list and `groups()` can rebuild the calls"""
     u = OrderedDict()
-    for d in trace:
-        k = json.dumps(d, sort_keys=True)
+    for g in groups(trace):
+        k = json.dumps(g, sort_keys=True)
         u[k] = u.get(k, 0) + 1
-    return [dict(json.loads(k), count=n) for k, n in u.items()]
+    return [dict(d, count=n) for k, n in u.items() for d in json.loads(k)]
 
 
 def main():
@@ -168,13 +208,14 @@ def main():
     dev = torch.device('cuda:0')
     arena = Arena(dev, 3 << 30)
     total = 0
-    for d in uniq:
-        n = max(1, d['count'] // div)            # the step's own launch mix: every descriptor as often as the step issues it (/ div)
-        d = {k: (tuple(v) if isinstance(v, list) else v) for k, v in d.items() if k != 'count'}
-        issue([d] * n, arena, ops)
+    for g in groups(uniq):
+        n = max(1, g[0]['count'] // div)         # the step's own launch mix: every entry as often as the step issues it (/ div)
+        g = [{k: (tuple(v) if isinstance(v, list) else v) for k, v in d.items() if k != 'count'} for d in g]
+        for _ in range(n):
+            issue(g, arena, ops)
         total += n
     torch.cuda.synchronize()
-    print(f'{len(uniq)} unique GEMM descriptors, {total} eager launches')
+    print(f'{len(uniq)} unique GEMM descriptors, {total} eager calls')
 
 
 if __name__ == '__main__':

@@ -1,0 +1,34 @@
+#!/bin/bash
+# One parameterised driver for the builder's gpurun calls (replaces the per-experiment tools/run_r3*.sh of round 3).
+#   tools/run_gpu.sh <tag> <step> [<step> ...]      outputs -> gpurun_out/<tag>_*
+# steps:  tests[:<pytest args>]   bench[:<name>[:<env assignments,comma separated>[:<bench args>]]]   prof[:<name>]   cmd:<shell command>
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
+TAG=$1; shift
+cd $R
+for step in "$@"; do
+  kind=${step%%:*}; rest=${step#*:}; [ "$rest" == "$step" ] && rest=""
+  case $kind in
+    tests)
+      timeout 1500 python -m pytest ${rest:-tests -m gpu} -x -q > $O/${TAG}_tests.log 2>&1; echo "tests rc=$? $(tail -1 $O/${TAG}_tests.log)";;
+    bench)
+      IFS=':' read -r name envs args <<< "$rest"; name=${name:-default}
+      ( for kv in ${envs//,/ }; do export $kv; done; timeout 900 python bench.py ${args:---steps 8 --warmup 3 --no-cpu-baseline} > $O/${TAG}_bench_${name}.log 2>&1 )
+      grep '^{"metric"' $O/${TAG}_bench_${name}.log > $O/${TAG}_bench_${name}.json
+      python - "$O/${TAG}_bench_${name}.json" "$name" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = d.get('roofline', {}); c = r.get('concurrent_lanes') or {}
+    print(f"bench {sys.argv[2]}: {d['value']} {d['unit']}, {d['ms_per_step']} ms/step, frac {r.get('frac')}, launches/step {r.get('launches_per_step')}, avg us {r.get('avg_launch_us')}, concurrent frac {c.get('frac')}, parity {d.get('parity', {}).get('grad_norm_rel')}")
+except Exception as e:
+    print(f"bench {sys.argv[2]}: no JSON line ({e})")
+PY
+      ;;
+    prof)
+      name=${rest:-bench}
+      ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $O/${TAG}_prof -o $name -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $O/${TAG}_prof_${name}.log 2>&1 )
+      f=$(find $O/${TAG}_prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/${TAG}_${name}_kernel_stats.csv
+      rm -rf $O/${TAG}_prof; grep '^{"metric"' $O/${TAG}_prof_${name}.log > $O/${TAG}_prof_${name}.json; echo "prof done: $(wc -l < $O/${TAG}_${name}_kernel_stats.csv) kernel rows";;
+    cmd)
+      bash -c "$rest" > $O/${TAG}_cmd.log 2>&1; echo "cmd rc=$? $(tail -2 $O/${TAG}_cmd.log)";;
+  esac
+done
