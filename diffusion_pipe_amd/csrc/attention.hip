@@ -35,7 +35,14 @@ struct AttnParams {
     int causal;
     int qsplit;            // dK/dV kernel: query tiles are split over `qsplit` workgroups per key block (short-key cross attention)
     float* part;           // fp32 partials [B][H][qsplit][2][Sk][D] when qsplit > 1
+    float* out32;          // forward, optional: O once more in fp32, [B][Sq][H][D] contiguous (unrounded accumulator / l) -- kept for the backward's delta
+    const float* o32;      // backward, optional: that tensor; delta = rowsum(dO . O) then uses it instead of the bf16 O
 };
+
+// delta = rowsum(dO . O) is subtracted from dP = dO . V^T element by element.  When the value rows share a large common component (V_j = c + v_j: activations
+// behind a LayerNorm usually do) both are ~ dO . c and the difference is what matters: the 2^-9 rounding of a bf16 O then lands on dS, dQ and dK amplified by
+// |c| / |v_j| (measured on the full-size SDXL step: 8 % of sum|g| on the to_q / to_k weights of the deepest self-attentions; a host simulation with |c| = 3 |v_j|:
+// dQ 25 % off with the bf16 O, 1.4 % with the fp32 one).  The forward therefore stores O a second time in fp32 for the backward (optional: NULL = bf16 O).
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
@@ -210,6 +217,15 @@ __global__ void __launch_bounds__(NW * 64, D == 64 ? 2 : 1) attn_fwd_kernel(cons
                 w.y = pack_bf16x2(oacc[db][4 * eg + 2] * inv, oacc[db][4 * eg + 3] * inv);
                 *reinterpret_cast<uint2*>(O + 32 * db + 8 * eg + 4 * h) = w;
             }
+        if (p.out32) {
+            float* O32 = p.out32 + (((long)b * p.Sq + qrow) * p.H + hh) * D;
+#pragma unroll
+            for (int db = 0; db < D / 32; ++db)
+#pragma unroll
+                for (int eg = 0; eg < 4; ++eg)
+                    *reinterpret_cast<float4*>(O32 + 32 * db + 8 * eg + 4 * h) =
+                        make_float4(oacc[db][4 * eg] * inv, oacc[db][4 * eg + 1] * inv, oacc[db][4 * eg + 2] * inv, oacc[db][4 * eg + 3] * inv);
+        }
         if (h == 0) p.lse[((long)b * p.H + hh) * p.Sq + qrow] = l > 0.f ? (m + __builtin_amdgcn_logf(l)) * LN2 : INFINITY;   // v_log_f32 = log2
     }
 }
@@ -387,6 +403,15 @@ __global__ void __launch_bounds__(NW * 64, (D == 64 && NW == 4) ? 2 : 1) attn_fw
                     w.y = pack_bf16x2(oacc[qb][db][4 * eg + 2] * inv, oacc[qb][db][4 * eg + 3] * inv);
                     *reinterpret_cast<uint2*>(O + 32 * db + 8 * eg + 4 * h) = w;
                 }
+            if (p.out32) {
+                float* O32 = p.out32 + (((long)b * p.Sq + qrow) * p.H + hh) * D;
+#pragma unroll
+                for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                    for (int eg = 0; eg < 4; ++eg)
+                        *reinterpret_cast<float4*>(O32 + 32 * db + 8 * eg + 4 * h) = make_float4(oacc[qb][db][4 * eg] * inv, oacc[qb][db][4 * eg + 1] * inv,
+                                                                                                 oacc[qb][db][4 * eg + 2] * inv, oacc[qb][db][4 * eg + 3] * inv);
+            }
             if (h == 0) p.lse[((long)b * p.H + hh) * p.Sq + qrow] = l[qb] > 0.f ? (m[qb] + __builtin_amdgcn_logf(l[qb])) * LN2 : INFINITY;
         }
     }
@@ -406,7 +431,11 @@ __global__ void __launch_bounds__(256) attn_delta_kernel(const AttnParams p) {
     const bf16_t* d = p.dout + b * p.do_sb + hh * p.do_sh + (long)q * p.do_ss;
     float acc = 0.f;
     constexpr int PER = D / 16;   // 8 (one uint4) or 4 (one uint2)
-    if (PER == 8) {
+    if (p.o32) {                  // the forward's unrounded O (see AttnParams)
+        const float* o32 = p.o32 + (((long)b * p.Sq + q) * p.H + hh) * D + sub * PER;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) acc += o32[j] * bf16_to_f32(d[sub * PER + j]);
+    } else if (PER == 8) {
         Vec16<bf16_t> vo, vd; vo.load(o + sub * 8); vd.load(d + sub * 8);
         float fo[8], fd[8]; vo.unpack(fo); vd.unpack(fd);
 #pragma unroll
@@ -550,7 +579,16 @@ __global__ void __launch_bounds__(NW * 64, (D == 64 && NW == 4) ? 2 : 1) attn_bw
     const float lse2 = qlive ? p.lse[stat] * LOG2E : INFINITY;
     // delta = rowsum(dO * O), fused here (the lane pair (i, h) holds the whole dO row): one launch less per attention backward; written for the dK kernels
     float dl = 0.f;
-    if (qlive) {
+    if (qlive && p.o32) {         // the forward's unrounded O (see AttnParams)
+        const float* O32 = p.o32 + (((long)b * p.Sq + qrow) * p.H + hh) * D;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const float4 a = *reinterpret_cast<const float4*>(O32 + 16 * ks + 8 * h), c = *reinterpret_cast<const float4*>(O32 + 16 * ks + 8 * h + 4);
+            const float of[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl += of[e] * bf16_to_f32((bf16_t)dof[ks][e]);
+        }
+    } else if (qlive) {
         const bf16_t* O = p.o + b * p.o_sb + hh * p.o_sh + (long)qrow * p.o_ss;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
@@ -1022,7 +1060,7 @@ extern "C" {
 
 int dpipe_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* kv_len, int B, int H,
                    int Sq, int Sk, int D, long q_sb, long q_ss, long q_sh, long k_sb, long k_ss, long k_sh, long v_sb,
-                   long v_ss, long v_sh, long o_sb, long o_ss, long o_sh, float scale, int causal, void* stream) {
+                   long v_ss, long v_sh, long o_sb, long o_ss, long o_sh, float scale, int causal, float* o_f32, void* stream) {
     if (!q || !k || !v || !o || !lse || B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) { set_last_error("dpipe_attn_fwd: bad argument"); return DPIPE_ERR_ARG; }
     if (D != 64 && D != 128) { set_last_error("dpipe_attn_fwd: head dim must be 64 or 128"); return DPIPE_ERR_UNSUPPORTED; }
     if (!strides_ok(q, q_sb, q_ss, q_sh) || !strides_ok(k, k_sb, k_ss, k_sh) || !strides_ok(v, v_sb, v_ss, v_sh) || !strides_ok(o, o_sb, o_ss, o_sh)) {
@@ -1032,6 +1070,8 @@ int dpipe_attn_fwd(const void* q, const void* k, const void* v, void* o, float* 
     p.B = B; p.H = H; p.Sq = Sq; p.Sk = Sk; p.scale = scale; p.causal = causal;
     p.q_sb = q_sb; p.q_ss = q_ss; p.q_sh = q_sh; p.k_sb = k_sb; p.k_ss = k_ss; p.k_sh = k_sh;
     p.v_sb = v_sb; p.v_ss = v_ss; p.v_sh = v_sh; p.o_sb = o_sb; p.o_ss = o_ss; p.o_sh = o_sh;
+    if (o_f32 && (reinterpret_cast<uintptr_t>(o_f32) & 15)) { set_last_error("dpipe_attn_fwd: o_f32 must be 16-byte aligned"); return DPIPE_ERR_ARG; }
+    p.out32 = o_f32;
     // The LDS-DMA kernel: 8 waves x 32 query rows (two waves per SIMD: one wave's softmax runs under the other's MFMAs) once 256-row workgroups alone
     // fill most of the chip, else 4 waves x 32 rows (twice the workgroups, 2 - 3 of them per CU).  Measured (tools/kernel_timing.py attn, profiles/):
     // head dim 128 at 4.6k / 9.2k / 61k tokens 737 / 914 / 990 TFLOP/s (the register-staged kernel below: 385 / 448 / 474); SDXL's 1024 x 1024 x 20 heads
@@ -1074,7 +1114,7 @@ int dpipe_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
                    long q_sb, long q_ss, long q_sh, long k_sb, long k_ss, long k_sh, long v_sb, long v_ss, long v_sh,
                    long o_sb, long o_ss, long o_sh, long do_sb, long do_ss, long do_sh, long dq_sb, long dq_ss,
                    long dq_sh, long dk_sb, long dk_ss, long dk_sh, long dv_sb, long dv_ss, long dv_sh, float scale,
-                   int causal, float* dkv_partial, long dkv_partial_floats, void* stream) {
+                   int causal, float* dkv_partial, long dkv_partial_floats, const float* o_f32, void* stream) {
     if (!q || !k || !v || !o || !dout || !lse || !delta || !dq || !dk || !dv || B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) {
         set_last_error("dpipe_attn_bwd: bad argument"); return DPIPE_ERR_ARG; }
     if (D != 64 && D != 128) { set_last_error("dpipe_attn_bwd: head dim must be 64 or 128"); return DPIPE_ERR_UNSUPPORTED; }
@@ -1089,6 +1129,8 @@ int dpipe_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
     p.v_sb = v_sb; p.v_ss = v_ss; p.v_sh = v_sh; p.o_sb = o_sb; p.o_ss = o_ss; p.o_sh = o_sh;
     p.do_sb = do_sb; p.do_ss = do_ss; p.do_sh = do_sh; p.dq_sb = dq_sb; p.dq_ss = dq_ss; p.dq_sh = dq_sh;
     p.dk_sb = dk_sb; p.dk_ss = dk_ss; p.dk_sh = dk_sh; p.dv_sb = dv_sb; p.dv_ss = dv_ss; p.dv_sh = dv_sh;
+    if (o_f32 && (reinterpret_cast<uintptr_t>(o_f32) & 15)) { set_last_error("dpipe_attn_bwd: o_f32 must be 16-byte aligned"); return DPIPE_ERR_ARG; }
+    p.o32 = o_f32;
     hipStream_t s = STREAM(stream);
     constexpr int NW = 4;
     const long rows = (long)B * H * Sq;

@@ -28,8 +28,6 @@ static int launch_by_tile(int tile, const GemmParams& p, bool a_mc, bool b_mc, i
     case 256: return launch_pipe<T256>(p, a_mc, b_mc, batch, s);
     case 129: return launch_pipe<T128R2>(p, a_mc, b_mc, batch, s);
     case 63: return launch_pipe<T64S3>(p, a_mc, b_mc, batch, s);
-    case 648: return launch_pipe<T64D8>(p, a_mc, b_mc, batch, s);
-    case 646: return launch_pipe<T64D6>(p, a_mc, b_mc, batch, s);
     case 128: return launch_pipe<T128>(p, a_mc, b_mc, batch, s);
     case 130: return launch_pipe<T128S5>(p, a_mc, b_mc, batch, s);
     case 1264: return launch_pipe<T128N64>(p, a_mc, b_mc, batch, s);
@@ -75,7 +73,7 @@ int gemm_pipe_group(GemmParams* ps, const int* transA, const int* transB, int n,
         }
     };
     plan_all(0);
-    auto groupable = [](int tile) { return tile == 64 || tile == 129 || tile == 128 || tile == 648 || tile == 646; };
+    auto groupable = [](int tile) { return tile == 64 || tile == 129 || tile == 128; };
     static const bool pair_unify = [] { const char* e = getenv("DPIPE_GEMM_GROUP_UNIFY"); return !e || atoi(e) != 0; }();
     if (pair_unify && n == 2 && pl[0].tile != pl[1].tile && groupable(pl[0].tile) && groupable(pl[1].tile)) plan_all(64);
     bool done[16] = {};
@@ -105,8 +103,6 @@ int gemm_pipe_group(GemmParams* ps, const int* transA, const int* transB, int n,
             } else { g.p[k] = ps[members[0]]; g.mode[k] = 0; g.start[k] = at; g.nwg[k] = 0; }
         }
         switch (pl[i].tile) {
-        case 648: rc = launch_pipe_group<T64D8>(g, at, s); break;
-        case 646: rc = launch_pipe_group<T64D6>(g, at, s); break;
         case 129: rc = launch_pipe_group<T128R2>(g, at, s); break;
         case 128: rc = launch_pipe_group<T128>(g, at, s); break;
         default: rc = launch_pipe_group<T64>(g, at, s); break;
@@ -189,13 +185,7 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
     if (c_ok && p.residual && reinterpret_cast<uintptr_t>(p.residual) % 8 == 0 && p.ldr % 4 == 0) p.vecA = 3;   // 8-byte residual loads too
     p.vecB = (p.bias && reinterpret_cast<uintptr_t>(p.bias) % 8 == 0) ? 2 : 0;
     if (force_tile == 258 || force_tile == 1283) { p.ksteps *= 2; p.ksteps_per_split *= 2; return force_tile; }      // T256K counts K in 32-wide half steps (slices keep their K ranges)
-    if (force_tile == 257 || force_tile == 256 || force_tile == 63 || force_tile == 130 || force_tile == 1264 || force_tile == 648 || force_tile == 646) return force_tile;
-    // DPIPE_OPT_GEMM_DEEP64 = 6 / 8: launches of at most ONE 64^2 workgroup per CU with a K walk of >= 6 steps (the 77-token linears, the slices of few-tile split
-    // problems) run on the 6- / 8-deep ring -- their time is the HBM round trips of the K walk, which a deeper ring overlaps; nothing else is resident to use the LDS
-    {
-        const int deep = option(DPIPE_OPT_GEMM_DEEP64, 0);
-        if (deep && force_tile == 0 && !big && tiles * p.splitk <= 256 && p.ksteps_per_split >= 6) return deep >= 8 ? 648 : 646;
-    }
+    if (force_tile == 257 || force_tile == 256 || force_tile == 63 || force_tile == 130 || force_tile == 1264) return force_tile;
     if (force_tile == 129 || (force_tile == 0 && big && tiles128 >= 256 && (a_mc || b_mc || tiles128 >= 1024))) return 129;
     // DPIPE_OPT_GEMM_SHALLOW: the shallow rings everywhere (128^2 on 2 x 32 KiB, 64^2 on 3 x 16 KiB) -- slower launches in isolation (step list: 23.5 vs 22.0 us
     // average), but a 64 KiB footprint lets a workgroup of ANOTHER micro-batch lane share the CU: 19.34 vs 18.93 images/s with 3 lanes

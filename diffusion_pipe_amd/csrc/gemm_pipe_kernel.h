@@ -71,10 +71,9 @@ using T128S5 = Tile<128, 128, 2, 4, 5>;     // 5-deep ring = all 160 KiB of LDS,
                                             // HBM-cold DMA pieces landing ~4 500 cycles after issue -- a 3-deep ring parks every wave ~900 cycles per K-step at vmcnt, this one ~460;
                                             // selectable (tile_hint 8000 + S), not chosen automatically: whole-kernel time is unchanged (52.9 vs 51.5 us on
                                             // [1024,1280] x [10240,1280]^T: 2.5 rounds of tiles at one workgroup per CU either way, longer prologue)
-using T64D8 = Tile<64, 64, 2, 2, 8>;         // DEEP ring for launches of <= one workgroup per CU (the 77-token linears, split slices of few-tile problems): 8 x 16 KiB = 128 KiB, seven K-steps
-                                            // (28 DMA pieces per wave) in flight -- such a launch is bound by the HBM round trip of its K walk (a 12-step tile: 8 us = launch + 12 exposed
-                                            // latencies on the 4-deep ring), not by occupancy: nothing else would use the CU's LDS.  tile_hint 12000 + S
-using T64D6 = Tile<64, 64, 2, 2, 6>;         // the same at 96 KiB (five K-steps in flight): leaves 64 KiB of the CU's LDS to a workgroup of another micro-batch lane.  tile_hint 13000 + S
+// (Round 4 negative result, profiles/r4a_bench_ab.jsonl: the 64^2 tile on 6- / 8-deep rings -- 96 / 128 KiB, five / seven K-steps of DMA in flight -- for launches of at most one
+//  workgroup per CU (the 77-token linears, split slices) left the step's launch list and the step itself unchanged (roofline.frac 0.1341 / 0.1344 vs 0.1345, 20.69 / 20.66 vs
+//  20.77 images/s): those launches already split their K range four ways, i.e. everything is in flight anyway.  Removed again.)
 using T64S3 = Tile<64, 64, 2, 2, 3>;         // selectable, not chosen automatically: 3-deep ring (3 workgroups per CU)
 using T128N64 = Tile<128, 64, 2, 2, 4>;     // skinny-M configuration (M <= 128: the 77-token text-encoder / cross-attention K,V linears): ONE tile row covers every
                                             // row of A, so each weight panel is fetched by exactly one workgroup (the 64^2 tile reads it twice for M = 77), 4-deep ring

@@ -1061,20 +1061,26 @@ def _bshd_strides(t):
     return t.stride(0), t.stride(1), t.stride(2)
 
 
-def _flash_fwd(q, k, v, kv_len, scale, causal):
+# The forward keeps O a second time in fp32 for the backward's delta = rowsum(dO . O) (csrc/attention.hip, AttnParams::out32: the bf16 rounding of O otherwise
+# reaches dQ / dK amplified by the common component of the value rows).  Costs 4 bytes per output element of saved activation; DPIPE_ATTN_O32=0 for the A/B.
+ATTN_SAVE_O32 = _os_mod.environ.get('DPIPE_ATTN_O32', '1') == '1'
+
+
+def _flash_fwd(q, k, v, kv_len, scale, causal, want_o32=False):
     B, Sq, H, D = q.shape
     Sk = k.shape[1]
     if q.dtype != torch.bfloat16 or k.dtype != q.dtype or v.dtype != q.dtype:
         raise DpipeHipError('flash attention kernel computes in bf16')
     o = torch.empty((B, Sq, H, D), device=q.device, dtype=q.dtype)
     lse = torch.empty((B, H, Sq), device=q.device, dtype=torch.float32)
+    o32 = torch.empty((B, Sq, H, D), device=q.device, dtype=torch.float32) if (want_o32 and ATTN_SAVE_O32) else None
     check(lib().dpipe_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(kv_len), B, H, Sq, Sk, D,
                                *_bshd_strides(q), *_bshd_strides(k), *_bshd_strides(v), *_bshd_strides(o),
-                               float(scale), int(causal), stream()), 'attn_fwd')
-    return o, lse
+                               float(scale), int(causal), ptr(o32), stream()), 'attn_fwd')
+    return o, lse, o32
 
 
-def _flash_bwd(q, k, v, o, do, lse, kv_len, dq, dk, dv, scale, causal):
+def _flash_bwd(q, k, v, o, do, lse, kv_len, dq, dk, dv, scale, causal, o32=None):
     B, Sq, H, D = q.shape
     Sk = k.shape[1]
     if do.stride(3) != 1:
@@ -1086,7 +1092,7 @@ def _flash_bwd(q, k, v, o, do, lse, kv_len, dq, dk, dv, scale, causal):
                                ptr(kv_len), B, H, Sq, Sk, D,
                                *_bshd_strides(q), *_bshd_strides(k), *_bshd_strides(v), *_bshd_strides(o), *_bshd_strides(do),
                                *_bshd_strides(dq), *_bshd_strides(dk), *_bshd_strides(dv), float(scale), int(causal),
-                               ptr(part), npart, stream()), 'attn_bwd')
+                               ptr(part), npart, ptr(o32), stream()), 'attn_bwd')
 
 
 class _FlashAttnFn(Function):
@@ -1095,18 +1101,18 @@ class _FlashAttnFn(Function):
     @staticmethod
     def forward(ctx, q, k, v, kv_len, scale, causal):
         require_cuda(q, k, v, kv_len)
-        o, lse = _flash_fwd(q, k, v, kv_len, scale, causal)
-        ctx.save_for_backward(q, k, v, o, lse, kv_len)
+        o, lse, o32 = _flash_fwd(q, k, v, kv_len, scale, causal, want_o32=any(ctx.needs_input_grad[:3]))
+        ctx.save_for_backward(q, k, v, o, lse, kv_len, o32)
         ctx.scale = scale
         ctx.causal = causal
         return o
 
     @staticmethod
     def backward(ctx, do):
-        q, k, v, o, lse, kv_len = ctx.saved_tensors
+        q, k, v, o, lse, kv_len, o32 = ctx.saved_tensors
         dq, dk, dv = torch.empty_like(q, memory_format=torch.contiguous_format), torch.empty_like(k, memory_format=torch.contiguous_format), \
             torch.empty_like(v, memory_format=torch.contiguous_format)
-        _flash_bwd(q, k, v, o, do, lse, kv_len, dq, dk, dv, ctx.scale, ctx.causal)
+        _flash_bwd(q, k, v, o, do, lse, kv_len, dq, dk, dv, ctx.scale, ctx.causal, o32)
         return dq, dk, dv, None, None, None
 
 
@@ -1133,14 +1139,14 @@ class _FlashAttnPackedFn(Function):
                 b = _contig(b)
             q = a.view(a.shape[0], a.shape[1], H, D)
             k, v = _split_heads(b, 2, H, D)
-        o, lse = _flash_fwd(q, k, v, kv_len, scale, causal)
-        ctx.save_for_backward(a, b, o, lse, kv_len)
+        o, lse, o32 = _flash_fwd(q, k, v, kv_len, scale, causal, want_o32=any(ctx.needs_input_grad[:2]))
+        ctx.save_for_backward(a, b, o, lse, kv_len, o32)
         ctx.meta = (H, D, scale, causal)
         return o.view(o.shape[0], o.shape[1], H * D)
 
     @staticmethod
     def backward(ctx, do):
-        a, b, o, lse, kv_len = ctx.saved_tensors
+        a, b, o, lse, kv_len, o32 = ctx.saved_tensors
         H, D, scale, causal = ctx.meta
         do = _contig(do).view(o.shape)
         da = torch.empty_like(a)
@@ -1153,7 +1159,7 @@ class _FlashAttnPackedFn(Function):
             q, dq = a.view(a.shape[0], a.shape[1], H, D), da.view(a.shape[0], a.shape[1], H, D)
             k, v = _split_heads(b, 2, H, D)
             dk, dv = _split_heads(db, 2, H, D)
-        _flash_bwd(q, k, v, o, do, lse, kv_len, dq, dk, dv, scale, causal)
+        _flash_bwd(q, k, v, o, do, lse, kv_len, dq, dk, dv, scale, causal, o32)
         return da, db, None, None, None, None, None
 
 

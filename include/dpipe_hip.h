@@ -45,9 +45,7 @@ const char* dpipe_last_error(void);
 #define DPIPE_OPT_GEMM_SHALLOW 5    /* ring depth of the plain GEMM's tiles.  0 (default): 128^2 on the 3-deep 96 KiB ring, 64^2 on the 4-deep 64 KiB ring -- the fastest launch
                                       in isolation; 2: 128^2 on the 2-deep 64 KiB ring (two workgroups per CU) -- slower alone, faster when concurrent streams share the
                                       chip: the engine selects it for >= 2 micro-batch lanes; 3: 64^2 on the 3-deep 48 KiB ring; 1: both */
-#define DPIPE_OPT_GEMM_DEEP64 6     /* 64^2 launches of at most one workgroup per CU (77-token linears, split slices): 0 (default) the 4-deep 64 KiB ring; 6 / 8: the 6- / 8-deep
-                                      ring (96 / 128 KiB, five / seven K-steps of DMA in flight) */
-#define DPIPE_OPTION_COUNT 7
+#define DPIPE_OPTION_COUNT 6
 int dpipe_set_option(int option, int value);
 int dpipe_get_option(int option);    /* the effective explicit / environment value, -1 if neither is set */
 /* Number of compute units / name of device `dev`; used by the host to sanity-check it runs on gfx950. */
@@ -306,7 +304,10 @@ int dpipe_tr16_probe(const void* in256_i16, void* out256_i16, void* stream);
  * models/sdxl.py:738-784). */
 int dpipe_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* kv_len, int B, int H,
                    int Sq, int Sk, int D, long q_sb, long q_ss, long q_sh, long k_sb, long k_ss, long k_sh, long v_sb,
-                   long v_ss, long v_sh, long o_sb, long o_ss, long o_sh, float scale, int causal, void* stream);
+                   long v_ss, long v_sh, long o_sb, long o_ss, long o_sh, float scale, int causal, float* o_f32, void* stream);
+/* o_f32 (optional, NULL = none): O once more in fp32, [B, Sq, H, D] contiguous, before its rounding to bf16 -- handed to dpipe_attn_bwd, whose
+ * delta = rowsum(dO . O) then does not carry the bf16 rounding of O into dS = P (dP - delta) (it matters when the value rows share a large
+ * common component: dP and delta are then both ~ dO . c and their difference is the signal). */
 /* delta: [B, H, Sq] fp32 workspace.  dq/dk/dv have the layouts (and strides) of q/k/v.
  * dkv_partial: fp32 workspace of dpipe_attn_bwd_partial_floats() elements (0 = not needed) -- when few key blocks x
  * heads cannot fill the chip (cross attention to 77 text tokens) the dK/dV kernel splits the queries over workgroups
@@ -317,7 +318,7 @@ int dpipe_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
                    long q_sb, long q_ss, long q_sh, long k_sb, long k_ss, long k_sh, long v_sb, long v_ss, long v_sh,
                    long o_sb, long o_ss, long o_sh, long do_sb, long do_ss, long do_sh, long dq_sb, long dq_ss,
                    long dq_sh, long dk_sb, long dk_ss, long dk_sh, long dv_sb, long dv_ss, long dv_sh, float scale,
-                   int causal, float* dkv_partial, long dkv_partial_floats, void* stream);
+                   int causal, float* dkv_partial, long dkv_partial_floats, const float* o_f32, void* stream);
 
 #ifdef __cplusplus
 }
