@@ -119,7 +119,12 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
     // tile (measured on the SDXL shapes, tools/kernel_timing.py): 128 x 128 from ~half a wave of workgroups on, or when a
     // long K can be split three ways over few tiles; else 64 x 64 (4 x the workgroups, 2 resident per CU)
     const bool long_k = p.ksteps >= 48;
-    const bool big = force_tile ? (force_tile >= 128) : (tiles128 >= 128 || (long_k && tiles128 >= 48));
+    // DPIPE_OPT_GEMM_BIG_TILES (default 128): fewest 128^2 tiles for which the 128^2 tile is chosen.  The default is the isolated-launch optimum (a launch of < 128
+    // tiles fills more CUs as 4 x as many 64^2 tiles); with several micro-batch lanes replaying at once the chip is full either way and what counts is the CU time a
+    // launch takes: a 64^2 tile moves twice the operand bytes per FLOP through the CU's global -> LDS path, which is what saturates -- the engine
+    // lowers the threshold when it runs >= 2 lanes
+    const int big_min = option(DPIPE_OPT_GEMM_BIG_TILES, 128);
+    const bool big = force_tile ? (force_tile >= 128) : (tiles128 >= big_min || (long_k && tiles128 >= (big_min < 48 ? big_min : 48)));
     // 256 x 256 (T256S) for DiT-sized forward / dgrad GEMMs: K-contiguous or mixed operands, >= 64 K-steps to amortise the
     // un-overlapped prologue / epilogue of the one resident workgroup, >= half a wave of 256^2 tiles.  Measured
     // (tools/kernel_timing.py large): +9 .. +21 % over T128R2 there (8192^3: 1.27 vs 1.08 PFLOP/s), -2 .. -6 % at K = 3072, and

@@ -45,7 +45,9 @@ const char* dpipe_last_error(void);
 #define DPIPE_OPT_GEMM_SHALLOW 5    /* ring depth of the plain GEMM's tiles.  0 (default): 128^2 on the 3-deep 96 KiB ring, 64^2 on the 4-deep 64 KiB ring -- the fastest launch
                                       in isolation; 2: 128^2 on the 2-deep 64 KiB ring (two workgroups per CU) -- slower alone, faster when concurrent streams share the
                                       chip: the engine selects it for >= 2 micro-batch lanes; 3: 64^2 on the 3-deep 48 KiB ring; 1: both */
-#define DPIPE_OPTION_COUNT 6
+#define DPIPE_OPT_GEMM_BIG_TILES 6  /* fewest 128^2 output tiles for which the plain GEMM takes the 128^2 tile instead of 64^2 (default 128 = best isolated launch; lower under
+                                      concurrent lanes, where CU time per FLOP is what counts: the engine's choice) */
+#define DPIPE_OPTION_COUNT 7
 int dpipe_set_option(int option, int value);
 int dpipe_get_option(int option);    /* the effective explicit / environment value, -1 if neither is set */
 /* Number of compute units / name of device `dev`; used by the host to sanity-check it runs on gfx950. */

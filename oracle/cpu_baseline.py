@@ -15,7 +15,7 @@ import torch
 from . import eager_step, sdxl_ref
 
 
-def sdxl_cpu_baseline(cfg, latent_hw=128, threads=None, micro_batch=None, state=None):
+def sdxl_cpu_baseline(cfg, latent_hw=128, threads=None, micro_batch=None, state=None, per_parameter=False):
     """-> cpu_baseline dict.  `micro_batch`: one prepared (features, label) pair as the engine receives it.  `state`: {module name: state dict}
     of the PRODUCT's weights (host tensors) -- loaded into the oracle so that its loss / gradient norm are comparable with the GPU path's on the
     same micro-batch (bench.py's `parity` object); None = the oracle's own seeded initialisation."""
@@ -36,8 +36,15 @@ def sdxl_cpu_baseline(cfg, latent_hw=128, threads=None, micro_batch=None, state=
         t0 = time.perf_counter()
         loss, norm = eager_step.eager_train_step(layers, eager_step.sdxl_loss_fn(), [micro_batch], None, gradient_clipping=1.0, params=ref.parameters())
         dt = time.perf_counter() - t0
+        rows = None
+        if per_parameter:          # tools/parity_probe.py: [sum |g|, sum g, <g, r>, ||g||_2] of every parameter's PRE-clip gradient (the step clipped in place)
+            from .checksums import checksum4
+            coef = min(1.0, 1.0 / (float(norm) + 1e-6))
+            rows = {f'{k}.{n}': [v / coef for v in checksum4(p.grad, f'{k}.{n}')] for k, m in ref.modules().items() for n, p in m.named_parameters() if p.grad is not None}
     finally:
         torch.set_num_threads(prev)
+    if per_parameter:
+        return {'loss': float(loss), 'grad_norm': float(norm), 'rows': rows}
     return {'value': round(1.0 / dt, 6), 'unit': 'images/s', 'cores': threads, 'kind': 'port', 'sample_seconds': round(dt, 3),
             'build_seconds': round(t_build, 1), 'loss': float(loss), 'grad_norm': float(norm), 'weights': 'product state dict' if state is not None else 'oracle seed 0',
             'sample': f'oracle fp32 eager path (oracle/sdxl_ref.py + eager_step.py): ONE whole micro-batch = one {latent_hw * 8}x{latent_hw * 8} image '
