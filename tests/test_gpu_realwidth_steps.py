@@ -72,9 +72,12 @@ def _check(case, loss, norm, rows, gold, record_property):
     kinds = ('abs_sum', 'signed_sum', 'proj', 'l2')
     worst = {k: (0.0, '') for k in kinds}
     num = den = 0.0
-    for n, got in rows.items():
+    floor = 1e-8 * sum(r[0] for r in ref.values())       # parameters whose gradient is analytically zero (attention key biases: softmax is invariant to them) hold
+    for n, got in rows.items():                          # rounding noise on both sides: skipped below an absolute floor of 1e-8 of the model's total sum |g|
         num += 12.0 * (got[2] - ref[n][2]) ** 2
         den += ref[n][3] ** 2
+        if ref[n][0] <= floor and got[0] <= 4 * floor:
+            continue
         for k, v in zip(kinds, relative_errors(got, ref[n])):
             if v > worst[k][0]:
                 worst[k] = (v, n)
