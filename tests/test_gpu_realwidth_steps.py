@@ -15,12 +15,13 @@ import torch
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'realwidth_steps.json')
 
-# (loss, norm, per-parameter max of: abs_sum, signed_sum (of sum |g|), projection (in sigma = ||g|| / sqrt(12)), l2; whole-gradient L2 error estimate)
-BOUNDS = {
-    'flux': dict(loss=3e-3, norm=1e-2, abs_sum=0.08, signed_sum=0.03, proj=1.5, l2=0.08, agg=0.05),
-    'wan': dict(loss=3e-3, norm=1e-2, abs_sum=0.08, signed_sum=0.03, proj=1.5, l2=0.08, agg=0.05),
-    'hv': dict(loss=3e-3, norm=1e-2, abs_sum=0.08, signed_sum=0.03, proj=1.5, l2=0.08, agg=0.05),
-}
+# (loss, norm, per-parameter max of: abs_sum, signed_sum (of sum |g|), projection (in sigma = ||g|| / sqrt(12)), l2; whole-gradient L2 error estimate).
+# Observed on MI355X (round 4, profiles/r4e_realwidth_steps.txt):
+#   flux  loss 1.0e-5  norm 5.2e-4  abs_sum 0.0043  signed_sum 0.0039  proj 0.029  l2 0.0034  agg 0.0085
+#   wan   loss 3.1e-5  norm 7.5e-4  abs_sum 0.0023  signed_sum 0.0015  proj 0.015  l2 0.0025  agg 0.0046
+#   hv    loss 4.5e-6  norm 1.3e-5  abs_sum 0.0037  signed_sum 0.0065  proj 0.022  l2 0.0036  agg 0.0093
+_B = dict(loss=3e-4, norm=2.5e-3, abs_sum=0.015, signed_sum=0.02, proj=0.1, l2=0.012, agg=0.03)
+BOUNDS = {'flux': _B, 'wan': _B, 'hv': _B}
 
 
 class _Rows(torch.optim.Optimizer):

@@ -71,14 +71,38 @@ def main():
         engine.train_batch(iter(pool[i % len(pool)]))
     torch.cuda.synchronize()
     names = {id(p): f'{k}.{n}' for k, m in work.modules().items() for n, p in m.named_parameters()}
-    rec = Rows(params, names)
-    engine.optimizer = rec
-    engine.reset_activation_shape()
-    loss = engine.train_batch(iter([sample] * gas)).item()
-    norm = engine.get_global_grad_norm().item()
-    torch.cuda.synchronize()
-    coef = min(1.0, 1.0 / (norm + 1e-6))
-    gpu = {k: [v / coef for v in r] for k, r in rec.rows.items()}
+    if os.environ.get('PROBE_FUSED', '0') == '1':
+        # bench.py's own path: the fused step end reads the lanes' bf16 accumulators (sum over lanes in fp32 inside adamw_sumsq / adamw_step).  Record the rows of the
+        # fp32 lane sum right before the fused update consumes (and zeroes) the accumulators; the update itself is skipped (weights stay what the oracle gets)
+        from oracle.checksums import checksum4
+        opt = engine.optimizer
+        byid = {id(p): p for p in params}
+        seen = {}
+
+        def fake_update(lane_grads=None, total_sumsq=None, max_norm=0.0, zero_grads=True):
+            for pid, p in byid.items():
+                gs = [lg[pid] for lg in lane_grads if pid in lg]
+                if gs:
+                    tot = gs[0].float().clone()
+                    for g_ in gs[1:]:
+                        tot += g_.float()
+                    seen[names[pid]] = checksum4(tot, names[pid])
+        opt.fused_update = fake_update
+        engine.reset_activation_shape()
+        loss = engine.train_batch(iter([sample] * gas)).item()
+        norm = engine.get_global_grad_norm().item()
+        torch.cuda.synchronize()
+        gpu = seen
+        print(f'fused step end: adamw_sumsq norm {norm:.6f}; sqrt(sum of per-parameter ||fp32 lane sum||^2) {sum(r[3] ** 2 for r in seen.values()) ** 0.5:.6f}')
+    else:
+        rec = Rows(params, names)
+        engine.optimizer = rec
+        engine.reset_activation_shape()
+        loss = engine.train_batch(iter([sample] * gas)).item()
+        norm = engine.get_global_grad_norm().item()
+        torch.cuda.synchronize()
+        coef = min(1.0, 1.0 / (norm + 1e-6))
+        gpu = {k: [v / coef for v in r] for k, r in rec.rows.items()}
     state = {k: {n: v.detach().to('cpu', torch.float32) for n, v in m.state_dict().items()} for k, m in work.modules().items()}
     cpu = sdxl_cpu_baseline(cfg, latent_hw=128, micro_batch=sample, state=state, per_parameter=True)
     ref = cpu['rows']
