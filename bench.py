@@ -566,13 +566,23 @@ def main():
             # eager path evaluates the same micro-batch on the same weights inside the cpu_baseline leg: loss and pre-clip gradient norm
             # must agree (the step's mean loss over identical micro-batches = that micro-batch's loss; GAS x (g / GAS) = g)
             state = {k: {n: v.detach().to('cpu', torch.float32) for n, v in m.state_dict().items()} for k, m in work.modules().items()}
+            # DPIPE_BENCH_PARITY_DETAIL=1: per-parameter view of the same comparison (tools/parity_report.py) -- the fused step end's update is replaced by a recorder of the
+            # fp32 lane sums' checksum rows, the oracle returns the rows of its gradients; the family table goes to stderr
+            detail = os.environ.get('DPIPE_BENCH_PARITY_DETAIL', '0') == '1' and hasattr(engine.optimizer, 'fused_update')
+            gpu_rows = None
+            if detail:
+                from tools.parity_report import record_fused_rows
+                gpu_rows = record_fused_rows(engine, {id(p_): f'{k}.{n}' for k, m in work.modules().items() for n, p_ in m.named_parameters()})
             engine.reset_activation_shape()
             p_loss = engine.train_batch(iter([cpu_sample] * gas))
             p_norm = engine.get_global_grad_norm()
             torch.cuda.synchronize()
             p_loss, p_norm = float(p_loss.item()), float(p_norm.item())
             from oracle.cpu_baseline import sdxl_cpu_baseline
-            out['cpu_baseline'] = cb = sdxl_cpu_baseline(cfg, latent_hw=latent, micro_batch=cpu_sample, state=state)
+            out['cpu_baseline'] = cb = sdxl_cpu_baseline(cfg, latent_hw=latent, micro_batch=cpu_sample, state=state, per_parameter=detail)
+            if detail:
+                from tools.parity_report import family_table
+                family_table(gpu_rows, cb.pop('rows'), out=lambda line: print(line, file=sys.stderr, flush=True))
             out['parity'] = {'loss_gpu': p_loss, 'loss_cpu': cb['loss'], 'loss_rel': abs(p_loss - cb['loss']) / abs(cb['loss']),
                              'grad_norm_gpu': p_norm, 'grad_norm_cpu': cb['grad_norm'], 'grad_norm_rel': abs(p_norm - cb['grad_norm']) / cb['grad_norm'],
                              'what': 'timed path (bf16 kernels, hipGraph, lanes) vs the oracle fp32 eager path: same weights (the product state dict after the '

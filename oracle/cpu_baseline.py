@@ -43,9 +43,7 @@ def sdxl_cpu_baseline(cfg, latent_hw=128, threads=None, micro_batch=None, state=
             rows = {f'{k}.{n}': [v / coef for v in checksum4(p.grad, f'{k}.{n}')] for k, m in ref.modules().items() for n, p in m.named_parameters() if p.grad is not None}
     finally:
         torch.set_num_threads(prev)
-    if per_parameter:
-        return {'loss': float(loss), 'grad_norm': float(norm), 'rows': rows}
-    return {'value': round(1.0 / dt, 6), 'unit': 'images/s', 'cores': threads, 'kind': 'port', 'sample_seconds': round(dt, 3),
+    return {**({'rows': rows} if per_parameter else {}), 'value': round(1.0 / dt, 6), 'unit': 'images/s', 'cores': threads, 'kind': 'port', 'sample_seconds': round(dt, 3),
             'build_seconds': round(t_build, 1), 'loss': float(loss), 'grad_norm': float(norm), 'weights': 'product state dict' if state is not None else 'oracle seed 0',
             'sample': f'oracle fp32 eager path (oracle/sdxl_ref.py + eager_step.py): ONE whole micro-batch = one {latent_hw * 8}x{latent_hw * 8} image '
                       f'through all 23 pipeline layers + loss + backward + clip (1 of the step\'s micro-batches, no optimizer step), {threads} threads'}

@@ -4,7 +4,6 @@ oracle's fp32 eager path on the same weights and micro-batch, and prints the con
 Test infrastructure (imports oracle/).   python tools/parity_probe.py [train_steps] [out.json]"""
 import json
 import os
-import re
 import sys
 
 import torch
@@ -24,20 +23,6 @@ class Rows(torch.optim.Optimizer):
             for p in group['params']:
                 if p.grad is not None:
                     self.rows[self.names[id(p)]] = checksum4(p.grad, self.names[id(p)])
-
-
-def family(name):
-    name = re.sub(r'\.\d+\.', '.N.', name)
-    for pat, fam in ((r'attn1\.to_[qk]', 'unet self-attn to_q/to_k'), (r'attn1\.to_v', 'unet self-attn to_v'), (r'attn1\.to_out', 'unet self-attn to_out'),
-                     (r'attn2\.to_q', 'unet cross-attn to_q'), (r'attn2\.to_[kv]', 'unet cross-attn to_k/to_v'), (r'attn2\.to_out', 'unet cross-attn to_out'),
-                     (r'\.ff\.', 'unet feed-forward'), (r'norm[123]\.', 'unet block LayerNorm'), (r'proj_in|proj_out', 'unet transformer proj_in/out'),
-                     (r'resnets.*conv|conv_shortcut|downsamplers|upsamplers|conv_in|conv_out', 'unet convolutions'), (r'resnets.*norm|conv_norm_out|attentions\.N\.norm', 'unet GroupNorm'),
-                     (r'time_emb|time_embedding|add_embedding', 'unet time / add embeddings'), (r'text_encoder.*(q_proj|k_proj)', 'CLIP q/k_proj'),
-                     (r'text_encoder.*(v_proj|out_proj)', 'CLIP v/out_proj'), (r'text_encoder.*mlp', 'CLIP mlp'), (r'text_encoder.*(layer_norm|final_layer_norm)', 'CLIP LayerNorm'),
-                     (r'text_encoder.*embed', 'CLIP embeddings'), (r'text_projection', 'CLIP text_projection')):
-        if re.search(pat, name):
-            return fam
-    return 'other'
 
 
 def main():
@@ -74,20 +59,8 @@ def main():
     if os.environ.get('PROBE_FUSED', '0') == '1':
         # bench.py's own path: the fused step end reads the lanes' bf16 accumulators (sum over lanes in fp32 inside adamw_sumsq / adamw_step).  Record the rows of the
         # fp32 lane sum right before the fused update consumes (and zeroes) the accumulators; the update itself is skipped (weights stay what the oracle gets)
-        from oracle.checksums import checksum4
-        opt = engine.optimizer
-        byid = {id(p): p for p in params}
-        seen = {}
-
-        def fake_update(lane_grads=None, total_sumsq=None, max_norm=0.0, zero_grads=True):
-            for pid, p in byid.items():
-                gs = [lg[pid] for lg in lane_grads if pid in lg]
-                if gs:
-                    tot = gs[0].float().clone()
-                    for g_ in gs[1:]:
-                        tot += g_.float()
-                    seen[names[pid]] = checksum4(tot, names[pid])
-        opt.fused_update = fake_update
+        from tools.parity_report import record_fused_rows
+        seen = record_fused_rows(engine, names)
         engine.reset_activation_shape()
         loss = engine.train_batch(iter([sample] * gas)).item()
         norm = engine.get_global_grad_norm().item()
@@ -107,30 +80,11 @@ def main():
     cpu = sdxl_cpu_baseline(cfg, latent_hw=128, micro_batch=sample, state=state, per_parameter=True)
     ref = cpu['rows']
     print(f'after {steps} training steps: loss gpu {loss:.7f} cpu {cpu["loss"]:.7f}; grad norm gpu {norm:.6f} cpu {cpu["grad_norm"]:.6f} rel {abs(norm - cpu["grad_norm"]) / cpu["grad_norm"]:.3e}')
-    fam = {}
-    per = []
-    for n, r in ref.items():
-        g = gpu.get(n)
-        if g is None:
-            continue
-        f = fam.setdefault(family(n), [0.0, 0.0, 0.0, 0])
-        f[0] += g[3] ** 2; f[1] += r[3] ** 2; f[2] += 12.0 * (g[2] - r[2]) ** 2; f[3] += 1
-        per.append((g[3] ** 2 - r[3] ** 2, n, g[3], r[3], relative_errors(g, r)))
-    tot_g, tot_r = sum(v[0] for v in fam.values()), sum(v[1] for v in fam.values())
-    print(f'sum of per-parameter norms^2: gpu {tot_g ** 0.5:.6f} cpu {tot_r ** 0.5:.6f}')
-    print(f'{"family":36s} {"n":>5s} {"share of |g|^2":>14s} {"norm gpu/cpu - 1":>17s} {"d(norm^2) / |g|^2":>18s} {"L2 err estimate":>16s}')
-    table = []
-    for k, (a, b, e, c) in sorted(fam.items(), key=lambda kv: -abs(kv[1][0] - kv[1][1])):
-        row = {'family': k, 'tensors': c, 'share': b / tot_r, 'norm_ratio_minus_1': (a / b) ** 0.5 - 1, 'dnorm2_over_total': (a - b) / tot_r, 'l2_err_estimate': (e / b) ** 0.5}
-        table.append(row)
-        print(f'{k:36s} {c:5d} {row["share"]:14.4f} {row["norm_ratio_minus_1"]:17.5f} {row["dnorm2_over_total"]:18.6f} {row["l2_err_estimate"]:16.4f}')
-    per.sort(key=lambda t: -abs(t[0]))
-    print('largest per-parameter contributions to the norm^2 difference:')
-    for d, n, g, r, e in per[:25]:
-        print(f'  {d / tot_r:+.6f}  {n:95s} norm gpu {g:.5f} cpu {r:.5f}  errs abs {e[0]:.4f} signed {e[1]:.4f} proj {e[2]:.3f} l2 {e[3]:.4f}')
+    from tools.parity_report import family_table
+    table, top = family_table(gpu, ref)
     if out_path:
-        json.dump({'train_steps': steps, 'loss_gpu': loss, 'loss_cpu': cpu['loss'], 'grad_norm_gpu': norm, 'grad_norm_cpu': cpu['grad_norm'], 'families': table,
-                   'top': [{'name': n, 'dnorm2_over_total': d / tot_r, 'norm_gpu': g, 'norm_cpu': r} for d, n, g, r, _ in per[:40]]}, open(out_path, 'w'), indent=1)
+        json.dump({'train_steps': steps, 'loss_gpu': loss, 'loss_cpu': cpu['loss'], 'grad_norm_gpu': norm, 'grad_norm_cpu': cpu['grad_norm'], 'families': table, 'top': top},
+                  open(out_path, 'w'), indent=1)
 
 
 if __name__ == '__main__':
