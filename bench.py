@@ -520,6 +520,7 @@ def main():
             traffic = json.load(f)
 
     parity_failed = False
+    gemm_policy = (getattr(engine, 'gemm_shallow_rings', None), getattr(engine, 'gemm_big_tiles', None))
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         images = gas * 1 * engine.dp_world_size
@@ -551,7 +552,7 @@ def main():
                          'algorithmic_bytes_per_launch': round(g_bytes / max(launches, 1)),
                          'gemm_gpu_ms_per_step': round(g_ms / world, 2),
                          'traffic_detail': traffic,
-                         'gemm_shallow_rings': getattr(engine, 'gemm_shallow_rings', None),
+                         'gemm_shallow_rings': gemm_policy[0], 'gemm_big_tiles': gemm_policy[1],
                          'method': 'GEMM-only hipGraph of the step\'s recorded launch list, HIP events on the replay stream, HBM-cold operands'},
         }
         if rc:

@@ -155,6 +155,7 @@ def flatten_grads(params, arenas=None):
 
 
 _SHALLOW_SET_BY_ENGINE = False      # the process-wide GEMM ring option currently holds an engine's 'auto' choice (a later engine may replace it)
+_BIG_SET_BY_ENGINE = False          # the same for the 128^2-tile threshold
 
 class PipelineEngine:
     def __init__(self, module, config, args=None, optimizer=None, lr_scheduler=None, model_parameters=None, device=None):
@@ -266,6 +267,19 @@ class PipelineEngine:
             else:
                 _hip.check(_hip.lib().dpipe_set_option(_hip.OPT_GEMM_SHALLOW, int(want)), 'set_option')
             self.gemm_shallow_rings = _hip.lib().dpipe_get_option(_hip.OPT_GEMM_SHALLOW)
+            # GEMM tile-size policy (C-ABI option DPIPE_OPT_GEMM_BIG_TILES): the dispatcher's 128^2-vs-64^2 threshold (128 tiles) is the isolated-launch optimum -- a launch of
+            # < 128 tiles fills more CUs as 64^2 tiles.  With >= 2 graphs replaying concurrently the chip is full either way and the CU time per FLOP decides: a 64^2 tile
+            # moves twice the operand bytes per FLOP through the CU's global -> LDS path.  Same box, 4 lanes: 20.85 vs 20.15 / 20.20 images/s with the threshold at 16
+            # (profiles/r4f_bench_big_tiles.jsonl); `gemm_big_tiles`: 'auto' (default) | int; an explicit DPIPE_GEMM_BIG_TILES / dpipe_set_option wins over 'auto'.
+            want_big = self._config.get('gemm_big_tiles', 'auto')
+            if want_big == 'auto':
+                global _BIG_SET_BY_ENGINE
+                if _BIG_SET_BY_ENGINE or _hip.lib().dpipe_get_option(_hip.OPT_GEMM_BIG_TILES) < 0:
+                    _hip.check(_hip.lib().dpipe_set_option(_hip.OPT_GEMM_BIG_TILES, 16 if concurrent >= 2 else 128), 'set_option')
+                    _BIG_SET_BY_ENGINE = True
+            else:
+                _hip.check(_hip.lib().dpipe_set_option(_hip.OPT_GEMM_BIG_TILES, int(want_big)), 'set_option')
+            self.gemm_big_tiles = _hip.lib().dpipe_get_option(_hip.OPT_GEMM_BIG_TILES)
         # Bounded host run-ahead.  train_batch returns a device scalar, so a tight loop could queue optimizer steps without limit.
         # Before enqueuing step n the host waits for the end of step n - max_steps_in_flight.  Default 1: measured on MI355X /
         # ROCm 7.2 (round 2, tools/hang_repro.sh, 20+ runs): with hipGraph launches of >= 2 lanes' graphs queued ACROSS a step

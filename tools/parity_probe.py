@@ -55,6 +55,25 @@ def main():
         engine.reset_activation_shape()
         engine.train_batch(iter(pool[i % len(pool)]))
     torch.cuda.synchronize()
+    if os.environ.get('PROBE_EAGER', '0') == '1':
+        # bench.py's roofline leg: ONE more optimizer step, eager (graphs off), with the GEMM launch list recorded; PROBE_ROOFLINE=1 also replays that list as bench.py does
+        from diffusion_pipe_amd import ops
+        ops.GEMM_TRACE = []
+        was = engine.use_graph
+        engine.use_graph = False
+        for p_ in module.parameters():
+            p_.grad = None
+        engine.reset_activation_shape()
+        engine.train_batch(iter(pool[0]))
+        engine.use_graph = was
+        trace, ops.GEMM_TRACE = ops.GEMM_TRACE, None
+        torch.cuda.synchronize()
+        if os.environ.get('PROBE_ROOFLINE', '0') == '1':
+            from tools import gemm_replay
+            gemm_replay.time_in_graph(trace, dev, reps=3)
+            per_lane = trace[:len(trace) // gas * max(1, gas // lanes)]
+            gemm_replay.time_concurrent(per_lane, dev, lanes)
+            torch.cuda.synchronize()
     names = {id(p): f'{k}.{n}' for k, m in work.modules().items() for n, p in m.named_parameters()}
     if os.environ.get('PROBE_FUSED', '0') == '1':
         # bench.py's own path: the fused step end reads the lanes' bf16 accumulators (sum over lanes in fp32 inside adamw_sumsq / adamw_step).  Record the rows of the
