@@ -134,11 +134,8 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
     // flight shorten the vmcnt wait: +5 .. +6 % (9216 x 5120 x 13824 NN: 996 vs 940 TFLOP/s).  A K-contiguous operand pays for half steps with 64-byte pieces
     // (half a cache line per row per step) and twice the barriers: NT is 8 % slower on T256K and stays on T256S (8192^3: 1 292 vs 1 184)
     if (force_tile == 0 && !a_mc && p.ksteps >= 64 && tiles256 >= 128) force_tile = b_mc ? 258 : 257;
-    // DPIPE_OPT_GEMM_T256_TILES = T > 0 (experiment, concurrent lanes): the 256^2 tile (half the operand bytes per FLOP of 128^2) already from T tiles and 16 K-steps on
-    {
-        const int t256 = option(DPIPE_OPT_GEMM_T256_TILES, 0);
-        if (t256 > 0 && force_tile == 0 && !a_mc && p.ksteps >= 16 && tiles256 >= t256 && p.M >= 256 && p.N >= 256) force_tile = 257;
-    }
+    // (Round 4 negative result, profiles/r4h_bench_tile_policy.jsonl: the 256^2 tile for SDXL-sized forward / dgrad problems under four lanes -- from 16 / 48 tiles and 16 K-steps on --
+    //  19.62 / 20.72 images/s against 21.10 with the 128^2 rule below, same box: one 128 KiB workgroup per CU leaves no room for another lane's workgroup.)
     // many tiles of a SHORT K with a K-contiguous A (>= 2 rounds of 128^2 tiles, <= 24 K-steps: the GEGLU / up-projection forwards [1024, 10240] <- 1280 and
     // [4096, 2560] <- 640): the occupancy-style tile (three 4-wave workgroups per CU on 48 KiB rings of half K-steps) -- a workgroup spends most of such a tile in
     // prologue / epilogue, which its two neighbours cover: 58.8 -> 52.2 us and 33.2 -> 27.4 us (profiles/r3k_gemm_desc_ledger_halfstep_4wave_tiles.jsonl); wgrad
