@@ -275,8 +275,11 @@ def measure_dit_workload(args, device, world, light=False):
         engine_mod.TRACE = None
         del engine, module, pool, loss
         work.transformer = None
+        ops.release_caches()
         gc.collect()
         torch.cuda.empty_cache()
+        free_b, total_b = torch.cuda.mem_get_info(device)
+        out['hbm_in_use_after_release_gb'] = round((total_b - free_b) / 2 ** 30, 2)
         return out
     if not trace_in_timed:
         # one eager step records the launch list the graphs replay; the lanes' graphs (and their static activation pools) are not needed any more
@@ -602,6 +605,7 @@ def main():
             # attention; eager): north_star's 1e-3 bound is asserted on THIS comparison -- it isolates the kernels' arithmetic from bf16 rounding noise
             try:
                 del engine, module
+                ops.release_caches()                  # the fused step end's pointer tables keep parameters / states / lane gradients alive
                 gc_ = __import__('gc'); gc_.collect(); torch.cuda.empty_cache()
                 w32 = sdxl.SDXLWorkload(cfg, dtype=torch.float32, seed=0, device=device)
                 for k, m in w32.modules().items():
@@ -629,6 +633,7 @@ def main():
             import gc
             engine = module = None
             del work, pool, layers, params, make_opt
+            ops.release_caches()
             gc.collect()
             torch.cuda.empty_cache()
             others = {}
@@ -640,8 +645,9 @@ def main():
                     others[wl] = measure_dit_workload(a2, device, 1, light=True)
                 except Exception as e:                      # noqa: BLE001
                     others[wl] = {'error': repr(e)[:300]}
-                    gc.collect()
-                    torch.cuda.empty_cache()
+                ops.release_caches()                        # (outside the handler: the failed call's frames -- and the tensors they hold -- are gone by now)
+                gc.collect()
+                torch.cuda.empty_cache()
                 others[wl]['wall_seconds'] = round(time.perf_counter() - t_wl, 1)
             out['other_configs'] = others
         print(json.dumps(out), flush=True)

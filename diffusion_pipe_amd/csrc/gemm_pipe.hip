@@ -173,6 +173,9 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
             // the 3x3 convolutions' 135 .. 225 tiles x 180 .. 256 steps gain 25 .. 45 % from 2 - 3 slices)
             S = (int)(512 / tiles); const int cap = p.ksteps / 48; if (S > cap) S = cap; if (S > 3) S = 3;
         }
+        // DPIPE_OPT_GEMM_MAX_SPLIT (default: no cap): upper bound on the automatic split-K factor -- split-K buys workgroups for a launch that cannot fill the chip alone and
+        // pays with slab traffic and a reduction tail; with concurrent lanes the other lanes' launches fill the chip (A/B knob; the skinny / forced paths ignore it)
+        if (force_splitk <= 0 && !skinny) { const int cap = option(DPIPE_OPT_GEMM_MAX_SPLIT, 16); if (S > cap) S = cap; }
         if (S < 1) S = 1;
         if (S > p.ksteps) S = p.ksteps;
         // (counter_base, slab_base: the share of the workspace problems planned earlier into the same grouped launch already own)

@@ -1424,6 +1424,15 @@ def adamw_step(params, exp_avgs, exp_avg_sqs, lane_grads, *, lr, beta1, beta2, e
         check(lib().dpipe_adamw_step(ptr(t['p']), ptr(t['m']), ptr(t['v']), ptr(t['g']), *tail), 'adamw_step')
 
 
+def release_caches():
+    """Drop the module-level caches that keep device memory alive after an engine is gone: the fused step end's pointer tables hold references to the parameters,
+    optimizer states and lane gradients they were built for (`keep`), the clip kernels' chunk tables to the gradients, the split-K workspaces to ~42 MB per lane.
+    Call between two workloads of one process (bench.py's `other_configs` leg) before `torch.cuda.empty_cache()`; everything is rebuilt on demand."""
+    _adam_tables.clear()
+    _table_cache.clear()
+    _SPLITK_WS.clear()
+
+
 # ----------------------------------------------------------------------------------------- small helpers (K7/K8)
 def sinusoidal_embedding(t, dim, max_period=10000.0, sin_first=False, downscale_shift=0.0, scale=1.0):
     """[cos | sin] (Wan, models/wan/model.py:15-25) or [sin | cos] (sin_first) timestep embedding, fp32."""
