@@ -627,7 +627,7 @@ def main():
                 out['parity']['fp32_kernels'] = {'error': repr(e)[:300]}
             engine = module = None
         if world == 1 and args.config == 'full' and not args.no_other_configs and not args.no_cpu_baseline:
-            # BASELINE configs 3 and 4 as real steps on this GPU, bounded (3 timed steps each, the SDXL state freed first): a driver-timed number for the DiT
+            # BASELINE configs 3 and 4 as real steps on this GPU, bounded (2 warm-up + 4 timed steps each, the SDXL state freed first): a driver-timed number for the DiT
             # workloads rides the default line (`--workload flux|wan|hv` gives the full record with roofline legs and cpu_baseline).  Never fatal.
             import copy
             import gc
@@ -639,7 +639,7 @@ def main():
             others = {}
             for wl in ('flux', 'wan'):
                 a2 = copy.copy(args)
-                a2.workload, a2.steps, a2.warmup, a2.gas, a2.lanes, a2.full_ft = wl, 3, 1, 0, 0, False
+                a2.workload, a2.steps, a2.warmup, a2.gas, a2.lanes, a2.full_ft = wl, 4, 2, 0, 0, False
                 t_wl = time.perf_counter()
                 try:
                     others[wl] = measure_dit_workload(a2, device, 1, light=True)

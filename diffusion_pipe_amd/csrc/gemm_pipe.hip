@@ -123,7 +123,10 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
     // tiles fills more CUs as 4 x as many 64^2 tiles); with several micro-batch lanes replaying at once the chip is full either way and what counts is the CU time a
     // launch takes: a 64^2 tile moves twice the operand bytes per FLOP through the CU's global -> LDS path, which is what saturates -- the engine
     // lowers the threshold when it runs >= 2 lanes
-    const int big_min = option(DPIPE_OPT_GEMM_BIG_TILES, 128);
+    // (a lowered threshold only applies where the 128^2 tiling covers the problem about as tightly as the 64^2 one -- padded area within 1.25 x: the rank-32 LoRA
+    //  projections, N = 32, keep 64^2 tiles; M = 77 pads to 128 rows either way)
+    const long area128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * 16384, area64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64) * 4096;
+    const int big_min = (area128 * 4 <= area64 * 5) ? option(DPIPE_OPT_GEMM_BIG_TILES, 128) : 128;
     const bool big = force_tile ? (force_tile >= 128) : (tiles128 >= big_min || (long_k && tiles128 >= (big_min < 48 ? big_min : 48)));
     // 256 x 256 (T256S) for DiT-sized forward / dgrad GEMMs: K-contiguous or mixed operands, >= 64 K-steps to amortise the
     // un-overlapped prologue / epilogue of the one resident workgroup, >= half a wave of 256^2 tiles.  Measured
@@ -173,9 +176,7 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
             // the 3x3 convolutions' 135 .. 225 tiles x 180 .. 256 steps gain 25 .. 45 % from 2 - 3 slices)
             S = (int)(512 / tiles); const int cap = p.ksteps / 48; if (S > cap) S = cap; if (S > 3) S = 3;
         }
-        // DPIPE_OPT_GEMM_MAX_SPLIT (default: no cap): upper bound on the automatic split-K factor -- split-K buys workgroups for a launch that cannot fill the chip alone and
-        // pays with slab traffic and a reduction tail; with concurrent lanes the other lanes' launches fill the chip (A/B knob; the skinny / forced paths ignore it)
-        if (force_splitk <= 0 && !skinny) { const int cap = option(DPIPE_OPT_GEMM_MAX_SPLIT, 16); if (S > cap) S = cap; }
+        // (Round 4: capping the automatic split factor at 1 / 2 under four lanes -- 20.90 / 21.14 vs 21.09 images/s, same box -- buys nothing: removed again.)
         if (S < 1) S = 1;
         if (S > p.ksteps) S = p.ksteps;
         // (counter_base, slab_base: the share of the workspace problems planned earlier into the same grouped launch already own)

@@ -93,6 +93,162 @@ __global__ void __launch_bounds__(NB) rmsnorm_bwd_dx_kernel(const T* __restrict_
         vg.pack(fg); vg.store(o + c);
     }
 }
+// ------------------------------------------------------------------ K2 + K3 fused: RMSNorm -> RoPE in ONE pass (models/wan/model.py:124-125,139-140: q = rope(norm_q(q(x)));
+// per-head form: hunyuan_image_modeling.py:181-190, diffusers FluxAttnProcessor): y = rot_s(type_as(x * rstd) * w) -- the normalised, weighted row never round-trips
+// through memory (and is not rounded to the storage type before the rotation).  A row is one normalisation group: the whole token (G = 1, cols = H D: Wan) or one head
+// (G = H, cols = D: Flux / HunyuanVideo); its token is s = (row / G) % S, the rotation (interleaved pairs (2i, 2i + 1), angle table row s + tok_off, column (c % D) / 2)
+// applies to tokens s < rope_tokens (HunyuanVideo's single-stream blocks rotate the image tokens of an [image ; text] sequence only).  Input rows may be strided views
+// of a fused QKV projection (token pitch x_ts elements, heads D apart); outputs and gradients are dense.
+struct RopeGeom { const float* cs; const float* sn; long S; int G; int D; long tok_off; long rope_tokens; long x_ts; };
+
+template <typename T, typename W, int LPR>
+__global__ void __launch_bounds__(NB) rmsnorm_rope_fwd_kernel(const T* __restrict__ x, const W* __restrict__ w, T* __restrict__ y, float* __restrict__ rstd_out,
+                                                              long rows, int cols, float eps, const RopeGeom rg) {
+    constexpr int V = Elem<T>::VEC;
+    constexpr int RPB = NB / LPR;
+    const int sub = threadIdx.x % LPR;
+    const long row = (long)blockIdx.x * RPB + threadIdx.x / LPR;
+    const bool live = row < rows;
+    const long r = live ? row : 0;
+    const long tok = r / rg.G;
+    const T* xr = x + tok * rg.x_ts + (r - tok * rg.G) * (long)cols;
+    float ss = 0.f;
+    for (int c = sub * V; c < cols; c += LPR * V) {
+        Vec16<T> v; v.load(xr + c);
+        float f[V]; v.unpack(f);
+#pragma unroll
+        for (int j = 0; j < V; ++j) ss += f[j] * f[j];
+    }
+    ss = group_sum<LPR>(ss);
+    const float rstd = rsqrtf(ss / (float)cols + eps);
+    if (!live) return;
+    if (sub == 0 && rstd_out) rstd_out[row] = rstd;
+    const long s = tok % rg.S;
+    const bool rot = s < rg.rope_tokens;
+    const float* cs = rg.cs + (s + rg.tok_off) * (rg.D / 2);
+    const float* sn = rg.sn + (s + rg.tok_off) * (rg.D / 2);
+    T* yr = y + row * (long)cols;
+    for (int c = sub * V; c < cols; c += LPR * V) {
+        Vec16<T> v; v.load(xr + c);
+        float f[V]; v.unpack(f);
+        const int cd = c % rg.D;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float n = Elem<T>::to_f(Elem<T>::from_f(f[j] * rstd));  // ".type_as(x)" rounding point of the reference norm
+            f[j] = w ? n * Elem<W>::to_f(w[c + j]) : n;
+        }
+        if (rot) {
+#pragma unroll
+            for (int j = 0; j < V; j += 2) {
+                const float co = cs[(cd + j) / 2], si = sn[(cd + j) / 2];
+                const float a = f[j], b = f[j + 1];
+                f[j] = a * co - b * si; f[j + 1] = a * si + b * co;
+            }
+        }
+        v.pack(f); v.store(yr + c);
+    }
+}
+// g_t = rot_s^T(gy) (inverse rotation), then the RMSNorm backward on it: dx = rstd * (g_t w - xhat * mean(g_t w xhat))
+template <typename T, typename W, int LPR>
+__global__ void __launch_bounds__(NB) rmsnorm_rope_bwd_dx_kernel(const T* __restrict__ x, const W* __restrict__ w, const T* __restrict__ gy,
+                                                                 const float* __restrict__ rstd_in, T* __restrict__ gx, long rows, int cols, const RopeGeom rg) {
+    constexpr int V = Elem<T>::VEC;
+    constexpr int RPB = NB / LPR;
+    const int sub = threadIdx.x % LPR;
+    const long row = (long)blockIdx.x * RPB + threadIdx.x / LPR;
+    const bool live = row < rows;
+    const long r = live ? row : 0;
+    const long tok = r / rg.G;
+    const T* xr = x + tok * rg.x_ts + (r - tok * rg.G) * (long)cols;
+    const T* gr = gy + r * (long)cols;
+    const float rstd = rstd_in[r];
+    const long s = tok % rg.S;
+    const bool rot = s < rg.rope_tokens;
+    const float* cs = rg.cs + (s + rg.tok_off) * (rg.D / 2);
+    const float* sn = rg.sn + (s + rg.tok_off) * (rg.D / 2);
+    auto unrotate = [&](float* fg, int c) {
+        if (!rot) return;
+        const int cd = c % rg.D;
+#pragma unroll
+        for (int j = 0; j < V; j += 2) {
+            const float co = cs[(cd + j) / 2], si = sn[(cd + j) / 2];
+            const float a = fg[j], b = fg[j + 1];
+            fg[j] = a * co + b * si; fg[j + 1] = b * co - a * si;
+        }
+    };
+    float dot = 0.f;
+    for (int c = sub * V; c < cols; c += LPR * V) {
+        Vec16<T> vx, vg; vx.load(xr + c); vg.load(gr + c);
+        float fx[V], fg[V]; vx.unpack(fx); vg.unpack(fg);
+        unrotate(fg, c);
+#pragma unroll
+        for (int j = 0; j < V; ++j) dot += fg[j] * (w ? Elem<W>::to_f(w[c + j]) : 1.f) * fx[j] * rstd;
+    }
+    dot = group_sum<LPR>(dot) / (float)cols;
+    if (!live) return;
+    T* o = gx + row * (long)cols;
+    for (int c = sub * V; c < cols; c += LPR * V) {
+        Vec16<T> vx, vg; vx.load(xr + c); vg.load(gr + c);
+        float fx[V], fg[V]; vx.unpack(fx); vg.unpack(fg);
+        unrotate(fg, c);
+#pragma unroll
+        for (int j = 0; j < V; ++j) fg[j] = rstd * (fg[j] * (w ? Elem<W>::to_f(w[c + j]) : 1.f) - fx[j] * rstd * dot);
+        vg.pack(fg); vg.store(o + c);
+    }
+}
+// dw partials: partial[slab][c] = sum over the slab's rows of rot^T(gy)[r, c] * x[r, c] * rstd[r]   (block / slab geometry of colreduce_kernel below)
+template <typename T>
+__global__ void __launch_bounds__(NB) rmsnorm_rope_dw_kernel(const T* __restrict__ x, const T* __restrict__ gy, const float* __restrict__ rstd, long rows, int cols,
+                                                             int slabs, float* __restrict__ p0, const RopeGeom rg) {
+    constexpr int V = Elem<T>::VEC;
+    constexpr int CT = 32, RT = 8;
+    __shared__ float red[RT][CT * V];
+    const int ct = threadIdx.x % CT, rl = threadIdx.x / CT;
+    const int c = (blockIdx.x * CT + ct) * V;
+    const bool live = c < cols;
+    const long rps = cdiv(rows, slabs);
+    const long r0 = blockIdx.y * rps, r1 = min(r0 + rps, rows);
+    float a0[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) a0[j] = 0.f;
+    if (live) {
+        const int cd = c % rg.D;
+#pragma unroll 4
+        for (long row = r0 + rl; row < r1; row += RT) {
+            const long tok = row / rg.G;
+            Vec16<T> vx, vg; vx.load(x + tok * rg.x_ts + (row - tok * rg.G) * (long)cols + c); vg.load(gy + row * (long)cols + c);
+            float fx[V], fg[V]; vx.unpack(fx); vg.unpack(fg);
+            const long s = tok % rg.S;
+            if (s < rg.rope_tokens) {
+                const float* cs = rg.cs + (s + rg.tok_off) * (rg.D / 2);
+                const float* sn = rg.sn + (s + rg.tok_off) * (rg.D / 2);
+#pragma unroll
+                for (int j = 0; j < V; j += 2) {
+                    const float co = cs[(cd + j) / 2], si = sn[(cd + j) / 2];
+                    const float a = fg[j], b = fg[j + 1];
+                    fg[j] = a * co + b * si; fg[j + 1] = b * co - a * si;
+                }
+            }
+            const float rs = rstd[row];
+#pragma unroll
+            for (int j = 0; j < V; ++j) a0[j] += fg[j] * Elem<T>::to_f(Elem<T>::from_f(fx[j] * rs));      // the weight multiplies the ROUNDED normalised value in the forward
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) red[rl][ct * V + j] = a0[j];
+    __syncthreads();
+    const int col_in = threadIdx.x;
+    if (col_in < CT * V) {
+        const int cc = blockIdx.x * CT * V + col_in;
+        if (cc < cols) {
+            float s0 = 0.f;
+#pragma unroll
+            for (int r = 0; r < RT; ++r) s0 += red[r][col_in];
+            p0[(long)blockIdx.y * cols + cc] = s0;
+        }
+    }
+}
+
 // column reductions over a slab of rows: partial[slab][c] = sum_r f(r, c).  grid = (colblocks, slabs, groups)
 // MODE 0: RMSNorm dw   = sum gy * x * rstd
 // MODE 1: LN (dgamma, dbeta) = (sum dn * xhat, sum dn)      with dn = gy * (1 + scale)
@@ -575,6 +731,56 @@ int dpipe_rmsnorm_bwd(const void* x, const void* w, const void* gy, const float*
         }
     })
     return check_launch("dpipe_rmsnorm_bwd");
+}
+
+static bool rope_geom(RopeGeom& rg, const float* cos_t, const float* sin_t, long rows, int cols, int head_dim, long S, int groups, long token_offset, long rope_tokens,
+                      long x_token_stride) {
+    if (!cos_t || !sin_t || head_dim <= 0 || (head_dim % 2) || S <= 0 || groups <= 0 || rows % groups || (rows / groups) % S) return false;
+    if (groups == 1 ? (cols % head_dim) != 0 : cols != head_dim) return false;
+    if (x_token_stride < (long)groups * cols || token_offset < 0) return false;
+    rg.cs = cos_t; rg.sn = sin_t; rg.S = S; rg.G = groups; rg.D = head_dim; rg.tok_off = token_offset; rg.rope_tokens = rope_tokens < 0 ? S : rope_tokens; rg.x_ts = x_token_stride;
+    return true;
+}
+
+int dpipe_rmsnorm_rope_fwd(const void* x, const void* w, const float* cos_t, const float* sin_t, void* y, float* rstd, long rows, int cols, int head_dim, long S,
+                           int groups_per_token, long token_offset, long rope_tokens, long x_token_stride, float eps, int dtype, int wdtype, void* stream) {
+    const int V = dtype == DPIPE_BF16 ? 8 : 4;
+    RopeGeom rg;
+    if (!x || !y || rows <= 0 || cols <= 0 || (cols % V) != 0 || (head_dim % V) != 0 || (x_token_stride % V) != 0 ||
+        !rope_geom(rg, cos_t, sin_t, rows, cols, head_dim, S, groups_per_token, token_offset, rope_tokens, x_token_stride)) BAD("dpipe_rmsnorm_rope_fwd: bad argument");
+    hipStream_t s = STREAM(stream);
+    const int lpr = pick_lpr(cols, V);
+    const unsigned grid = (unsigned)cdiv(rows, NB / lpr);
+    DISPATCH_TW(dtype, wdtype, {
+        if (lpr == 16) rmsnorm_rope_fwd_kernel<T, W, 16><<<grid, NB, 0, s>>>((const T*)x, (const W*)w, (T*)y, rstd, rows, cols, eps, rg);
+        else rmsnorm_rope_fwd_kernel<T, W, 64><<<grid, NB, 0, s>>>((const T*)x, (const W*)w, (T*)y, rstd, rows, cols, eps, rg);
+    })
+    return check_launch("dpipe_rmsnorm_rope_fwd");
+}
+
+// workspace: dpipe_norm_slabs(rows) * cols floats (only when dw != null)
+int dpipe_rmsnorm_rope_bwd(const void* x, const void* w, const void* gy, const float* rstd, const float* cos_t, const float* sin_t, void* gx, void* dw, float* workspace,
+                           long rows, int cols, int head_dim, long S, int groups_per_token, long token_offset, long rope_tokens, long x_token_stride, int dtype,
+                           int wdtype, int accumulate_params, void* stream) {
+    const int V = dtype == DPIPE_BF16 ? 8 : 4;
+    RopeGeom rg;
+    if (!x || !gy || !rstd || !gx || rows <= 0 || cols <= 0 || (cols % V) != 0 || (head_dim % V) != 0 || (x_token_stride % V) != 0 ||
+        !rope_geom(rg, cos_t, sin_t, rows, cols, head_dim, S, groups_per_token, token_offset, rope_tokens, x_token_stride)) BAD("dpipe_rmsnorm_rope_bwd: bad argument");
+    if (dw && !workspace) BAD("dpipe_rmsnorm_rope_bwd: workspace required for dw");
+    hipStream_t s = STREAM(stream);
+    const int lpr = pick_lpr(cols, V);
+    const unsigned grid = (unsigned)cdiv(rows, NB / lpr);
+    const int slabs = dpipe_norm_slabs(rows);
+    DISPATCH_TW(dtype, wdtype, {
+        if (lpr == 16) rmsnorm_rope_bwd_dx_kernel<T, W, 16><<<grid, NB, 0, s>>>((const T*)x, (const W*)w, (const T*)gy, rstd, (T*)gx, rows, cols, rg);
+        else rmsnorm_rope_bwd_dx_kernel<T, W, 64><<<grid, NB, 0, s>>>((const T*)x, (const W*)w, (const T*)gy, rstd, (T*)gx, rows, cols, rg);
+        if (dw) {
+            dim3 g2((unsigned)cdiv(cols / V, 32), slabs, 1);
+            rmsnorm_rope_dw_kernel<T><<<g2, NB, 0, s>>>((const T*)x, (const T*)gy, rstd, rows, cols, slabs, workspace, rg);
+            slabsum_kernel<W><<<(unsigned)cdiv(cols, NB), NB, 0, s>>>(workspace, (W*)dw, 1, cols, slabs, accumulate_params);
+        }
+    })
+    return check_launch("dpipe_rmsnorm_rope_bwd");
 }
 
 int dpipe_lnmod_fwd(const void* x, const void* gamma, const void* beta, const void* scale, const void* shift, void* y,

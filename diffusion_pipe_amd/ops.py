@@ -1054,6 +1054,71 @@ def rope(x, cos, sin, interleaved=True):
     return _RopeFn.apply(x, cos, sin, interleaved)
 
 
+# K2 + K3 fused: RMSNorm -> RoPE -> Q / K written once.  A/B switch DPIPE_FUSE_NORM_ROPE=0 restores the two-kernel route (+ the contiguous copy of a strided q / k).
+FUSE_NORM_ROPE = _os_mod.environ.get('DPIPE_FUSE_NORM_ROPE', '1') == '1'
+
+
+class _RMSNormRopeFn(Function):
+    """y = rope(rms_norm(x) * weight) on [B, S, H, D] in ONE pass (models/wan/model.py:124-125,139-140 q = rope(norm_q(q(x))): the norm spans the whole token,
+    weight [H D]; hunyuan_image_modeling.py:181-190 / diffusers FluxAttnProcessor: per-head norm, weight [D]).  x may be a strided view of a fused QKV projection
+    (`qkv.view(B, S, 3, H, D).unbind(2)`): the kernel takes the token pitch, no contiguous copy is made.  cos / sin: fp32 [>= token_offset + S, D / 2], interleaved pairs;
+    tokens s >= rope_tokens are normalised but not rotated (the text tokens of an [image ; text] sequence)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, cos, sin, eps, per_head, token_offset, rope_tokens):
+        require_cuda(x, weight, cos, sin)
+        B, S, H, D = x.shape
+        if x.stride(3) != 1 or x.stride(2) != D or x.stride(1) < H * D or (B > 1 and x.stride(0) != S * x.stride(1)) or x.stride(1) % 8:
+            x = x.contiguous()
+        if cos.dtype != torch.float32 or cos.dim() != 2 or cos.shape[1] != D // 2 or cos.shape[0] < token_offset + S or sin.shape != cos.shape:
+            raise DpipeHipError(f'rms_norm_rope: tables must be fp32 [>= {token_offset + S}, {D // 2}]; got {tuple(cos.shape)} {cos.dtype}')
+        cos, sin = _contig(cos), _contig(sin)
+        groups, cols = (H, D) if per_head else (1, H * D)
+        if weight is not None and weight.numel() != cols:
+            raise DpipeHipError(f'rms_norm_rope: weight has {weight.numel()} elements, the normalised row {cols}')
+        rows = B * S * groups
+        y = torch.empty((B, S, H, D), device=x.device, dtype=x.dtype)
+        rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+        wd = dtype_code(weight.dtype) if weight is not None else dtype_code(x.dtype)
+        rt = S if rope_tokens is None else int(rope_tokens)
+        check(lib().dpipe_rmsnorm_rope_fwd(ptr(x), ptr(weight), ptr(cos), ptr(sin), ptr(y), ptr(rstd), rows, cols, D, S, groups, int(token_offset), rt, x.stride(1), float(eps),
+                                           dtype_code(x.dtype), wd, stream()), 'rmsnorm_rope_fwd')
+        ctx.save_for_backward(x, weight, rstd, cos, sin)
+        ctx.meta = (rows, cols, D, S, groups, int(token_offset), rt)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, rstd, cos, sin = ctx.saved_tensors
+        rows, cols, D, S, groups, tok_off, rt = ctx.meta
+        gy = _contig(gy)
+        gx = torch.empty(gy.shape, device=gy.device, dtype=gy.dtype)
+        dw = ws = None
+        fused = False
+        if weight is not None and ctx.needs_input_grad[1]:
+            dw = _accum_target(weight)
+            fused = dw is not None
+            if dw is None:
+                dw = torch.empty_like(weight)
+            ws = torch.empty(lib().dpipe_norm_slabs(rows) * cols, device=gy.device, dtype=torch.float32)
+        wd = dtype_code(weight.dtype) if weight is not None else dtype_code(x.dtype)
+        check(lib().dpipe_rmsnorm_rope_bwd(ptr(x), ptr(weight), ptr(gy), ptr(rstd), ptr(cos), ptr(sin), ptr(gx), ptr(dw), ptr(ws), rows, cols, D, S, groups, tok_off, rt,
+                                           x.stride(1), dtype_code(x.dtype), wd, int(fused), stream()), 'rmsnorm_rope_bwd')
+        return gx, (None if fused else dw), None, None, None, None, None, None
+
+
+def rms_norm_rope(x, weight, cos, sin, eps=1e-6, per_head=True, token_offset=0, rope_tokens=None):
+    """[B, S, H, D] -> rope(rms_norm(x) * weight); see _RMSNormRopeFn.  Falls back to the two-kernel composition when the fusion is switched off."""
+    if not FUSE_NORM_ROPE:
+        B, S, H, D = x.shape
+        n = rms_norm(x if per_head else x.reshape(B, S, H * D), weight, eps).view(B, S, H, D)
+        c, s_ = cos[token_offset:token_offset + S], sin[token_offset:token_offset + S]
+        if rope_tokens is None or rope_tokens >= S:
+            return rope(n, c, s_, interleaved=True)
+        return torch.cat([rope(n[:, :rope_tokens].contiguous(), c[:rope_tokens], s_[:rope_tokens], interleaved=True), n[:, rope_tokens:]], dim=1)
+    return _RMSNormRopeFn.apply(x, weight, cos, sin, eps, per_head, token_offset, rope_tokens)
+
+
 # -------------------------------------------------------------------------------------------- attention (K4)
 def _bshd_strides(t):
     if t.stride(3) != 1:

@@ -129,18 +129,21 @@ class FluxAttention(nn.Module):
             self.norm_added_q, self.norm_added_k = dnn.RMSNorm(head_dim, eps=eps), dnn.RMSNorm(head_dim, eps=eps)
             self.to_add_out = dnn.Linear(inner, dim)
 
-    def _qkv(self, x, projections, norm_q, norm_k):
+    def _qkv(self, x, projections, norm_q, norm_k, cos, sin, offset):
+        """per-head RMSNorm of q / k fused with the rotation (K2 + K3, one pass over each, read straight from the fused projection's output); `offset`: row of the
+        [text ; image] angle tables at which this stream's tokens start"""
         B, S, _ = x.shape
         q, k, v = _project3(x, *projections).view(B, S, 3, self.heads, self.head_dim).unbind(2)
-        return norm_q(q), norm_k(k), v
+        return (ops.rms_norm_rope(q, norm_q.weight, cos, sin, norm_q.eps, per_head=True, token_offset=offset),
+                ops.rms_norm_rope(k, norm_k.weight, cos, sin, norm_k.eps, per_head=True, token_offset=offset), v)
 
     def forward(self, hidden, encoder, cos, sin):
         """-> attention output over [text ; image] tokens, [B, L + S, inner] (text first)."""
-        q, k, v = self._qkv(hidden, (self.to_q, self.to_k, self.to_v), self.norm_q, self.norm_k)
+        L = encoder.shape[1] if encoder is not None else 0
+        q, k, v = self._qkv(hidden, (self.to_q, self.to_k, self.to_v), self.norm_q, self.norm_k, cos, sin, L)
         if encoder is not None:
-            eq, ek, ev = self._qkv(encoder, (self.add_q_proj, self.add_k_proj, self.add_v_proj), self.norm_added_q, self.norm_added_k)
+            eq, ek, ev = self._qkv(encoder, (self.add_q_proj, self.add_k_proj, self.add_v_proj), self.norm_added_q, self.norm_added_k, cos, sin, 0)
             q, k, v = torch.cat([eq, q], dim=1), torch.cat([ek, k], dim=1), torch.cat([ev, v], dim=1)
-        q, k = ops.rope(q, cos, sin, interleaved=True), ops.rope(k, cos, sin, interleaved=True)
         o = ops.attention(q, k, v.contiguous())
         return o.reshape(o.shape[0], o.shape[1], -1)
 

@@ -74,10 +74,12 @@ class MMDoubleStreamBlock(nn.Module):
     def _stream_qkv(self, s, x, shift, scale, cos, sin):
         h, skip = getattr(self, f'{s}_norm1')(x, scale=scale, shift=shift, with_skip=True)
         q, k, v = _qkv_heads(getattr(self, f'{s}_attn_qkv')(h), self.heads_num)
-        q = getattr(self, f'{s}_attn_q_norm')(q)
-        k = getattr(self, f'{s}_attn_k_norm')(k)
-        if cos is not None:
-            q, k = ops.rope(q, cos, sin, interleaved=True), ops.rope(k, cos, sin, interleaved=True)
+        qn, kn = getattr(self, f'{s}_attn_q_norm'), getattr(self, f'{s}_attn_k_norm')
+        if cos is not None:       # image stream: per-head RMSNorm + RoPE in one pass over q and k (K2 + K3), read straight from the fused QKV output
+            q = ops.rms_norm_rope(q, qn.weight, cos, sin, qn.eps, per_head=True)
+            k = ops.rms_norm_rope(k, kn.weight, cos, sin, kn.eps, per_head=True)
+        else:
+            q, k = qn(q), kn(k)
         return (q, k, v), skip
 
     def forward(self, img, txt, vec, cos=None, sin=None, text_len=None):
@@ -118,11 +120,12 @@ class MMSingleStreamBlock(nn.Module):
         h = self.linear1(n)
         qkv, mlp = torch.split(h, [3 * self.hidden_size, self.mlp_hidden_dim], dim=-1)
         q, k, v = _qkv_heads(qkv.contiguous(), self.heads_num)
-        q, k = self.q_norm(q), self.k_norm(k)
         Si = x.shape[1] - txt_len
-        if cos is not None:
-            q = torch.cat([ops.rope(q[:, :Si].contiguous(), cos, sin, interleaved=True), q[:, Si:]], dim=1)
-            k = torch.cat([ops.rope(k[:, :Si].contiguous(), cos, sin, interleaved=True), k[:, Si:]], dim=1)
+        if cos is not None:       # one pass over q and k: per-head RMSNorm of every token, rotation of the Si image tokens only (no slice / concatenate copies)
+            q = ops.rms_norm_rope(q, self.q_norm.weight, cos, sin, self.q_norm.eps, per_head=True, rope_tokens=Si)
+            k = ops.rms_norm_rope(k, self.k_norm.weight, cos, sin, self.k_norm.eps, per_head=True, rope_tokens=Si)
+        else:
+            q, k = self.q_norm(q), self.k_norm(k)
         kv_len = (text_len.to(torch.int32) + Si).contiguous() if text_len is not None else None
         o = ops.attention(q.contiguous(), k.contiguous(), v, kv_len=kv_len)
         attn = o.reshape(o.shape[0], o.shape[1], -1)

@@ -38,8 +38,9 @@ class WanSelfAttention(nn.Module):
     def forward(self, x, cos, sin):
         B, S, _ = x.shape
         n, d = self.num_heads, self.head_dim
-        q = ops.rope(self.norm_q(self.q(x)).view(B, S, n, d), cos, sin, interleaved=True)
-        k = ops.rope(self.norm_k(self.k(x)).view(B, S, n, d), cos, sin, interleaved=True)
+        # K2 + K3 in one pass each: RMSNorm over the whole token, RoPE per head, q / k written once (models/wan/model.py:124-125,139-140)
+        q = ops.rms_norm_rope(self.q(x).view(B, S, n, d), self.norm_q.weight, cos, sin, self.norm_q.eps, per_head=False)
+        k = ops.rms_norm_rope(self.k(x).view(B, S, n, d), self.norm_k.weight, cos, sin, self.norm_k.eps, per_head=False)
         v = self.v(x).view(B, S, n, d)
         return self.o(ops.attention(q, k, v, impl=self.attn_impl).reshape(B, S, n * d))
 

@@ -47,8 +47,7 @@ const char* dpipe_last_error(void);
                                       chip: the engine selects it for >= 2 micro-batch lanes; 3: 64^2 on the 3-deep 48 KiB ring; 1: both */
 #define DPIPE_OPT_GEMM_BIG_TILES 6  /* fewest 128^2 output tiles for which the plain GEMM takes the 128^2 tile instead of 64^2 (default 128 = best isolated launch; lower under
                                       concurrent lanes, where CU time per FLOP is what counts: the engine's choice) */
-#define DPIPE_OPT_GEMM_MAX_SPLIT 7  /* cap on the automatic split-K factor of the plain GEMM / convolution (default 16 = the dispatcher's own choice) */
-#define DPIPE_OPTION_COUNT 8
+#define DPIPE_OPTION_COUNT 7
 int dpipe_set_option(int option, int value);
 int dpipe_get_option(int option);    /* the effective explicit / environment value, -1 if neither is set */
 /* Number of compute units / name of device `dev`; used by the host to sanity-check it runs on gfx950. */
@@ -166,6 +165,16 @@ int dpipe_norm_slabs(long rows_per_group);
  * gradient-accumulation step of the micro-batch loop fused into the reduction; dw then is the persistent .grad). */
 int dpipe_rmsnorm_bwd(const void* x, const void* w, const void* gy, const float* rstd, void* gx, void* dw,
                       float* workspace, long rows, int cols, int dtype, int wdtype, int accumulate_params, void* stream);
+/* K2 + K3 fused (RMSNorm -> RoPE -> Q/K write-out in one pass; models/wan/model.py:124-125,139-140, hunyuan_image_modeling.py:181-190):
+ * y = rope(type_as(x * rstd) * w).  A row is one normalisation group: the whole token (groups_per_token = 1, cols = H * head_dim: Wan's norm_q / norm_k) or
+ * one head (groups_per_token = H, cols = head_dim: Flux / HunyuanVideo); rows = B * S * groups_per_token.  The rotation (interleaved pairs, cos_t / sin_t:
+ * fp32 [>= token_offset + S, head_dim / 2]) applies to tokens s < rope_tokens (-1 = all).  x may be a strided view of a fused QKV projection: token pitch
+ * x_token_stride elements, the token's groups `cols` apart; y, gy, gx are dense [rows, cols].  workspace / dw / accumulate_params as dpipe_rmsnorm_bwd. */
+int dpipe_rmsnorm_rope_fwd(const void* x, const void* w, const float* cos_t, const float* sin_t, void* y, float* rstd, long rows, int cols, int head_dim, long S,
+                           int groups_per_token, long token_offset, long rope_tokens, long x_token_stride, float eps, int dtype, int wdtype, void* stream);
+int dpipe_rmsnorm_rope_bwd(const void* x, const void* w, const void* gy, const float* rstd, const float* cos_t, const float* sin_t, void* gx, void* dw, float* workspace,
+                           long rows, int cols, int head_dim, long S, int groups_per_token, long token_offset, long rope_tokens, long x_token_stride, int dtype,
+                           int wdtype, int accumulate_params, void* stream);
 /* out[c] (+)= sum_r x[r, c], x: [rows, cols] with row stride ld -- the bias gradient of nn.Linear (column sums of dy).
  * dtype: x; out_dtype: out (bf16 x -> bf16 or fp32 out; fp32 x -> fp32 out).  workspace as above. */
 int dpipe_colsum(const void* x, long rows, int cols, long ld, void* out, float* workspace, int dtype, int out_dtype,

@@ -787,3 +787,69 @@ def test_norms_fold_the_bypass_gradient_into_their_backward(gpu, dtype, tol):
     y, xs = ops.group_norm(xg, 8, gw.to(gpu, dtype), gb.to(gpu, dtype), 1e-5, 'silu', with_skip=True)
     ((y.float() * wy.to(gpu)).sum() + (xs.float() * ws.to(gpu)).sum()).backward()
     assert _rel_err(y, yr) < tol and _rel_err(xg.grad, xr.grad) < tol
+
+
+# ------------------------------------------------------------------------------------------- K2 + K3 fused: RMSNorm -> RoPE in one pass
+def _norm_rope_reference(x, w, cos, sin, eps, per_head, token_offset, rope_tokens):
+    """float64: rope(rms_norm(x) * w) with interleaved pairs, norm over D (per head) or H * D (whole token), rotation of tokens < rope_tokens only"""
+    B, S, H, D = x.shape
+    x = x.double()
+    if per_head:
+        n = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps) * w.double().view(1, 1, 1, D)
+    else:
+        flat = x.reshape(B, S, H * D)
+        n = (flat * torch.rsqrt(flat.pow(2).mean(-1, keepdim=True) + eps) * w.double().view(1, 1, H * D)).view(B, S, H, D)
+    c = cos.double()[token_offset:token_offset + S].view(1, S, 1, D // 2)
+    s = sin.double()[token_offset:token_offset + S].view(1, S, 1, D // 2)
+    a, b = n[..., 0::2], n[..., 1::2]
+    rot = torch.stack([a * c - b * s, a * s + b * c], dim=-1).reshape(B, S, H, D)
+    rt = S if rope_tokens is None else rope_tokens
+    keep = (torch.arange(S, device=x.device) < rt).view(1, S, 1, 1)
+    return torch.where(keep, rot, n)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('case', ['wan_full_row', 'flux_per_head_offset', 'hv_partial_rope_strided', 'tiny_head64'])
+def test_rms_norm_rope_fused_matches_float64_and_the_two_kernel_route(gpu, dtype, case):
+    """ops.rms_norm_rope (csrc/norm.hip rmsnorm_rope_*: SURVEY 2b's "RMSNorm -> RoPE -> Q/K write-out in one pass") -- forward, input gradient and weight gradient
+    against a float64 reference; and against the unfused composition (rms_norm, rope [, slice + concatenate]) it replaces.  Cases: Wan (norm over the whole token, weight
+    [H D]); Flux (per-head norm, image tokens at an offset of the [text ; image] tables); HunyuanVideo's single-stream form (strided q out of a fused QKV projection,
+    rotation of the image tokens only); head dim 64."""
+    from diffusion_pipe_amd import ops
+    g = torch.Generator().manual_seed(31)
+    B, S, H, D, per_head, off, rt, strided = {'wan_full_row': (2, 150, 5, 128, False, 0, None, False), 'flux_per_head_offset': (1, 200, 3, 128, True, 37, None, True),
+                                               'hv_partial_rope_strided': (2, 96, 4, 128, True, 0, 70, True), 'tiny_head64': (1, 33, 2, 64, True, 0, None, False)}[case]
+    qkv = torch.randn(B, S, 3 * H * D, generator=g).to(gpu, dtype)
+    w = (1.0 + 0.2 * torch.randn(D if per_head else H * D, generator=g)).to(gpu, dtype).requires_grad_(True)
+    ang = torch.rand(off + S, D // 2, generator=g) * 6.28
+    cos, sin = ang.cos().float().to(gpu), ang.sin().float().to(gpu)
+    gy = torch.randn(B, S, H, D, generator=g).to(gpu, dtype)
+    src = qkv.clone().requires_grad_(True)
+    q = src.view(B, S, 3, H, D).unbind(2)[1] if strided else src.view(B, S, 3, H, D)[:, :, 1].contiguous()
+    y = ops.rms_norm_rope(q, w, cos, sin, 1e-6, per_head=per_head, token_offset=off, rope_tokens=rt)
+    y.backward(gy)
+    torch.cuda.synchronize()
+    gq, gw = src.grad.view(B, S, 3, H, D)[:, :, 1].clone(), w.grad.clone()
+    assert src.grad.view(B, S, 3, H, D)[:, :, 0].abs().max().item() == 0                      # the other slices of the projection receive nothing
+    # float64 reference
+    xd = qkv.view(B, S, 3, H, D)[:, :, 1].double().requires_grad_(True)
+    wd = w.detach().double().requires_grad_(True)
+    yd = _norm_rope_reference(xd, wd, cos, sin, 1e-6, per_head, off, rt)
+    yd.backward(gy.double())
+    tol = 2.5e-2 if dtype == torch.bfloat16 else 2e-5
+    assert _worst_elem(y, yd) < tol, _worst_elem(y, yd)
+    assert _worst_elem(gq, xd.grad) < tol * 2, _worst_elem(gq, xd.grad)
+    assert _rel_err(gw, wd.grad) < tol, _rel_err(gw, wd.grad)
+    # the two-kernel route it replaces
+    old, ops.FUSE_NORM_ROPE = ops.FUSE_NORM_ROPE, False
+    try:
+        src2 = qkv.clone().requires_grad_(True)
+        w2 = w.detach().clone().requires_grad_(True)
+        q2 = src2.view(B, S, 3, H, D).unbind(2)[1]
+        y2 = ops.rms_norm_rope(q2, w2, cos, sin, 1e-6, per_head=per_head, token_offset=off, rope_tokens=rt)
+        y2.backward(gy)
+    finally:
+        ops.FUSE_NORM_ROPE = old
+    torch.cuda.synchronize()
+    assert _worst_elem(y, y2) < tol and _rel_err(gw, w2.grad) < tol
+    assert _worst_elem(gq, src2.grad.view(B, S, 3, H, D)[:, :, 1]) < tol * 2
