@@ -248,7 +248,11 @@ class PipelineEngine:
         # half of the 256 CUs, so `graph_lanes` micro-batches replay at the same time on separate HIP streams, each lane
         # accumulating into its own gradient buffers (288 GB HBM: +5 GB per lane for SDXL); the lanes' gradients are summed
         # once before ReduceGrads / clip / optimizer.  Same math as sequential accumulation up to fp summation order.
-        self.graph_lanes = max(1, int(self._config.get('graph_lanes', 1))) if self.use_graph else 1     # bench: 3 (best of 1..4 on MI355X)
+        self.graph_lanes = max(1, int(self._config.get('graph_lanes', 1))) if self.use_graph else 1     # bench: 4 (lane 0 on the caller's stream)
+        # `store_first_micro_batch` (default on; DPIPE_STORE_FIRST=0 for the A/B): every lane owns a second graph per tuple layout for the FIRST micro-batch it runs in
+        # a step, whose parameter-gradient kernels STORE into the lane's accumulators instead of adding (ops.GRAD_STORE) -- the fused step end then has nothing to zero
+        # (4 lanes x 5.2 GB of writes per SDXL step).  Used on the fused-step-end, single-replica path only; the two graphs of a lane share one memory pool.
+        self.store_first = bool(self._config.get('store_first_micro_batch', os.environ.get('DPIPE_STORE_FIRST', '1') == '1')) and self.use_graph
         self._lanes = []
         self._lane_streams = None
         # GEMM ring-depth policy (C-ABI option DPIPE_OPT_GEMM_SHALLOW): with >= 2 graphs replaying concurrently (micro-batch lanes, or forward + backward stage
@@ -523,6 +527,8 @@ class PipelineEngine:
         for lane in lanes:
             lane['loss'].zero_()
             lane['stream'].wait_stream(main)          # ordered after the previous step end AND after whatever the iterator enqueued on the caller's stream
+        store_first = self.store_first and self._fused_step_end() and not self.is_data_parallel
+        started = set()
         for i in range(self.micro_batches):
             lane = lanes[i % K]
             feats, labels = batches[i]
@@ -541,7 +547,9 @@ class PipelineEngine:
                         dst.copy_(src, non_blocking=True)
                 if TRACE_TIMING:
                     _trace(('launch', self.global_steps, i, lane['id']), lane['stream'])
-                entry['graph'].replay()
+                first = store_first and lane['id'] not in started and entry.get('graph_first') is not None
+                started.add(lane['id'])
+                (entry['graph_first'] if first else entry['graph']).replay()
                 _trace(('replay', self.global_steps, i, lane['id']), lane['stream'])
         for lane in lanes:
             main.wait_stream(lane['stream'])
@@ -557,7 +565,9 @@ class PipelineEngine:
                 p.grad = base['grads'].get(id(p))
             self.total_loss = base['loss']
             self._exec_reduce_tied_grads()
-            self._exec_optimizer_step(lane_grads=[lane['grads'] for lane in lanes])
+            # nothing to zero when every lane's next first micro-batch stores (all of this step's lanes hold a first-micro-batch graph for every layout they captured)
+            keep = store_first and all(e.get('graph_first') is not None for lane in lanes for e in lane['graphs'].values())
+            self._exec_optimizer_step(lane_grads=[lane['grads'] for lane in lanes], zero_lane_grads=not keep)
             _trace(('step_end', self.global_steps - 1), main)
             return
         # lane 0 owns the step's gradients; add the other lanes' accumulators and losses into it
@@ -632,6 +642,28 @@ class PipelineEngine:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode=_capture_mode()):
             body()
+        graph_first = None
+        if self.store_first and self._fused_step_end() and not self.is_data_parallel:
+            # the lane's first-micro-batch-of-a-step graph: one eager pass with ops.GRAD_STORE on finds the gradient buffers no fused kernel first-touches (autograd's own
+            # accumulation: embedding tables) -- those are zeroed at the head of the graph, everything else is stored into by its first gradient kernel
+            _ops.GRAD_STORE = {}
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                body()
+            cur.wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            spans = sorted(_ops.GRAD_STORE.items())
+            def covered(g):
+                a, b = g.data_ptr(), g.data_ptr() + g.numel() * g.element_size()
+                return any(lo <= a and b <= lo + n for lo, n in spans)
+            unhandled = [p.grad for p in params if p.grad is not None and not covered(p.grad)]
+            _ops.GRAD_STORE = {}
+            graph_first = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_first, pool=graph.pool(), capture_error_mode=_capture_mode()):
+                if unhandled:
+                    torch._foreach_zero_(unhandled)
+                body()
+            _ops.GRAD_STORE = None
         # undo the warm-up's side effects: gradient buffers stay allocated (persistent, addresses baked into the
         # graph); parameters that receive no gradient keep grad = None like the eager path.
         for p in params:
@@ -645,7 +677,7 @@ class PipelineEngine:
         lane['loss'].copy_(saved_loss)
         _ops.WS_LANE = None
         _offload.POOL_TAG = None
-        return {'graph': graph, 'inputs': static_in, 'labels': static_lab}
+        return {'graph': graph, 'graph_first': graph_first, 'inputs': static_in, 'labels': static_lab}
 
     # ------------------------------------------------------------------------- hipGraph path, pipeline stages
     def _stage_slot(self, buffer_id, inputs, labels):
@@ -982,7 +1014,7 @@ class PipelineEngine:
         return (self.optimizer is not None and hasattr(self.optimizer, 'fused_update') and self.clip_grad_fn is None
                 and self.grad_kernels is None and self.device.type == 'cuda')
 
-    def _fused_optimizer_step(self, lane_grads):
+    def _fused_optimizer_step(self, lane_grads, zero_lane_grads=True):
         """Norm of the (lane-summed) gradients -> the reference's cross-stage / DP composition of the scalar
         (utils/patches.py:222-239) -> one pass: clip, AdamW, zero."""
         opt = self.optimizer
@@ -1000,11 +1032,11 @@ class PipelineEngine:
                 dist.all_reduce(norm, group=self.grid.get_data_parallel_group())
                 sumsq = norm * norm
             self._last_grad_norm = sumsq.sqrt()
-        opt.fused_update(lane_grads, sumsq, self._gradient_clipping, zero_grads=persistent)
+        opt.fused_update(lane_grads, sumsq, self._gradient_clipping, zero_grads=persistent and zero_lane_grads)
 
-    def _exec_optimizer_step(self, lr_kwargs=None, lane_grads=None):
+    def _exec_optimizer_step(self, lr_kwargs=None, lane_grads=None, zero_lane_grads=True):
         if self._fused_step_end():
-            self._fused_optimizer_step(lane_grads)
+            self._fused_optimizer_step(lane_grads, zero_lane_grads)
             if not (self.use_graph or self.use_stage_graphs):
                 for p in self.module.parameters():
                     p.grad = None

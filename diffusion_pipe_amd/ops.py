@@ -196,6 +196,34 @@ def gemm_group(problems):
 FUSE_GRAD_ACCUM = False
 
 
+# "First micro-batch of a step" graphs (engine config `store_first_micro_batch`): while the engine captures a lane's FIRST-micro-batch graph it sets GRAD_STORE to
+# a dict; the first fused gradient write into a persistent .grad buffer inside that graph then STORES (accumulate flag off) and registers the buffer, later writes to
+# the same buffer in the same micro-batch accumulate as usual.  The step end then has no accumulators to zero (16 GB of writes per SDXL step on four lanes).
+GRAD_STORE = None
+
+
+def _acc(tgt):
+    """accumulate flag of a fused gradient write into `tgt` (a persistent .grad buffer, a packed view of several, or None = fresh output)"""
+    if tgt is None:
+        return False
+    if GRAD_STORE is None:
+        return True
+    key = tgt.data_ptr()
+    if key in GRAD_STORE:
+        return True
+    GRAD_STORE[key] = tgt.numel() * tgt.element_size()
+    return False
+
+
+def _acc_all(fused, *tgts):
+    """accumulate flag shared by the parameter gradients one kernel writes together (gamma + beta): every buffer is registered, the first one's answer is returned
+    (they are written by the same set of kernels, so they are first-touched together)"""
+    if not fused:
+        return 0
+    flags = [_acc(t) for t in tgts if t is not None]
+    return int(flags[0]) if flags else 0
+
+
 def _accum_target(param):
     if not FUSE_GRAD_ACCUM or param is None or not param.is_leaf:
         return None
@@ -265,17 +293,17 @@ class _LinearFn(Function):
                 tw, tb = _accum_target(weight), _accum_target(bias)
                 w_out = tw if tw is not None else torch.empty(weight.shape, device=weight.device, dtype=weight.dtype)
                 b_out = tb if tb is not None else torch.empty(bias.shape, device=bias.device, dtype=bias.dtype)
-                if mm(gy2, x2, True, False, out=w_out, accumulate=tw is not None, colsum=b_out, colsum_accumulate=tb is not None) is not None:
+                if mm(gy2, x2, True, False, out=w_out, accumulate=_acc(tw), colsum=b_out, colsum_accumulate=_acc(tb)) is not None:
                     return (None if tw is not None else w_out), (None if tb is not None else b_out)
             if need_w:
                 tgt = _accum_target(weight)
                 if tgt is not None:
-                    mm(gy2, x2, True, False, out=tgt, accumulate=True)      # dW += dy^T . x  (fused accumulation)
+                    mm(gy2, x2, True, False, out=tgt, accumulate=_acc(tgt))      # dW += dy^T . x  (fused accumulation)
                 else:
                     gw_ = mm(gy2, x2, True, False)                            # dW = dy^T . x
             if need_b:
                 tgt = _accum_target(bias)
-                gb_ = column_sum(gy2, out=tgt)
+                gb_ = column_sum(gy2, out=tgt, accumulate=_acc(tgt))
                 if tgt is not None:
                     gb_ = None
             return gw_, gb_
@@ -291,7 +319,7 @@ class _LinearFn(Function):
             b_out = (tb if tb is not None else torch.empty(bias.shape, device=bias.device, dtype=bias.dtype)) if fuse_b else None
             gx2 = torch.empty((gy2.shape[0], weight.shape[1]), device=gy2.device, dtype=gy2.dtype)
             done = gemm_group([mm_problem(gy2, weight, False, False, out=gx2),
-                               mm_problem(gy2, x2, True, False, out=w_out, accumulate=tw is not None, colsum=b_out, colsum_accumulate=tb is not None)])
+                               mm_problem(gy2, x2, True, False, out=w_out, accumulate=_acc(tw), colsum=b_out, colsum_accumulate=_acc(tb))])
             if done is not None:
                 gx = gx2.view(ctx.x_shape)
                 if gx.dtype != ctx.x_dtype:
@@ -301,7 +329,7 @@ class _LinearFn(Function):
                     gb = None if tb is not None else b_out
                 elif need_b:
                     tgt = _accum_target(bias)
-                    gb = column_sum(gy2, out=tgt)
+                    gb = column_sum(gy2, out=tgt, accumulate=_acc(tgt))
                     if tgt is not None:
                         gb = None
                 gres = gy if (ctx.has_res and ctx.needs_input_grad[3]) else None
@@ -412,7 +440,7 @@ class _FusedLinearFn(Function):
                 if all(g is not None for g in grads):
                     gv = packed_view(grads)
                     if gv is not None:
-                        return 'accum', gv, True
+                        return 'accum', gv, _acc(gv)
             return 'return', None, False
 
         def finish(group, mode, gcat):
@@ -457,7 +485,7 @@ class _FusedLinearFn(Function):
         if wmode != 'skip' and gwcat is None:
             gwcat = mm(gy2, x2, True, False, out=w_out, accumulate=w_acc)
         if bmode != 'skip' and gbcat is None:
-            gbcat = column_sum(gy2, out=b_out if b_acc else None)      # `out` given = accumulate into it
+            gbcat = column_sum(gy2, out=b_out if bmode == 'accum' else None, accumulate=b_acc)
         gws = finish(ws, wmode, gwcat)
         gbs = finish(bs, bmode, gbcat) if ctx.has_bias else [None] * n
         return (gx, None, *gws, *gbs)
@@ -501,14 +529,14 @@ def split_columns(x, widths):
     return _SplitColumnsFn.apply(x, tuple(int(w) for w in widths))
 
 
-def column_sum(x2, out=None, out_dtype=None):
+def column_sum(x2, out=None, out_dtype=None, accumulate=None):
     """sum over the rows of a [rows, cols] matrix (fp32 accumulate, two-stage slab reduction).  `out` given: out += sum
-    (the fused gradient-accumulation form); else a new [cols] tensor in x2's dtype (or out_dtype)."""
+    (the fused gradient-accumulation form; `accumulate=False`: out = sum); else a new [cols] tensor in x2's dtype (or out_dtype)."""
     require_cuda(x2, out)
     if x2.stride(1) != 1:
         x2 = x2.contiguous()
     rows, cols = x2.shape
-    accumulate = out is not None
+    accumulate = (out is not None) if accumulate is None else bool(accumulate and out is not None)
     if out is None:
         out = torch.empty(cols, device=x2.device, dtype=out_dtype or x2.dtype)
     ws = torch.empty(lib().dpipe_norm_slabs(rows) * cols, device=x2.device, dtype=torch.float32)
@@ -660,7 +688,7 @@ class _RMSNormFn(Function):
             ws = torch.empty(lib().dpipe_norm_slabs(rows) * cols, device=x2.device, dtype=torch.float32)
         wd = dtype_code(weight.dtype) if weight is not None else dtype_code(x2.dtype)
         check(lib().dpipe_rmsnorm_bwd(ptr(x2), ptr(weight), ptr(gy2), ptr(rstd), ptr(gx), ptr(dw), ptr(ws), rows, cols,
-                                      dtype_code(x2.dtype), wd, int(fused), stream()), 'rmsnorm_bwd')
+                                      dtype_code(x2.dtype), wd, _acc_all(fused, dw), stream()), 'rmsnorm_bwd')
         return gx.view(ctx.shape), (None if fused else dw), None
 
 
@@ -737,7 +765,7 @@ class _LNModFn(Function):
             ws = torch.empty(lib().dpipe_lnmod_workspace_floats(rows, cols, rows_per_mod), device=x2.device, dtype=torch.float32)
         check(lib().dpipe_lnmod_bwd(ptr(x2), ptr(gy2), ptr(gamma), ptr(beta), ptr(sc), ptr(mean), ptr(rstd), ptr(gx),
                                     ptr(dgamma), ptr(dbeta), ptr(dscale), ptr(dshift), ptr(ws), rows, cols, rows_per_mod,
-                                    dtype_code(x2.dtype), wdt, mdt, int(fused), ptr(gadd), stream()), 'lnmod_bwd')
+                                    dtype_code(x2.dtype), wdt, mdt, _acc_all(fused, dgamma, dbeta), ptr(gadd), stream()), 'lnmod_bwd')
         g_scale = dscale.view(scale_shape) if scale_shape is not None else None
         g_shift = dshift.view(shift_shape) if shift_shape is not None else None
         if fused:
@@ -800,7 +828,7 @@ class _GroupNormFn(Function):
                 dbeta = torch.empty_like(bias) if bias is not None else None
         ws = torch.empty(lib().dpipe_groupnorm_workspace_floats(N, C, HW, G), device=xc.device, dtype=torch.float32)
         check(lib().dpipe_groupnorm_bwd(ptr(xc), ptr(gy), ptr(weight), ptr(bias), ptr(mean), ptr(rstd), ptr(gx), ptr(dgamma), ptr(dbeta), ptr(ws),
-                                        N, C, HW, G, ACT[act], dtype_code(xc.dtype), wdt, int(fused), ptr(gadd), stream()), 'groupnorm_bwd')
+                                        N, C, HW, G, ACT[act], dtype_code(xc.dtype), wdt, _acc_all(fused, dgamma, dbeta), ptr(gadd), stream()), 'groupnorm_bwd')
         if fused:
             dgamma = dbeta = None
         return gx, None, dgamma, dbeta, None, None, None
@@ -872,7 +900,7 @@ class _GroupNormNHWCFn(Function):
                 dbeta = torch.empty_like(bias) if bias is not None else None
         ws = torch.empty(lib().dpipe_groupnorm_nhwc_workspace_floats(N, C, H * W, G), device=xv.device, dtype=torch.float32)
         check(lib().dpipe_groupnorm_nhwc_bwd(ptr(xv), ptr(gyv), ptr(weight), ptr(bias), ptr(mean), ptr(rstd), ptr(gx), ptr(dgamma), ptr(dbeta), ptr(ws),
-                                             N, C, H * W, G, ACT[act], dtype_code(xv.dtype), wdt, int(fused), ptr(gadd), stream()), 'groupnorm_nhwc_bwd')
+                                             N, C, H * W, G, ACT[act], dtype_code(xv.dtype), wdt, _acc_all(fused, dgamma, dbeta), ptr(gadd), stream()), 'groupnorm_nhwc_bwd')
         if fused:
             dgamma = dbeta = None
         return gx.permute(0, 3, 1, 2), None, dgamma, dbeta, None, None, None
@@ -992,17 +1020,17 @@ class _Conv2dNHWCFn(Function):
                                                int(acc), int(bacc), int(out_f32), ptr(ws), ws.numel(), CONV_TILE_HINTS[2], stream()), 'conv2d_wgrad')
             if f32:
                 xh, xl = _split_bf16(xv)
-                wgrad(gh, xh, tw is not None, None, 0, 1)
+                wgrad(gh, xh, _acc(tw), None, 0, 1)
                 wgrad(gl, xh, True, None, 0, 1)
                 wgrad(gh, xl, True, None, 0, 1)
                 if need_b:                       # the fused bias gradient is written in the operand dtype: fp32 takes the column-sum kernel
                     g2 = gyv.reshape(-1, Cout)
                     if tb is not None:
-                        column_sum(g2, out=tb)
+                        column_sum(g2, out=tb, accumulate=_acc(tb))
                     else:
                         b_out = column_sum(g2)
             else:
-                wgrad(gyv, xv, tw is not None, b_out, tb is not None, 0)
+                wgrad(gyv, xv, _acc(tw), b_out, _acc(tb), 0)
             gw = None if tw is not None else w_out
             gb = None if (tb is not None or not need_b) else b_out
         gres = gy if (has_res and ctx.needs_input_grad[3]) else None
@@ -1070,8 +1098,9 @@ class _RMSNormRopeFn(Function):
         B, S, H, D = x.shape
         if x.stride(3) != 1 or x.stride(2) != D or x.stride(1) < H * D or (B > 1 and x.stride(0) != S * x.stride(1)) or x.stride(1) % 8:
             x = x.contiguous()
-        if cos.dtype != torch.float32 or cos.dim() != 2 or cos.shape[1] != D // 2 or cos.shape[0] < token_offset + S or sin.shape != cos.shape:
-            raise DpipeHipError(f'rms_norm_rope: tables must be fp32 [>= {token_offset + S}, {D // 2}]; got {tuple(cos.shape)} {cos.dtype}')
+        rt = S if rope_tokens is None else min(int(rope_tokens), S)
+        if cos.dtype != torch.float32 or cos.dim() != 2 or cos.shape[1] != D // 2 or cos.shape[0] < token_offset + rt or sin.shape != cos.shape:
+            raise DpipeHipError(f'rms_norm_rope: tables must be fp32 [>= {token_offset + rt}, {D // 2}] (the rotated tokens); got {tuple(cos.shape)} {cos.dtype}')
         cos, sin = _contig(cos), _contig(sin)
         groups, cols = (H, D) if per_head else (1, H * D)
         if weight is not None and weight.numel() != cols:
@@ -1080,7 +1109,6 @@ class _RMSNormRopeFn(Function):
         y = torch.empty((B, S, H, D), device=x.device, dtype=x.dtype)
         rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
         wd = dtype_code(weight.dtype) if weight is not None else dtype_code(x.dtype)
-        rt = S if rope_tokens is None else int(rope_tokens)
         check(lib().dpipe_rmsnorm_rope_fwd(ptr(x), ptr(weight), ptr(cos), ptr(sin), ptr(y), ptr(rstd), rows, cols, D, S, groups, int(token_offset), rt, x.stride(1), float(eps),
                                            dtype_code(x.dtype), wd, stream()), 'rmsnorm_rope_fwd')
         ctx.save_for_backward(x, weight, rstd, cos, sin)
@@ -1103,7 +1131,7 @@ class _RMSNormRopeFn(Function):
             ws = torch.empty(lib().dpipe_norm_slabs(rows) * cols, device=gy.device, dtype=torch.float32)
         wd = dtype_code(weight.dtype) if weight is not None else dtype_code(x.dtype)
         check(lib().dpipe_rmsnorm_rope_bwd(ptr(x), ptr(weight), ptr(gy), ptr(rstd), ptr(cos), ptr(sin), ptr(gx), ptr(dw), ptr(ws), rows, cols, D, S, groups, tok_off, rt,
-                                           x.stride(1), dtype_code(x.dtype), wd, int(fused), stream()), 'rmsnorm_rope_bwd')
+                                           x.stride(1), dtype_code(x.dtype), wd, _acc_all(fused, dw), stream()), 'rmsnorm_rope_bwd')
         return gx, (None if fused else dw), None, None, None, None, None, None
 
 
