@@ -47,7 +47,9 @@ const char* dpipe_last_error(void);
                                       chip: the engine selects it for >= 2 micro-batch lanes; 3: 64^2 on the 3-deep 48 KiB ring; 1: both */
 #define DPIPE_OPT_GEMM_BIG_TILES 6  /* fewest 128^2 output tiles for which the plain GEMM takes the 128^2 tile instead of 64^2 (default 128 = best isolated launch; lower under
                                       concurrent lanes, where CU time per FLOP is what counts: the engine's choice) */
-#define DPIPE_OPTION_COUNT 7
+#define DPIPE_OPT_ATTN_BIG_WG 7     /* fewest 256-query-row workgroups for which flash attention's forward / dQ kernels take their 8-wave 256-row form (default 192 = the
+                                      isolated-launch rule; lower under concurrent lanes: half the K / V bytes per FLOP) */
+#define DPIPE_OPTION_COUNT 8
 int dpipe_set_option(int option, int value);
 int dpipe_get_option(int option);    /* the effective explicit / environment value, -1 if neither is set */
 /* Number of compute units / name of device `dev`; used by the host to sanity-check it runs on gfx950. */
