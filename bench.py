@@ -527,7 +527,8 @@ def main():
         dist.all_reduce(rl)
     g_flops, g_ms, launches, g_bytes = rl.tolist()
     traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'r3_pmc_gemm_traffic.json')      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this launch list
+    tpath = next((q for q in (os.path.join(ROOT, 'profiles', f) for f in ('r4_pmc_gemm_traffic.json', 'r3_pmc_gemm_traffic.json')) if os.path.isfile(q)), '')
+    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this launch list: tools/run_gpu.sh pmc; the newest committed pass wins)
     if os.path.isfile(tpath):
         with open(tpath) as f:
             traffic = json.load(f)

@@ -14,7 +14,7 @@ from tools import gemm_replay  # noqa: E402
 def total(path, counter):
     kb, n = 0.0, 0
     for row in csv.DictReader(open(path)):
-        if 'gemm_pipe_kernel' in row['kernel'] or 'gemm_kernel' in row['kernel']:
+        if 'gemm_pipe_kernel' in row['kernel'] or 'gemm_pipe_group_kernel' in row['kernel'] or 'gemm_kernel' in row['kernel']:
             if row['counter'] == counter:
                 kb += float(row['sum_value']); n += int(row['dispatches'])
     return kb, n
@@ -26,11 +26,13 @@ def main():
     wkb, wn = total(write_csv, 'WRITE_SIZE')
     uniq = json.load(open(trace))
     rd = wr = n = 0
-    for d in uniq:
-        c = max(1, d['count'] // int(div))
-        dd = {k: (tuple(v) if isinstance(v, list) else v) for k, v in d.items()}
-        r, w = gemm_replay.algorithmic_bytes(dd)
-        rd += r * c; wr += w * c; n += c
+    for g in gemm_replay.groups(uniq):                 # a grouped call (dpipe_gemm_group) is `grp_l` launches (normally one) for all its problems
+        c = max(1, g[0]['count'] // int(div))
+        for d in g:
+            dd = {k: (tuple(v) if isinstance(v, list) else v) for k, v in d.items()}
+            r, w = gemm_replay.algorithmic_bytes(dd)
+            rd += r * c; wr += w * c
+        n += c * ((g[0].get('grp_l') or len(g)) if len(g) > 1 else 1)
     fetch_b, write_b = 2.0 * fkb * 1024, wkb * 1024
     res = {'source': f'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over tools/gemm_replay.py {trace} {div} (one micro-batch of the step\'s GEMM launch list, '
                      'eager, HBM-cold operands); FETCH_SIZE (KB) doubled per MI355X_MICROARCH.md, WRITE_SIZE (KB) as reported',

@@ -28,6 +28,13 @@ PY
       ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $O/${TAG}_prof -o $name -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $O/${TAG}_prof_${name}.log 2>&1 )
       f=$(find $O/${TAG}_prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/${TAG}_${name}_kernel_stats.csv
       rm -rf $O/${TAG}_prof; grep '^{"metric"' $O/${TAG}_prof_${name}.log > $O/${TAG}_prof_${name}.json; echo "prof done: $(wc -l < $O/${TAG}_${name}_kernel_stats.csv) kernel rows";;
+    pmc)      # pmc:<trace.json>:<div>  -- FETCH_SIZE / WRITE_SIZE passes (separate, counters only) over the step's GEMM launch list under the engine's lane policy
+      IFS=':' read -r trace div <<< "$rest"
+      for c in FETCH_SIZE WRITE_SIZE; do
+        ( cd /tmp && export TMPDIR=/tmp DPIPE_GEMM_SHALLOW=2 DPIPE_GEMM_BIG_TILES=16 && timeout 600 rocprofv3 --pmc $c -f csv -d $O/${TAG}_pmc_$c -o pmc -- python $R/tools/gemm_replay.py $R/$trace $div > $O/${TAG}_pmc_$c.log 2>&1 )
+        python tools/pmc_agg.py $O/${TAG}_pmc_$c $O/${TAG}_pmc_gemm_step_$c.csv >> $O/${TAG}_pmc_$c.log 2>&1; rm -rf $O/${TAG}_pmc_$c
+      done
+      python tools/pmc_traffic_json.py $O/${TAG}_pmc_gemm_step_FETCH_SIZE.csv $O/${TAG}_pmc_gemm_step_WRITE_SIZE.csv $trace $div $O/${TAG}_pmc_gemm_traffic.json | tail -1;;
     cmd)
       bash -c "$rest" > $O/${TAG}_cmd.log 2>&1; echo "cmd rc=$? $(tail -2 $O/${TAG}_cmd.log)";;
   esac
