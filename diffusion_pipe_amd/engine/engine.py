@@ -632,9 +632,15 @@ class PipelineEngine:
         cur = torch.cuda.current_stream(self.device)
         side = torch.cuda.Stream(self.device)
         side.wait_stream(cur)
+        want_first = self.store_first and self._fused_step_end() and not self.is_data_parallel
+        spans = None
         with torch.cuda.stream(side):
-            for _ in range(2):                      # eager warm-up (library autotuning, allocator pools, .grad buffers)
-                body()
+            body()                                  # eager warm-up (library autotuning, allocator pools, .grad buffers) ...
+            if want_first:                          # ... the second pass in store mode: it finds the gradient buffers a fused kernel first-touches (ops.GRAD_STORE).  Done
+                _ops.GRAD_STORE = {}                # here, before this lane's graph pool exists, so it adds nothing to the memory peak (Wan-14B: 98 GB per eager pass)
+            body()
+            if want_first:
+                spans, _ops.GRAD_STORE = sorted(_ops.GRAD_STORE.items()), None
         cur.wait_stream(side)
         torch.cuda.synchronize(self.device)
         if self.flat_grads:                          # the warm-up created this lane's .grad buffers: re-home them into one flat arena per dtype before
@@ -643,16 +649,9 @@ class PipelineEngine:
         with torch.cuda.graph(graph, capture_error_mode=_capture_mode()):
             body()
         graph_first = None
-        if self.store_first and self._fused_step_end() and not self.is_data_parallel:
-            # the lane's first-micro-batch-of-a-step graph: one eager pass with ops.GRAD_STORE on finds the gradient buffers no fused kernel first-touches (autograd's own
-            # accumulation: embedding tables) -- those are zeroed at the head of the graph, everything else is stored into by its first gradient kernel
-            _ops.GRAD_STORE = {}
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                body()
-            cur.wait_stream(side)
-            torch.cuda.synchronize(self.device)
-            spans = sorted(_ops.GRAD_STORE.items())
+        if want_first:
+            # the lane's first-micro-batch-of-a-step graph: the gradient buffers no fused kernel first-touches (autograd's own accumulation: embedding tables; found by
+            # the store-mode warm-up pass above) are zeroed at the head of the graph, everything else is stored into by its first gradient kernel
             def covered(g):
                 a, b = g.data_ptr(), g.data_ptr() + g.numel() * g.element_size()
                 return any(lo <= a and b <= lo + n for lo, n in spans)
