@@ -68,11 +68,13 @@ def test_full_size_sdxl_four_lanes_twelve_unsynchronised_steps_match_one_lane(gp
 # bf16 path loss 1.7e-4, norm 2.2e-4, per-parameter max abs_sum 0.083, l2 0.092, proj 0.84 -- all three on the self-attention to_q / to_k weights of the
 # deepest transformer blocks, whose gradient is a small difference of bf16-rounded softmax terms (dS = P o (dP - delta)); bounds ~3 x observed.
 FP32_BOUNDS = dict(loss=1e-3, norm=1e-3, abs_sum=5e-3, signed_sum=5e-3, proj=1.5e-2, l2=5e-3, agg=5e-3)
-BF16_BOUNDS = dict(loss=6e-4, norm=2e-3, abs_sum=0.25, signed_sum=1.5e-2, proj=2.5, l2=0.28, agg=0.026)
+# Round 4 (the attention backward's delta reads the forward's fp32 O, csrc/attention.hip): bf16 per-parameter max abs_sum 0.0062, signed_sum 0.0050, proj 0.084, l2 0.0058
+# (two runs: 0.0055 / 0.0043 / 0.079 / 0.0059), q99 0.0035 / 0.0021 / 0.058 / 0.0037, aggregate 0.0093 -- the to_q / to_k outliers of round 3 (0.083 / 0.84 sigma) are gone.
+BF16_BOUNDS = dict(loss=6e-4, norm=2e-3, abs_sum=0.02, signed_sum=1.5e-2, proj=0.3, l2=0.02, agg=0.026)
 # 99th percentile over the parameters (observed bf16: abs_sum 0.035, signed_sum 0.002, proj 0.18, l2 0.032; fp32: 2.6e-6, 1.4e-6, 3.6e-5, 2.7e-6; whole-gradient L2 error
 # estimate 0.0086 / 5.3e-6)
 FP32_Q99 = dict(abs_sum=1e-4, signed_sum=1e-4, proj=1e-3, l2=1e-4)
-BF16_Q99 = dict(abs_sum=0.1, signed_sum=6e-3, proj=0.55, l2=0.1)
+BF16_Q99 = dict(abs_sum=0.012, signed_sum=6e-3, proj=0.18, l2=0.012)
 
 
 def _compare_grad_rows(rows, meta, bounds, what, q99=None):
