@@ -248,3 +248,40 @@ def test_lane_streams_are_probed_to_run_concurrently(gpu):
     four = min(spin([main] + picked) for _ in range(3))
     assert four < 1.6 * one, (one, four)
     del junk
+
+
+def test_first_micro_batch_stores_graphs_equal_the_zeroing_path_bit_for_bit(gpu):
+    """`store_first_micro_batch` (engine default on the fused-step-end path): each lane's first micro-batch of a step replays a graph whose gradient kernels STORE into
+    the lane's accumulators (ops.GRAD_STORE), later micro-batches accumulate, and the fused step end zeroes nothing.  bf16(0 + x) = bf16(x), so the trajectory --
+    losses, gradient norms and every parameter after four AdamW steps, GAS 6 on 2 lanes (three micro-batches per lane and step) -- is IDENTICAL to the path that
+    zeroes the accumulators at the step end and accumulates everywhere."""
+    from diffusion_pipe_amd import optim
+    from diffusion_pipe_amd.data import split_batch
+    from diffusion_pipe_amd.engine import ManualPipelineModule, initialize
+    from diffusion_pipe_amd.workloads import sdxl
+    cfg = sdxl.tiny_config()
+    gas = 6
+
+    def run(store_first):
+        work = sdxl.SDXLWorkload(cfg, dtype=torch.bfloat16, seed=2, device=gpu)
+        module = ManualPipelineModule(layers=work.to_layers(), num_stages=1, partition_method='parameters', loss_fn=work.get_loss_fn(), dynamic_shape=True)
+        engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 1, 'gradient_accumulation_steps': gas, 'gradient_clipping': 1.0,
+                                                             'hip_graph': True, 'graph_lanes': 2, 'store_first_micro_batch': store_first}, device=gpu)
+        work.train_config = {'optimizer': {'type': 'adamw', 'lr': 1e-3, 'betas': [0.9, 0.99], 'weight_decay': 0.01, 'eps': 1e-8}}
+        engine._configure_optimizer(optim.make_optimizer_factory(work.train_config, work, global_batch_size=gas), [p for p in module.parameters() if p.requires_grad])
+        assert engine._fused_step_end()
+        res = []
+        for step in range(4):
+            torch.manual_seed(100 + step)
+            feats, label = work.prepare_inputs(sdxl.synthetic_batch(cfg, batch_size=gas, latent_hw=32, seed=10 + step))
+            loss = engine.train_batch(iter(split_batch((feats, label), gas)))
+            res.append((loss.item(), engine.get_global_grad_norm().item()))
+        has_first = all(e.get('graph_first') is not None for lane in engine._lanes for e in lane['graphs'].values())
+        params = {f'{k}.{n}': p.detach().clone() for k, m in work.modules().items() for n, p in m.named_parameters()}
+        return res, params, has_first
+
+    on, p_on, first_on = run(True)
+    off, p_off, first_off = run(False)
+    assert first_on and not first_off
+    assert on == off, (on, off)
+    assert all(torch.equal(p_on[k], p_off[k]) for k in p_on)
