@@ -232,3 +232,24 @@ def test_adamw8bit_small_tensor_path_matches_the_oracle(kahan):
                 gs = st['shift'].float().numpy().reshape(-1)
                 assert (np.abs(gs - sr['shift']) <= 2.0 ** -7 * (np.abs(sr['shift']) + np.abs(r)) + 1e-12).all()
                 sr['shift'] = gs.copy()
+
+
+def test_grad_store_first_touch_protocol():
+    """ops._acc / ops.GRAD_STORE (first-micro-batch-stores graphs): outside store mode a fused gradient write into a persistent buffer accumulates; inside, the FIRST
+    write to a buffer stores and registers its byte span, later writes to the same buffer accumulate; a fresh output (no buffer) never accumulates."""
+    from diffusion_pipe_amd import ops
+    a, b = torch.zeros(8), torch.zeros(4, 4)
+    assert ops.GRAD_STORE is None
+    assert ops._acc(a) is True and ops._acc(None) is False
+    ops.GRAD_STORE = {}
+    try:
+        assert ops._acc(a) is False and ops._acc(a) is True and ops._acc(a) is True          # first touch stores, then accumulates
+        assert ops._acc(b) is False and ops._acc(None) is False
+        assert ops.GRAD_STORE == {a.data_ptr(): 32, b.data_ptr(): 64}
+        assert ops._acc_all(True, a, b) == 1 and ops._acc_all(False, a) == 0
+        c, d = torch.zeros(3), torch.zeros(3)
+        assert ops._acc_all(True, c, d) == 0 and ops._acc_all(True, c, d) == 1               # gamma + beta written together: both registered, one answer
+        assert c.data_ptr() in ops.GRAD_STORE and d.data_ptr() in ops.GRAD_STORE
+    finally:
+        ops.GRAD_STORE = None
+    assert ops._acc(b) is True
