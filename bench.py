@@ -9,8 +9,8 @@ A "step" is one optimizer step of the hot path (`engine.train_batch`): GAS micro
 (latents [1,4,128,128], 75-token prompts through both trained CLIP text encoders) through the SDXL UNet split over N
 pipeline stages, 1F1B schedule, fused loss, gradient clip, AdamW -- full fine-tune, bf16, synthetic data resident in HBM before the
 timed region, random weights.  GAS = 8 * N so per-GPU work is constant as N grows ("weak"); at N = 1 the eight micro-batches of a step
-run on four concurrent hipGraph lanes (rounds 1 - 2 and most of round 3: GAS 6 on three lanes; `--lanes 3 --gas 6` reproduces that line).  The host waits for the end of step n - 1 before it enqueues step n (engine
-`max_steps_in_flight = 1`).  Prints ONE JSON line on rank 0.
+run on four concurrent hipGraph lanes (rounds 1 - 2 and most of round 3: GAS 6 on three lanes; `--lanes 3 --gas 6` reproduces that line).  The host waits for the end of step n - 2 before it enqueues step n (engine
+`max_steps_in_flight`: 2 on the probed lane path since round 4's 2 000-step soak, 1 under pp > 1).  Prints ONE JSON line on rank 0.
 
 Extra objects: `roofline` (dominant kernel = the hand-written MFMA GEMM: the step's recorded GEMM launch list replayed as one
 GEMM-only hipGraph between HIP events, `traffic` from the committed rocprofv3 --pmc passes over the same list) and `cpu_baseline`
@@ -108,7 +108,8 @@ def parse():
                     help='TEST ONLY: all ranks share cuda:0, collectives over gloo, stage payloads staged through the host')
     ap.add_argument('--torch-adamw', action='store_true', help='A/B switch: torch.optim.AdamW(fused=True) + separate lane-sum / clip / zero passes')
     ap.add_argument('--parallel-wgrad', action='store_true', help='fork wgrad onto a side stream (A/B switch; measured slower)')
-    ap.add_argument('--steps-in-flight', type=int, default=1, help='bound on the host run-ahead in optimizer steps (0 = unbounded; see engine.max_steps_in_flight)')
+    ap.add_argument('--steps-in-flight', type=int, default=-1, help='bound on the host run-ahead in optimizer steps (0 = unbounded; default: the engine\'s own choice, '
+                    '2 on the probed single-stage lane path, else 1 -- see engine.max_steps_in_flight)')
     ap.add_argument('--save-gemm-trace', default='', help='write the step\'s unique GEMM descriptors (+ counts) as JSON (input of tools/gemm_replay.py)')
     ap.add_argument('--sync-each-step', action='store_true', help='bisect switch: device synchronize after every step')
     ap.add_argument('--host-inputs', action='store_true', help='hand every micro-batch over as pageable host tensors (the loader contract); '
@@ -230,7 +231,7 @@ def measure_dit_workload(args, device, world, light=False):
     module = ManualPipelineModule(layers=work.to_layers(), num_stages=1, partition_method=args.partition, loss_fn=work.get_loss_fn(), dynamic_shape=True, **kwargs)
     engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 1, 'gradient_accumulation_steps': gas, 'gradient_clipping': 1.0,
                                                          'steps_per_print': 1 << 30, 'hip_graph': graph, 'graph_lanes': lanes,
-                                                         'max_steps_in_flight': args.steps_in_flight}, device=device)
+                                                         **({'max_steps_in_flight': args.steps_in_flight} if args.steps_in_flight >= 0 else {})}, device=device)
     work.train_config = {'optimizer': {'type': 'adamw', 'lr': 1e-5, 'betas': [0.9, 0.99], 'weight_decay': 0.01, 'eps': 1e-8}}
     engine._configure_optimizer(optim.make_optimizer_factory(work.train_config, work, global_batch_size=gas), [p for p in module.parameters() if p.requires_grad])
     torch.manual_seed(1234)
@@ -412,7 +413,7 @@ def main():
                                                          'gradient_clipping': 1.0, 'steps_per_print': 1 << 30, 'hip_graph': not args.no_graph,
                                                          'parallel_wgrad': args.parallel_wgrad, 'p2p_via_host': args.test_single_device, 'graph_lanes': args.lanes, 'p2p_backend': args.p2p,
                                                          'stage_fwd_streams': int(os.environ.get('DPIPE_STAGE_FWD_STREAMS', '1' if args.test_single_device else '2')),
-                                                         'max_steps_in_flight': args.steps_in_flight}, device=device)
+                                                         **({'max_steps_in_flight': args.steps_in_flight} if args.steps_in_flight >= 0 else {})}, device=device)
     params = [p for p in module.parameters() if p.requires_grad]
 
     # the reference's optimizer construction (train.py:650-815): AdamW on the raw bf16 parameters, per-component groups split into
@@ -554,7 +555,7 @@ def main():
                        'rccl_ranks': comm_ranks if comm_backend == 'nccl' else 0, 'process_group': comm_backend,
                        'graph_packet_capture': os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '1') != '0',
                        'activation_checkpointing': bool(args.activation_checkpointing), 'partition': module.parts, 'hip_graph': bool(engine.use_graph or engine.use_stage_graphs),
-                       'concurrent_micro_batch_lanes': engine.graph_lanes, 'stream_probe': engine.stream_probe},
+                       'concurrent_micro_batch_lanes': engine.graph_lanes, 'stream_probe': engine.stream_probe, 'max_steps_in_flight': engine.max_steps_in_flight},
             'loss': float(loss.item()), 'grad_norm': float(gnorm),
             'step_tflop_algorithmic': round(step_flops / 1e12, 2),
             'mfu_vs_bf16_mfma_peak': round(step_flops / (elapsed / args.steps) / (peak * 1e12 * world), 5),

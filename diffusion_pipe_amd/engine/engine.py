@@ -284,16 +284,16 @@ class PipelineEngine:
             else:
                 _hip.check(_hip.lib().dpipe_set_option(_hip.OPT_GEMM_BIG_TILES, int(want_big)), 'set_option')
             self.gemm_big_tiles = _hip.lib().dpipe_get_option(_hip.OPT_GEMM_BIG_TILES)
-        # Bounded host run-ahead.  train_batch returns a device scalar, so a tight loop could queue optimizer steps without limit.
-        # Before enqueuing step n the host waits for the end of step n - max_steps_in_flight.  Default 1: measured on MI355X /
-        # ROCm 7.2 (round 2, tools/hang_repro.sh, 20+ runs): with hipGraph launches of >= 2 lanes' graphs queued ACROSS a step
-        # boundary the runtime's graph AQL-packet-capture path wedges a lane's queue within 2 - 13 steps (GPU 100 % busy, the
-        # pending launch never retires; independent of AQL queue size, signal pool size, HW queue count, per-lane launch depth,
-        # host- or device-resident inputs, fused or torch step end); every run with the queue drained between steps
-        # (65 / 150 steps) or with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (155 steps, but host-bound: 13.4 vs 15.4 images/s)
-        # finished.  The reference's loop reads the loss with .item() after every train_batch (train.py:918), i.e. it drains
-        # the queue per step as well; inside a step the host still runs up to GAS replays ahead.  0 = unbounded.
-        self.max_steps_in_flight = int(self._config.get('max_steps_in_flight', 1))
+        # Bounded host run-ahead.  train_batch returns a device scalar, so a tight loop could queue optimizer steps without limit: before enqueuing step n the host
+        # waits for the end of step n - max_steps_in_flight (0 = unbounded).  History: in round 2 hipGraph launches of >= 2 lanes queued ACROSS a step boundary wedged a
+        # lane's queue within 2 - 13 steps in 6 of 6 runs (HISTORY.md section 2a) and the default became 1 -- which the reference's loop implies anyway (.item() after
+        # every train_batch, train.py:918).  Round 3 found the cause of the wedge's trigger (lanes sharing one of the 4 hardware queues with the caller's stream: a lane
+        # graph of step n + 1 can sit ahead of step n's step end in the same in-order queue) and removed it (lane 0 on the caller's stream, the others probed onto queues
+        # of their own): 175 steps of run-ahead finished; round 4 soaked 400 + 1 600 more (22.7 images/s against 22.0: the host's launch latency of step n + 1 hides under
+        # step n's tail).  Default since: 2 on the single-stage lane path WHEN every lane stream passed the probe, 1 otherwise (pipeline stages with P2P between graphs,
+        # unprobed lanes, DPIPE_LANE_STREAM_PROBE=0); an explicit config value wins.
+        self._steps_in_flight_explicit = 'max_steps_in_flight' in self._config
+        self.max_steps_in_flight = int(self._config.get('max_steps_in_flight', 2 if (self.use_graph and not self.is_pipe_parallel) else 1))
         self._step_done = []
         if self.device.type == 'cuda' and self._config.get('fuse_grad_accumulation', True):
             from .. import ops as _ops
@@ -506,6 +506,10 @@ class PipelineEngine:
         main = torch.cuda.current_stream(self.device)
         if len(self._lanes) < K and self._lane_streams is None:
             self._lane_streams = concurrent_streams(self.device, self.graph_lanes - 1, main, report=self._probe_report) if os.environ.get('DPIPE_LANE_STREAM_PROBE', '1') != '0' else []
+            probed = os.environ.get('DPIPE_LANE_STREAM_PROBE', '1') != '0' and os.environ.get('DPIPE_LANE0_MAIN', '1') != '0' and \
+                (self.graph_lanes == 1 or (self._probe_report.get('unprobed_fallback', 1) == 0 and self._probe_report.get('error') is None))
+            if not probed and not self._steps_in_flight_explicit:
+                self.max_steps_in_flight = 1          # lanes that may share a hardware queue with the caller's stream: no run-ahead across the step boundary
         while len(self._lanes) < K:
             # Lane 0 replays on the CALLER'S stream, lanes 1 .. K - 1 on streams of their own (probed to be concurrent: concurrent_streams).  The runtime multiplexes HIP streams onto 4 hardware queues
             # (GPU_MAX_HW_QUEUES = 8 / 16 changes nothing measurable): with K lane streams NEXT TO an idle caller's stream, the 4th lane shares a queue with
