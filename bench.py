@@ -106,6 +106,8 @@ def parse():
     ap.add_argument('--lanes', type=int, default=0, help='concurrent micro-batch lanes of the single-stage hipGraph path (default: 4 for sdxl, 2 for flux / wan, 1 for hv)')
     ap.add_argument('--test-single-device', action='store_true',
                     help='TEST ONLY: all ranks share cuda:0, collectives over gloo, stage payloads staged through the host')
+    ap.add_argument('--pipe-lanes', type=int, default=int(os.environ.get('DPIPE_PIPE_LANES', '1')),
+                    help='pp > 1: interleaved 1F1B instruction streams per stage (engine `pipe_lanes`; default 1 = the reference\'s single stream)')
     ap.add_argument('--torch-adamw', action='store_true', help='A/B switch: torch.optim.AdamW(fused=True) + separate lane-sum / clip / zero passes')
     ap.add_argument('--parallel-wgrad', action='store_true', help='fork wgrad onto a side stream (A/B switch; measured slower)')
     ap.add_argument('--steps-in-flight', type=int, default=-1, help='bound on the host run-ahead in optimizer steps (0 = unbounded; default: the engine\'s own choice, '
@@ -413,6 +415,7 @@ def main():
                                                          'gradient_clipping': 1.0, 'steps_per_print': 1 << 30, 'hip_graph': not args.no_graph,
                                                          'parallel_wgrad': args.parallel_wgrad, 'p2p_via_host': args.test_single_device, 'graph_lanes': args.lanes, 'p2p_backend': args.p2p,
                                                          'stage_fwd_streams': int(os.environ.get('DPIPE_STAGE_FWD_STREAMS', '1' if args.test_single_device else '2')),
+                                                         'pipe_lanes': args.pipe_lanes,
                                                          **({'max_steps_in_flight': args.steps_in_flight} if args.steps_in_flight >= 0 else {})}, device=device)
     params = [p for p in module.parameters() if p.requires_grad]
 
@@ -555,7 +558,8 @@ def main():
                        'rccl_ranks': comm_ranks if comm_backend == 'nccl' else 0, 'process_group': comm_backend,
                        'graph_packet_capture': os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '1') != '0',
                        'activation_checkpointing': bool(args.activation_checkpointing), 'partition': module.parts, 'hip_graph': bool(engine.use_graph or engine.use_stage_graphs),
-                       'concurrent_micro_batch_lanes': engine.graph_lanes, 'stream_probe': engine.stream_probe, 'max_steps_in_flight': engine.max_steps_in_flight},
+                       'concurrent_micro_batch_lanes': engine.graph_lanes, 'pipe_lanes': engine.pipe_lanes, 'stream_probe': engine.stream_probe,
+                       'max_steps_in_flight': engine.max_steps_in_flight},
             'loss': float(loss.item()), 'grad_norm': float(gnorm),
             'step_tflop_algorithmic': round(step_flops / 1e12, 2),
             'mfu_vs_bf16_mfma_peak': round(step_flops / (elapsed / args.steps) / (peak * 1e12 * world), 5),

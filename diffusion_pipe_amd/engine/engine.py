@@ -236,7 +236,16 @@ class PipelineEngine:
         # consecutive micro-batches alternate between two streams (pipe buffer id parity), so in the fill phase and whenever the previous stage runs
         # ahead TWO forward graphs and one backward graph share the GPU -- the concurrency the three micro-batch lanes give the single-stage path.
         # Backwards stay on ONE stream: their wgrad kernels accumulate into the same .grad buffers.
-        n_fwd = max(1, int(self._config.get('stage_fwd_streams', 2))) if (self.use_stage_graphs and self.stage_id != self.num_stages - 1) else 1
+        # Pipeline lanes (`pipe_lanes` = L, default 1): L independent 1F1B instruction streams per stage, micro-batch i of a step on lane i % L, interleaved tick by
+        # tick (_train_batch_pipe_lanes).  1F1B lets a stage hold (stages - stage id) micro-batches, of which ONE forward and ONE backward can overlap -- the last
+        # stage of a deep pipeline computes one micro-batch at a time, on a chip that needs four to be full (the single-stage lane path).  With L lanes every stage
+        # has L micro-batches in the same phase at once, each lane on a HIP stream of its own with its own slots, gradient accumulators and loss scalar; the
+        # lanes' accumulators meet in the (fused) step end exactly like the single-stage lanes'.  Same sums as one 1F1B stream up to fp summation order.
+        self.pipe_lanes = max(1, int(self._config.get('pipe_lanes', 1))) if self.is_pipe_parallel else 1
+        self._pipe_lane_state = []
+        self._pipe_lane_streams = []
+        self._cur_pipe_lane = None
+        n_fwd = max(1, int(self._config.get('stage_fwd_streams', 2))) if (self.use_stage_graphs and self.stage_id != self.num_stages - 1 and self.pipe_lanes == 1) else 1
         self._fwd_streams = [torch.cuda.Stream(self.device) for _ in range(n_fwd)] if self.use_stage_graphs else []
         self._fwd_stream = self._fwd_streams[0] if self._fwd_streams else None
         # the backward half runs on the caller's stream unless `stage_bwd_own_stream` is set: with two forward streams and the link's communication stream a
@@ -262,7 +271,7 @@ class PipelineEngine:
         if self.device.type == 'cuda':
             from .. import hip as _hip
             want = self._config.get('gemm_shallow_rings', 'auto')
-            concurrent = self.graph_lanes if self.use_graph else ((len(self._fwd_streams) + 1) if self.use_stage_graphs else 1)
+            concurrent = self.graph_lanes if self.use_graph else ((self.pipe_lanes if self.pipe_lanes > 1 else len(self._fwd_streams) + 1) if self.use_stage_graphs else 1)
             if want == 'auto':
                 global _SHALLOW_SET_BY_ENGINE
                 if _SHALLOW_SET_BY_ENGINE or _hip.lib().dpipe_get_option(_hip.OPT_GEMM_SHALLOW) < 0:      # never override the user's explicit choice
@@ -304,9 +313,13 @@ class PipelineEngine:
             # forward streams + the link's communication stream next to the caller's stream (backward half): streams probed to sit on distinct hardware
             # queues -- chosen BEFORE the link is built, so its self-test and every later transfer run on the stream it keeps
             want_comm = not self._config.get('p2p_via_host', False)
-            sts = concurrent_streams(self.device, len(self._fwd_streams) + (1 if want_comm else 0), report=self._probe_report)
-            self._fwd_streams = sts[:len(self._fwd_streams)]
-            self._fwd_stream = self._fwd_streams[0]
+            if self.pipe_lanes > 1:        # lane 0 runs on the caller's stream, lanes 1 .. L - 1 and the link's stream on probed queues of their own (4 hardware queues: L <= 3 next to a link)
+                sts = concurrent_streams(self.device, self.pipe_lanes - 1 + (1 if want_comm else 0), report=self._probe_report)
+                self._pipe_lane_streams = sts[:self.pipe_lanes - 1]
+            else:
+                sts = concurrent_streams(self.device, len(self._fwd_streams) + (1 if want_comm else 0), report=self._probe_report)
+                self._fwd_streams = sts[:len(self._fwd_streams)]
+                self._fwd_stream = self._fwd_streams[0]
             if want_comm:
                 comm_stream = sts[-1]
         self.link = self._make_link(comm_stream) if self.is_pipe_parallel else None
@@ -421,11 +434,14 @@ class PipelineEngine:
                 if self._g_total_loss is None:
                     self._g_total_loss = torch.zeros((), device=self.device, dtype=torch.float32)
                 self._g_total_loss.zero_()
-            schedule = sched.TrainSchedule(micro_batches=self.micro_batches, stages=self.num_stages, stage_id=self.stage_id)
-            self._reserve_buffers(schedule.num_pipe_buffers())
-            self._exec_schedule(schedule)
-            if self.use_stage_graphs and self.is_last_stage():
-                self.total_loss = self._g_total_loss
+            if self.pipe_lanes > 1 and self.micro_batches > 1:
+                self._train_batch_pipe_lanes()
+            else:
+                schedule = sched.TrainSchedule(micro_batches=self.micro_batches, stages=self.num_stages, stage_id=self.stage_id)
+                self._reserve_buffers(schedule.num_pipe_buffers())
+                self._exec_schedule(schedule)
+                if self.use_stage_graphs and self.is_last_stage():
+                    self.total_loss = self._g_total_loss
         self.agg_train_loss = self._aggregate_total_loss(self.micro_batches)
         self.global_samples += self.train_batch_size_
         if self.link is not None:
@@ -495,6 +511,91 @@ class PipelineEngine:
             if self._bwd_stream is not None:
                 main.wait_stream(self._bwd_stream)
             self._streams_forked = False
+
+    # ------------------------------------------------------------------------------------------- pipeline lanes
+    _STEP_END_INSTR = (sched.ReduceTiedGrads, sched.ReduceGrads, sched.OptimizerStep)
+
+    def _pipe_lanes_for(self, n):
+        while len(self._pipe_lane_state) < n:
+            li = len(self._pipe_lane_state)
+            stream = None                                   # lane 0 (and every lane of the eager path): the caller's stream
+            if self.use_stage_graphs and li > 0:
+                stream = self._pipe_lane_streams[li - 1] if li - 1 < len(self._pipe_lane_streams) else torch.cuda.Stream(self.device)
+            self._pipe_lane_state.append({'id': li, 'stream': stream, 'grads': {}, 'arena': {}, 'slot_of_buffer': {},
+                                          'loss': torch.zeros((), device=self.device, dtype=torch.float32) if self.use_stage_graphs else None})
+        return self._pipe_lane_state[:n]
+
+    def _train_batch_pipe_lanes(self):
+        """One optimizer step as L interleaved 1F1B streams (`pipe_lanes`).  Lane l runs the reference's patched TrainSchedule (utils/patches.py:113-160) over the
+        micro-batches l, l + L, l + 2 L, ... of the step; tick t of every lane is issued before tick t + 1 of any.  Why this cannot deadlock and keeps the wire order:
+        the schedule's step -> micro-batch arithmetic does not depend on the micro-batch count, so tick t means the same thing on every lane, and every send of the
+        schedule is received by the neighbour in the SAME tick -- neighbours therefore post (tick, lane, instruction)-ordered sequences that are complementary
+        message by message, which is all an in-order link (RCCL on one communication stream, gloo's FIFO per pair) needs.  The end stages pull the whole step from
+        the iterator first (as train.py:164-173 pre-pulls a step), so (features, label) pair i reaches the same lane on the first and on the last stage.
+        ReduceTiedGrads / ReduceGrads / OptimizerStep close every lane's stream and run ONCE, after all lanes drained."""
+        import contextlib
+        counts = sched.lane_micro_batches(self.micro_batches, self.pipe_lanes)
+        L = len(counts)
+        lanes = self._pipe_lanes_for(L)
+        graphed = self.use_stage_graphs
+        main = torch.cuda.current_stream(self.device) if graphed else None
+        ends = self.is_first_stage() or self.is_last_stage()
+        batches = [self._next_batch() for _ in range(self.micro_batches)] if ends else None
+        schedules = []
+        for lane, n in zip(lanes, counts):
+            schedule = sched.TrainSchedule(micro_batches=n, stages=self.num_stages, stage_id=self.stage_id)
+            lane['pipe_buffers'] = {k: [None] * schedule.num_pipe_buffers() for k in ('inputs', 'labels', 'outputs', 'grads', 'slot')}
+            lane['data_iter'] = iter(batches[lane['id']::L]) if ends else None
+            if graphed:
+                lane['loss'].zero_()
+                if lane['stream'] is not None:
+                    lane['stream'].wait_stream(main)          # previous optimizer step / data preparation
+            schedules.append(schedule)
+        own_slots = self._slot_of_buffer
+        try:
+            for li, cmds in sched.interleave_lanes(schedules):
+                lane = lanes[li]
+                self.pipe_buffers, self._slot_of_buffer, self._data_iter, self._cur_pipe_lane = lane['pipe_buffers'], lane['slot_of_buffer'], lane['data_iter'], lane
+                with (torch.cuda.stream(lane['stream']) if lane['stream'] is not None else contextlib.nullcontext()):
+                    for cmd in cmds:
+                        if isinstance(cmd, self._STEP_END_INSTR):
+                            continue
+                        handler = self._INSTRUCTION_MAP.get(type(cmd))
+                        if handler is None:
+                            raise RuntimeError(f'{self.__class__.__name__} does not understand instruction {cmd!r}')
+                        handler(self, **cmd.kwargs)
+        finally:
+            self._slot_of_buffer, self._cur_pipe_lane, self._data_iter = own_slots, None, None
+            for lane in lanes:
+                lane['data_iter'] = None
+        if not graphed:          # eager path: every lane ran on the caller's stream and autograd accumulated into the one set of .grad tensors
+            self._exec_reduce_tied_grads()
+            self._exec_reduce_grads()
+            self._exec_optimizer_step()
+            return
+        for lane in lanes[1:]:
+            main.wait_stream(lane['stream'])
+        base = lanes[0]
+        for p in self.module.parameters():
+            p.grad = base['grads'].get(id(p))
+        if self.is_last_stage():
+            for lane in lanes[1:]:
+                base['loss'].add_(lane['loss'])
+            self.total_loss = base['loss']
+        self._exec_reduce_tied_grads()
+        if self._fused_step_end() and not self.is_data_parallel:
+            self._exec_optimizer_step(lane_grads=[lane['grads'] for lane in lanes])      # lanes summed, clipped, applied and zeroed in one pass
+            return
+        for lane in lanes[1:]:
+            ks = [k for k in lane['grads'] if k in base['grads']]
+            if ks:
+                torch._foreach_add_([base['grads'][k] for k in ks], [lane['grads'][k] for k in ks])
+        self._stage_arena = base['arena']
+        self._exec_reduce_grads()
+        self._exec_optimizer_step()                              # zeroes lane 0's buffers (p.grad)
+        for lane in lanes[1:]:
+            if lane['grads']:
+                torch._foreach_zero_(list(lane['grads'].values()))
 
     # ------------------------------------------------------------------------------------------- hipGraph path
     def _train_batch_graphed(self):
@@ -686,7 +787,8 @@ class PipelineEngine:
     def _stage_slot(self, buffer_id, inputs, labels):
         ins = tuple(_as_list(inputs))
         labs = tuple(_as_list(labels)) if labels is not None else ()
-        sig = (buffer_id, torch.is_tensor(inputs), torch.is_tensor(labels), tuple((tuple(t.shape), t.dtype) for t in ins + labs))
+        lane_id = self._cur_pipe_lane['id'] if self._cur_pipe_lane is not None else -1
+        sig = (lane_id, buffer_id, torch.is_tensor(inputs), torch.is_tensor(labels), tuple((tuple(t.shape), t.dtype) for t in ins + labs))
         slot = self._stage_slots.get(sig)
         if slot is None:
             self._capturing_buffer = buffer_id
@@ -704,8 +806,13 @@ class PipelineEngine:
         from . import offload as _offload
         _offload.POOL_TAG = ('slot', len(self._stage_slots))      # host-offloaded checkpoints: pinned buffers private to this slot's graphs
         params = [p for p in self.module.parameters() if p.requires_grad]
+        lane = self._cur_pipe_lane                                # pipeline lanes: this lane's accumulators become the parameters' .grad, its scalar collects the loss
+        if lane is not None:
+            for p in params:
+                p.grad = lane['grads'].get(id(p))
+        loss_acc = lane['loss'] if lane is not None else self._g_total_loss
         saved_grads = {id(p): p.grad.clone() for p in params if p.grad is not None}     # micro-batches already accumulated
-        saved_loss = self._g_total_loss.clone()
+        saved_loss = loss_acc.clone()
 
         def make_inputs():
             xs = tuple(t.detach().clone() for t in ins)
@@ -719,7 +826,7 @@ class PipelineEngine:
             out = self.module(xs[0] if single_in else xs)
             if last:
                 loss = self.module.loss_fn(out, static_lab[0] if single_lab else static_lab) if self.module.loss_fn is not None else out
-                self._g_total_loss.add_(loss.detach().to(torch.float32))
+                loss_acc.add_(loss.detach().to(torch.float32))
                 return loss
             return out
 
@@ -744,16 +851,21 @@ class PipelineEngine:
         cur.wait_stream(side)
         torch.cuda.synchronize(self.device)
         if self.flat_grads:
-            self._stage_arena = flatten_grads(params, self._stage_arena)
+            if lane is not None:
+                lane['arena'] = flatten_grads(params, lane['arena'])
+            else:
+                self._stage_arena = flatten_grads(params, self._stage_arena)
 
         from .. import ops as _ops
         static_in = make_inputs()
         fwd_graph, bwd_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        _ops.WS_LANE = ('stage-fwd', self._capturing_buffer % max(1, len(self._fwd_streams)))   # forward graphs of the two forward streams and the backward graph replay at the same time:
-        with torch.cuda.graph(fwd_graph, capture_error_mode=_capture_mode()):   # they must not share split-K ticket counters / slabs
+        # forward graphs of the two forward streams and the backward graph replay at the same time: they must not share split-K ticket counters / slabs.
+        # A pipeline lane replays its forward and backward graphs on ONE stream: one workspace per lane.
+        _ops.WS_LANE = ('pipe-lane', lane['id']) if lane is not None else ('stage-fwd', self._capturing_buffer % max(1, len(self._fwd_streams)))
+        with torch.cuda.graph(fwd_graph, capture_error_mode=_capture_mode()):
             out = forward(static_in)
         static_gout = None if last else grads_like(out)
-        _ops.WS_LANE = 'stage-bwd'
+        _ops.WS_LANE = ('pipe-lane', lane['id']) if lane is not None else 'stage-bwd'
         with torch.cuda.graph(bwd_graph, pool=fwd_graph.pool(), capture_error_mode=_capture_mode()):
             backward(out, static_gout)
         _ops.WS_LANE = None
@@ -764,7 +876,11 @@ class PipelineEngine:
                     p.grad.copy_(saved_grads[id(p)])
                 else:
                     p.grad.zero_()
-        self._g_total_loss.copy_(saved_loss)
+        loss_acc.copy_(saved_loss)
+        if lane is not None:
+            for p in params:
+                if p.grad is not None:
+                    lane['grads'][id(p)] = p.grad                # persistent: their addresses are baked into this lane's backward graphs
         _offload.POOL_TAG = None
         return {'fwd': fwd_graph, 'bwd': bwd_graph, 'inputs': static_in, 'labels': static_lab, 'out': out, 'gout': static_gout,
                 'single_in': single_in, 'fwd_done': None, 'bwd_done': None}

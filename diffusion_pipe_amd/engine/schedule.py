@@ -229,3 +229,28 @@ class TrainSchedule(PipeSchedule):
 
     def _odd_step_backward_id(self, step_id):
         return int(((step_id - 1) // 2) - self.stages + 1 + self.stage_id // 2)
+
+
+# ---- pipeline lanes: L independent TrainSchedules per stage, interleaved tick by tick (engine `pipe_lanes`)
+def lane_micro_batches(micro_batches, lanes):
+    """micro-batch i of a step runs on lane i % lanes: -> how many micro-batches each lane's schedule covers (lanes clipped to the micro-batch count)"""
+    lanes = max(1, min(lanes, micro_batches))
+    return [micro_batches // lanes + (1 if lane < micro_batches % lanes else 0) for lane in range(lanes)]
+
+
+def interleave_lanes(schedules):
+    """(lane, instructions) in issue order: tick t of every lane that still has one, lane 0 first, before tick t + 1 of any.
+
+    TrainSchedule's step -> micro-batch arithmetic does not depend on the micro-batch count and every SendActivation / SendGrad it emits is received by the
+    neighbour stage in the SAME tick, so two neighbours that both issue in this order post complementary sequences message by message: the property an
+    in-order link needs (tests/test_intlogic.py simulates it under blocking receives and under full rendezvous)."""
+    runs = [iter(s) for s in schedules]
+    alive = list(range(len(runs)))
+    while alive:
+        for lane in list(alive):
+            try:
+                cmds = next(runs[lane])
+            except StopIteration:
+                alive.remove(lane)
+                continue
+            yield lane, cmds

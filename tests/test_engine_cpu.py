@@ -77,13 +77,13 @@ def oracle_run(steps, gas, clip, batches_per_step, n_mid=4):
     return losses, [p.detach().clone() for p in params]
 
 
-def engine_run(steps, gas, clip, batches_for_rank, num_stages, partition_method='uniform', split=None, scope='global', n_mid=4):
+def engine_run(steps, gas, clip, batches_for_rank, num_stages, partition_method='uniform', split=None, scope='global', n_mid=4, extra=None):
     layers = make_layers(n_mid=n_mid)
     all_params = [p for l in layers for p in l.parameters()]
     module = ManualPipelineModule(layers=layers, num_stages=num_stages, partition_method=partition_method,
                                   manual_partition_split=split, loss_fn=oracle.default_loss_fn(), dynamic_shape=True)
     engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 2, 'gradient_accumulation_steps': gas,
-                                                         'gradient_clipping': clip, 'clip_norm_scope': scope}, device='cpu')
+                                                         'gradient_clipping': clip, 'clip_norm_scope': scope, **(extra or {})}, device='cpu')
     engine.grad_kernels = oracle.TorchGradKernels
     local = [p for p in module.parameters() if p.requires_grad]
     engine._configure_optimizer(lambda ps: torch.optim.AdamW(ps, lr=1e-2), local)
@@ -133,6 +133,18 @@ def _worker(rank, world, port, mode, outdir):
         elif mode == 'pp8':          # the BASELINE pp = 8 depth: 10 layers over 8 stages, 16 micro-batches
             batches = [make_batches(16, 2, 100 + s) for s in range(steps)]
             losses, params, engine = engine_run(steps, 16, 0.5, batches, num_stages=8, partition_method='uniform', scope='global', n_mid=8)
+        elif mode == 'pp2_lanes2':   # two interleaved 1F1B streams per stage (pipe_lanes): micro-batches {0, 2} on lane 0, {1, 3} on lane 1
+            batches = [make_batches(gas, 2, 100 + s) for s in range(steps)]
+            losses, params, engine = engine_run(steps, gas, 0.5, batches, num_stages=2, partition_method='manual', split=[2], scope='global', extra={'pipe_lanes': 2})
+            assert engine.pipe_lanes == 2 and len(engine._pipe_lane_state) == 2
+        elif mode == 'pp4_lanes3':   # 7 micro-batches over 3 lanes (3 + 2 + 2: lanes of unequal length drain at different ticks), 4 stages
+            batches = [make_batches(7, 2, 100 + s) for s in range(steps)]
+            losses, params, engine = engine_run(steps, 7, 0.5, batches, num_stages=4, partition_method='uniform', scope='global', extra={'pipe_lanes': 3})
+            assert len(engine._pipe_lane_state) == 3
+        elif mode == 'pp2dp2_lanes2':
+            d = engine_dp_rank(rank)
+            batches = [make_batches(2 * gas, 2, 100 + s)[d * gas:(d + 1) * gas] for s in range(steps)]
+            losses, params, engine = engine_run(steps, gas, 0.5, batches, num_stages=2, partition_method='manual', split=[3], scope='global', extra={'pipe_lanes': 2})
         elif mode == 'pp2dp2':       # 2 stages x 2 replicas: replica d sees its own micro-batches, gradients averaged over the DP group
             d = engine_dp_rank(rank)
             batches = [make_batches(2 * gas, 2, 100 + s)[d * gas:(d + 1) * gas] for s in range(steps)]
@@ -449,3 +461,41 @@ def test_engine_pp8_gloo_matches_oracle():
     got = _stage_params(res, [2] * 10)
     for a, b in zip(got, want_p):
         assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+
+
+def test_engine_pp2_two_pipeline_lanes_gloo_match_oracle():
+    """`pipe_lanes: 2`: two interleaved 1F1B instruction streams per stage reproduce the sequential oracle step (same sums, other summation order)."""
+    steps, gas = 2, 4
+    batches = [make_batches(gas, 2, 100 + s) for s in range(steps)]
+    want_l, want_p = oracle_run(steps, gas, 0.5, batches)
+    res = _spawn('pp2_lanes2')
+    for r in res:
+        assert r['losses'] == pytest.approx(want_l, rel=1e-6)
+    got = _stage_params(res, [2] * 6)
+    for a, b in zip(got, want_p):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+def test_engine_pp4_three_uneven_pipeline_lanes_gloo_match_oracle():
+    steps, gas = 2, 7
+    batches = [make_batches(gas, 2, 100 + s) for s in range(steps)]
+    want_l, want_p = oracle_run(steps, gas, 0.5, batches)
+    res = _spawn('pp4_lanes3', world=4)
+    for r in res:
+        assert r['losses'] == pytest.approx(want_l, rel=1e-6)
+    got = _stage_params(res, [2] * 6)
+    for a, b in zip(got, want_p):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+def test_engine_pp2_dp2_two_pipeline_lanes_gloo_match_oracle():
+    steps, gas = 2, 4
+    batches = [make_batches(2 * gas, 2, 100 + s) for s in range(steps)]
+    want_l, want_p = oracle_run(steps, 2 * gas, 0.5, batches)
+    res = _spawn('pp2dp2_lanes2', world=4)
+    for r in res:
+        assert r['losses'] == pytest.approx(want_l, rel=1e-5)
+    for replica in (0, 1):
+        got = _stage_params([res[replica], res[2 + replica]], [2] * 6)
+        for a, b in zip(got, want_p):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)

@@ -35,6 +35,7 @@ gas = total_mb // world if dp_mode else total_mb
 work = sdxl.SDXLWorkload(cfg, model_config={'min_snr_gamma': 5.0}, dtype=torch.bfloat16, seed=2, device=dev)
 module = ManualPipelineModule(layers=work.to_layers(), num_stages=1 if dp_mode else world, partition_method='parameters', loss_fn=work.get_loss_fn(), dynamic_shape=True)
 extra = {'graph_lanes': 2, 'flat_grads': True, 'dp_bucket_bytes': 1 << 20} if (dp_mode or (len(sys.argv) > 4 and sys.argv[4] == 'flat')) else {}
+extra.update(json.loads(os.environ.get('DPIPE_TEST_EXTRA_CONFIG', '{}')))
 engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 1, 'gradient_accumulation_steps': gas, 'gradient_clipping': 1.0,
                                                      'hip_graph': mode != 'eager', 'p2p_via_host': True, 'clip_norm_scope': 'global', **extra}, device=dev)
 params = [p for p in module.parameters() if p.requires_grad]
@@ -57,7 +58,8 @@ for step in range(3):
     loss = engine.train_batch(iter(micro) if need else None)
     res.append((loss.item(), engine.get_global_grad_norm().item()))
 if rank == 0:
-    json.dump({'mode': mode, 'world': world, 'res': res, 'graphs': engine.use_graph, 'stage_graphs': engine.use_stage_graphs}, open(out_path, 'w'))
+    json.dump({'mode': mode, 'world': world, 'res': res, 'graphs': engine.use_graph, 'stage_graphs': engine.use_stage_graphs,
+               'pipe_lanes': len(engine._pipe_lane_state), 'lane_slots': len(engine._stage_slots)}, open(out_path, 'w'))
 if world > 1:
     dist.barrier()
     dist.destroy_process_group()
@@ -70,11 +72,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(tmp_path, mode, world, opt='sgd', par='pp', total_mb=4):
+def _run(tmp_path, mode, world, opt='sgd', par='pp', total_mb=4, extra=None):
     script = tmp_path / 'worker.py'
     script.write_text(WORKER)
-    out = tmp_path / f'{mode}_{world}_{opt}_{par}.json'
-    env = dict(os.environ, DPIPE_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = tmp_path / f'{mode}_{world}_{opt}_{par}_{total_mb}_{"_".join(f"{k}{v}" for k, v in (extra or {}).items())}.json'
+    env = dict(os.environ, DPIPE_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0', DPIPE_TEST_EXTRA_CONFIG=json.dumps(extra or {}))
     if world == 1:
         env.update(RANK='0', WORLD_SIZE='1')
         cmd = [sys.executable, str(script), mode, str(out), opt, par, str(total_mb)]
@@ -111,6 +113,20 @@ def test_pp2_fused_step_end_matches_single_stage_engine(gpu, tmp_path):
     for (l0, n0), (l1, n1), (l2, n2) in zip(base['res'], eager2['res'], graph2['res']):
         assert abs(l1 - l0) / abs(l0) < 2e-2 and abs(l2 - l0) / abs(l0) < 2e-2, (l0, l1, l2)
         assert abs(n1 - n0) / n0 < 3e-2 and abs(n2 - n0) / n0 < 3e-2, (n0, n1, n2)
+
+
+def test_pp2_two_pipeline_lanes_on_stage_graphs_match_one_instruction_stream(gpu, tmp_path):
+    """`pipe_lanes: 2` on the per-stage hipGraph path: every stage runs two interleaved 1F1B streams (micro-batches {0, 2, 4} and {1, 3, 5}), each lane on a stream,
+    slots, gradient accumulators and loss scalar of its own; the lanes meet in the fused step end (AdamW) or are summed into lane 0 (SGD).  Same kernels on the same
+    data as the single instruction stream, other summation order across micro-batches."""
+    for opt in ('fused_adamw', 'sgd'):
+        one = _run(tmp_path, 'graph', 2, opt, total_mb=6)
+        two = _run(tmp_path, 'graph', 2, opt, total_mb=6, extra={'pipe_lanes': 2})
+        assert two['stage_graphs'] and two['pipe_lanes'] == 2 and one['pipe_lanes'] == 0
+        assert abs(two['res'][0][0] - one['res'][0][0]) / abs(one['res'][0][0]) < 2e-3, (one['res'], two['res'])
+        assert abs(two['res'][0][1] - one['res'][0][1]) / one['res'][0][1] < 2e-3, (one['res'], two['res'])
+        for (l0, n0), (l1, n1) in zip(one['res'], two['res']):
+            assert abs(l1 - l0) / abs(l0) < 2e-2 and abs(n1 - n0) / n0 < 3e-2, (one['res'], two['res'])
 
 
 @pytest.mark.parametrize('opt', ['sgd', 'fused_adamw'])

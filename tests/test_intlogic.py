@@ -175,3 +175,83 @@ def test_partition_methods_on_real_layer_lists():
     assert parts(fm, 'type:transformerwrapper', 2)[0] == ol.partition_balanced([1 if 'TransformerWrapper' in type(l).__name__ else 0 for l in fl], 2)
     with pytest.raises(NotImplementedError):
         parts(m, 'profile', 4)
+
+
+# ---- pipeline lanes (engine `pipe_lanes`): wire order and deadlock freedom of L interleaved 1F1B streams per stage
+def _lane_wire_ops(stages, micro_batches, lanes):
+    """per stage: the P2P operations in ISSUE order, as (op, peer stage, message id); a message id names (kind, lane, micro-batch of that lane)"""
+    from diffusion_pipe_amd.engine import schedule as sched
+    counts = sched.lane_micro_batches(micro_batches, lanes)
+    seqs = []
+    for stage in range(stages):
+        scheds = [sched.TrainSchedule(micro_batches=n, stages=stages, stage_id=stage) for n in counts]
+        held = [dict() for _ in counts]                  # lane -> {pipe buffer id: micro-batch it holds}
+        loaded = [0] * len(counts)
+        ops = []
+        for lane, cmds in sched.interleave_lanes(scheds):
+            for cmd in cmds:
+                b = cmd.kwargs.get('buffer_id')
+                if isinstance(cmd, sched.RecvActivation):
+                    held[lane][b] = loaded[lane]; loaded[lane] += 1
+                    ops.append(('recv', stage - 1, ('act', lane, held[lane][b])))
+                elif isinstance(cmd, sched.LoadMicroBatch) and stage == 0:
+                    held[lane][b] = loaded[lane]; loaded[lane] += 1
+                elif isinstance(cmd, sched.SendActivation):
+                    ops.append(('send', stage + 1, ('act', lane, held[lane][b])))
+                elif isinstance(cmd, sched.RecvGrad):
+                    ops.append(('recv', stage + 1, ('grad', lane, held[lane][b])))
+                elif isinstance(cmd, sched.SendGrad):
+                    ops.append(('send', stage - 1, ('grad', lane, held[lane][b])))
+        seqs.append(ops)
+    return counts, seqs
+
+
+@pytest.mark.parametrize('stages,micro_batches,lanes', [(2, 4, 2), (2, 16, 3), (3, 7, 2), (4, 7, 3), (4, 32, 3), (8, 64, 3), (8, 9, 4), (5, 5, 5), (2, 3, 8)])
+def test_interleaved_pipeline_lanes_keep_the_wire_order_and_cannot_deadlock(stages, micro_batches, lanes):
+    counts, seqs = _lane_wire_ops(stages, micro_batches, lanes)
+    assert sum(counts) == micro_batches
+    # (1) per ordered pair of neighbours the k-th message sent is the k-th message the receiver expects (in-order links carry no tags)
+    for a in range(stages):
+        for b in (a - 1, a + 1):
+            if 0 <= b < stages:
+                sent = [m for op, peer, m in seqs[a] if op == 'send' and peer == b]
+                expected = [m for op, peer, m in seqs[b] if op == 'recv' and peer == a]
+                assert sent == expected, (a, b)
+    # every micro-batch of every lane crosses every boundary once in each direction
+    for a in range(stages - 1):
+        acts = {m for op, peer, m in seqs[a] if op == 'send' and peer == a + 1}
+        assert acts == {('act', lane, k) for lane, n in enumerate(counts) for k in range(n)}
+    # (2) blocking receives + asynchronous sends (gloo / the host-staged link): runs to completion
+    pos = [0] * stages
+    chan = {}
+    progressed = True
+    while progressed:
+        progressed = False
+        for s in range(stages):
+            while pos[s] < len(seqs[s]):
+                op, peer, m = seqs[s][pos[s]]
+                if op == 'send':
+                    chan.setdefault((s, peer), []).append(m)
+                elif chan.get((peer, s)):
+                    assert chan[(peer, s)].pop(0) == m
+                else:
+                    break
+                pos[s] += 1
+                progressed = True
+    assert all(pos[s] == len(seqs[s]) for s in range(stages)), 'deadlock under blocking receives'
+    # (3) full rendezvous, every stage strictly in issue order (the most conservative model of RCCL send / recv kernels on ONE communication stream: an
+    # operation retires only together with its partner, and nothing of a stage overtakes it): runs to completion
+    pos = [0] * stages
+    progressed = True
+    while progressed:
+        progressed = False
+        for s in range(stages):
+            if pos[s] == len(seqs[s]):
+                continue
+            op, peer, m = seqs[s][pos[s]]
+            if pos[peer] < len(seqs[peer]):
+                pop, ppeer, pm = seqs[peer][pos[peer]]
+                if ppeer == s and pm == m and pop != op:
+                    pos[s] += 1; pos[peer] += 1
+                    progressed = True
+    assert all(pos[s] == len(seqs[s]) for s in range(stages)), 'deadlock under rendezvous in issue order'
