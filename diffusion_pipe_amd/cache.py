@@ -10,7 +10,10 @@
 feeds the engine: shards are mmap'd once (no seek + read + copy per item), and `CachePrefetcher` reads ahead on worker
 threads into PINNED host memory and issues the host-to-device copies on a side HIP stream, so `train_batch` never waits on
 unpickling or on a pageable-memory copy.  (The reference reads with one DataLoader worker and pageable tensors,
-utils/dataset.py:1303,1367.)
+utils/dataset.py:1303,1367.)  Measured on the host (tools/cache_feed_rate.py, profiles/r4w_cache_feed_rate_host.json; page cache warm, shuffled order): SDXL-shaped
+items 2 100 / s through the reference's reader, this reader and the prefetcher alike (torch.load-bound; the step takes 22.6 / s); Wan-shaped 6.6 MB items 390 / s
+(reference: seek + read + BytesIO) vs 730 / s (storages read out of the mapping); the prefetcher's threads cost throughput (330 - 530 / s: the GIL) and buy what they are
+for -- a consumer that computes 5 ms per item spends 6 % of that time waiting in next().
 """
 import io
 import mmap
@@ -56,6 +59,8 @@ class _View(io.RawIOBase):
 
 
 class Cache:
+    SMALL_ITEM_BYTES = 1 << 20
+
     def __init__(self, path, fingerprint, shard_size_gb=1, verbose=False):
         self.path = Path(path)
         self.fingerprint = fingerprint
@@ -99,7 +104,12 @@ class Cache:
             with open(self.path / f'shard_{shard_id}.bin', 'rb') as f:
                 f.seek(offset)
                 return torch.load(io.BytesIO(f.read(size)), map_location='cpu')
-        view = _View(self._shard_map(shard_id), offset, size)
+        m = self._shard_map(shard_id)
+        if size <= self.SMALL_ITEM_BYTES:
+            # small items (SDXL: 0.27 MB of latents + token ids): torch.load issues dozens of tiny reads per blob, each a Python-level readinto on the view --
+            # one C-speed copy of the blob out of the mapping into a BytesIO is cheaper (measured on the host, tools/cache_feed_rate.py)
+            return torch.load(io.BytesIO(m[offset:offset + size]), map_location='cpu')
+        view = _View(m, offset, size)                     # large items (text-encoder states, video latents): storages are read straight out of the mapping
         try:
             return torch.load(view, map_location='cpu')
         finally:
