@@ -73,5 +73,19 @@ int main() {
         printf("{\"case\": \"cu mask: first %d bits\", \"distinct_xcc_se_sh_cu\": %d}\n", bits, distinct);
         CHECK(hipStreamDestroy(ms));
     }
+    // case 3: stride-8 patterns (bit b enabled iff b % 8 in the set) -- the layout diffusion_pipe_amd/hip.py cu_mask_for_xcds assumes: do the workgroups stay on those XCDs?
+    for (unsigned set : {0x03u, 0x0cu, 0x0fu, 0x01u}) {
+        uint32_t mask[8] = {0};
+        for (int b = 0; b < 256; ++b) if ((set >> (b % 8)) & 1) mask[b / 32] |= 1u << (b % 32);
+        hipStream_t ms;
+        hipError_t e = hipExtStreamCreateWithCUMask(&ms, 8, mask);
+        if (e != hipSuccess) { printf("{\"case\": \"stride-8 mask 0x%02x\", \"error\": \"%s\"}\n", set, hipGetErrorString(e)); continue; }
+        probe<<<nwg, 256, 0, ms>>>(d[0], spin);
+        CHECK(hipStreamSynchronize(ms));
+        CHECK(hipMemcpy(h.data(), d[0], nwg * 8, hipMemcpyDeviceToHost));
+        char name[64]; snprintf(name, sizeof name, "stride-8 mask, XCD set 0x%02x", set);
+        report(name, h, nwg);
+        CHECK(hipStreamDestroy(ms));
+    }
     return 0;
 }
