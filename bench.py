@@ -108,6 +108,8 @@ def parse():
                     help='TEST ONLY: all ranks share cuda:0, collectives over gloo, stage payloads staged through the host')
     ap.add_argument('--pipe-lanes', type=int, default=int(os.environ.get('DPIPE_PIPE_LANES', '1')),
                     help='pp > 1: interleaved 1F1B instruction streams per stage (engine `pipe_lanes`; default 1 = the reference\'s single stream)')
+    ap.add_argument('--stack', type=int, default=int(os.environ.get('DPIPE_STACK', '1')),
+                    help='run K consecutive micro-batches of a step as ONE pass of K x the size (engine `stack_micro_batches`; same samples, same gradient; default 1)')
     ap.add_argument('--torch-adamw', action='store_true', help='A/B switch: torch.optim.AdamW(fused=True) + separate lane-sum / clip / zero passes')
     ap.add_argument('--parallel-wgrad', action='store_true', help='fork wgrad onto a side stream (A/B switch; measured slower)')
     ap.add_argument('--steps-in-flight', type=int, default=-1, help='bound on the host run-ahead in optimizer steps (0 = unbounded; default: the engine\'s own choice, '
@@ -415,7 +417,7 @@ def main():
                                                          'gradient_clipping': 1.0, 'steps_per_print': 1 << 30, 'hip_graph': not args.no_graph,
                                                          'parallel_wgrad': args.parallel_wgrad, 'p2p_via_host': args.test_single_device, 'graph_lanes': args.lanes, 'p2p_backend': args.p2p,
                                                          'stage_fwd_streams': int(os.environ.get('DPIPE_STAGE_FWD_STREAMS', '1' if args.test_single_device else '2')),
-                                                         'pipe_lanes': args.pipe_lanes,
+                                                         'pipe_lanes': args.pipe_lanes, 'stack_micro_batches': args.stack,
                                                          **({'max_steps_in_flight': args.steps_in_flight} if args.steps_in_flight >= 0 else {})}, device=device)
     params = [p for p in module.parameters() if p.requires_grad]
 
@@ -524,7 +526,8 @@ def main():
     # CUs idle; this is the dominant kernel's sustained rate in the product's execution mode, reported NEXT TO the single-stream figure, never instead of it)
     rc = None
     if trace and world == 1 and engine.graph_lanes > 1:
-        per_lane = trace[:len(trace) // gas * max(1, gas // engine.graph_lanes)]      # a lane's share of the step: GAS / lanes micro-batches
+        passes = engine.micro_batches                                                     # graph replays per step (GAS, or GAS / K with --stack K)
+        per_lane = trace[:len(trace) // passes * max(1, passes // engine.graph_lanes)]    # a lane's share of the step: passes / lanes replays
         rc = gemm_replay.time_concurrent(per_lane, device, engine.graph_lanes)
     rl = torch.tensor([rt['flops'], rt['ms'], rt['launches'], rt['read_bytes'] + rt['write_bytes']], device=device, dtype=torch.float64)
     if world > 1:
@@ -552,13 +555,14 @@ def main():
             'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': f'SDXL {latent * 8}x{latent * 8} full fine-tune (UNet + both CLIP text encoders trained), micro-batch 1 per stage, '
-                                   f'pp={pp}, GAS={gas}, AdamW, clip 1.0' + (' [tiny test config]' if args.config != 'full' else ''),
+                                   f'pp={pp}, GAS={gas}, AdamW, clip 1.0' + (f', {args.stack} micro-batches stacked per pass' if args.stack > 1 else '') +
+                                   (' [tiny test config]' if args.config != 'full' else ''),
                        'global_batch': images, 'parallelism': f'pp{pp}' + (f' x dp{dp}' if dp > 1 else ''), 'gradient_accumulation_steps': gas,
                        'stage_link': type(engine.link).__name__ if engine.link is not None else None,
                        'rccl_ranks': comm_ranks if comm_backend == 'nccl' else 0, 'process_group': comm_backend,
                        'graph_packet_capture': os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '1') != '0',
                        'activation_checkpointing': bool(args.activation_checkpointing), 'partition': module.parts, 'hip_graph': bool(engine.use_graph or engine.use_stage_graphs),
-                       'concurrent_micro_batch_lanes': engine.graph_lanes, 'pipe_lanes': engine.pipe_lanes, 'stream_probe': engine.stream_probe,
+                       'concurrent_micro_batch_lanes': engine.graph_lanes, 'pipe_lanes': engine.pipe_lanes, 'micro_batch_stacking': engine.stack_micro_batches, 'stream_probe': engine.stream_probe,
                        'max_steps_in_flight': engine.max_steps_in_flight},
             'loss': float(loss.item()), 'grad_norm': float(gnorm),
             'step_tflop_algorithmic': round(step_flops / 1e12, 2),

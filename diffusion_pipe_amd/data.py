@@ -28,6 +28,43 @@ def split_batch(batch, pieces):
     return [(tuple(fp[i] for fp in f_parts), tuple(lp[i] for lp in l_parts)) for i in range(pieces)]
 
 
+def stack_micro_batches(micro_batches, k):
+    """The inverse of `split_batch` over runs of k consecutive micro-batches: [(features, label)] * n -> [(features, label)] * ceil(n / k), every tensor
+    concatenated along dim 0 (the axis split_batch cut, utils/dataset.py:1273-1281); the empty tensors that stand for None stay one empty tensor.  Used by the
+    engine option `stack_micro_batches`: k micro-batches of size b run as ONE pass of size k b -- same samples, same per-sample loss terms, a k-times larger M in
+    every GEMM (one read of the weights per k samples)."""
+    def cat(ts):
+        if not torch.is_tensor(ts[0]):
+            return ts[0]
+        if all(t.numel() == 0 for t in ts):
+            return ts[0]
+        return torch.cat(list(ts), 0)
+
+    def merge(parts):
+        if torch.is_tensor(parts[0]) or not isinstance(parts[0], (tuple, list)):
+            return cat(parts)
+        return tuple(cat([p[j] for p in parts]) for j in range(len(parts[0])))
+
+    out = []
+    for i in range(0, len(micro_batches), k):
+        group = micro_batches[i:i + k]
+        out.append(group[0] if len(group) == 1 else (merge([g[0] for g in group]), merge([g[1] for g in group])))
+    return out
+
+
+class StackedIterator:
+    """Iterator view for `stack_micro_batches`: every next() pulls k micro-batches from the underlying iterator and returns them stacked."""
+
+    def __init__(self, it, k):
+        self.it, self.k = it, k
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        return stack_micro_batches([next(self.it) for _ in range(self.k)], self.k)[0]
+
+
 def broadcast_target(target, engine, device=None):
     """Send the noise-dependent target from the first to the last pipeline stage (utils/dataset.py:1387-1405)."""
     if not engine.is_pipe_parallel:
@@ -45,7 +82,7 @@ def broadcast_target(target, engine, device=None):
 
 def get_data_iterator_for_step(dataloader, engine, num_micro_batches=None):
     """Pre-pull the step's micro-batches on the first / last stage only (train.py:164-173)."""
-    n = num_micro_batches or engine.micro_batches
+    n = num_micro_batches or engine.gradient_accumulation_steps()      # micro-batches the iterator hands over (not passes: engine `stack_micro_batches`)
     if not (engine.is_first_stage() or engine.is_last_stage()):
         return None
     it = iter(dataloader)

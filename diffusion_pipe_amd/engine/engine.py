@@ -177,9 +177,20 @@ class PipelineEngine:
 
         self.micro_batch_size = int(self._config.get('train_micro_batch_size_per_gpu', 1))
         self.micro_batches = int(self._config.get('gradient_accumulation_steps', 1))
+        # `stack_micro_batches` = k (default 1): train_batch still pulls gradient_accumulation_steps micro-batches of train_micro_batch_size_per_gpu samples from the
+        # iterator, but runs k consecutive ones as ONE pass of k x the size (data.stack_micro_batches = the inverse of the reference's split_batch along dim 0).  Same
+        # samples, same per-sample loss terms, same gradient and mean loss up to fp summation order (the loss is a mean over equal-sized samples; nothing in the path
+        # mixes samples: GroupNorm / LayerNorm / attention are per sample) -- and every weight is read once per k samples, every GEMM has a k-times larger M.  What 288 GB
+        # of HBM per GPU are for; the reference's 24 GB cards are why its configs say micro-batch 1.  From here on self.micro_batches counts PASSES per step.
+        self.stack_micro_batches = max(1, int(self._config.get('stack_micro_batches', 1)))
+        self._user_micro_batches = self.micro_batches
+        if self.stack_micro_batches > 1:
+            if self.micro_batches % self.stack_micro_batches:
+                raise ValueError(f'stack_micro_batches = {self.stack_micro_batches} does not divide gradient_accumulation_steps = {self.micro_batches}')
+            self.micro_batches //= self.stack_micro_batches
         self._gradient_clipping = float(self._config.get('gradient_clipping', 0.0))
         self._steps_per_print = int(self._config.get('steps_per_print', 10))
-        self.train_batch_size_ = self.micro_batch_size * self.micro_batches * self.dp_world_size
+        self.train_batch_size_ = self.micro_batch_size * self._user_micro_batches * self.dp_world_size
 
         if device is None:
             if torch.cuda.is_available():
@@ -354,7 +365,7 @@ class PipelineEngine:
         return self.micro_batch_size
 
     def gradient_accumulation_steps(self):
-        return self.micro_batches
+        return self._user_micro_batches
 
     def train_batch_size(self):
         return self.train_batch_size_
@@ -426,6 +437,9 @@ class PipelineEngine:
         self._eval_mode = False
         self.total_loss = None
         self._data_iter = data_iter
+        if self.stack_micro_batches > 1 and data_iter is not None:
+            from ..data import StackedIterator
+            self._data_iter = StackedIterator(data_iter, self.stack_micro_batches)
         self._throttle()
         if self.use_graph:
             self._train_batch_graphed()

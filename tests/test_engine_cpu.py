@@ -133,6 +133,17 @@ def _worker(rank, world, port, mode, outdir):
         elif mode == 'pp8':          # the BASELINE pp = 8 depth: 10 layers over 8 stages, 16 micro-batches
             batches = [make_batches(16, 2, 100 + s) for s in range(steps)]
             losses, params, engine = engine_run(steps, 16, 0.5, batches, num_stages=8, partition_method='uniform', scope='global', n_mid=8)
+        elif mode == 'pp2_stack2':   # stack_micro_batches: 2 -- the four micro-batches of a step run as two passes of twice the size on both stages
+            batches = [make_batches(gas, 2, 100 + s) for s in range(steps)]
+            losses, params, engine = engine_run(steps, gas, 0.5, batches, num_stages=2, partition_method='manual', split=[2], scope='global', extra={'stack_micro_batches': 2})
+            assert engine.micro_batches == 2 and engine.gradient_accumulation_steps() == 4 and engine.train_batch_size() == 8
+        elif mode == 'pp2_stack2_lanes2':   # 8 micro-batches -> 4 passes of two, on two interleaved pipeline lanes
+            batches = [make_batches(8, 2, 100 + s) for s in range(steps)]
+            losses, params, engine = engine_run(steps, 8, 0.5, batches, num_stages=2, partition_method='manual', split=[2], scope='global',
+                                                extra={'stack_micro_batches': 2, 'pipe_lanes': 2})
+        elif mode == 'dp2_stack2':
+            batches = [make_batches(2 * gas, 2, 100 + s)[rank * gas:(rank + 1) * gas] for s in range(steps)]
+            losses, params, engine = engine_run(steps, gas, 0.5, batches, num_stages=1, extra={'stack_micro_batches': 2})
         elif mode == 'pp2_lanes2':   # two interleaved 1F1B streams per stage (pipe_lanes): micro-batches {0, 2} on lane 0, {1, 3} on lane 1
             batches = [make_batches(gas, 2, 100 + s) for s in range(steps)]
             losses, params, engine = engine_run(steps, gas, 0.5, batches, num_stages=2, partition_method='manual', split=[2], scope='global', extra={'pipe_lanes': 2})
@@ -499,3 +510,53 @@ def test_engine_pp2_dp2_two_pipeline_lanes_gloo_match_oracle():
         got = _stage_params([res[replica], res[2 + replica]], [2] * 6)
         for a, b in zip(got, want_p):
             assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+def test_stack_micro_batches_is_the_inverse_of_split_batch():
+    g = torch.Generator().manual_seed(0)
+    feats = (torch.randn(8, 4, 3, generator=g), torch.randint(0, 9, (8, 5), generator=g), None)
+    label = (torch.randn(8, 4, generator=g), None)
+    micro = dpdata.split_batch((feats, label), 8)
+    stacked = dpdata.stack_micro_batches(micro, 4)
+    assert len(stacked) == 2
+    for i, (f, l) in enumerate(stacked):
+        assert torch.equal(f[0], feats[0][4 * i:4 * i + 4]) and torch.equal(f[1], feats[1][4 * i:4 * i + 4]) and f[2].numel() == 0
+        assert torch.equal(l[0], label[0][4 * i:4 * i + 4]) and l[1].numel() == 0
+    assert len(dpdata.stack_micro_batches(micro, 3)) == 3 and dpdata.stack_micro_batches(micro, 3)[2][0][0].shape[0] == 2     # ragged tail: a smaller last pass
+    it = dpdata.StackedIterator(iter(micro), 2)
+    assert [b[0][0].shape[0] for b in it] == [2, 2, 2, 2]
+    single = dpdata.stack_micro_batches([(torch.ones(1, 2), torch.zeros(1, 2)), (torch.ones(1, 2) * 2, torch.zeros(1, 2))], 2)      # bare-tensor features / labels
+    assert single[0][0].shape == (2, 2) and single[0][1].shape == (2, 2)
+
+
+def test_engine_pp1_stacked_micro_batches_match_oracle():
+    """`stack_micro_batches: 2` (and 4 = the whole step as one pass): the step over UNSTACKED micro-batches in the oracle = the engine's stacked passes"""
+    steps, gas = 3, 4
+    batches = [make_batches(gas, 2, 100 + s) for s in range(steps)]
+    want_l, want_p = oracle_run(steps, gas, 0.5, batches)
+    for k in (2, 4):
+        got_l, got_p, engine = engine_run(steps, gas, 0.5, batches, num_stages=1, extra={'stack_micro_batches': k})
+        assert engine.micro_batches == gas // k and engine.gradient_accumulation_steps() == gas
+        assert got_l == pytest.approx(want_l, rel=1e-6)
+        for a, b in zip(got_p, want_p):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    with pytest.raises(ValueError):
+        engine_run(1, gas, 0.5, batches, num_stages=1, extra={'stack_micro_batches': 3})
+
+
+@pytest.mark.parametrize('mode,world,total', [('pp2_stack2', 2, 4), ('pp2_stack2_lanes2', 2, 8), ('dp2_stack2', 2, 8)])
+def test_engine_stacked_micro_batches_gloo_match_oracle(mode, world, total):
+    steps = 2
+    batches = [make_batches(total, 2, 100 + s) for s in range(steps)]
+    want_l, want_p = oracle_run(steps, total, 0.5, batches)
+    res = _spawn(mode, world=world)
+    for r in res:
+        assert r['losses'] == pytest.approx(want_l, rel=1e-5)
+    if mode.startswith('pp2'):
+        got = _stage_params(res, [2] * 6)
+        for a, b in zip(got, want_p):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    else:
+        for r in res:
+            for a, b in zip(r['params'], want_p):
+                assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
