@@ -497,6 +497,8 @@ def main():
         dist.all_reduce(ones)
         comm_ranks, comm_backend = int(ones.item()), dist.get_backend()
     elapsed = t.item()
+    free_b, total_b = torch.cuda.mem_get_info(device)
+    peak_hbm = max(torch.cuda.max_memory_reserved(device), total_b - free_b)      # after the timed steps, before the roofline / parity legs allocate; hipGraph pools are "reserved"
     gnorm = engine.get_global_grad_norm()
     gnorm = float(gnorm.item()) if gnorm is not None else float('nan')
 
@@ -564,7 +566,7 @@ def main():
                        'activation_checkpointing': bool(args.activation_checkpointing), 'partition': module.parts, 'hip_graph': bool(engine.use_graph or engine.use_stage_graphs),
                        'concurrent_micro_batch_lanes': engine.graph_lanes, 'pipe_lanes': engine.pipe_lanes, 'micro_batch_stacking': engine.stack_micro_batches, 'stream_probe': engine.stream_probe,
                        'max_steps_in_flight': engine.max_steps_in_flight},
-            'loss': float(loss.item()), 'grad_norm': float(gnorm),
+            'loss': float(loss.item()), 'grad_norm': float(gnorm), 'peak_hbm_gb': round(peak_hbm / 2 ** 30, 2),
             'step_tflop_algorithmic': round(step_flops / 1e12, 2),
             'mfu_vs_bf16_mfma_peak': round(step_flops / (elapsed / args.steps) / (peak * 1e12 * world), 5),
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_pipe_kernel<bf16> (dpipe_gemm_ex: every Linear forward / dgrad / wgrad)', 'achieved': round(achieved, 2), 'peak': peak,
