@@ -475,7 +475,7 @@ class PipelineEngine:
         self._eval_mode = True
         self.total_loss = None
         self._data_iter = data_iter
-        micro_batches = self.micro_batches if num_micro_batches is None else num_micro_batches
+        micro_batches = self._user_micro_batches if num_micro_batches is None else num_micro_batches     # eval never stacks: the iterator's own micro-batches
         schedule = sched.InferenceSchedule(micro_batches=micro_batches, stages=self.num_stages, stage_id=self.stage_id)
         self._reserve_buffers(schedule.num_pipe_buffers())
         with torch.no_grad():

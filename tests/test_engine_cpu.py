@@ -538,6 +538,8 @@ def test_engine_pp1_stacked_micro_batches_match_oracle():
         got_l, got_p, engine = engine_run(steps, gas, 0.5, batches, num_stages=1, extra={'stack_micro_batches': k})
         assert engine.micro_batches == gas // k and engine.gradient_accumulation_steps() == gas
         assert got_l == pytest.approx(want_l, rel=1e-6)
+        ev = engine.eval_batch(iter(batches[0])).item()              # eval pulls the iterator's own (unstacked) micro-batches, all GAS of them
+        assert ev == pytest.approx(oracle.eager_eval(list(engine.module.forward_funcs), oracle.default_loss_fn(), batches[0]).item(), rel=1e-6)
         for a, b in zip(got_p, want_p):
             assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
     with pytest.raises(ValueError):
