@@ -35,7 +35,8 @@ PY
         python tools/pmc_agg.py $O/${TAG}_pmc_$c $O/${TAG}_pmc_gemm_step_$c.csv >> $O/${TAG}_pmc_$c.log 2>&1; rm -rf $O/${TAG}_pmc_$c
       done
       python tools/pmc_traffic_json.py $O/${TAG}_pmc_gemm_step_FETCH_SIZE.csv $O/${TAG}_pmc_gemm_step_WRITE_SIZE.csv $trace $div $O/${TAG}_pmc_gemm_traffic.json | tail -1;;
-    cmd)
-      bash -c "$rest" > $O/${TAG}_cmd.log 2>&1; echo "cmd rc=$? $(tail -2 $O/${TAG}_cmd.log)";;
+    cmd)      # every cmd step gets its own log: <tag>_cmd1.log, <tag>_cmd2.log, ...
+      NCMD=$((${NCMD:-0} + 1))
+      bash -c "$rest" > $O/${TAG}_cmd${NCMD}.log 2>&1; echo "cmd${NCMD} rc=$? $(tail -2 $O/${TAG}_cmd${NCMD}.log)";;
   esac
 done
