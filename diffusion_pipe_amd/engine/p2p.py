@@ -80,7 +80,11 @@ class StageLink:
         self._pending.append((works, tensors))
 
     @torch.no_grad()            # the buffers may be a stage graph's static inputs (leaves that require grad)
-    def _recv(self, buffers, peer):
+    def _recv(self, buffers, peer, fresh=True):
+        if self.on_gpu and fresh:
+            # freshly allocated buffers may be a block the caching allocator just recycled on the CALLER'S stream: kernels already enqueued there can still read its
+            # previous contents, so the transfer is ordered behind them (receives into a slot's static buffers are ordered by their own `after` event instead)
+            self.comm_stream.wait_event(torch.cuda.current_stream(self.device).record_event())
         if self.on_gpu:
             with torch.cuda.stream(self.comm_stream):
                 works = [dist.irecv(_wire(b), src=peer) for b in buffers]
@@ -146,7 +150,7 @@ class StageLink:
         if self.comm_stream is not None:
             self.comm_stream.wait_event(after)
             torch.cuda.current_stream(self.device).wait_event(after)     # host-staged endpoints copy on the current stream
-        return self._recv(buffers, peer)
+        return self._recv(buffers, peer, fresh=False)
 
     def recv_like(self, templates, peer_stage, into=None, after=None):
         """Receive tensors whose layouts are known locally (gradients of tensors this stage sent)."""
@@ -337,6 +341,8 @@ class RcclLink(StageLink):
     def _recv(self, buffers, peer, after=None):
         if after is not None:
             self.comm_stream.wait_event(after)           # the buffers' previous consumer (a stage graph replay) has finished
+        else:                                            # fresh buffers: behind whatever the caller's stream still runs on the recycled block (see StageLink._recv)
+            self.comm_stream.wait_event(torch.cuda.current_stream(self.device).record_event())
         self._grouped(buffers, peer, lambda lib: lib.dpipe_recv)
         done = self.comm_stream.record_event()
         for b in buffers:
@@ -361,7 +367,7 @@ class HostStagedLink(StageLink):
         works = [dist.isend(h, dst=peer) for h in host]
         self._pending.append((works, host))
 
-    def _recv(self, buffers, peer):
+    def _recv(self, buffers, peer, fresh=True):
         for b in buffers:
             w = _wire(b)
             h = torch.empty(w.shape, dtype=w.dtype)
