@@ -235,6 +235,7 @@ def measure_dit_workload(args, device, world, light=False):
     module = ManualPipelineModule(layers=work.to_layers(), num_stages=1, partition_method=args.partition, loss_fn=work.get_loss_fn(), dynamic_shape=True, **kwargs)
     engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 1, 'gradient_accumulation_steps': gas, 'gradient_clipping': 1.0,
                                                          'steps_per_print': 1 << 30, 'hip_graph': graph, 'graph_lanes': lanes,
+                                                         'stack_micro_batches': args.stack if gas % max(1, args.stack) == 0 else 1,
                                                          **({'max_steps_in_flight': args.steps_in_flight} if args.steps_in_flight >= 0 else {})}, device=device)
     work.train_config = {'optimizer': {'type': 'adamw', 'lr': 1e-5, 'betas': [0.9, 0.99], 'weight_decay': 0.01, 'eps': 1e-8}}
     engine._configure_optimizer(optim.make_optimizer_factory(work.train_config, work, global_batch_size=gas), [p for p in module.parameters() if p.requires_grad])
