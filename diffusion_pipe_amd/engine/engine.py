@@ -619,25 +619,8 @@ class PipelineEngine:
         from .. import ops as _ops
         K = min(self.graph_lanes, self.micro_batches)
         main = torch.cuda.current_stream(self.device)
-        masks = self._config.get('lane_cu_masks', os.environ.get('DPIPE_LANE_CU_MASKS'))
-        if len(self._lanes) < K and self._lane_streams is None and masks:
-            # EXPERIMENT (off by default): every lane, lane 0 included, on a stream confined to its own XCDs, so that each lane's GEMMs have
-            # an L2 of their own.  'xcd-pairs' = lane l on XCDs {2l, 2l + 1} (4 lanes), 'xcd-quads' = {4l .. 4l + 3} (2 lanes); or explicit ';'-separated
-            # lists of XCD ids per lane ('0,1;2,3;4,5;6,7').  No hardware-queue probe: distinct masks are distinct queues.
-            from .. import hip as _hipmod
-            if masks == 'xcd-pairs':
-                sets = [{2 * l, 2 * l + 1} for l in range(4)]
-            elif masks == 'xcd-quads':
-                sets = [{4 * l + i for i in range(4)} for l in range(2)]
-            else:
-                sets = [{int(x) for x in part.split(',')} for part in str(masks).split(';')]
-            if len(sets) < K:
-                raise ValueError(f'lane_cu_masks names {len(sets)} lanes, the step runs {K}')
-            self._masked_lane_streams = [_hipmod.masked_stream(self.device, _hipmod.cu_mask_for_xcds(xs)) for xs in sets[:self.graph_lanes]]
-            self._lane_streams = []
-            self._probe_report.update({'lane_cu_masks': [sorted(xs) for xs in sets[:self.graph_lanes]]})
-            if not self._steps_in_flight_explicit:
-                self.max_steps_in_flight = 1
+        # (Round 5 negative result, profiles/r5a_bench_stacking_lanes_cu_masks.jsonl: every lane on a CU-masked stream confined to its own pair of XCDs -- 15.91 vs 22.76 images/s,
+        #  same box: a lane's small launches can no longer spill onto the CUs the other lanes leave idle.  Removed.)
         if len(self._lanes) < K and self._lane_streams is None:
             self._lane_streams = concurrent_streams(self.device, self.graph_lanes - 1, main, report=self._probe_report) if os.environ.get('DPIPE_LANE_STREAM_PROBE', '1') != '0' else []
             probed = os.environ.get('DPIPE_LANE_STREAM_PROBE', '1') != '0' and os.environ.get('DPIPE_LANE0_MAIN', '1') != '0' and \
@@ -650,9 +633,7 @@ class PipelineEngine:
             # another one and the two serialise -- 4 lanes on own streams 16.4 images/s, the same 4 lanes with lane 0 on the caller's stream 20.6 (MI355X,
             # round 3, profiles/r3t_*, r3u_*); 5 lanes fall back to 17.8.  DPIPE_LANE0_MAIN=0 restores a separate stream for lane 0 (A/B).
             li = len(self._lanes)
-            if getattr(self, '_masked_lane_streams', None):
-                st = self._masked_lane_streams[li]
-            elif li == 0 and os.environ.get('DPIPE_LANE0_MAIN', '1') != '0':
+            if li == 0 and os.environ.get('DPIPE_LANE0_MAIN', '1') != '0':
                 st = main
             else:
                 st = self._lane_streams[li - 1] if 0 < li <= len(self._lane_streams) else torch.cuda.Stream(self.device)

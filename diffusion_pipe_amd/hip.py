@@ -172,30 +172,3 @@ def device_info(dev=0):
     buf = ctypes.create_string_buffer(256)
     check(lib().dpipe_device_info(dev, ctypes.byref(cu), buf, 256), 'dpipe_device_info')
     return cu.value, buf.value.decode()
-
-
-# ---- experiment scaffolding (engine option `lane_cu_masks`, off by default): HIP streams confined to a subset of the CUs
-def cu_mask_for_xcds(xcds, total_cus=256, n_xcd=8):
-    """Bit pattern for hipExtStreamCreateWithCUMask that enables the CUs of the XCDs in `xcds`, ASSUMING mask bit b belongs to XCD b % n_xcd -- what
-    profiles/r4x_xcc_map_probe.jsonl suggests (32 consecutive bits = 4 CUs on each of the 8 XCDs) but does not yet prove: check a new pattern with
-    tools/probes/xcc_map_probe.hip before trusting an A/B built on it.  -> list of uint32 words."""
-    words = [0] * ((total_cus + 31) // 32)
-    for b in range(total_cus):
-        if b % n_xcd in xcds:
-            words[b // 32] |= 1 << (b % 32)
-    return words
-
-
-def masked_stream(device, words):
-    """A torch stream object over a HIP stream created with a CU mask (the mask is a property of the hardware queue behind the stream; kernels launched or
-    graph-replayed on it run on the enabled CUs only).  Goes to the HIP runtime torch already loaded; the stream lives until the process ends."""
-    rt = ctypes.CDLL('libamdhip64.so')
-    rt.hipExtStreamCreateWithCUMask.argtypes = [ctypes.POINTER(c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
-    rt.hipExtStreamCreateWithCUMask.restype = c_int
-    arr = (ctypes.c_uint32 * len(words))(*words)
-    st = c_void_p()
-    with torch.cuda.device(device):
-        rc = rt.hipExtStreamCreateWithCUMask(ctypes.byref(st), len(words), arr)
-    if rc != 0 or not st.value:
-        raise DpipeHipError(f'hipExtStreamCreateWithCUMask failed (hipError {rc})')
-    return torch.cuda.ExternalStream(st.value, device=device)

@@ -286,25 +286,30 @@ class _LinearFn(Function):
         need_w = ctx.needs_input_grad[1]
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
 
+        # accumulate flags: asked ONCE per target.  `_acc` registers a buffer in GRAD_STORE the first time it is asked (the first-micro-batch graphs store instead of
+        # accumulating); a launch that is then refused (gemm_group / mm(colsum=...) returning None: rc -2, not pipe-eligible) falls through to the unfused kernels,
+        # which must see the SAME answer -- a second `_acc` call would say "accumulate" and the store graph would add into a stale buffer, step after step
+        tw = _accum_target(weight) if need_w else None
+        tb = _accum_target(bias) if need_b else None
+        acc_w = _acc(tw) if need_w else False
+        acc_b = _acc(tb) if need_b else False
+
         def param_grads():
             gw_ = gb_ = None
             if FUSE_BIAS_GRAD and need_w and need_b and gy2.dtype == torch.bfloat16:
                 # one launch: dW (+)= dy^T . x with db (+)= column sums of dy taken from the A fragments inside the GEMM
-                tw, tb = _accum_target(weight), _accum_target(bias)
                 w_out = tw if tw is not None else torch.empty(weight.shape, device=weight.device, dtype=weight.dtype)
                 b_out = tb if tb is not None else torch.empty(bias.shape, device=bias.device, dtype=bias.dtype)
-                if mm(gy2, x2, True, False, out=w_out, accumulate=_acc(tw), colsum=b_out, colsum_accumulate=_acc(tb)) is not None:
+                if mm(gy2, x2, True, False, out=w_out, accumulate=acc_w, colsum=b_out, colsum_accumulate=acc_b) is not None:
                     return (None if tw is not None else w_out), (None if tb is not None else b_out)
             if need_w:
-                tgt = _accum_target(weight)
-                if tgt is not None:
-                    mm(gy2, x2, True, False, out=tgt, accumulate=_acc(tgt))      # dW += dy^T . x  (fused accumulation)
+                if tw is not None:
+                    mm(gy2, x2, True, False, out=tw, accumulate=acc_w)        # dW += dy^T . x  (fused accumulation)
                 else:
                     gw_ = mm(gy2, x2, True, False)                            # dW = dy^T . x
             if need_b:
-                tgt = _accum_target(bias)
-                gb_ = column_sum(gy2, out=tgt, accumulate=_acc(tgt))
-                if tgt is not None:
+                gb_ = column_sum(gy2, out=tb, accumulate=acc_b)
+                if tb is not None:
                     gb_ = None
             return gw_, gb_
 
@@ -312,14 +317,12 @@ class _LinearFn(Function):
         if not fork and ctx.needs_input_grad[0] and need_w and gy2.dtype == torch.bfloat16:
             # dgrad and wgrad (+ the bias column sums inside it) as ONE grouped launch: dx = dy . W next to dW (+)= dy^T . x -- independent problems that share
             # dy, each filling well under half of the chip at micro-batch 1
-            tw = _accum_target(weight)
             w_out = tw if tw is not None else torch.empty(weight.shape, device=weight.device, dtype=weight.dtype)
             fuse_b = FUSE_BIAS_GRAD and need_b
-            tb = _accum_target(bias) if fuse_b else None
             b_out = (tb if tb is not None else torch.empty(bias.shape, device=bias.device, dtype=bias.dtype)) if fuse_b else None
             gx2 = torch.empty((gy2.shape[0], weight.shape[1]), device=gy2.device, dtype=gy2.dtype)
             done = gemm_group([mm_problem(gy2, weight, False, False, out=gx2),
-                               mm_problem(gy2, x2, True, False, out=w_out, accumulate=_acc(tw), colsum=b_out, colsum_accumulate=_acc(tb))])
+                               mm_problem(gy2, x2, True, False, out=w_out, accumulate=acc_w, colsum=b_out, colsum_accumulate=acc_b if fuse_b else False)])
             if done is not None:
                 gx = gx2.view(ctx.x_shape)
                 if gx.dtype != ctx.x_dtype:
@@ -328,9 +331,8 @@ class _LinearFn(Function):
                 if fuse_b:
                     gb = None if tb is not None else b_out
                 elif need_b:
-                    tgt = _accum_target(bias)
-                    gb = column_sum(gy2, out=tgt, accumulate=_acc(tgt))
-                    if tgt is not None:
+                    gb = column_sum(gy2, out=tb, accumulate=acc_b)
+                    if tb is not None:
                         gb = None
                 gres = gy if (ctx.has_res and ctx.needs_input_grad[3]) else None
                 return gx, gw, gb, gres

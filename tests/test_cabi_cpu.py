@@ -65,13 +65,3 @@ def test_no_cpu_fallback():
         ops.rms_norm(x)
 
 
-def test_cu_mask_pattern_for_xcd_sets():
-    """experiment scaffolding (engine `lane_cu_masks`): 256 CUs, bit b <-> XCD b % 8 (the layout the probe suggests); disjoint XCD sets give disjoint masks that tile the chip"""
-    from diffusion_pipe_amd import hip
-    pairs = [hip.cu_mask_for_xcds({2 * l, 2 * l + 1}) for l in range(4)]
-    assert all(len(w) == 8 and sum(bin(x).count('1') for x in w) == 64 for w in pairs)
-    union = [0] * 8
-    for w in pairs:
-        assert all(a & b == 0 for a, b in zip(union, w))
-        union = [a | b for a, b in zip(union, w)]
-    assert union == [0xffffffff] * 8

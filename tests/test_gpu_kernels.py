@@ -853,3 +853,33 @@ def test_rms_norm_rope_fused_matches_float64_and_the_two_kernel_route(gpu, dtype
     torch.cuda.synchronize()
     assert _worst_elem(y, y2) < tol and _rel_err(gw, w2.grad) < tol
     assert _worst_elem(gq, src2.grad.view(B, S, 3, H, D)[:, :, 1]) < tol * 2
+
+
+@pytest.mark.parametrize('k_in', [72, 20])
+def test_linear_backward_under_store_mode_stores_once_even_when_the_fused_launch_is_refused(gpu, k_in):
+    """`_LinearFn.backward` asked `ops._acc` for the weight / bias buffers while it BUILT the grouped dgrad + wgrad launch; when that launch is refused
+    (rc -2: in_features % 8 != 0 is not eligible for the LDS-DMA kernel with fused column sums) the unfused fall-back asked again, got "accumulate" and added into the
+    stale buffer inside a first-micro-batch (store) graph.  The flag is now drawn once per target: with GRAD_STORE on, pre-filled .grad buffers must come back holding
+    exactly this micro-batch's gradient -- k_in = 72 takes the grouped launch, k_in = 20 the refused one."""
+    from diffusion_pipe_amd import ops
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(k_in, 48).to(gpu, torch.bfloat16)
+    x = torch.randn(64, k_in, device=gpu, dtype=torch.bfloat16, requires_grad=True)
+    gy = torch.randn(64, 48, device=gpu, dtype=torch.bfloat16)
+    want_w = gy.float().t() @ x.detach().float()
+    want_b = gy.float().sum(0)
+    old_fuse, old_store = ops.FUSE_GRAD_ACCUM, ops.GRAD_STORE
+    try:
+        ops.FUSE_GRAD_ACCUM, ops.GRAD_STORE = True, {}
+        lin.weight.grad = torch.full_like(lin.weight, 1000.0)        # what a previous optimizer step left in the lane's accumulators
+        lin.bias.grad = torch.full_like(lin.bias, 1000.0)
+        ops.linear(x, lin.weight, lin.bias).backward(gy)
+        assert lin.weight.grad.data_ptr() in ops.GRAD_STORE and lin.bias.grad.data_ptr() in ops.GRAD_STORE
+        assert _rel_err(lin.weight.grad, want_w) < _tol(torch.bfloat16), 'stale accumulator leaked into the stored weight gradient'
+        assert _rel_err(lin.bias.grad, want_b) < _tol(torch.bfloat16), 'stale accumulator leaked into the stored bias gradient'
+        x.grad = None
+        ops.linear(x, lin.weight, lin.bias).backward(gy)              # second micro-batch inside the same graph: accumulates
+        assert _rel_err(lin.weight.grad, 2 * want_w) < _tol(torch.bfloat16)
+        assert _rel_err(lin.bias.grad, 2 * want_b) < _tol(torch.bfloat16)
+    finally:
+        ops.FUSE_GRAD_ACCUM, ops.GRAD_STORE = old_fuse, old_store

@@ -287,9 +287,6 @@ def test_first_micro_batch_stores_graphs_equal_the_zeroing_path_bit_for_bit(gpu)
     assert all(torch.equal(p_on[k], p_off[k]) for k in p_on)
 
 
-@pytest.mark.skipif(__import__('os').environ.get('DPIPE_TEST_STACKING') != '1',
-                    reason='engine option stack_micro_batches: verified on CPU against the oracle (tests/test_engine_cpu.py), written after the round-4 GPU budget was spent -- '
-                           'first GPU action of the next round: DPIPE_TEST_STACKING=1')
 def test_stacked_micro_batches_match_the_unstacked_graph_path(gpu):
     """`stack_micro_batches: 2 / 4`: the step's four micro-batches of one sample run as two passes of two / one pass of four (hipGraph, lanes) -- loss and global gradient
     norm of every step agree with the unstacked path (same samples and loss terms; other GEMM shapes, so bf16 rounding differs: the pp = 2 tests' tolerances)."""
