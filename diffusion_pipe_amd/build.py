@@ -17,6 +17,11 @@ LIB_PATH = PKG_DIR / 'libdpipe_hip.so'
 ARCH = 'gfx950'
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 CFLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-ffp-contract=fast']
+# The GEMM / convolution template's `#pragma unroll` nests over the accumulator tiles must ALL unroll (a loop left rolled indexes the accumulators dynamically and they
+# move to scratch): the 256^2 tiles exceed LLVM's default pragma-unroll cost cap (16 384).  Round 5: with the default cap the 8-wave 256^2 kernels (the DiT-sized GEMMs of
+# Flux / Wan / HunyuanVideo) carried 100 - 324 bytes of scratch per lane, the 4-wave 256^2 tile 1 088; with the cap raised: 0 - 8.  Every other instantiation is unchanged
+# (same register counts, profiles/r5_kernel_resources.csv).
+EXTRA_CFLAGS = {'gemm_pipe.hip': ['-mllvm', '-pragma-unroll-threshold=200000'], 'conv_pipe.hip': ['-mllvm', '-pragma-unroll-threshold=200000']}
 
 
 def _sources():
@@ -33,7 +38,7 @@ def _compile(src: Path, force: bool) -> Path:
     newest = max(src.stat().st_mtime, _deps_mtime())
     if not force and obj.exists() and obj.stat().st_mtime >= newest:
         return obj
-    cmd = [HIPCC, *CFLAGS, '-c', str(src), '-o', str(obj)]
+    cmd = [HIPCC, *CFLAGS, *EXTRA_CFLAGS.get(src.name, []), '-c', str(src), '-o', str(obj)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'hipcc failed for {src.name}:\n{r.stdout}\n{r.stderr}')

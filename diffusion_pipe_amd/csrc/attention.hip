@@ -237,6 +237,12 @@ __global__ void __launch_bounds__(NW * 64, D == 64 ? 2 : 1) attn_fwd_kernel(cons
 // ds_read_b128, V as an MN-contiguous image read transposed with ds_read_b64_tr_b16), one barrier per tile, the next tile's DMA in flight
 // under the current tile's MFMAs -- no staging VGPRs, no ds_write pass.  Keys past kv_len come back as zeros from the buffer bounds check.
 // Within a tile both 32-key blocks' score MFMAs are issued before the first softmax, so exponentials overlap matrix work of the same wave.
+// (Round 5 negative results, profiles/r5b_attention_ring_qb_negative.jsonl, head dim 64, in-graph us forward / backward, S = 1024 x 20 heads and S = 4096 x 10 heads:
+//  two-deep ring (this kernel) 26.1 / 76.3 and 110.2 / 267.8; a THREE-deep ring with counted vmcnt in the forward and dQ kernels 27.5 / 75.8 and 114.9 / 269.3; the same in
+//  the one-pass dK / dV kernel (99 KiB: one workgroup per CU) 83.4 and 450.9 backward; 64 query rows per wave (QB = 2: K / V fragments shared by two score blocks, 202 VGPRs)
+//  as 4-wave 256-row workgroups 39.0 and 126.6 forward, as 2-wave 128-row workgroups 38.2 and 183.5.  The vmcnt(0) wait of the two-deep ring is not DMA latency a deeper
+//  ring could hide (a tile's 16 KiB land well inside one tile of compute; the wait share the PMC pass saw is then the per-tile barrier itself: unmeasured), and
+//  halving the LDS reads per MFMA costs more in occupancy than it saves.  All variants removed again.)
 template <int D, int QB, int NW>
 __global__ void __launch_bounds__(NW * 64, (D == 64 && NW == 4) ? 2 : 1) attn_fwd_dma_kernel(const AttnParams p) {
     constexpr int QW = 32 * QB, QWG = QW * NW;          // query rows per wave / per workgroup

@@ -30,6 +30,7 @@ struct GemmParams {
     int act, accumulate, out_f32;
     int vecA, vecB;                       // 16-byte global loads legal for A / B
     int tiles_m, tiles_n;
+    int gr;                               // pipelined kernel: tile-rows a run of consecutive tiles walks before it moves one tile-column over (rasterisation group height)
     // split-K (pipelined kernel only)
     int splitk, ksteps, ksteps_per_split;
     float* slabs; int* counters;

@@ -32,6 +32,7 @@ static int launch_by_tile(int tile, const GemmParams& p, bool a_mc, bool b_mc, i
     case 130: return launch_pipe<T128S5>(p, a_mc, b_mc, batch, s);
     case 1264: return launch_pipe<T128N64>(p, a_mc, b_mc, batch, s);
     case 1283: return launch_pipe<T128Q3>(p, a_mc, b_mc, batch, s);
+    case 132: return launch_pipe<T128V>(p, a_mc, b_mc, batch, s);
     default: return launch_pipe<T64>(p, a_mc, b_mc, batch, s);
     }
 }
@@ -55,7 +56,7 @@ int gemm_pipe_group(GemmParams* ps, const int* transA, const int* transB, int n,
     struct Plan { int tile; bool a_mc, b_mc; long tiles; int counter_base; long slab_base; };
     Plan pl[16];
     if (n > 16) { set_last_error("dpipe_gemm_group: at most 16 problems"); return DPIPE_ERR_ARG; }
-    auto slab_bytes_of = [](int tile) { const long bm = (tile == 128 || tile == 129) ? 128 : 64; return (bm * bm + bm) * 4L; };
+    auto slab_bytes_of = [](int tile) { const long bm = (tile == 128 || tile == 129 || tile == 132) ? 128 : 64; return (bm * bm + bm) * 4L; };
     auto plan_all = [&](int force) {
         int cbase = 0; long sbase = 0;
         for (int i = 0; i < n; ++i) {
@@ -73,9 +74,10 @@ int gemm_pipe_group(GemmParams* ps, const int* transA, const int* transB, int n,
         }
     };
     plan_all(0);
-    auto groupable = [](int tile) { return tile == 64 || tile == 129 || tile == 128; };
+    auto groupable = [](int tile) { return tile == 64 || tile == 129 || tile == 128 || tile == 132; };
+    auto geom = [](int tile) { return tile == 132 ? 129 : tile; };        // the register-staged tile shares T128R2's geometry and LDS: one grouped launch carries both
     static const bool pair_unify = [] { const char* e = getenv("DPIPE_GEMM_GROUP_UNIFY"); return !e || atoi(e) != 0; }();
-    if (pair_unify && n == 2 && pl[0].tile != pl[1].tile && groupable(pl[0].tile) && groupable(pl[1].tile)) plan_all(64);
+    if (pair_unify && n == 2 && geom(pl[0].tile) != geom(pl[1].tile) && groupable(pl[0].tile) && groupable(pl[1].tile)) plan_all(64);
     bool done[16] = {};
     int launches = 0, rc = DPIPE_OK;
     for (int i = 0; i < n && rc == DPIPE_OK; ++i) {
@@ -84,7 +86,7 @@ int gemm_pipe_group(GemmParams* ps, const int* transA, const int* transB, int n,
         members[m++] = i;
         if (groupable(pl[i].tile))
             for (int j = i + 1; j < n && m < GROUP_MAX; ++j)
-                if (!done[j] && pl[j].tile == pl[i].tile) members[m++] = j;
+                if (!done[j] && geom(pl[j].tile) == geom(pl[i].tile)) members[m++] = j;
         for (int k = 0; k < m; ++k) done[members[k]] = true;
         ++launches;
         if (m == 1) { rc = launch_by_tile(pl[i].tile, ps[i], pl[i].a_mc, pl[i].b_mc, 1, s); continue; }
@@ -97,12 +99,12 @@ int gemm_pipe_group(GemmParams* ps, const int* transA, const int* transB, int n,
         for (int k = 0; k < GROUP_MAX; ++k) {
             if (k < m) {
                 const int id = members[k];
-                g.p[k] = ps[id]; g.mode[k] = 2 * (int)pl[id].a_mc + (int)pl[id].b_mc;
+                g.p[k] = ps[id]; g.mode[k] = 2 * (int)pl[id].a_mc + (int)pl[id].b_mc + (pl[id].tile == 132 ? 4 : 0);
                 g.start[k] = at; g.nwg[k] = (int)(pl[id].tiles * ps[id].splitk);
                 at += (g.nwg[k] + 7) & ~7;
             } else { g.p[k] = ps[members[0]]; g.mode[k] = 0; g.start[k] = at; g.nwg[k] = 0; }
         }
-        switch (pl[i].tile) {
+        switch (geom(pl[i].tile)) {
         case 129: rc = launch_pipe_group<T128R2>(g, at, s); break;
         case 128: rc = launch_pipe_group<T128>(g, at, s); break;
         default: rc = launch_pipe_group<T64>(g, at, s); break;
@@ -186,6 +188,15 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
     }
     p.ksteps_per_split = (p.ksteps + S - 1) / S;
     p.splitk = (p.ksteps + p.ksteps_per_split - 1) / p.ksteps_per_split;
+    {   // rasterisation group height: an XCD owns a contiguous run of R = tiles / 8 tiles (the slices of a tile are adjacent); walking g tile-rows before moving a tile-column
+        // over, the run touches ~g + R / g operand panels -- least at g = sqrt(R).  DPIPE_GEMM_GR=8 restores the fixed height of rounds 1 - 4 (A/B)
+        static const int gr_fixed = [] { const char* e = getenv("DPIPE_GEMM_GR"); return e ? atoi(e) : 0; }();
+        const long run = (long)p.tiles_m * p.tiles_n / 8;
+        int g = 1;
+        while ((long)(g + 1) * (g + 1) <= run) ++g;
+        if ((long)g * (g + 1) < run) ++g;          // round to nearest
+        p.gr = gr_fixed > 0 ? gr_fixed : (g < 1 ? 1 : g > 8 ? 8 : g);
+    }
     p.counters = ws ? reinterpret_cast<int*>(ws) + counter_base : nullptr;
     p.slabs = ws ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + COUNTER_BYTES + slab_base) : nullptr;
     // vector epilogue flags (re-using the generic kernel's fields): vecA >= 2 -> C rows allow 4-element vector accesses,
@@ -196,7 +207,12 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
     if (c_ok && p.residual && reinterpret_cast<uintptr_t>(p.residual) % 8 == 0 && p.ldr % 4 == 0) p.vecA = 3;   // 8-byte residual loads too
     p.vecB = (p.bias && reinterpret_cast<uintptr_t>(p.bias) % 8 == 0) ? 2 : 0;
     if (force_tile == 258 || force_tile == 1283) { p.ksteps *= 2; p.ksteps_per_split *= 2; return force_tile; }      // T256K counts K in 32-wide half steps (slices keep their K ranges)
-    if (force_tile == 257 || force_tile == 256 || force_tile == 63 || force_tile == 130 || force_tile == 1264) return force_tile;
+    if (force_tile == 257 || force_tile == 256 || force_tile == 63 || force_tile == 130 || force_tile == 1264 || force_tile == 132) return force_tile;
+    // Register-staged 128^2 tile (T128V, round 5) wherever A is K-contiguous (forward NT, dgrad NN), the tile runs unsplit and walks >= 8 K-steps: -3 .. -19 % against the
+    // better of the two DMA rings on every such descriptor of the SDXL step (gemm_pipe_kernel.h has the table); the wgrad layouts and split tiles stay on the DMA rings.
+    // DPIPE_GEMM_VS=0 switches the rule off (A/B).
+    static const bool vs_rule = [] { const char* e = getenv("DPIPE_GEMM_VS"); return !e || atoi(e) != 0; }();
+    if (vs_rule && force_tile == 0 && big && !a_mc && p.splitk == 1 && p.ksteps >= 8 && batch == 1) return 132;
     if (force_tile == 129 || (force_tile == 0 && big && tiles128 >= 256 && (a_mc || b_mc || tiles128 >= 1024))) return 129;
     // DPIPE_OPT_GEMM_SHALLOW: the shallow rings everywhere (128^2 on 2 x 32 KiB, 64^2 on 3 x 16 KiB) -- slower launches in isolation (step list: 23.5 vs 22.0 us
     // average), but a 64 KiB footprint lets a workgroup of ANOTHER micro-batch lane share the CU: 19.34 vs 18.93 images/s with 3 lanes

@@ -51,8 +51,9 @@ using namespace dpipe_tiles;   // LDS image formats of the DMA'd operand tiles (
 // the small-problem configuration (4 x the workgroups of T128: aggregate L1/L2 bandwidth of more CUs is what bounds a
 // GEMM whose whole operand set is a few MB).  T128: 128 x 128 tile, 8 waves (2 x 4, 64 x 32 each) = 2 waves per SIMD so
 // one wave's DMA issue (60..180 cycles per 1 KiB piece, MI355X_MICROARCH.md) hides under the other's MFMAs; 3 x 32 KiB.
-template <int BM_, int BN_, int WM_, int WN_, int STAGES_, int BK_ = 64> struct Tile {
+template <int BM_, int BN_, int WM_, int WN_, int STAGES_, int BK_ = 64, int VS_ = 0> struct Tile {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, STAGES = STAGES_, BK = BK_;   // BK: k extent of a ring stage (64, or 32 for the 4-deep 256^2 ring)
+    static constexpr int VS = VS_;                                                             // register stages in front of a 2-deep LDS ring (0 = the LDS-DMA ring)
     static constexpr int NW = WM * WN, NT = NW * 64;
     static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;       // 32x32 MFMA tiles per wave
     static constexpr int IMG_A = BM * BK * 2, IMG_B = BN * BK * 2, STAGE_BYTES = IMG_A + IMG_B;
@@ -97,6 +98,22 @@ using T128Q3 = Tile<128, 128, 2, 2, 3, 32>;  // OCCUPANCY-style 128^2 tile: 4 wa
 using T256S = Tile<256, 256, 2, 4, 2>;      // 256 x 256, 8 waves of 128 x 64 (128 accumulator VGPRs), 2 x 64 KiB: twice the MFMA work per DMA'd
                                             // byte of the 128^2 tile -- the large-GEMM configuration (DiT-sized linears: Flux / Wan / HunyuanVideo)
 
+// ---- REGISTER-STAGED tile (round 5; VS > 0): global -> VGPR -> LDS instead of the LDS-DMA ring.  What four rounds of measurements asked for: the DMA
+// ring can only hold as many bytes in flight as the LDS has room to land (2 x 64 KiB per CU = ~15 B / clk / CU at the ~4 500-cycle loaded latency of a piece), the
+// register file is not full.  A K-step is fetched with `buffer_load_dwordx4` into one of VS register sets (NLOAD x 4 VGPRs each) VS + 1 K-steps ahead of its use and
+// written to the free slot of a 2-deep LDS ring one K-step ahead (`ds_write_b128`, lane-linear = the DMA's own destination pattern, so the images, the source swizzles
+// and every fragment read are unchanged): VS K-steps are in flight per workgroup whatever the LDS size.  The price is the ds_write pass (13 LDS cycles per 1 KiB piece).
+// Measured (profiles/r5b_gemm_ledger_register_staged_tiles.jsonl, the step's >= 9 GFLOP descriptors, HBM-cold, us per launch: T128 / T128R2 / this tile / hipBLASLt):
+//   [1024, 10240] <- 1280 NT 60.3 / 58.9 / 49.6 / 35.6      [4096, 5120] <- 640 NT 68.3 / 57.7 / 52.7 / 45.5      [1024, 3840] <- 1280 NT 19.6 / 26.6 / 18.9 / 18.6
+//   [4096, 2560] <- 640 NN 35.5 / 32.4 / 27.8 / 26.5         [4096, 640] <- 5120 NN 61.3 / 80.1 / 50.3 / 49.7      [4096, 640] <- 1920 NN 26.2 / 33.6 / 22.5 / 28.3
+// i.e. -3 .. -19 % wherever A is K-contiguous (forward / dgrad) and the tile runs unsplit; the wgrad layouts (A MN-contiguous: 146 - 150 VGPRs, one workgroup per CU) lose
+// 5 - 15 % and stay on the DMA ring.  Also built and measured in the same pass, removed again: FOUR register sets (156 - 202 VGPRs = one workgroup per CU: within +-3 % of
+// two sets except [1024, 10240] <- 1280, 51.8) and the 256^2 tile as FOUR waves of 128 x 128 (hipBLASLt's shape for these problems: 256 accumulator registers, one wave per
+// SIMD), register-staged and on the DMA ring: 2 - 4 x SLOWER than the 8-wave tiles (118.8 / 114.8 us on [1024, 10240] <- 1280) -- with one wave per SIMD nothing hides the
+// compiler's read-then-wait fragment schedule, the same finding as round 3's 4-wave tiles; that shape needs a hand-scheduled instruction stream, not this template.
+using T128V = Tile<128, 128, 2, 4, 2, 64, 2>;     // the 8-wave 128^2 tile, 64 KiB of LDS, 2 K-steps (64 KiB) in flight in registers per workgroup, <= 128 VGPRs (two workgroups
+                                                  // per CU); tile code 132, tile_hint 12000 + S
+
 // sum of the 8 bf16 of an MFMA operand fragment (fp32)
 __device__ __forceinline__ float frag_sum(bf16x8_t f) {
     const uint4 u = __builtin_bit_cast(uint4, f);
@@ -110,7 +127,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 template <int NLOAD, int MAXAHEAD> __device__ __forceinline__ void wait_dma_ahead(int ahead) {
-    static_assert(NLOAD == 4 || NLOAD == 6 || NLOAD == 8 || NLOAD == 12, "DMA pieces per wave per K-step");
+    static_assert(NLOAD == 4 || NLOAD == 6 || NLOAD == 8 || NLOAD == 12 || NLOAD == 16, "DMA pieces per wave per K-step");
     static_assert(MAXAHEAD >= 1 && MAXAHEAD <= 7 && NLOAD * MAXAHEAD <= 63, "look-ahead of the ring vs the vmcnt field");
     switch (ahead) {       // (ahead <= MAXAHEAD = STAGES - 2 by construction; the unreachable cases fold away)
     case 0: wait_vmcnt<0>(); break;
@@ -132,9 +149,10 @@ template <int NLOAD, int MAXAHEAD> __device__ __forceinline__ void wait_dma_ahea
 // The body of one workgroup: `orig` = its index among the problem's tiles_m * tiles_n * splitk workgroups (the launch's blockIdx.x, or the workgroup's index
 // inside its problem's share of a GROUPED launch), `bz` = batch index / CONV 2 tap (blockIdx.y), `lds` = the launch's one LDS array (STAGES * STAGE_BYTES, 1 KiB
 // aligned).  Always inlined: the array's address space reaches the ds_read / DMA instructions through the inliner.
-template <int BM_, int BN_, int WM_, int WN_, int STAGES_, bool A_MC, bool B_MC, int CONV = 0, int BKT = 64>
+template <int BM_, int BN_, int WM_, int WN_, int STAGES_, bool A_MC, bool B_MC, int CONV = 0, int BKT = 64, int VS = 0>
 __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, char* const lds, const int orig, const int bz) {
-    using TL = Tile<BM_, BN_, WM_, WN_, STAGES_, BKT>;
+    using TL = Tile<BM_, BN_, WM_, WN_, STAGES_, BKT, VS>;
+    static_assert(VS == 0 || (STAGES_ == 2 && CONV != 2 && BKT == 64), "register-staged tiles: plain GEMM / gathered-row convolution on a 2-deep LDS ring of whole K-steps");
     constexpr int BM = TL::BM, BN = TL::BN, STAGES = TL::STAGES, TM = TL::TM, TN = TL::TN, NLOAD = TL::NLOAD;
     constexpr int BK = BKT, KS = BKT / 16;          // (shadows the namespace default) k extent of a stage, 16-wide k-slices per stage
     static_assert(CONV == 0 || BKT == 64, "the convolution gathers are written for 64-channel K-steps");
@@ -151,7 +169,8 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, char* const 
     // grouped rasterisation: consecutive tiles walk 8 tile-rows before moving one tile-column over, so the ~32 tiles an
     // XCD works on at any moment form an 8 x 4 block sharing 8 + 4 operand panels (instead of 32 + 1): ~2.7x less
     // L2 miss traffic once the operands outgrow the 4 MiB L2.
-    constexpr int GR = 8;
+    // (round 5: the group height follows the run an XCD owns -- ~sqrt(tiles per XCD), 8 at most: a run of 10 tiles as 3 x 3.3 touches 7 operand panels, as 8 x 1.25 ten)
+    const int GR = p.gr;
     const int gsz = GR * p.tiles_n;
     const int grp = tile / gsz, first_m = grp * GR;
     const int rows_in = min(p.tiles_m - first_m, GR);
@@ -313,21 +332,80 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, char* const 
     const bool colsum_here = A_MC && p.colsum != nullptr && tile_n == 0 && (CONV != 2 || bz == 0);   // CONV 2: every tap sees the same dy
     const bool do_colsum = colsum_here && (wid % TL::WN) == 0;
 
-    // ---- prologue: STAGES - 1 K-steps in flight
+    // ---- register-staged feed (VS > 0): set r of rg holds one K-step's pieces of this wave on their way global -> LDS
+    // The steady-state loop carries NO branch around a load or a ds_write: hipcc's s_waitcnt insertion gives up counting at control-flow joins (the first version, with
+    // `if (reload)` around the loads, waited vmcnt(0) ahead of every ds_write -- every load in flight drained, i.e. no pipeline).  A K-step past the end is therefore
+    // still "loaded", from an offset beyond the buffer extent (the bounds check returns zeros without a memory request), and its ds_write lands in the slot nobody reads.
+    u32x4_t rg[VS > 0 ? VS : 1][NLOAD];
+    constexpr unsigned VS_OOB = 0x80000000u;
+    // (same rule as the DMA builtin: the buffer builtins only ever see non-dependent locals)
+#define VS_LOAD(r, J0, J1, LIVE)                                                                                              \
+    do {                                                                                                                      \
+        const unsigned kofsB_ = (CONV == 1 && B_MC) ? (unsigned)(((long)c_kc * BK * p.ldb + (long)(c_ky * cg.kw + c_kx) * cg.b_tap_stride) * 2) : 0u; \
+        _Pragma("unroll") for (int j = (J0); j < (J1); ++j) {                                                                 \
+            if (j < TL::PA) {                                                                                                 \
+                unsigned off_;                                                                                                \
+                if constexpr (CONV == 1) off_ = conv_off_a(j); else { off_ = voA[j]; voA[j] += stepA; }                       \
+                off_ = (LIVE) ? off_ : VS_OOB;                                                                                \
+                rg[r][j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off_, 0, 0);                                            \
+            } else {                                                                                                          \
+                unsigned off_;                                                                                                \
+                if constexpr (CONV == 1 && B_MC) off_ = voB[j - TL::PA] + kofsB_;                                             \
+                else { off_ = voB[j - TL::PA]; voB[j - TL::PA] += stepB; }                                                    \
+                off_ = (LIVE) ? off_ : VS_OOB;                                                                                \
+                rg[r][j] = __builtin_amdgcn_raw_buffer_load_b128(rsB, off_, 0, 0);                                            \
+            }                                                                                                                 \
+        }                                                                                                                     \
+        if ((J1) == NLOAD) {          /* the whole K-step is issued: move the gather state on by one K-step */               \
+            if constexpr (CONV == 1) {                                                                                        \
+                if (++c_kc == cg.cchunks) { c_kc = 0; if (++c_kx == cg.kw) { c_kx = 0; ++c_ky; } }                            \
+            }                                                                                                                 \
+        }                                                                                                                     \
+    } while (0)
+    // piece j of an operand -> LDS byte (j * NW + wid) * 1024 + 16 * lane of its image: the LDS-DMA's own lane-linear destination, so the image formats, the source
+    // swizzles (dma_voffset) and every fragment read are the DMA ring's
+#define VS_WRITE(r, buf, J0, J1)                                                                                              \
+    do {                                                                                                                      \
+        char* base_ = lds + (buf) * TL::STAGE_BYTES + wid * 1024 + lane * 16;                                                 \
+        _Pragma("unroll") for (int j = (J0); j < (J1); ++j) {                                                                 \
+            char* dst_ = base_ + (j < TL::PA ? j * TL::NW * 1024 : TL::IMG_A + (j - TL::PA) * TL::NW * 1024);                 \
+            *reinterpret_cast<u32x4_t*>(dst_) = rg[r][j];                                                                     \
+        }                                                                                                                     \
+    } while (0)
+
+    // ---- prologue: STAGES - 1 K-steps in flight (VS > 0: K-steps 0 .. VS - 1 into the register sets, step 0 on into LDS slot 0, step VS behind it)
+    if constexpr (VS == 0) {
 #pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s)
-        if (s < nk) ISSUE_STAGE(s);
+        for (int s = 0; s < STAGES - 1; ++s)
+            if (s < nk) ISSUE_STAGE(s);
+    } else {
+#pragma unroll
+        for (int r = 0; r < VS; ++r) VS_LOAD(r, 0, NLOAD, r < nk);
+        VS_WRITE(0, 0, 0, NLOAD);
+        VS_LOAD(0, 0, NLOAD, VS < nk);
+    }
 
     TL_STAMP(1);
     int cur = 0, nxt = STAGES - 1;
-    for (int it = 0; it < nk; ++it) {
+    constexpr int UNR = VS > 0 ? VS : 1;       // VS > 0: the loop is unrolled by VS so that every iteration names its register set statically
+    for (int it0 = 0; it0 < nk; it0 += UNR) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int it = it0 + u;      // (VS > 1: the last group may run past nk -- no break: a branch inside the unrolled group makes hipcc's s_waitcnt insertion fall back to
+                                     //  conservative counts (ISA checked: vmcnt 15 / 11 / 4 / 3 over the four copies instead of 15 everywhere).  K-steps past nk were "loaded"
+                                     //  from beyond the buffer extent, i.e. are zeros in registers and LDS: their MFMAs add nothing; at most VS - 1 dead K-steps per tile)
+        constexpr int RSET_BASE = 1;           // iteration it writes K-step it + 1 (register set (it + 1) % VS) into the other LDS slot and reloads that set with step it + 1 + VS
+        const int rset = VS > 0 ? (u + RSET_BASE) % UNR : 0;
         // retire this wave's DMA of K-step `it` (later steps stay in flight), then one barrier: every wave's share of
         // step `it` has landed AND every wave has finished reading buffer `nxt` (it computed step it-1 from it).
-        wait_dma_ahead<NLOAD, (STAGES > 2 ? STAGES - 2 : 1)>(min(nk - it - 1, STAGES - 2));
+        // (VS > 0: this wave's ds_writes of step `it` -- issued one iteration ago -- have completed)
+        if constexpr (VS == 0) wait_dma_ahead<NLOAD, (STAGES > 2 ? STAGES - 2 : 1)>(min(nk - it - 1, STAGES - 2));
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         TL_STAMP(4 + 4 * it);
         __builtin_amdgcn_s_barrier();
         TL_STAMP(5 + 4 * it);
-        const bool refill = it + STAGES - 1 < nk;
+        const bool refill = VS == 0 && it + STAGES - 1 < nk;
+        const bool reload = VS > 0 && it + 1 + VS < nk;        // VS > 0: K-step it + 1 moves registers -> LDS during this iteration, K-step it + 1 + VS (if any) takes its registers
         TL_STAMP(6 + 4 * it);
         const char* imgA = lds + cur * TL::STAGE_BYTES;
         const char* imgB = imgA + TL::IMG_A;
@@ -352,7 +430,11 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, char* const 
             for (int ks = 0; ks < KS; ++ks) {
                 // the refill of ring buffer `nxt` is issued a quarter at a time BETWEEN the k-slices' MFMAs: a DMA piece costs the wave
                 // 75 .. 85 issue cycles (timeline probe), which now run while the matrix pipe works instead of ahead of the whole K-step
-                if (refill) ISSUE_RANGE(nxt, ks * NLOAD / KS, (ks + 1) * NLOAD / KS);
+                if constexpr (VS == 0) { if (refill) ISSUE_RANGE(nxt, ks * NLOAD / KS, (ks + 1) * NLOAD / KS); }
+                else {
+                    VS_WRITE(rset, nxt, ks * NLOAD / KS, (ks + 1) * NLOAD / KS);
+                    VS_LOAD(rset, ks * NLOAD / KS, (ks + 1) * NLOAD / KS, reload);
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -373,12 +455,18 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, char* const 
                 // this wave's share of the next K-step's DMA is spread over the first two k-slices: a piece costs the issuing wave
                 // 60 .. 180 cycles (MI355X_MICROARCH.md), which now falls into the shadow of the other wave's MFMAs instead of
                 // both waves of a SIMD issuing all their pieces right after the barrier
-                if (refill && ks < 2) ISSUE_RANGE(nxt, ks * NLOAD / 2, (ks + 1) * NLOAD / 2);   // first half of the K-step: the second half is the landing window
+                if constexpr (VS == 0) {
+                    if (refill && ks < 2) ISSUE_RANGE(nxt, ks * NLOAD / 2, (ks + 1) * NLOAD / 2);   // first half of the K-step: the second half is the landing window
+                }
                 if (ks + 1 < KS) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i) fa[(ks + 1) & 1][i] = read_frag<A_MC, BM, BKT>(imgA, wm0 + i * 32, ks + 1, lane);
 #pragma unroll
                     for (int j = 0; j < TN; ++j) fb[(ks + 1) & 1][j] = read_frag<B_MC, BN, BKT>(imgB, wn0 + j * 32, ks + 1, lane);
+                }
+                if constexpr (VS > 0) {      // register-staged: a quarter of the pieces per k-slice, behind the slice's fragment reads (LDS operations retire in order)
+                    VS_WRITE(rset, nxt, ks * NLOAD / KS, (ks + 1) * NLOAD / KS);
+                    VS_LOAD(rset, ks * NLOAD / KS, (ks + 1) * NLOAD / KS, reload);
                 }
                 if (do_colsum) {
 #pragma unroll
@@ -395,11 +483,14 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, char* const 
         TL_STAMP(7 + 4 * it);
         cur = (cur + 1 == STAGES) ? 0 : cur + 1;
         nxt = (nxt + 1 == STAGES) ? 0 : nxt + 1;
+      }
     }
     TL_STAMP(2);
 
 #undef ISSUE_STAGE
 #undef ISSUE_RANGE
+#undef VS_LOAD
+#undef VS_WRITE
     // ---- split-K: publish this slice's slab; the last arriver of the tile reduces all slabs in slice order
     if (p.splitk > 1) {
         float4* slab0 = reinterpret_cast<float4*>(p.slabs) + ((long)(z * nt + tile) * p.splitk) * TL::SLAB_F4;
@@ -594,11 +685,11 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, char* const 
     TL_STAMP(3);
 }
 
-template <int BM_, int BN_, int WM_, int WN_, int STAGES_, bool A_MC, bool B_MC, int CONV = 0, int BKT = 64>
-__global__ void __launch_bounds__(WM_ * WN_ * 64, (WM_ * WN_ == 4 && BKT == 32) ? 3 : 1) gemm_pipe_kernel(const GemmParams p) {     // half-step 4-wave tiles: three waves per SIMD (<= 168 VGPRs)
-    using TL = Tile<BM_, BN_, WM_, WN_, STAGES_, BKT>;
+template <int BM_, int BN_, int WM_, int WN_, int STAGES_, bool A_MC, bool B_MC, int CONV = 0, int BKT = 64, int VS = 0>
+__global__ void __launch_bounds__(WM_ * WN_ * 64, (WM_ * WN_ == 4 && BKT == 32) ? 3 : (VS > 0 && !A_MC) ? 2 : 1) gemm_pipe_kernel(const GemmParams p) {     // half-step 4-wave tiles: three waves per SIMD (<= 168 VGPRs); register-staged 128^2: two workgroups per CU (<= 128)
+    using TL = Tile<BM_, BN_, WM_, WN_, STAGES_, BKT, VS>;
     __shared__ __attribute__((aligned(1024))) char lds[TL::STAGES * TL::STAGE_BYTES];
-    gemm_pipe_body<BM_, BN_, WM_, WN_, STAGES_, A_MC, B_MC, CONV, BKT>(p, lds, (int)blockIdx.x, (int)blockIdx.y);
+    gemm_pipe_body<BM_, BN_, WM_, WN_, STAGES_, A_MC, B_MC, CONV, BKT, VS>(p, lds, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // ---- grouped launch: up to GROUP_MAX INDEPENDENT plain GEMMs (batch 1, one tile geometry, any mix of operand layouts) as ONE kernel launch.  Each workgroup
@@ -610,12 +701,12 @@ struct GemmGroup {
     GemmParams p[GROUP_MAX];
     int start[GROUP_MAX];        // first workgroup of problem i (multiple of 8)
     int nwg[GROUP_MAX];          // its workgroups: tiles_m * tiles_n * splitk
-    int mode[GROUP_MAX];         // 2 * a_mc + b_mc
+    int mode[GROUP_MAX];         // 2 * a_mc + b_mc (+ 4: the problem was planned onto the register-staged form of the tile, T128V next to T128R2 -- same geometry, same LDS)
     int n;
 };
 
 template <int BM_, int BN_, int WM_, int WN_, int STAGES_>
-__global__ void __launch_bounds__(WM_ * WN_ * 64, 1) gemm_pipe_group_kernel(const GemmGroup g) {
+__global__ void __launch_bounds__(WM_ * WN_ * 64, (BM_ == 128 && STAGES_ == 2) ? 2 : 1) gemm_pipe_group_kernel(const GemmGroup g) {
     using TL = Tile<BM_, BN_, WM_, WN_, STAGES_, 64>;
     __shared__ __attribute__((aligned(1024))) char lds[TL::STAGES * TL::STAGE_BYTES];
     const int b = (int)blockIdx.x;
@@ -626,6 +717,10 @@ __global__ void __launch_bounds__(WM_ * WN_ * 64, 1) gemm_pipe_group_kernel(cons
     const int local = b - g.start[i];
     if (local >= g.nwg[i]) return;
     const GemmParams& p = g.p[i];
+    if constexpr (BM_ == 128 && STAGES_ == 2) {      // T128R2's group also carries problems planned onto T128V (K-contiguous A only)
+        if (g.mode[i] == 4) { gemm_pipe_body<BM_, BN_, WM_, WN_, STAGES_, false, false, 0, 64, T128V::VS>(p, lds, local, 0); return; }
+        if (g.mode[i] == 5) { gemm_pipe_body<BM_, BN_, WM_, WN_, STAGES_, false, true, 0, 64, T128V::VS>(p, lds, local, 0); return; }
+    }
     switch (g.mode[i]) {
     case 0: gemm_pipe_body<BM_, BN_, WM_, WN_, STAGES_, false, false>(p, lds, local, 0); break;
     case 1: gemm_pipe_body<BM_, BN_, WM_, WN_, STAGES_, false, true>(p, lds, local, 0); break;
@@ -643,7 +738,7 @@ int launch_pipe_group(const GemmGroup& g, int total_wg, hipStream_t s) {
 template <typename TL, int CONV = 0>
 int launch_pipe(const GemmParams& p, bool a_mc, bool b_mc, int batch, hipStream_t s) {
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n * p.splitk), (unsigned)batch);
-#define DPIPE_PIPE_LAUNCH(AM, BMC) gemm_pipe_kernel<TL::BM, TL::BN, TL::WM, TL::WN, TL::STAGES, AM, BMC, CONV, TL::BK><<<grid, TL::NT, 0, s>>>(p)
+#define DPIPE_PIPE_LAUNCH(AM, BMC) gemm_pipe_kernel<TL::BM, TL::BN, TL::WM, TL::WN, TL::STAGES, AM, BMC, CONV, TL::BK, TL::VS><<<grid, TL::NT, 0, s>>>(p)
     if constexpr (CONV == 1) {          // A rows gathered: A is K-contiguous; B = weight K-contiguous (forward) or MN-contiguous (dgrad)
         if (b_mc) DPIPE_PIPE_LAUNCH(false, true); else DPIPE_PIPE_LAUNCH(false, false);
         return check_launch("dpipe_conv2d");

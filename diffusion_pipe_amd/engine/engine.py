@@ -756,16 +756,23 @@ class PipelineEngine:
         want_first = self.store_first and self._fused_step_end() and not self.is_data_parallel
         spans = None
         with torch.cuda.stream(side):
-            body()                                  # eager warm-up (library autotuning, allocator pools, .grad buffers) ...
-            if want_first:                          # ... the second pass in store mode: it finds the gradient buffers a fused kernel first-touches (ops.GRAD_STORE).  Done
-                _ops.GRAD_STORE = {}                # here, before this lane's graph pool exists, so it adds nothing to the memory peak (Wan-14B: 98 GB per eager pass)
+            body()                                  # eager warm-up (library autotuning, allocator pools, .grad buffers)
+        cur.wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        if self.flat_grads:                          # the warm-up created this lane's .grad buffers: re-home them into one flat arena per dtype before
+            lane['arena'] = flatten_grads(params, lane['arena'])      # their addresses are baked into the graph
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            # ... the second pass runs in store mode: it finds the gradient buffers a fused kernel first-touches (ops.GRAD_STORE), by address -- hence AFTER the
+            # re-homing above (spans recorded before flatten_grads named the freed buffers, every arena view counted as "not covered" and was zeroed at
+            # the head of the store graph: safe, but the optimisation silently off).  Still before this lane's graph pool exists: nothing added to the memory peak
+            if want_first:
+                _ops.GRAD_STORE = {}
             body()
             if want_first:
                 spans, _ops.GRAD_STORE = sorted(_ops.GRAD_STORE.items()), None
         cur.wait_stream(side)
         torch.cuda.synchronize(self.device)
-        if self.flat_grads:                          # the warm-up created this lane's .grad buffers: re-home them into one flat arena per dtype before
-            lane['arena'] = flatten_grads(params, lane['arena'])      # their addresses are baked into the graph
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode=_capture_mode()):
             body()
@@ -1047,15 +1054,14 @@ class PipelineEngine:
         of the bucket and writes the result back."""
         comm_dt = self.communication_data_type
         buf = chunk if (comm_dt is None or comm_dt == chunk.dtype) else chunk.to(comm_dt)
-        if self._dp_avg_ok is None or self._dp_avg_ok:
-            try:
-                dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=group)
-                self._dp_avg_ok = True
-            except (RuntimeError, ValueError):
-                if self._dp_avg_ok:                # it worked before: a real failure, not a missing capability
-                    raise
-                self._dp_avg_ok = False
-        if self._dp_avg_ok is False:
+        if self._dp_avg_ok is None:
+            # decided ONCE, from the backend's name, before any collective is issued (ADVICE round 4: probing ReduceOp.AVG by catching the exception of a live
+            # collective lets a single failing rank issue a second all-reduce its peers never post -- a hang instead of an error).  RCCL / NCCL have AVG; gloo
+            # takes sum + scale (exact for the power-of-two world sizes the CPU tests use, and never a capability question).
+            self._dp_avg_ok = str(dist.get_backend(group)).lower() == 'nccl'
+        if self._dp_avg_ok:
+            dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=group)
+        else:
             dist.all_reduce(buf, group=group)
             buf.div_(self.dp_world_size)
         if buf is not chunk:

@@ -80,10 +80,19 @@ class StageLink:
         self._pending.append((works, tensors))
 
     @torch.no_grad()            # the buffers may be a stage graph's static inputs (leaves that require grad)
-    def _recv(self, buffers, peer, fresh=True):
-        if self.on_gpu and fresh:
-            # freshly allocated buffers may be a block the caching allocator just recycled on the CALLER'S stream: kernels already enqueued there can still read its
-            # previous contents, so the transfer is ordered behind them (receives into a slot's static buffers are ordered by their own `after` event instead)
+    def _fresh(self, make):
+        """Receive buffers nobody owns yet, allocated ON THE COMMUNICATION STREAM: the caching allocator recycles a block only for the stream it was
+        freed on, so a block handed out here was last used by this link's own transfers (or by a consumer whose use `record_stream` registered) -- the receive needs no
+        wait on the caller's stream, i.e. it is NOT serialised behind the compute already enqueued there (round 4 ordered every fresh receive behind it)."""
+        if self.on_gpu and self.comm_stream is not None:
+            with torch.cuda.stream(self.comm_stream):
+                return make(), True
+        return make(), False
+
+    def _recv(self, buffers, peer, fresh=True, owned=False):
+        if self.on_gpu and fresh and not owned:
+            # buffers allocated on the CALLER'S stream may be a block the caching allocator just recycled there: kernels already enqueued can still read its previous
+            # contents, so the transfer is ordered behind them (receives into a slot's static buffers are ordered by their own `after` event instead)
             self.comm_stream.wait_event(torch.cuda.current_stream(self.device).record_event())
         if self.on_gpu:
             with torch.cuda.stream(self.comm_stream):
@@ -91,9 +100,10 @@ class StageLink:
                 for w in works:
                     w.wait()                          # comm stream ordered after the transfers
                 done = self.comm_stream.record_event()
+            cur = torch.cuda.current_stream(self.device)
             for b in buffers:
-                b.record_stream(self.comm_stream)
-            torch.cuda.current_stream(self.device).wait_event(done)   # consumers run after the payload landed
+                b.record_stream(cur if owned else self.comm_stream)      # the stream that did NOT allocate the block uses it too
+            cur.wait_event(done)   # consumers run after the payload landed
         else:
             for w in [dist.irecv(_wire(b), src=peer) for b in buffers]:
                 w.wait()
@@ -137,14 +147,18 @@ class StageLink:
         specs, is_tuple = layout
         direct = into is not None and len(into) == len(specs) and all(
             b.dtype == dtype and tuple(b.shape) == tuple(shape) and b.is_contiguous() for b, (dtype, shape) in zip(into, specs))
-        buffers = list(into) if direct else [torch.empty(shape, dtype=dtype, device=self.device) for dtype, shape in specs]
+        owned = False
+        if direct:
+            buffers = list(into)
+        else:
+            buffers, owned = self._fresh(lambda: [torch.empty(shape, dtype=dtype, device=self.device) for dtype, shape in specs])
         if buffers:
-            self._recv_after(buffers, peer, after if direct else None)
+            self._recv_after(buffers, peer, after if direct else None, owned=owned)
         return tuple(buffers) if is_tuple else buffers[0]
 
-    def _recv_after(self, buffers, peer, after):
+    def _recv_after(self, buffers, peer, after, owned=False):
         if after is None:
-            return self._recv(buffers, peer)
+            return self._recv(buffers, peer, owned=owned)
         if isinstance(self, RcclLink):
             return self._recv(buffers, peer, after)
         if self.comm_stream is not None:
@@ -157,9 +171,13 @@ class StageLink:
         peer = self.grid.stage_to_global(peer_stage)
         direct = into is not None and len(into) == len(templates) and all(
             b.dtype == t.dtype and b.shape == t.shape and b.is_contiguous() for b, t in zip(into, templates))
-        buffers = list(into) if direct else [torch.empty_like(t, memory_format=torch.contiguous_format) for t in templates]
+        owned = False
+        if direct:
+            buffers = list(into)
+        else:
+            buffers, owned = self._fresh(lambda: [torch.empty_like(t, memory_format=torch.contiguous_format) for t in templates])
         if buffers:
-            self._recv_after(buffers, peer, after if direct else None)
+            self._recv_after(buffers, peer, after if direct else None, owned=owned)
         return buffers
 
     def send_plain(self, tensors, peer_stage):
@@ -338,16 +356,17 @@ class RcclLink(StageLink):
             t.record_stream(self.comm_stream)
         self._pending.append(([], tensors))              # kept alive until flush(); completion is stream-ordered
 
-    def _recv(self, buffers, peer, after=None):
+    def _recv(self, buffers, peer, after=None, owned=False):
         if after is not None:
             self.comm_stream.wait_event(after)           # the buffers' previous consumer (a stage graph replay) has finished
-        else:                                            # fresh buffers: behind whatever the caller's stream still runs on the recycled block (see StageLink._recv)
-            self.comm_stream.wait_event(torch.cuda.current_stream(self.device).record_event())
+        elif not owned:                                  # buffers allocated on the caller's stream: behind whatever it still runs on the recycled block (see StageLink._recv);
+            self.comm_stream.wait_event(torch.cuda.current_stream(self.device).record_event())      # `owned` = allocated on the communication stream (StageLink._fresh): no wait
         self._grouped(buffers, peer, lambda lib: lib.dpipe_recv)
         done = self.comm_stream.record_event()
+        cur = torch.cuda.current_stream(self.device)
         for b in buffers:
-            b.record_stream(self.comm_stream)
-        torch.cuda.current_stream(self.device).wait_event(done)
+            b.record_stream(cur if owned else self.comm_stream)
+        cur.wait_event(done)
 
     def flush(self):
         if self._pending:
@@ -367,7 +386,10 @@ class HostStagedLink(StageLink):
         works = [dist.isend(h, dst=peer) for h in host]
         self._pending.append((works, host))
 
-    def _recv(self, buffers, peer, fresh=True):
+    def _fresh(self, make):
+        return make(), False                 # the staging copy runs on the caller's stream: allocate there
+
+    def _recv(self, buffers, peer, fresh=True, owned=False):
         for b in buffers:
             w = _wire(b)
             h = torch.empty(w.shape, dtype=w.dtype)

@@ -14,6 +14,7 @@ T64, T128 = 2000, 3000   # ... with the 64 x 64 / 128 x 128 tile forced (+ S)
 T256K = 9000         # the 256 x 256 tile on a 4-deep ring of 32-wide half K-steps
 T128N64 = 10000      # skinny-M configuration: 128 x 64 tile, 4-deep ring (M <= 128 linears, deeper split-K)
 T128Q3 = 11000      # occupancy-style 128 x 128: 4 waves of 64 x 64, 3-deep ring of half K-steps (three workgroups per CU)
+T128V = 12000        # round 5: the 8-wave 128 x 128 tile with a register-staged feed (global -> VGPR -> LDS, two K-steps in flight in registers, 2-deep LDS ring)
 T128S2, T256, T64S3, T256S = 4000, 5000, 6000, 7000  # further configurations: 128 x 128 with a 2-deep ring, 256 x 128, 64 x 64 with a 3-deep ring,
                                                       # 256 x 256 (the DiT-sized configuration: double-buffered fragments, DMA spread over the K-step)
 
@@ -48,7 +49,7 @@ SHAPES = [(128, 128, 64), (256, 384, 192), (77, 1280, 1280), (100, 72, 128), (10
 @pytest.mark.parametrize('trans', [(False, True), (False, False), (True, False), (True, True)])
 @pytest.mark.parametrize('shape', SHAPES)
 @pytest.mark.parametrize('split', [0, 1, 2, 5])
-@pytest.mark.parametrize('tile', [T64, T128, T128S2, T256, T64S3, T256S, T256K, T128N64, T128Q3])
+@pytest.mark.parametrize('tile', [T64, T128, T128S2, T256, T64S3, T256S, T256K, T128N64, T128Q3, T128V])
 def test_pipe_gemm_matches_fp32_matmul(gpu, trans, shape, split, tile):
     from diffusion_pipe_amd import ops
     from diffusion_pipe_amd.hip import DpipeHipError

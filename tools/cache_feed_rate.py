@@ -71,9 +71,9 @@ def main():
                     r.con.close()
                 c = Cache(d, 'fp')
                 row['mmap_reader'] = timed(lambda i: c[i], order)
-                pf = CachePrefetcher(c, order, depth=8, workers=2, pin=torch.cuda.is_available())
+                pf = CachePrefetcher(c, order, depth=8, pin=torch.cuda.is_available())
                 it = iter(pf)
-                row['prefetcher_2_workers'] = timed(lambda i: next(it), order)
+                row['prefetcher'] = dict(timed(lambda i: next(it), order), workers=pf.workers)
                 pf.close()
                 c.close()
             out[kind] = row

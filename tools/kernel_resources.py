@@ -7,6 +7,8 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from diffusion_pipe_amd import build  # noqa: E402
 CSRC = ROOT / 'diffusion_pipe_amd' / 'csrc'
 FIELDS = {'VGPRs': 'vgprs', 'AGPRs': 'agprs', 'SGPRs': 'sgprs', 'ScratchSize [bytes/lane]': 'scratch_bytes', 'Occupancy [waves/SIMD]': 'occupancy',
           'SGPRs Spill': 'sgpr_spill', 'VGPRs Spill': 'vgpr_spill', 'LDS Size [bytes/block]': 'lds_bytes'}
@@ -15,7 +17,8 @@ FIELDS = {'VGPRs': 'vgprs', 'AGPRs': 'agprs', 'SGPRs': 'sgprs', 'ScratchSize [by
 def main():
     rows = []
     for src in sorted(CSRC.glob('*.hip')):
-        r = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', str(src), '-o', '/dev/null',
+        # the build's own flags (diffusion_pipe_amd/build.py), per-file extras included
+        r = subprocess.run([build.HIPCC, *build.CFLAGS, *build.EXTRA_CFLAGS.get(src.name, []), '-c', str(src), '-o', '/dev/null',
                             '-Rpass-analysis=kernel-resource-usage'], capture_output=True, text=True, cwd=CSRC)
         cur = None
         for line in r.stderr.splitlines():
