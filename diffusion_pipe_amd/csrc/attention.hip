@@ -1087,9 +1087,9 @@ int dpipe_attn_fwd(const void* q, const void* k, const void* v, void* o, float* 
     if (fits && dma_mode != 0) {
         hipStream_t st = STREAM(stream);
         const long wg256 = (long)cdiv(Sq, 256) * H * B, wg128 = (long)cdiv(Sq, 128) * H * B;
-        // DPIPE_OPT_ATTN_BIG_WG (default 192): fewest 256-row workgroups for which the 8-wave form is taken.  A 256-row workgroup streams its head's K / V once for twice
-        // the queries of a 128-row one (half the global -> LDS bytes per FLOP); alone it must fill the chip to pay, under concurrent micro-batch lanes the other lanes do
-        if (wg256 >= option(DPIPE_OPT_ATTN_BIG_WG, 192) && Sq >= 256) {
+        // 8-wave form from 192 256-row workgroups on.  (A 256-row workgroup streams its head's K / V once for twice the queries of a 128-row one; taking it from 16 / 64
+        // workgroups on under concurrent lanes was neutral -- 22.10 / 22.14 vs 22.06 images/s, profiles/r4m_* -- and the option that selected it is gone)
+        if (wg256 >= 192 && Sq >= 256) {
             if (D == 64) attn_fwd_dma_kernel<64, 1, 8><<<(unsigned)wg256, 512, 0, st>>>(p);
             else attn_fwd_dma_kernel<128, 1, 8><<<(unsigned)wg256, 512, 0, st>>>(p);
         } else {
@@ -1150,7 +1150,7 @@ int dpipe_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
     const unsigned gred = (unsigned)cdiv((long)B * H * Sk * (D / 4), 256);
     // head dim 128: the 4-wave dQ kernel needs > 256 registers (one wave per SIMD); 8 waves x 32 rows fit 2 per SIMD (220 VGPRs) -- DPIPE_ATTN_DQ8 = 0 for A/B timing
     const bool dq8_on = option(DPIPE_OPT_ATTN_DQ8, 1) != 0;
-    const bool dq8 = dq8_on && (long)cdiv(Sq, 256) * H * B >= option(DPIPE_OPT_ATTN_BIG_WG, 192) && Sq >= 256;
+    const bool dq8 = dq8_on && (long)cdiv(Sq, 256) * H * B >= 192 && Sq >= 256;
     dim3 gq8((unsigned)cdiv(Sq, 256), (unsigned)H, (unsigned)B);
     // LDS-DMA forms of the backward kernels (K / V extents within the 32-bit buffer offsets) -- DPIPE_ATTN_BWD_DMA = 0 for A/B timing
     const bool bwd_dma_on = option(DPIPE_OPT_ATTN_BWD_DMA, 1) != 0;

@@ -25,9 +25,6 @@ int launch_conv(GemmParams& p, bool b_mc, int batch, void* ws, long ws_bytes, in
     const int force_s = tile_hint >= 1000 ? tile_hint % 1000 : 0;
     const bool a_mc = CONV == 2;
     int tile = gemm_pipe_plan(p, a_mc, b_mc, batch, ws, ws_bytes, force_s, force_tile);
-    if (tile == 256 || tile == 63) tile = 128;
-    if (tile == 1283) tile = gemm_pipe_plan(p, a_mc, b_mc, batch, ws, ws_bytes, force_s, 129);    // the half-K-step occupancy tile is a plain-GEMM one too (its K-steps are counted in halves)
-    if (tile == 1264) tile = gemm_pipe_plan(p, a_mc, b_mc, batch, ws, ws_bytes, force_s, 64);     // the skinny-M configuration is a plain-GEMM one (a few-pixel convolution: 64^2 tiles)
     if (force_tile == 0) {
         // measured on the SDXL convolutions (tools/conv_timing.py): the 256^2 tile loses on the UNet's 320 / 640-wide outputs (37 % of a 256-wide tile is padding:
         // 152 vs 95 us for 128^2 x 640 -> 320), and the forward's gathered A rows favour two workgroups per CU (2-deep ring) from one round of tiles on

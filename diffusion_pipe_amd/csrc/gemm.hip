@@ -280,7 +280,11 @@ int dpipe_gemm_ex(int dtype, int transA, int transB, int M, int N, int K,
     // 64 x 64 / 128 x 128 tile forced -- an error when the problem is not eligible.
     if (dtype == DPIPE_BF16 && (tile_hint == 0 || tile_hint >= 1000)) {
         int rc = 0;
-        const int force_tile = tile_hint >= 12000 ? 132 : tile_hint >= 11000 ? 1283 : tile_hint >= 10000 ? 1264 : tile_hint >= 9000 ? 258 : tile_hint >= 8000 ? 130 : tile_hint >= 7000 ? 257 : tile_hint >= 6000 ? 63 : tile_hint >= 5000 ? 256 : tile_hint >= 4000 ? 129 : tile_hint >= 3000 ? 128 : tile_hint >= 2000 ? 64 : 0;   // 4000: 128^2 4-deep ring, 5000: 256 x 128 (experiments)
+        // tile_hint >= 1000: the pipelined kernel, hint % 1000 = forced split-K (0 / 1000: automatic).  2000: 64^2, 3000: 128^2 3-deep ring, 4000: 128^2 2-deep ring,
+        // 7000: 256^2, 9000: 256^2 on half K-steps, 12000: 128^2 register-staged.  (5000 / 6000 / 8000 / 10000 / 11000 named tiles that were removed in round 5: refused.)
+        const int th = tile_hint / 1000;
+        if (th == 5 || th == 6 || th == 8 || th == 10 || th == 11 || th > 12) { set_last_error("dpipe_gemm: tile_hint names a tile configuration that no longer exists"); return DPIPE_ERR_UNSUPPORTED; }
+        const int force_tile = th == 12 ? 132 : th == 9 ? 258 : th == 7 ? 257 : th == 4 ? 129 : th == 3 ? 128 : th == 2 ? 64 : 0;
         const int force_s = tile_hint >= 1000 ? tile_hint % 1000 : 0;
         if (gemm_pipe_try(p, transA, transB, batch, splitk_ws, splitk_ws_bytes, force_s, force_tile, s, &rc)) return rc;
         if (tile_hint >= 1000) { set_last_error("dpipe_gemm: problem not eligible for the pipelined kernel"); return DPIPE_ERR_UNSUPPORTED; }

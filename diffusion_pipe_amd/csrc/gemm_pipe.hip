@@ -25,13 +25,8 @@ static int launch_by_tile(int tile, const GemmParams& p, bool a_mc, bool b_mc, i
     switch (tile) {
     case 257: return launch_pipe<T256S>(p, a_mc, b_mc, batch, s);
     case 258: return launch_pipe<T256K>(p, a_mc, b_mc, batch, s);
-    case 256: return launch_pipe<T256>(p, a_mc, b_mc, batch, s);
     case 129: return launch_pipe<T128R2>(p, a_mc, b_mc, batch, s);
-    case 63: return launch_pipe<T64S3>(p, a_mc, b_mc, batch, s);
     case 128: return launch_pipe<T128>(p, a_mc, b_mc, batch, s);
-    case 130: return launch_pipe<T128S5>(p, a_mc, b_mc, batch, s);
-    case 1264: return launch_pipe<T128N64>(p, a_mc, b_mc, batch, s);
-    case 1283: return launch_pipe<T128Q3>(p, a_mc, b_mc, batch, s);
     case 132: return launch_pipe<T128V>(p, a_mc, b_mc, batch, s);
     default: return launch_pipe<T64>(p, a_mc, b_mc, batch, s);
     }
@@ -141,30 +136,16 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
     if (force_tile == 0 && !a_mc && p.ksteps >= 64 && tiles256 >= 128) force_tile = b_mc ? 258 : 257;
     // (Round 4 negative result, profiles/r4h_bench_tile_policy.jsonl: the 256^2 tile for SDXL-sized forward / dgrad problems under four lanes -- from 16 / 48 tiles and 16 K-steps on --
     //  19.62 / 20.72 images/s against 21.10 with the 128^2 rule below, same box: one 128 KiB workgroup per CU leaves no room for another lane's workgroup.)
-    // many tiles of a SHORT K with a K-contiguous A (>= 2 rounds of 128^2 tiles, <= 24 K-steps: the GEGLU / up-projection forwards [1024, 10240] <- 1280 and
-    // [4096, 2560] <- 640): the occupancy-style tile (three 4-wave workgroups per CU on 48 KiB rings of half K-steps) -- a workgroup spends most of such a tile in
-    // prologue / epilogue, which its two neighbours cover: 58.8 -> 52.2 us and 33.2 -> 27.4 us (profiles/r3k_gemm_desc_ledger_halfstep_4wave_tiles.jsonl); wgrad
-    // (A MN-contiguous) and long-K shapes lose on it and stay where they are.  In the four-lane step the rule LOSES (20.25 / 20.40 vs 20.51 / 20.49 images/s, same box:
-    // the lanes already cover those gaps, and three 4-wave workgroups per CU crowd out the other lanes' workgroups) while the single-stream list gains 0.7 % --
-    // so it is opt-in: DPIPE_GEMM_Q3=1 (a workload without lanes)
-    static const bool q3_rule = [] { const char* e = getenv("DPIPE_GEMM_Q3"); return e && atoi(e) != 0; }();
-    if (q3_rule && force_tile == 0 && !a_mc && force_splitk <= 1 && p.ksteps <= 24 && p.ksteps >= 8 && tiles128 >= 512 && p.M >= 512 && p.N >= 512) force_tile = 1283;
-    // skinny M (<= 128 rows: the 77-token linears of the text encoders / cross-attention K, V): one 128-row tile covers A, 64-wide N tiles, K cut into
-    // slices of ~4 K-steps.  MEASURED SLOWER than the 64^2 tile on every such shape of the SDXL step (profiles/r3_gemm_desc_ledger.jsonl: 10.0 - 36 vs
-    // 7.9 - 27 us unsplit, 56 vs 39 ms per step over the M <= 128 launches): opt-in only (DPIPE_GEMM_SKINNY=1 / tile_hint 10000 + S)
-    const bool skinny = force_tile == 1264 || (force_tile == 0 && p.M <= 128 && p.N >= 256 && p.ksteps >= 4 && option(DPIPE_OPT_GEMM_SKINNY, 0) != 0);
-    if (skinny) force_tile = 1264;
-    const int bm = (force_tile == 256 || force_tile == 257 || force_tile == 258) ? 256 : (big || skinny) ? 128 : 64,
-              bn = force_tile == 256 ? 128 : skinny ? 64 : bm;
+    // (Removed in round 5 after losing twice: the occupancy-style 4-wave tile for short-K forwards (DPIPE_GEMM_Q3: single-stream list +0.7 %, four-lane step -0.8 %) and the
+    //  skinny 128 x 64 tile for M <= 128 (DPIPE_GEMM_SKINNY: 56 vs 39 ms per step over those launches).)
+    const int bm = (force_tile == 257 || force_tile == 258) ? 256 : big ? 128 : 64, bn = bm;
     p.tiles_m = (p.M + bm - 1) / bm; p.tiles_n = (p.N + bn - 1) / bn;
     const long tiles = (long)p.tiles_m * p.tiles_n * batch;
     const long slab_bytes = ((long)bm * bn + bm) * 4;
     int S = 1;
     if (ws && ws_bytes > COUNTER_BYTES) {
         if (force_splitk > 0) S = force_splitk;
-        else if (skinny) {
-            S = (int)(512 / tiles); const int cap = p.ksteps / 4; if (S > cap) S = cap; if (S > 16) S = 16;
-        } else if (!big && tiles <= 128 && p.ksteps >= 32) {   // few, long tiles split
+        else if (!big && tiles <= 128 && p.ksteps >= 32) {   // few, long tiles split
             // up to 4 slices; 8 once a slice would still walk >= 32 K-steps (the batched context K / V dgrad [77, 2048] <- [77, 25600]: 69.8 -> 44.9 us)
             S = (int)(512 / tiles); const int cap = p.ksteps / 8; if (S > cap) S = cap; const int smax = p.ksteps >= 256 ? 8 : 4; if (S > smax) S = smax;
         } else if (!big && tiles <= 64 && p.ksteps >= 16) {
@@ -206,19 +187,18 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
     p.vecA = c_ok ? 2 : 0;
     if (c_ok && p.residual && reinterpret_cast<uintptr_t>(p.residual) % 8 == 0 && p.ldr % 4 == 0) p.vecA = 3;   // 8-byte residual loads too
     p.vecB = (p.bias && reinterpret_cast<uintptr_t>(p.bias) % 8 == 0) ? 2 : 0;
-    if (force_tile == 258 || force_tile == 1283) { p.ksteps *= 2; p.ksteps_per_split *= 2; return force_tile; }      // T256K counts K in 32-wide half steps (slices keep their K ranges)
-    if (force_tile == 257 || force_tile == 256 || force_tile == 63 || force_tile == 130 || force_tile == 1264 || force_tile == 132) return force_tile;
-    // Register-staged 128^2 tile (T128V, round 5) wherever A is K-contiguous (forward NT, dgrad NN), the tile runs unsplit and walks >= 8 K-steps: -3 .. -19 % against the
-    // better of the two DMA rings on every such descriptor of the SDXL step (gemm_pipe_kernel.h has the table); the wgrad layouts and split tiles stay on the DMA rings.
-    // DPIPE_GEMM_VS=0 switches the rule off (A/B).
+    if (force_tile == 258) { p.ksteps *= 2; p.ksteps_per_split *= 2; return force_tile; }      // T256K counts K in 32-wide half steps (slices keep their K ranges)
+    if (force_tile == 257 || force_tile == 132) return force_tile;
+    // Register-staged 128^2 tile (T128V, round 5) wherever A is K-contiguous (forward NT, dgrad NN) and a workgroup walks >= 8 K-steps: -3 .. -19 % against the better of
+    // the two DMA rings on every such descriptor of the SDXL step (gemm_pipe_kernel.h has the table), split tiles included ([1024, 1280] <- 10240 NN in three slices 42.6 vs
+    // 49.7 us, <- 3840 23.4 vs 25.2: profiles/r5c_gemm_desc_ledger_register_staged_and_gr.jsonl); the wgrad layouts stay on the DMA rings.  DPIPE_GEMM_VS=0: rule off (A/B).
     static const bool vs_rule = [] { const char* e = getenv("DPIPE_GEMM_VS"); return !e || atoi(e) != 0; }();
-    if (vs_rule && force_tile == 0 && big && !a_mc && p.splitk == 1 && p.ksteps >= 8 && batch == 1) return 132;
+    if (vs_rule && force_tile == 0 && big && !a_mc && p.ksteps_per_split >= 8 && batch == 1) return 132;
     if (force_tile == 129 || (force_tile == 0 && big && tiles128 >= 256 && (a_mc || b_mc || tiles128 >= 1024))) return 129;
-    // DPIPE_OPT_GEMM_SHALLOW: the shallow rings everywhere (128^2 on 2 x 32 KiB, 64^2 on 3 x 16 KiB) -- slower launches in isolation (step list: 23.5 vs 22.0 us
-    // average), but a 64 KiB footprint lets a workgroup of ANOTHER micro-batch lane share the CU: 19.34 vs 18.93 images/s with 3 lanes
-    // (profiles/r3e_bench_variants.jsonl).  The engine sets 2 (128^2 only) when it replays >= 2 lanes
-    const int shallow = option(DPIPE_OPT_GEMM_SHALLOW, 0);
-    if (shallow && force_tile == 0) { if (big && shallow != 3) return 129; if (!big && shallow != 2) return 63; }     // 1: both, 2: 128^2 only, 3: 64^2 only
+    // DPIPE_OPT_GEMM_SHALLOW: the 128^2 tile on its 2-deep 64 KiB ring everywhere -- slower launches in isolation (step list: 23.5 vs 22.0 us average), but a 64 KiB
+    // footprint lets a workgroup of ANOTHER micro-batch lane share the CU: 19.34 vs 18.93 images/s with 3 lanes (profiles/r3e_bench_variants.jsonl).  The engine sets
+    // it when it replays >= 2 lanes.  (The 64^2 tile's 3-deep variant never paid and is gone.)
+    if (option(DPIPE_OPT_GEMM_SHALLOW, 0) != 0 && force_tile == 0 && big) return 129;
     return big ? 128 : 64;
 }
 

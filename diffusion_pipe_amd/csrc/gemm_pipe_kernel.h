@@ -68,33 +68,14 @@ using T128 = Tile<128, 128, 2, 4, 3>;
 using T128R2 = Tile<128, 128, 2, 4, 2>;     // 2-deep ring, 64 KiB -> 2 workgroups per CU: one tile's epilogue / prologue overlaps the other's K-loop.
                                             // Measured (tools/kernel_timing.py cold): 1.3-1.7x over T128 once there are >= 256 tiles and an
                                             // MN-contiguous operand (dgrad / wgrad), 1.2x at 8192^3; slower with few tiles (no second workgroup).
-using T128S5 = Tile<128, 128, 2, 4, 5>;     // 5-deep ring = all 160 KiB of LDS, 4 K-steps (128 KiB) in flight: the timeline probe (tools/probes/gemm_timeline.hip) shows
-                                            // HBM-cold DMA pieces landing ~4 500 cycles after issue -- a 3-deep ring parks every wave ~900 cycles per K-step at vmcnt, this one ~460;
-                                            // selectable (tile_hint 8000 + S), not chosen automatically: whole-kernel time is unchanged (52.9 vs 51.5 us on
-                                            // [1024,1280] x [10240,1280]^T: 2.5 rounds of tiles at one workgroup per CU either way, longer prologue)
-// (Round 4 negative result, profiles/r4a_bench_ab.jsonl: the 64^2 tile on 6- / 8-deep rings -- 96 / 128 KiB, five / seven K-steps of DMA in flight -- for launches of at most one
-//  workgroup per CU (the 77-token linears, split slices) left the step's launch list and the step itself unchanged (roofline.frac 0.1341 / 0.1344 vs 0.1345, 20.69 / 20.66 vs
-//  20.77 images/s): those launches already split their K range four ways, i.e. everything is in flight anyway.  Removed again.)
-using T64S3 = Tile<64, 64, 2, 2, 3>;         // selectable, not chosen automatically: 3-deep ring (3 workgroups per CU)
-using T128N64 = Tile<128, 64, 2, 2, 4>;     // skinny-M configuration (M <= 128: the 77-token text-encoder / cross-attention K,V linears): ONE tile row covers every
-                                            // row of A, so each weight panel is fetched by exactly one workgroup (the 64^2 tile reads it twice for M = 77), 4-deep ring
-                                            // of 24 KiB stages; meant to be combined with deeper split-K (a few K-steps per workgroup, all in flight at once)
-using T256 = Tile<256, 128, 4, 2, 3>;       // selectable, not chosen automatically: 256 x 128, 8 waves of 64 x 64, 144 KiB (T128R2 beats it)
-using T256K = Tile<256, 256, 2, 4, 4, 32>;  // the same 256 x 256 tile on a 4-deep ring of HALF K-steps (32 k, 32 KiB each; the same 128 KiB of LDS): three half steps in flight instead of
+// Tiles built, measured and removed again (the measurements stay in profiles/; HISTORY.md section 4 has the numbers): T128S5 (5-deep ring = all of the LDS: whole-kernel
+// time unchanged, 52.9 vs 51.5 us), T64 on 6- / 8-deep rings (round 4: list and step unchanged), T64S3 (3-deep 48 KiB ring: never dispatched), T128N64 (skinny M <= 128 with
+// deep split-K: 56 vs 39 ms per step over those launches), T256 (256 x 128: T128R2 beats it), FOUR-wave tiles of every shape (15 .. 55 % slower: nothing covers a lone
+// wave's waits; round 5's 4-wave 256^2 register-staged tile: 2 - 4 x slower), T128Q3 / Q4 (occupancy-style 4-wave 128^2 on half K-steps: -11 % on one shape, -2 % on
+// the step), the 8-wave 128^2 tile on half-K-step rings (within +-5 %, behind in the step).
+using T256K = Tile<256, 256, 2, 4, 4, 32>;  // the 256 x 256 tile on a 4-deep ring of HALF K-steps (32 k, 32 KiB each; the same 128 KiB of LDS): three half steps in flight instead of
                                             // one whole step -- the 2-deep ring parks every wave ~1 100 cycles per K-step at vmcnt (timeline probe), its refill can only be issued
                                             // once the whole previous step has been consumed
-// (Round 3 negative result, profiles/r3_gemm_desc_ledger_4wave_tiles_negative.jsonl: FOUR-wave workgroups -- 128 x 64 wave tiles on 128 x 256 / 256 x 128, 64 x 64 wave tiles
-//  on 128 x 128, one wave per SIMD -- read a third less from the LDS per MFMA but run 15 .. 55 % SLOWER than the eight-wave tiles on every SDXL shape >= 9 GFLOP
-//  ([1024, 10240, 1280]: 90 / 69 us vs 59): with one wave per SIMD nothing covers the wave's own DMA issue, fragment reads and barrier waits.  Removed again.)
-using T128Q3 = Tile<128, 128, 2, 2, 3, 32>;  // OCCUPANCY-style 128^2 tile: 4 waves of 64 x 64 on a 3-deep ring of HALF K-steps (3 x 16 KiB = 48 KiB) -> THREE workgroups per CU, one wave of
-                                             // each per SIMD: a workgroup's vmcnt wait / barrier / fragment-read latency is covered by the other two (the deep-ring tiles rely on one
-                                             // workgroup's own look-ahead instead).  tile_hint 11000 + S.  Measured (profiles/r3k_gemm_desc_ledger_halfstep_4wave_tiles.jsonl):
-                                             // -11 % on [1024,1280] x [10240,1280]^T (52.2 vs 58.8 us) and -17 % on [4096,640] x [640,2560], +5 .. +15 % on the wgrad (TN) shapes and far
-                                             // behind wherever split-K is what fills the chip; forced for every 128^2 launch of the step: 19.06 vs 19.44 images/s.  Selectable, not dispatched.
-// (T128Q4, the same on a 4-deep ring = 64 KiB, two workgroups per CU, was never ahead of T128Q3: removed.)
-// (Round 3 negative result, profiles/r3q_gemm_desc_ledger_halfstep_8wave_tiles_negative.jsonl: the 8-wave 128^2 tile on 5- / 4-deep rings of half K-steps -- 80 / 64 KiB, two
-//  workgroups per CU WITH two / one and a half K-steps of look-ahead -- lands within +-5 % of the better of T128 / T128R2 on every shape and never ahead in the step
-//  (18.35 / 18.45 vs 18.74 images/s): look-ahead and co-residency buy the same thing.  Removed again.)
 using T256S = Tile<256, 256, 2, 4, 2>;      // 256 x 256, 8 waves of 128 x 64 (128 accumulator VGPRs), 2 x 64 KiB: twice the MFMA work per DMA'd
                                             // byte of the 128^2 tile -- the large-GEMM configuration (DiT-sized linears: Flux / Wan / HunyuanVideo)
 
@@ -686,7 +667,7 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, char* const 
 }
 
 template <int BM_, int BN_, int WM_, int WN_, int STAGES_, bool A_MC, bool B_MC, int CONV = 0, int BKT = 64, int VS = 0>
-__global__ void __launch_bounds__(WM_ * WN_ * 64, (WM_ * WN_ == 4 && BKT == 32) ? 3 : (VS > 0 && !A_MC) ? 2 : 1) gemm_pipe_kernel(const GemmParams p) {     // half-step 4-wave tiles: three waves per SIMD (<= 168 VGPRs); register-staged 128^2: two workgroups per CU (<= 128)
+__global__ void __launch_bounds__(WM_ * WN_ * 64, (VS > 0 && !A_MC) ? 2 : 1) gemm_pipe_kernel(const GemmParams p) {     // register-staged 128^2: two workgroups per CU (<= 128 VGPRs)
     using TL = Tile<BM_, BN_, WM_, WN_, STAGES_, BKT, VS>;
     __shared__ __attribute__((aligned(1024))) char lds[TL::STAGES * TL::STAGE_BYTES];
     gemm_pipe_body<BM_, BN_, WM_, WN_, STAGES_, A_MC, B_MC, CONV, BKT, VS>(p, lds, (int)blockIdx.x, (int)blockIdx.y);

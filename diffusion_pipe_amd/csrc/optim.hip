@@ -179,6 +179,50 @@ __device__ __forceinline__ int nearest_code(const float* q, float x) {
     return (q[hi] - x) < (x - q[lo]) ? hi : lo;
 }
 
+// ---- direct quantiser (round 5).  The library's maps are not arbitrary tables: `create_dynamic_map` lays 7 decades 10^-6 .. 10^0 side by side, decade i holding
+// 2^i (signed map) / 2^(i+1) (unsigned) EVENLY spaced values in (0.1, 1) x 10^(i-6), plus 0 and 1 (mirrored negatives in the signed map).  So the index of the code
+// nearest to x follows from 6 threshold comparisons (the decade), one multiply-add and a round (the slot) -- right to within +-1 across decade borders and rounding
+// (checked on 6 M points incl. every code, every midpoint +- ulps: oracle-side emulation in tests/test_optim_cpu.py) -- and the exact answer, ties included, is the
+// nearest of the three map entries around the guess: 3 INDEPENDENT LDS reads instead of the binary search's 9 dependent ones per moment per element (the kernel was
+// bound by that chain: 1.8 of 6.3 TB/s).  Whether a launch's maps ARE the dynamic maps is checked by the workgroup itself (one closed-form comparison per thread while it
+// stages the map into LDS); any other table keeps the search.
+__device__ __forceinline__ float dyn_map_value(int idx, bool is_signed) {
+    int pos; float sgn = 1.f;
+    if (is_signed) { if (idx == 127) return 0.f; if (idx == 255) return 1.f; pos = idx < 127 ? 126 - idx : idx - 128; sgn = idx < 127 ? -1.f : 1.f; }
+    else { if (idx == 0) return 0.f; if (idx == 255) return 1.f; pos = idx - 1; }
+    const int base = is_signed ? 1 : 2;
+    const int i = 31 - __clz(pos + base) - (is_signed ? 0 : 1);        // decade: its first slot sits at pos = nper - base
+    const int nper = is_signed ? (1 << i) : (2 << i);
+    const int j = pos + base - nper;
+    float scale = 1e-6f;
+    for (int d = 0; d < i; ++d) scale *= 10.f;
+    return sgn * scale * (0.1f + 0.9f * ((float)j + 0.5f) / (float)nper);
+}
+// true when the staged map equals the dynamic map to 1e-5 relative (every thread of the 256-thread workgroup checks its own entry)
+__device__ __forceinline__ bool is_dynamic_map(float mine, bool is_signed) {
+    const float want = dyn_map_value((int)threadIdx.x, is_signed);
+    return __syncthreads_and(fabsf(mine - want) <= 1e-5f * fabsf(want) + 1e-12f) != 0;
+}
+template <bool SIGNED>
+__device__ __forceinline__ int direct_code(const float* q, float x) {
+    const float a = fabsf(x);
+    const int i = (a >= 1e-6f) + (a >= 1e-5f) + (a >= 1e-4f) + (a >= 1e-3f) + (a >= 1e-2f) + (a >= 1e-1f);
+    float inv = 1e6f;
+    inv = a >= 1e-6f ? 1e5f : inv; inv = a >= 1e-5f ? 1e4f : inv; inv = a >= 1e-4f ? 1e3f : inv;
+    inv = a >= 1e-3f ? 1e2f : inv; inv = a >= 1e-2f ? 1e1f : inv; inv = a >= 1e-1f ? 1e0f : inv;
+    const int nper = SIGNED ? (1 << i) : (2 << i);
+    const float t = (a * inv - 0.1f) * ((float)nper * (1.f / 0.9f)) - 0.5f;
+    const int j = min(max((int)rintf(t), 0), nper - 1);
+    const int pos = nper - (SIGNED ? 1 : 2) + j;
+    const int k = SIGNED ? (x >= 0.f ? 128 + pos : 126 - pos) : 1 + pos;
+    const int km = max(k - 1, 0), kp = min(k + 1, 255);
+    const float dm = fabsf(q[km] - x), d0 = fabsf(q[k] - x), dp = fabsf(q[kp] - x);
+    int best = km; float db = dm;
+    if (d0 < db) { best = k; db = d0; }       // ties keep the lower index, like the search's `(q[hi] - x) < (x - q[lo]) ? hi : lo`
+    if (dp < db) best = kp;
+    return best;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) adamw8bit_kernel(T* __restrict__ p, const T* __restrict__ g, uint8_t* __restrict__ c1, uint8_t* __restrict__ c2,
                                                         float* __restrict__ absmax1, float* __restrict__ absmax2, const float* __restrict__ qmap1,
@@ -186,7 +230,7 @@ __global__ void __launch_bounds__(256) adamw8bit_kernel(T* __restrict__ p, const
                                                         float lr, float weight_decay, float step_size, float correction2, float gnorm_scale) {
     __shared__ float q1[256], q2[256], red[2][4];
     q1[threadIdx.x] = qmap1[threadIdx.x]; q2[threadIdx.x] = qmap2[threadIdx.x];
-    __syncthreads();
+    const bool dyn = is_dynamic_map(q1[threadIdx.x], true) & is_dynamic_map(q2[threadIdx.x], false);      // (two barriers: the maps are staged)
     const long nblocks = (n + 255) / 256;
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
@@ -226,8 +270,9 @@ __global__ void __launch_bounds__(256) adamw8bit_kernel(T* __restrict__ p, const
         } else {
             p[i] = Elem<T>::from_f(t);
         }
-        int k1 = nearest_code(q1, new1 > 0.f ? m / new1 : 0.f);
-        const int k2 = nearest_code(q2, new2 > 0.f ? v / new2 : 0.f);
+        const float x1 = new1 > 0.f ? m / new1 : 0.f, x2 = new2 > 0.f ? v / new2 : 0.f;
+        int k1 = dyn ? direct_code<true>(q1, x1) : nearest_code(q1, x1);
+        const int k2 = dyn ? direct_code<false>(q2, x2) : nearest_code(q2, x2);
         if (signbit(q1[k1]) != signbit(m)) k1 = m > 0.f ? min(k1 + 1, 255) : max(k1 - 1, 0);   // the first moment keeps its sign through quantisation
         c1[i] = (uint8_t)k1; c2[i] = (uint8_t)k2;
     }
@@ -244,13 +289,16 @@ __global__ void __launch_bounds__(256) adamw8bit_multi_kernel(void* const* __res
                                                               void* const* __restrict__ s_ptrs, const long* __restrict__ sizes, const int* __restrict__ chunk_tensor,
                                                               const long* __restrict__ chunk_off, const float* __restrict__ qmap1, const float* __restrict__ qmap2,
                                                               float beta1, float beta2, float eps, float lr, float weight_decay, float step_size, float correction2,
-                                                              float gnorm_scale) {
+                                                              float gnorm_scale, int nchunks) {
     __shared__ float q1[256], q2[256];
     q1[threadIdx.x] = qmap1[threadIdx.x]; q2[threadIdx.x] = qmap2[threadIdx.x];
-    __syncthreads();
+    const bool dyn = is_dynamic_map(q1[threadIdx.x], true) & is_dynamic_map(q2[threadIdx.x], false);      // (two barriers: the maps are staged)
     constexpr int E = 8;
-    const int ti = chunk_tensor[blockIdx.x];
-    const long off = chunk_off[blockIdx.x], n = sizes[ti];
+    // grid-stride over the chunk table (round 5): a workgroup stages the two maps once and walks ~nchunks / gridDim chunks -- with one chunk per workgroup (296 k workgroups
+    // for the SDXL UNet) every 20 KiB of traffic paid a map load, two barriers and a cold start of its own
+    for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const int ti = chunk_tensor[c];
+    const long off = chunk_off[c], n = sizes[ti];
     T* p = reinterpret_cast<T*>(p_ptrs[ti]);
     const T* g = reinterpret_cast<const T*>(g_ptrs[ti]);
     uint8_t* c1 = reinterpret_cast<uint8_t*>(c1_ptrs[ti]);
@@ -331,8 +379,9 @@ __global__ void __launch_bounds__(256) adamw8bit_multi_kernel(void* const* __res
         } else {
             outp[e] = t; outs[e] = 0.f;
         }
-        int n1 = nearest_code(q1, a1 > 0.f ? m[e] / a1 : 0.f);
-        const int n2 = nearest_code(q2, a2 > 0.f ? v[e] / a2 : 0.f);
+        const float x1 = a1 > 0.f ? m[e] / a1 : 0.f, x2 = a2 > 0.f ? v[e] / a2 : 0.f;
+        int n1 = dyn ? direct_code<true>(q1, x1) : nearest_code(q1, x1);
+        const int n2 = dyn ? direct_code<false>(q2, x2) : nearest_code(q2, x2);
         if (signbit(q1[n1]) != signbit(m[e])) n1 = m[e] > 0.f ? min(n1 + 1, 255) : max(n1 - 1, 0);
         k1[e] = (uint8_t)n1; k2[e] = (uint8_t)n2;
     }
@@ -359,6 +408,7 @@ __global__ void __launch_bounds__(256) adamw8bit_multi_kernel(void* const* __res
             if (shift) shift[i0 + e] = Elem<T>::from_f(outs[e]);
             c1[i0 + e] = k1[e]; c2[i0 + e] = k2[e];
         }
+    }
     }
 }
 
@@ -448,12 +498,13 @@ int dpipe_adamw8bit_multi(void* const* p_ptrs, void* const* g_ptrs, void* const*
     const float correction1 = 1.f - powf(beta1, (float)step), correction2 = sqrtf(1.f - powf(beta2, (float)step));
     const float step_size = -lr * correction2 / correction1;
     hipStream_t s = STREAM(stream);
+    const int grid = nchunks < 8192 ? nchunks : 8192;          // 256 CUs x 7 resident workgroups x ~4.5: every workgroup walks a few dozen chunks at SDXL size
     if (dtype == DPIPE_BF16)
-        adamw8bit_multi_kernel<bf16_t><<<nchunks, 256, 0, s>>>(p_ptrs, g_ptrs, state1_ptrs, state2_ptrs, absmax1_ptrs, absmax2_ptrs, shift_ptrs, sizes, chunk_tensor, chunk_off,
-                                                               qmap1, qmap2, beta1, beta2, eps, lr, weight_decay, step_size, correction2, gnorm_scale);
+        adamw8bit_multi_kernel<bf16_t><<<grid, 256, 0, s>>>(p_ptrs, g_ptrs, state1_ptrs, state2_ptrs, absmax1_ptrs, absmax2_ptrs, shift_ptrs, sizes, chunk_tensor, chunk_off,
+                                                            qmap1, qmap2, beta1, beta2, eps, lr, weight_decay, step_size, correction2, gnorm_scale, nchunks);
     else if (dtype == DPIPE_F32)
-        adamw8bit_multi_kernel<float><<<nchunks, 256, 0, s>>>(p_ptrs, g_ptrs, state1_ptrs, state2_ptrs, absmax1_ptrs, absmax2_ptrs, shift_ptrs, sizes, chunk_tensor, chunk_off,
-                                                              qmap1, qmap2, beta1, beta2, eps, lr, weight_decay, step_size, correction2, gnorm_scale);
+        adamw8bit_multi_kernel<float><<<grid, 256, 0, s>>>(p_ptrs, g_ptrs, state1_ptrs, state2_ptrs, absmax1_ptrs, absmax2_ptrs, shift_ptrs, sizes, chunk_tensor, chunk_off,
+                                                           qmap1, qmap2, beta1, beta2, eps, lr, weight_decay, step_size, correction2, gnorm_scale, nchunks);
     else { set_last_error("dpipe_adamw8bit_multi: dtype"); return DPIPE_ERR_UNSUPPORTED; }
     return check_launch("dpipe_adamw8bit_multi");
 }

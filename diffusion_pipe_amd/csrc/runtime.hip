@@ -21,9 +21,9 @@ int check_launch(const char* what) {
 }
 // Process-wide kernel-selection options (dpipe_set_option): A/B timing and tests of the fallback kernels.  -1 = unset: the environment variable of the
 // same meaning, if any, then the built-in default (see include/dpipe_hip.h for the names).
-static int g_options[DPIPE_OPTION_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1};
+static int g_options[DPIPE_OPTION_COUNT] = {-1, -1, -1, -1, -1, -1};
 static const char* const g_option_env[DPIPE_OPTION_COUNT] = {"DPIPE_ATTN_FWD_DMA", "DPIPE_ATTN_BWD_DMA", "DPIPE_ATTN_DQ8", "DPIPE_ATTN_DKV_SPLIT",
-                                                                "DPIPE_GEMM_SKINNY", "DPIPE_GEMM_SHALLOW", "DPIPE_GEMM_BIG_TILES", "DPIPE_ATTN_BIG_WG"};
+                                                                "DPIPE_GEMM_SHALLOW", "DPIPE_GEMM_BIG_TILES"};
 int option(int id, int dflt) {
     if (id < 0 || id >= DPIPE_OPTION_COUNT) return dflt;
     if (g_options[id] >= 0) return g_options[id];

@@ -318,7 +318,6 @@ class PipelineEngine:
         if self.device.type == 'cuda' and self._config.get('fuse_grad_accumulation', True):
             from .. import ops as _ops
             _ops.FUSE_GRAD_ACCUM = True     # wgrad / bias / norm-weight kernels add straight into existing .grad buffers
-            _ops.PARALLEL_WGRAD = self.use_graph and bool(self._config.get('parallel_wgrad', False))   # dgrad || wgrad as parallel graph branches (measured: no gain on MI355X, off)
         comm_stream = None
         if self.use_stage_graphs and self.device.type == 'cuda' and os.environ.get('DPIPE_LANE_STREAM_PROBE', '1') != '0':
             # forward streams + the link's communication stream next to the caller's stream (backward half): streams probed to sit on distinct hardware

@@ -13,7 +13,6 @@ from torch import nn
 from . import ops
 
 import os as _os
-_ATEN_GROUPNORM = _os.environ.get('DPIPE_ATEN_GROUPNORM', '0') == '1'
 _NORM_SKIP = _os.environ.get('DPIPE_NORM_SKIP', '1') == '1'      # A/B switch: fold the bypass branch's gradient into the norm backward kernels
 
 
@@ -136,10 +135,6 @@ class GroupNorm(nn.Module):
         self.bias = nn.Parameter(torch.zeros(num_channels, device=device, dtype=dtype)) if affine else None
 
     def forward(self, x, act=None, with_skip=False):
-        if _ATEN_GROUPNORM:     # A/B switch (DPIPE_ATEN_GROUPNORM=1): ATen's GroupNorm + the separate SiLU kernel
-            y = torch.nn.functional.group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
-            y = ops.silu(y) if act == 'silu' else y
-            return (y, x) if with_skip else y
         nhwc = x.dim() == 4 and not x.is_contiguous() and ops.is_channels_last(x)      # channels-last UNet (csrc/groupnorm_nhwc.hip)
         fn = ops.group_norm_nhwc if nhwc else ops.group_norm
         if with_skip and not _NORM_SKIP:

@@ -38,18 +38,12 @@ _SPLITK_WS_BYTES = 4096 + 640 * 65536
 # Set by the engine while it captures / runs one of several concurrent micro-batch lanes: graphs captured on the same
 # capture stream but replayed on different streams must not share ticket counters, so the lane id replaces the stream key.
 WS_LANE = None
-# Streams on which a model forks a parallel branch inside a lane (workloads/sdxl.py: CLIP-L next to CLIP-G): stream handle -> branch tag.  A branch's
-# launches -- forward AND backward: autograd runs a node on the stream of its forward -- take their own workspace.
-BRANCH_TAGS = {}
 
 
 def _splitk_workspace(device):
     cur = torch.cuda.current_stream(device)
     if WS_LANE is not None:
-        # a lane's graph may fork wgrad onto the side stream (PARALLEL_WGRAD) or a model branch onto a tagged stream: parallel branches need separate ticket counters
-        side = _SIDE_STREAMS.get(device.index)
-        tag = BRANCH_TAGS.get(cur.cuda_stream) or ('side' if (side is not None and cur == side) else 'main')
-        key = (device.index, ('lane', WS_LANE, tag))
+        key = (device.index, ('lane', WS_LANE))
     else:
         key = (device.index, cur.cuda_stream)
     ws = _SPLITK_WS.get(key)
@@ -233,27 +227,13 @@ def _accum_target(param):
     return g
 
 
-# Backward-pass concurrency (set by the engine): dgrad (dx = dy W) and wgrad (dW = dy^T x, + the bias column sum) of a
-# Linear are independent; at micro-batch 1 each fills well under half of the 256 CUs (40 .. 320 workgroups), so wgrad is
-# forked onto a side HIP stream and joined before the function returns.  Under hipGraph capture the fork / join become
-# parallel graph branches.  The split-K workspace is per stream, so the two GEMMs never share ticket counters.
-PARALLEL_WGRAD = False
+# (Round 2 / 3 negative result: wgrad forked onto a side stream next to dgrad -- `parallel_wgrad`, no gain at micro-batch 1 once the pair leaves as ONE grouped launch; removed
+#  in round 5 together with its side streams.)
 # Bias gradient inside the wgrad GEMM (dpipe_gemm_ex `colsum`) and residual add inside the output projection's epilogue.
 # Same-box A/B on the SDXL step: +2.7 % and +0.3 % images/s (env switches kept for that measurement).
 import os as _os
 FUSE_BIAS_GRAD = _os.environ.get('DPIPE_FUSE_BIAS_GRAD', '1') == '1'
 FUSE_RESIDUAL = _os.environ.get('DPIPE_FUSE_RESIDUAL', '1') == '1'
-_SIDE_STREAMS = {}
-
-
-def _side_stream(device):
-    st = _SIDE_STREAMS.get(device.index)
-    if st is None:
-        st = torch.cuda.Stream(device)
-        _SIDE_STREAMS[device.index] = st
-    return st
-
-
 class _LinearFn(Function):
     """y = x W^T + b (+ residual)  (nn.Linear; reference: models/wan/model.py:120-122,138-142,270-272).  `residual` folds the
     transformer block's "x + proj(...)" add into the GEMM epilogue; its gradient is the incoming gradient itself."""
@@ -313,8 +293,7 @@ class _LinearFn(Function):
                     gb_ = None
             return gw_, gb_
 
-        fork = PARALLEL_WGRAD and ctx.needs_input_grad[0] and (need_w or need_b)
-        if not fork and ctx.needs_input_grad[0] and need_w and gy2.dtype == torch.bfloat16:
+        if ctx.needs_input_grad[0] and need_w and gy2.dtype == torch.bfloat16:
             # dgrad and wgrad (+ the bias column sums inside it) as ONE grouped launch: dx = dy . W next to dW (+)= dy^T . x -- independent problems that share
             # dy, each filling well under half of the chip at micro-batch 1
             w_out = tw if tw is not None else torch.empty(weight.shape, device=weight.device, dtype=weight.dtype)
@@ -336,19 +315,11 @@ class _LinearFn(Function):
                         gb = None
                 gres = gy if (ctx.has_res and ctx.needs_input_grad[3]) else None
                 return gx, gw, gb, gres
-        if fork:
-            main, side = torch.cuda.current_stream(gy2.device), _side_stream(gy2.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                gw, gb = param_grads()
         if ctx.needs_input_grad[0]:
             gx = mm(gy2, weight, False, False).view(ctx.x_shape)          # dx = dy . W
             if gx.dtype != ctx.x_dtype:
                 gx = gx.to(ctx.x_dtype)
-        if fork:
-            main.wait_stream(side)      # join before dy / x can be released (and before autograd consumes gw / gb)
-        else:
-            gw, gb = param_grads()
+        gw, gb = param_grads()
         gres = gy if (ctx.has_res and ctx.needs_input_grad[3]) else None
         return gx, gw, gb, gres
 
@@ -843,6 +814,33 @@ def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, act=None, with_s
 
 
 # ------------------------------------------------------------------------- channels-last (NHWC) UNet ops: GroupNorm, Conv2d
+class _AddSampleChannelBiasFn(Function):
+    """y[b, c, h, w] = x[b, c, h, w] + t[b, c] on a channels-last x (the ResnetBlock's time-embedding addend at batch > 1: models/sdxl.py -> diffusers ResnetBlock2D,
+    `hidden_states + temb[:, :, None, None]`).  The backward's dt[b, c] = sum_hw dy[b, c, h, w] is one deterministic `column_sum` per sample over the [H W, C] memory of
+    that sample -- NOT autograd's broadcast reduction: ATen's reduce kernel returned garbage in single elements of exactly this sum under hipGraph REPLAY on MI355X
+    (round 5: stacked micro-batches at full size went NaN from the second step on; tools/stack_debug_graph.py localised it to the dt of up_blocks.1.resnets.1)."""
+
+    @staticmethod
+    def forward(ctx, x, t):
+        ctx.t_dtype = t.dtype
+        return x + t[:, :, None, None].to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, gy):
+        gt = None
+        if ctx.needs_input_grad[1]:
+            B, C, H, W = gy.shape
+            g = gy if is_channels_last(gy) else gy.contiguous(memory_format=torch.channels_last)
+            rows = g.permute(0, 2, 3, 1).reshape(B, H * W, C)          # a view: channels-last memory is [B, H W, C]
+            gt = torch.stack([column_sum(rows[b]) for b in range(B)], 0).to(ctx.t_dtype)
+        return (gy if ctx.needs_input_grad[0] else None), gt
+
+
+def add_sample_channel_bias(x, t):
+    """x [B, C, H, W] (channels-last) + t [B, C] broadcast over the pixels; gradients without an ATen reduction (see _AddSampleChannelBiasFn)."""
+    return _AddSampleChannelBiasFn.apply(x, t)
+
+
 def is_channels_last(x):
     """4-D tensor with logical shape [N, C, H, W] whose memory is dense [N, H, W, C]."""
     return x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous()

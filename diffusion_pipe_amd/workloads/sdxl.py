@@ -202,7 +202,7 @@ class ResnetBlock2D(nn.Module):
         if x.shape[0] == 1:        # batch 1: the time-embedding addend is one value per channel -> it joins conv1's bias vector in the epilogue
             h = self.conv1(h, extra_bias=t.reshape(-1).to(x.dtype))
         else:
-            h = self.conv1(h) + t[:, :, None, None].to(x.dtype)
+            h = ops.add_sample_channel_bias(self.conv1(h), t)      # (its dt is summed per sample by this repo's column_sum, not by ATen's broadcast reduction)
         if self.conv_shortcut is not None:
             x = self.conv_shortcut(x)
         return self.conv2(self.norm2(h, act='silu'), residual=x)       # the block's "x + h" rides conv2's epilogue
@@ -345,17 +345,8 @@ class UNet2DConditionModel(nn.Module):
 
 
 # -------------------------------------------------------------------------------------- pipeline layer wrappers
-PARALLEL_TEXT_ENCODERS = os.environ.get('DPIPE_PARALLEL_TEXT_ENCODERS', '0') == '1'     # A/B switch: CLIP-L on a forked stream next to CLIP-G
-_SIDE_STREAMS = {}
-
-
-def _side_stream(device):
-    """One side stream per (device, current stream): every micro-batch lane forks onto its own."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = st = torch.cuda.Stream(device)
-        ops.BRANCH_TAGS[st.cuda_stream] = 'text_encoder_1'        # its GEMMs (forward and backward) use their own split-K workspace
-    return _SIDE_STREAMS[key]
+# (Round 3 negative result, profiles/r3l_parallel_text_encoders_negative.jsonl: CLIP-L on a forked stream next to CLIP-G inside the lane's graph -- slower; the switch and
+#  its side streams were removed in round 5.)
 
 
 class InitialLayer(nn.Module):
@@ -391,19 +382,6 @@ class InitialLayer(nn.Module):
         return make_contiguous(sample, timestep, emb, encoder_hidden_states, sample, forward_upsample_size)
 
     def get_text_conditioning(self, input_ids, input_ids_2):
-        if PARALLEL_TEXT_ENCODERS and input_ids.is_cuda:
-            # The two CLIP encoders are independent chains of ~40 launches per layer on 77 tokens -- latency-bound, a few workgroups each.  CLIP-L (12 layers) runs
-            # on a forked stream next to CLIP-G (32 layers): inside a hipGraph capture that is a parallel branch, and autograd replays the fork in the backward (a
-            # node runs on the stream of its forward).  Joined before the concatenation below.
-            cur = torch.cuda.current_stream(input_ids.device)
-            side = _side_stream(input_ids.device)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                e1, _ = self.get_prompt_embeds(input_ids, self.text_encoder, False)
-            e2, pooled = self.get_prompt_embeds(input_ids_2, self.text_encoder_2, True)
-            cur.wait_stream(side)
-            e1.record_stream(cur)
-            return torch.cat([e1, e2], dim=-1), pooled
         e1, _ = self.get_prompt_embeds(input_ids, self.text_encoder, False)
         e2, pooled = self.get_prompt_embeds(input_ids_2, self.text_encoder_2, True)
         return torch.cat([e1, e2], dim=-1), pooled

@@ -32,7 +32,7 @@ extern "C" {
 #define DPIPE_LOSS_SMOOTH_L1 2
 
 /* ABI version: bumped whenever a signature of this header changes; the host binding refuses a library of another version. */
-#define DPIPE_ABI_VERSION 5
+#define DPIPE_ABI_VERSION 6
 int dpipe_version(void);
 const char* dpipe_last_error(void);
 /* Kernel-selection options (process-wide; for A/B timing and for testing the fallback kernels -- every default is the measured-faster choice).
@@ -41,15 +41,14 @@ const char* dpipe_last_error(void);
 #define DPIPE_OPT_ATTN_BWD_DMA 1    /* 1 (default): LDS-DMA dQ / dK / dV kernels (delta fused into dQ); 0: register-staged kernels + attn_delta */
 #define DPIPE_OPT_ATTN_DQ8 2        /* register-staged path, head dim 128: 1 (default) 8-wave dQ kernel for long sequences */
 #define DPIPE_OPT_ATTN_DKV_SPLIT 3  /* head dim 128, long key sequences: 1 (default) dV and dK as two 8-wave kernels; 0: one pass */
-#define DPIPE_OPT_GEMM_SKINNY 4     /* M <= 128 GEMMs (77-token text-encoder / cross-attention linears): 1 = the 128 x 64 tile with deeper split-K; 0 (default: measured faster) = the 64 x 64 tile */
-#define DPIPE_OPT_GEMM_SHALLOW 5    /* ring depth of the plain GEMM's tiles.  0 (default): 128^2 on the 3-deep 96 KiB ring, 64^2 on the 4-deep 64 KiB ring -- the fastest launch
-                                      in isolation; 2: 128^2 on the 2-deep 64 KiB ring (two workgroups per CU) -- slower alone, faster when concurrent streams share the
-                                      chip: the engine selects it for >= 2 micro-batch lanes; 3: 64^2 on the 3-deep 48 KiB ring; 1: both */
-#define DPIPE_OPT_GEMM_BIG_TILES 6  /* fewest 128^2 output tiles for which the plain GEMM takes the 128^2 tile instead of 64^2 (default 128 = best isolated launch; lower under
+#define DPIPE_OPT_GEMM_SHALLOW 4    /* ring depth of the plain GEMM's 128^2 tile.  0 (default): the 3-deep 96 KiB ring -- the fastest launch in isolation; non-zero: the 2-deep
+                                      64 KiB ring (two workgroups per CU) -- slower alone, faster when concurrent streams share the chip: the engine selects it for
+                                      >= 2 micro-batch lanes */
+#define DPIPE_OPT_GEMM_BIG_TILES 5  /* fewest 128^2 output tiles for which the plain GEMM takes the 128^2 tile instead of 64^2 (default 128 = best isolated launch; lower under
                                       concurrent lanes, where CU time per FLOP is what counts: the engine's choice) */
-#define DPIPE_OPT_ATTN_BIG_WG 7     /* fewest 256-query-row workgroups for which flash attention's forward / dQ kernels take their 8-wave 256-row form (default 192 = the
-                                      isolated-launch rule; lower under concurrent lanes: half the K / V bytes per FLOP) */
-#define DPIPE_OPTION_COUNT 8
+/* (ABI 6, round 5: options that lost their measurements twice are gone -- DPIPE_OPT_GEMM_SKINNY (128 x 64 tile for M <= 128: 56 vs 39 ms per step) and
+ *  DPIPE_OPT_ATTN_BIG_WG (256-row attention workgroups from fewer workgroups on: neutral under lanes); the rule values they overrode are fixed in the dispatchers) */
+#define DPIPE_OPTION_COUNT 6
 int dpipe_set_option(int option, int value);
 int dpipe_get_option(int option);    /* the effective explicit / environment value, -1 if neither is set */
 /* Number of compute units / name of device `dev`; used by the host to sanity-check it runs on gfx950. */

@@ -35,7 +35,7 @@ def test_header_constants_match_the_python_binding():
     defs = {k: int(v) for k, v in re.findall(r'^#define\s+(DPIPE_\w+)\s+(-?\d+)\b', text, flags=re.M)}
     assert defs['DPIPE_ABI_VERSION'] == hip.ABI_VERSION == hip.lib().dpipe_version()
     opts = {'DPIPE_OPT_ATTN_FWD_DMA': hip.OPT_ATTN_FWD_DMA, 'DPIPE_OPT_ATTN_BWD_DMA': hip.OPT_ATTN_BWD_DMA, 'DPIPE_OPT_ATTN_DQ8': hip.OPT_ATTN_DQ8,
-            'DPIPE_OPT_ATTN_DKV_SPLIT': hip.OPT_ATTN_DKV_SPLIT, 'DPIPE_OPT_GEMM_SKINNY': hip.OPT_GEMM_SKINNY, 'DPIPE_OPT_GEMM_SHALLOW': hip.OPT_GEMM_SHALLOW, 'DPIPE_OPT_GEMM_BIG_TILES': hip.OPT_GEMM_BIG_TILES, 'DPIPE_OPT_ATTN_BIG_WG': hip.OPT_ATTN_BIG_WG}
+            'DPIPE_OPT_ATTN_DKV_SPLIT': hip.OPT_ATTN_DKV_SPLIT, 'DPIPE_OPT_GEMM_SHALLOW': hip.OPT_GEMM_SHALLOW, 'DPIPE_OPT_GEMM_BIG_TILES': hip.OPT_GEMM_BIG_TILES}
     for name, val in opts.items():
         assert defs[name] == val, name
     assert sorted(opts.values()) == list(range(defs['DPIPE_OPTION_COUNT'])), 'an option id of the header has no binding in hip.py'

@@ -624,27 +624,6 @@ def test_fused_gradient_accumulation_matches_autograd_accumulation(gpu, dtype):
         assert _rel_err(a, b) < (2e-2 if dtype == torch.bfloat16 else 1e-4)
 
 
-def test_parallel_wgrad_fork_join_matches_single_stream(gpu):
-    """dgrad on the current stream, wgrad + bias column sum forked onto the side stream and joined: same numbers."""
-    from diffusion_pipe_amd import nn as dnn, ops
-
-    def run(parallel):
-        torch.manual_seed(5)
-        lin1, lin2 = dnn.Linear(256, 384).to(gpu, torch.bfloat16), dnn.Linear(384, 128).to(gpu, torch.bfloat16)
-        ops.PARALLEL_WGRAD = parallel
-        try:
-            x = torch.randn(4, 100, 256, generator=torch.Generator().manual_seed(1)).to(gpu, torch.bfloat16).requires_grad_(True)
-            for _ in range(3):
-                lin2(ops.gelu_tanh(lin1(x))).float().square().mean().backward()
-            torch.cuda.synchronize()
-        finally:
-            ops.PARALLEL_WGRAD = False
-        return [x.grad] + [p.grad for m in (lin1, lin2) for p in m.parameters()]
-
-    for a, b in zip(run(True), run(False)):
-        assert torch.equal(a, b)
-
-
 @pytest.mark.parametrize('cross', [False, True])
 @pytest.mark.parametrize('fuse_accum', [False, True])
 def test_fused_qkv_projection_and_packed_attention_match_separate_path(gpu, cross, fuse_accum):

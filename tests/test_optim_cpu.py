@@ -253,3 +253,43 @@ def test_grad_store_first_touch_protocol():
     finally:
         ops.GRAD_STORE = None
     assert ops._acc(b) is True
+
+
+def test_direct_quantiser_of_the_8bit_adamw_kernel_is_exact_on_the_dynamic_maps():
+    """csrc/optim.hip `direct_code` (round 5) restated in numpy fp32: decade by six thresholds, slot by one multiply-add and a round, then the nearest of the three map
+    entries around that guess (ties -> lower index).  Must equal the oracle's nearest-code search on both of bitsandbytes' dynamic maps for every code, every midpoint
+    between codes +- a few ulps, the decade borders and two million log-uniform / uniform points; and the guess itself must stay within one index of the answer (that
+    is what makes three entries enough)."""
+    import numpy as np
+    from oracle.adam8bit_ref import create_dynamic_map, quantize_nearest
+    f = np.float32
+    rng = np.random.default_rng(0)
+    for signed in (True, False):
+        q = create_dynamic_map(signed)
+
+        def guess(x):
+            a = np.abs(x)
+            i = np.zeros(a.shape, np.int32)
+            for t in (1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1):
+                i += (a >= f(t))
+            inv = np.array([1e6, 1e5, 1e4, 1e3, 1e2, 1e1, 1e0], dtype=f)[i]
+            nper = (1 << i) if signed else (2 << i)
+            t = (a * inv - f(0.1)) * (nper.astype(f) * f(1.0 / 0.9)) - f(0.5)
+            j = np.clip(np.rint(t), 0, nper - 1).astype(np.int32)
+            pos = nper - (1 if signed else 2) + j
+            return np.where(x >= 0, 128 + pos, 126 - pos) if signed else 1 + pos
+
+        mid = ((q[:-1].astype(np.float64) + q[1:]) / 2).astype(f)
+        pts = [q, np.array([0, 1, 1e-7, 1e-8, 0.1, 0.01, 1e-3, 1e-4, 1e-5, 1e-6, 0.09999999, 0.100000001], dtype=f)]
+        for d in (0, 1, -1, 2, -2, 7, -7):
+            pts += [(mid.view(np.int32) + d).view(f), (q.view(np.int32) + d).view(f)]
+        lu = (10 ** rng.uniform(-9, 0, 1_000_000)).astype(f)
+        pts += [lu, rng.uniform(-1 if signed else 0, 1, 1_000_000).astype(f)] + ([-lu] if signed else [])
+        x = np.concatenate(pts)
+        x = np.clip(x[np.isfinite(x)], -1 if signed else 0, 1).astype(f)
+        k = guess(x)
+        want = quantize_nearest(q, x).astype(np.int32)
+        assert np.abs(k - want).max() <= 1
+        cand = np.stack([np.clip(k - 1, 0, 255), np.clip(k, 0, 255), np.clip(k + 1, 0, 255)], 1)
+        got = cand[np.arange(len(x)), np.argmin(np.abs(q[cand] - x[:, None]), 1)]      # argmin: the first (= lowest index) of equal distances
+        assert np.array_equal(got, want)

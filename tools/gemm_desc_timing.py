@@ -16,9 +16,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tools import gemm_replay  # noqa: E402
 
 DEFAULT_HINTS = {'auto': 0, 't64': 2001, 't64k2': 2002, 't64k4': 2004, 't128': 3001, 't128k2': 3002, 't128k3': 3003, 't128r2': 4001, 't128r2k2': 4002,
-                 't256x128': 5001, 't256': 7001, 't256k2': 7002, 't256h': 9001,
-                 'sk1': 10001, 'sk2': 10002, 'sk4': 10004, 'sk8': 10008, 'sk16': 10016,      # 128 x 64 skinny tile (M <= 128 only)
-                 'q3': 11001, 'q3k2': 11002, 'q3k3': 11003, 't64k8': 2008, 't64k16': 2016,
+                 't256': 7001, 't256k2': 7002, 't256h': 9001, 't64k8': 2008, 't64k16': 2016,
+                 # (hints 5000 / 6000 / 8000 / 10000 / 11000 -- 256 x 128, 64^2 3-deep, 128^2 5-deep, skinny 128 x 64, 4-wave half-K-step 128^2 -- named tiles removed in round 5)
                  't128v': 12001, 't128vk2': 12002, 't128vk3': 12003}      # round 5: register-staged 128^2 tile     # 4-wave 128^2 on a 3-deep ring of half K-steps (3 workgroups per CU); deeper 64^2 splits
 # (round 3 also timed hints 12000 - 14000: T128Q4, T128H5, T128H4 -- profiles/r3k_*, r3q_*; removed from the library)
 # (round 3 also timed four-wave tiles under hints 11000 - 14000: profiles/r3_gemm_desc_ledger_4wave_tiles_negative.jsonl; removed from the library)
@@ -115,8 +114,8 @@ def main():
         rec = {'ta': d['ta'], 'tb': d['tb'], 'M': d['M'], 'N': d['N'], 'K': d['K'], 'batch': d['bo'] * d['bi'], 'count': d['count'], 'acc': int(d['acc']),
                'colsum': int(d['colsum']), 'bias': int(d['bias']), 'res': int(d['res']), 'gflop': round(gemm_replay.flops(d) / 1e9, 3), 'us': {}}
         for name, hint in hints.items():
-            if (10000 <= hint < 11000 and d['M'] > 128) or (7000 <= hint < 8000 or 9000 <= hint < 10000 or 11000 <= hint < 12000 ) and (d['M'] < 512 or d['N'] < 512):
-                continue                     # skinny tile: M <= 128 only; 256^2 tiles: not for slivers
+            if (7000 <= hint < 8000 or 9000 <= hint < 10000) and (d['M'] < 512 or d['N'] < 512):
+                continue                     # 256^2 tiles: not for slivers
             try:
                 rec['us'][name] = round(time_desc(d, hint, dev, arena, ops), 2)
             except Exception as e:       # configuration not eligible for this descriptor
