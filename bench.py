@@ -373,7 +373,7 @@ def main():
     # as the GPU stops retiring the step's graph replays
     import faulthandler
     faulthandler.enable()
-    faulthandler.dump_traceback_later(int(os.environ.get('DPIPE_BENCH_WATCHDOG_S', '900')), exit=True)
+    faulthandler.dump_traceback_later(int(os.environ.get('DPIPE_BENCH_WATCHDOG_S', '1500')), exit=True)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -642,71 +642,88 @@ def main():
                 gpu_l.append(float(l_.item())); gpu_n.append(float(n_.item()))
             p_loss, p_norm = gpu_l[0], gpu_n[0]
             from oracle.cpu_baseline import sdxl_cpu_baseline
+            # the oracle times its first sample alone (= `cpu_baseline`), then evaluates the other parity samples on a background thread (~25 s of host time each) while this
+            # process goes on with the GPU legs below; `finish_parity()` joins it
             out['cpu_baseline'] = cb = sdxl_cpu_baseline(cfg, latent_hw=latent, micro_batch=cpu_sample, state=state, per_parameter=detail,
-                                                         extra_micro_batches=cpu_samples[1:], extra_budget_s=args.parity_budget)
+                                                         extra_micro_batches=cpu_samples[1:], extra_budget_s=args.parity_budget, extra_async=not detail)
             if detail:
                 from tools.parity_report import family_table
                 family_table(gpu_rows, cb.pop('rows'), out=lambda line: print(line, file=sys.stderr, flush=True))
-            cpu_l, cpu_n = cb.pop('loss_all'), cb.pop('grad_norm_all')
-            n_s = len(cpu_n)
-            e_n = [(g - c) / c for g, c in zip(gpu_n, cpu_n)]
-            e_l = [abs(g - c) / abs(c) for g, c in zip(gpu_l, cpu_l)]
-            mean_n = sum(e_n) / n_s
-            sig_n = (sum((e - mean_n) ** 2 for e in e_n) / max(n_s - 1, 1)) ** 0.5
-            out['parity'] = {'loss_gpu': p_loss, 'loss_cpu': cb['loss'], 'loss_rel': abs(p_loss - cb['loss']) / abs(cb['loss']),
-                             'grad_norm_gpu': p_norm, 'grad_norm_cpu': cb['grad_norm'], 'grad_norm_rel': abs(p_norm - cb['grad_norm']) / cb['grad_norm'],
-                             'samples': n_s, 'grad_norm_rel_signed': [round(e, 6) for e in e_n], 'grad_norm_rel_mean': mean_n, 'grad_norm_rel_sigma': sig_n,
-                             'grad_norm_rel_median': sorted(abs(e) for e in e_n)[n_s // 2], 'grad_norm_rel_max': max(abs(e) for e in e_n), 'loss_rel_max': max(e_l),
-                             'what': 'timed path (bf16 kernels, hipGraph, lanes) vs the oracle fp32 eager path: same weights (the product state dict after the '
-                                     'timed steps), `samples` distinct micro-batches (entry 0 = the fields above); pre-clip global gradient norm, signed relative error',
-                             'bounds': {'loss_rel_max': PARITY_BOUND, 'grad_norm_rel_max': PARITY_BOUND_BF16_NORM, 'grad_norm_rel_mean': PARITY_BOUND_BF16_NORM_MEAN, 'grad_norm_rel_median': PARITY_BOUND_BF16_NORM_MEAN}}
             # ... and the same micro-batch on the same weights through this repo's kernels in their exact-fp32 mode (fp32 MFMA GEMM, fp32 split convolution, unfused
             # attention; eager): north_star's 1e-3 bound is asserted on THIS comparison -- it isolates the kernels' arithmetic from bf16 rounding noise
+            f32_leg = {}
+            eval32 = None
+            gc_ = __import__('gc')
             try:
                 if args.light:
                     raise RuntimeError('skipped (--light)')
                 del engine, module
                 ops.release_caches()                  # the fused step end's pointer tables keep parameters / states / lane gradients alive
-                gc_ = __import__('gc'); gc_.collect(); torch.cuda.empty_cache()
-                w32 = sdxl.SDXLWorkload(cfg, dtype=torch.float32, seed=0, device=device)
-                for k, m in w32.modules().items():
+                gc_.collect(); torch.cuda.empty_cache()
+                w32 = [sdxl.SDXLWorkload(cfg, dtype=torch.float32, seed=0, device=device)]
+                for k, m in w32[0].modules().items():
                     m.load_state_dict({n: v.to(device) for n, v in state[k].items()})
 
                 def eval32(smp):
-                    for m in w32.modules().values():
+                    for m in w32[0].modules().values():
                         for p_ in m.parameters():
                             p_.grad = None
                     x32 = tuple(t.to(device) for t in smp[0])
-                    for layer in w32.to_layers():
+                    for layer in w32[0].to_layers():
                         x32 = layer(x32)
-                    l32 = w32.get_loss_fn()(x32, tuple(t.to(device) for t in smp[1]))
+                    l32 = w32[0].get_loss_fn()(x32, tuple(t.to(device) for t in smp[1]))
                     l32.backward()
                     torch.cuda.synchronize()
-                    n32 = float(sum(float(p_.grad.double().pow(2).sum()) for m in w32.modules().values() for p_ in m.parameters() if p_.grad is not None) ** 0.5)
+                    n32 = float(sum(float(p_.grad.double().pow(2).sum()) for m in w32[0].modules().values() for p_ in m.parameters() if p_.grad is not None) ** 0.5)
                     return float(l32.item()), n32
 
                 l32, n32 = eval32(cpu_sample)
-                out['parity']['fp32_kernels'] = {'loss_gpu': l32, 'grad_norm_gpu': n32, 'loss_rel': abs(l32 - cb['loss']) / abs(cb['loss']),
-                                                 'grad_norm_rel': abs(n32 - cb['grad_norm']) / cb['grad_norm'], 'bound': PARITY_BOUND,
-                                                 'what': 'the same weights and micro-batch through the HIP kernels in exact-fp32 mode (eager) vs the oracle fp32 eager path'}
-                worst = max(range(n_s), key=lambda j: abs(e_n[j]))
-                if worst != 0:
-                    # ... and the sample on which the bf16 path strayed furthest: is that distance bf16 rounding (the fp32 kernels land on the oracle) or a kernel's arithmetic?
-                    lw, nw = eval32(cpu_samples[worst])
-                    out['parity']['fp32_kernels']['worst_bf16_sample'] = {'index': worst, 'bf16_grad_norm_rel': e_n[worst], 'loss_rel': abs(lw - cpu_l[worst]) / abs(cpu_l[worst]),
-                                                                          'grad_norm_rel': abs(nw - cpu_n[worst]) / cpu_n[worst]}
-                del w32
-                gc_.collect(); torch.cuda.empty_cache()
+                f32_leg = {'loss_gpu': l32, 'grad_norm_gpu': n32, 'loss_rel': abs(l32 - cb['loss']) / abs(cb['loss']),
+                           'grad_norm_rel': abs(n32 - cb['grad_norm']) / cb['grad_norm'], 'bound': PARITY_BOUND,
+                           'what': 'the same weights and micro-batch through the HIP kernels in exact-fp32 mode (eager) vs the oracle fp32 eager path'}
             except Exception as e:                                  # noqa: BLE001 -- reported, and counted as a parity failure below
-                out['parity']['fp32_kernels'] = {'error': repr(e)[:300]}
+                f32_leg = {'error': repr(e)[:300]}
+                eval32 = None
+
+            def finish_parity():
+                """join the oracle's background samples, turn the two lists into the `parity` object, then the fp32-kernel evaluation of the worst bf16 sample"""
+                cpu_l, cpu_n = cb.pop('extra_join')() if 'extra_join' in cb else (cb['loss_all'], cb['grad_norm_all'])
+                cb.pop('loss_all', None); cb.pop('grad_norm_all', None)
+                n_s = len(cpu_n)
+                e_n = [(g - c) / c for g, c in zip(gpu_n, cpu_n)]
+                e_l = [abs(g - c) / abs(c) for g, c in zip(gpu_l, cpu_l)]
+                mean_n = sum(e_n) / n_s
+                sig_n = (sum((e - mean_n) ** 2 for e in e_n) / max(n_s - 1, 1)) ** 0.5
+                out['parity'] = {'loss_gpu': p_loss, 'loss_cpu': cb['loss'], 'loss_rel': abs(p_loss - cb['loss']) / abs(cb['loss']),
+                                 'grad_norm_gpu': p_norm, 'grad_norm_cpu': cb['grad_norm'], 'grad_norm_rel': abs(p_norm - cb['grad_norm']) / cb['grad_norm'],
+                                 'samples': n_s, 'grad_norm_rel_signed': [round(e, 6) for e in e_n], 'grad_norm_rel_mean': mean_n, 'grad_norm_rel_sigma': sig_n,
+                                 'grad_norm_rel_median': sorted(abs(e) for e in e_n)[n_s // 2], 'grad_norm_rel_max': max(abs(e) for e in e_n), 'loss_rel_max': max(e_l),
+                                 'what': 'timed path (bf16 kernels, hipGraph, lanes) vs the oracle fp32 eager path: same weights (the product state dict after the '
+                                         'timed steps), `samples` distinct micro-batches (entry 0 = the fields above); pre-clip global gradient norm, signed relative error',
+                                 'bounds': {'loss_rel_max': PARITY_BOUND, 'grad_norm_rel_max': PARITY_BOUND_BF16_NORM, 'grad_norm_rel_mean': PARITY_BOUND_BF16_NORM_MEAN,
+                                            'grad_norm_rel_median': PARITY_BOUND_BF16_NORM_MEAN},
+                                 'fp32_kernels': f32_leg}
+                worst = max(range(n_s), key=lambda j: abs(e_n[j]))
+                if worst != 0 and eval32 is not None:
+                    # the sample on which the bf16 path strayed furthest: is that distance bf16 rounding (the fp32 kernels land on the oracle) or a kernel's arithmetic?
+                    try:
+                        lw, nw = eval32(cpu_samples[worst])
+                        f32_leg['worst_bf16_sample'] = {'index': worst, 'bf16_grad_norm_rel': e_n[worst], 'loss_rel': abs(lw - cpu_l[worst]) / abs(cpu_l[worst]),
+                                                        'grad_norm_rel': abs(nw - cpu_n[worst]) / cpu_n[worst]}
+                    except Exception as e:                      # noqa: BLE001
+                        f32_leg['worst_bf16_sample'] = {'error': repr(e)[:300]}
+                if eval32 is not None:
+                    w32.clear()
+                gc_.collect(); torch.cuda.empty_cache()
             engine = module = None
+        parity_done = False
         if world == 1 and args.config == 'full' and not args.no_other_configs and not args.no_cpu_baseline and not args.light:
             # BASELINE configs 3 and 4 as real steps on this GPU, bounded (2 warm-up + 4 timed steps each, the SDXL state freed first): a driver-timed number for the DiT
             # workloads rides the default line (`--workload flux|wan|hv` gives the full record with roofline legs and cpu_baseline).  Never fatal.
             import copy
             import gc
             engine = module = None
-            state = cb = None                     # 10 GB of fp32 host copies of the weights: not needed by the legs below (their children build their own)
+            state = None                          # 10 GB of fp32 host copies of the weights: the fp32 leg has loaded them, the oracle holds its own
             del work, pool, layers, params, make_opt
             ops.release_caches()
             gc.collect()
@@ -733,6 +750,19 @@ def main():
             except Exception as e:                          # noqa: BLE001
                 others['sdxl_stacked'] = {'error': repr(e)[:300]}
             others['sdxl_stacked']['wall_seconds'] = round(time.perf_counter() - t_wl, 1)
+            # (3) BASELINE config 5 (HunyuanVideo 720p x 65 frames, full fine-tune, host-offloaded checkpoints: 10.9 PFLOP per step, ~22 s) as ONE warm-up + ONE timed step in a
+            # child process of its own (128 GB of HBM and 25 GB of pinned host memory that must be gone again when it ends, whatever happens inside)
+            t_wl = time.perf_counter()
+            try:
+                cmd = [sys.executable, os.path.abspath(__file__), '--workload', 'hv', '--steps', '1', '--warmup', '1', '--light']
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+                others['hv'] = json.loads(line[-1]) if line else {'error': f'child rc {r.returncode}: ' + r.stderr[-300:]}
+            except Exception as e:                          # noqa: BLE001
+                others['hv'] = {'error': repr(e)[:300]}
+            others['hv']['wall_seconds'] = round(time.perf_counter() - t_wl, 1)
+            finish_parity()                                 # the oracle's background samples are (nearly) done by now; frees the fp32 model before the 232 GB Wan step
+            parity_done = True
             for wl in ('flux', 'wan'):
                 a2 = copy.copy(args)
                 a2.workload, a2.steps, a2.warmup, a2.gas, a2.lanes, a2.full_ft, a2.stack = wl, 4, 2, 0, 0, False, 1
@@ -745,18 +775,9 @@ def main():
                 gc.collect()
                 torch.cuda.empty_cache()
                 others[wl]['wall_seconds'] = round(time.perf_counter() - t_wl, 1)
-            # (3) BASELINE config 5 (HunyuanVideo 720p x 65 frames, full fine-tune, host-offloaded checkpoints: 10.9 PFLOP per step, ~22 s) as ONE warm-up + ONE timed step in a
-            # child process of its own (128 GB of HBM and 25 GB of pinned host memory that must be gone again when it ends, whatever happens inside)
-            t_wl = time.perf_counter()
-            try:
-                cmd = [sys.executable, os.path.abspath(__file__), '--workload', 'hv', '--steps', '1', '--warmup', '1', '--light']
-                r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
-                line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
-                others['hv'] = json.loads(line[-1]) if line else {'error': f'child rc {r.returncode}: ' + r.stderr[-300:]}
-            except Exception as e:                          # noqa: BLE001
-                others['hv'] = {'error': repr(e)[:300]}
-            others['hv']['wall_seconds'] = round(time.perf_counter() - t_wl, 1)
             out['other_configs'] = others
+        if world == 1 and not args.no_cpu_baseline and not parity_done:
+            finish_parity()
         print(json.dumps(out), flush=True)
         par = out.get('parity')
         if par and args.config == 'full':
@@ -774,7 +795,7 @@ def main():
             else:
                 bad += [f'fp32 kernels {k} = {f32[k]:.3e} > {PARITY_BOUND:g}' for k in ('loss_rel', 'grad_norm_rel') if not (f32[k] <= PARITY_BOUND)]
                 w_ = f32.get('worst_bf16_sample')
-                if w_:
+                if w_ and 'error' not in w_:
                     bad += [f'fp32 kernels on the worst bf16 sample {k} = {w_[k]:.3e} > {PARITY_BOUND:g}' for k in ('loss_rel', 'grad_norm_rel') if not (w_[k] <= PARITY_BOUND)]
             if bad:
                 print('[bench] PARITY FAILURE (vs the oracle fp32 eager path): ' + '; '.join(bad), file=sys.stderr, flush=True)

@@ -15,17 +15,20 @@ import torch
 from . import eager_step, sdxl_ref
 
 
-def sdxl_cpu_baseline(cfg, latent_hw=128, threads=None, micro_batch=None, state=None, per_parameter=False, extra_micro_batches=(), extra_budget_s=0.0):
+def sdxl_cpu_baseline(cfg, latent_hw=128, threads=None, micro_batch=None, state=None, per_parameter=False, extra_micro_batches=(), extra_budget_s=0.0, extra_async=False):
     """-> cpu_baseline dict.  `micro_batch`: one prepared (features, label) pair as the engine receives it.  `state`: {module name: state dict}
     of the PRODUCT's weights (host tensors) -- loaded into the oracle so that its loss / gradient norm are comparable with the GPU path's on the
     same micro-batch (bench.py's `parity` object); None = the oracle's own seeded initialisation.
     `extra_micro_batches` (round 5: parity as a statistic): further micro-batches evaluated on the same weights AFTER the timed sample, as many as fit
     `extra_budget_s` seconds of host time (each costs about `sample_seconds`); their losses / pre-clip gradient norms come back as `loss_all` / `grad_norm_all`
-    (entry 0 = the timed sample)."""
+    (entry 0 = the timed sample).  `extra_async`: the extra samples are evaluated on a background thread (the caller goes on with GPU work; torch's CPU kernels release
+    the GIL) -- the dict then carries `extra_join`, a callable that waits for the thread and returns (loss_all, grad_norm_all); the timed first sample is never concurrent
+    with anything."""
     # many-core hosts (the GPU box has 256 hardware threads) run these mid-sized fp32 ops fastest on a subset
     threads = threads or min(os.cpu_count() or 1, int(os.environ.get('DPIPE_CPU_BASELINE_THREADS', '32')))
     prev = torch.get_num_threads()
     torch.set_num_threads(threads)
+    extra_thread = None
     try:
         t_build = time.perf_counter()
         ref = sdxl_ref.SDXLRef(cfg, seed=0)
@@ -40,25 +43,38 @@ def sdxl_cpu_baseline(cfg, latent_hw=128, threads=None, micro_batch=None, state=
         loss, norm = eager_step.eager_train_step(layers, eager_step.sdxl_loss_fn(), [micro_batch], None, gradient_clipping=1.0, params=ref.parameters())
         dt = time.perf_counter() - t0
         loss_all, norm_all = [float(loss)], [float(norm)]
-        t_extra = time.perf_counter()
-        for mb in extra_micro_batches:
-            if time.perf_counter() - t_extra + dt > extra_budget_s:       # the next sample would overrun the budget
-                break
-            if per_parameter:
-                break
-            for p_ in ref.parameters():
-                p_.grad = None
-            mb = (tuple(t.cpu() for t in mb[0]), tuple(t.cpu() for t in mb[1]))
-            l_, n_ = eager_step.eager_train_step(layers, eager_step.sdxl_loss_fn(), [mb], None, gradient_clipping=1.0, params=ref.parameters())
-            loss_all.append(float(l_)); norm_all.append(float(n_))
+
+        def run_extras():
+            t_extra = time.perf_counter()
+            for mb in extra_micro_batches:
+                if time.perf_counter() - t_extra + dt > extra_budget_s or per_parameter:       # the next sample would overrun the budget
+                    break
+                for p_ in ref.parameters():
+                    p_.grad = None
+                mb = (tuple(t.cpu() for t in mb[0]), tuple(t.cpu() for t in mb[1]))
+                l_, n_ = eager_step.eager_train_step(layers, eager_step.sdxl_loss_fn(), [mb], None, gradient_clipping=1.0, params=ref.parameters())
+                loss_all.append(float(l_)); norm_all.append(float(n_))
+            return loss_all, norm_all
+        if extra_async and extra_micro_batches and not per_parameter:
+            import threading
+            extra_thread = threading.Thread(target=run_extras, name='oracle-parity-samples', daemon=True)
+            extra_thread.start()
+        else:
+            run_extras()
         rows = None
         if per_parameter:          # tools/parity_probe.py: [sum |g|, sum g, <g, r>, ||g||_2] of every parameter's PRE-clip gradient (the step clipped in place)
             from .checksums import checksum4
             coef = min(1.0, 1.0 / (float(norm) + 1e-6))
             rows = {f'{k}.{n}': [v / coef for v in checksum4(p.grad, f'{k}.{n}')] for k, m in ref.modules().items() for n, p in m.named_parameters() if p.grad is not None}
     finally:
+        if extra_thread is None:
+            torch.set_num_threads(prev)
+
+    def extra_join():
+        extra_thread.join()
         torch.set_num_threads(prev)
-    return {**({'rows': rows} if per_parameter else {}), 'value': round(1.0 / dt, 6), 'unit': 'images/s', 'cores': threads, 'kind': 'port', 'sample_seconds': round(dt, 3),
+        return loss_all, norm_all
+    return {**({'rows': rows} if per_parameter else {}), **({'extra_join': extra_join} if extra_thread is not None else {}), 'value': round(1.0 / dt, 6), 'unit': 'images/s', 'cores': threads, 'kind': 'port', 'sample_seconds': round(dt, 3),
             'build_seconds': round(t_build, 1), 'loss': float(loss), 'grad_norm': float(norm), 'loss_all': loss_all, 'grad_norm_all': norm_all, 'weights': 'product state dict' if state is not None else 'oracle seed 0',
             'sample': f'oracle fp32 eager path (oracle/sdxl_ref.py + eager_step.py): ONE whole micro-batch = one {latent_hw * 8}x{latent_hw * 8} image '
                       f'through all 23 pipeline layers + loss + backward + clip (1 of the step\'s micro-batches, no optimizer step), {threads} threads'}
