@@ -113,8 +113,9 @@ def parse():
     ap.add_argument('--lanes', type=int, default=0, help='concurrent micro-batch lanes of the single-stage hipGraph path (default: 4 for sdxl, 2 for flux / wan, 1 for hv)')
     ap.add_argument('--test-single-device', action='store_true',
                     help='TEST ONLY: all ranks share cuda:0, collectives over gloo, stage payloads staged through the host')
-    ap.add_argument('--pipe-lanes', type=int, default=int(os.environ.get('DPIPE_PIPE_LANES', '1')),
-                    help='pp > 1: interleaved 1F1B instruction streams per stage (engine `pipe_lanes`; default 1 = the reference\'s single stream)')
+    ap.add_argument('--pipe-lanes', type=int, default=int(os.environ.get('DPIPE_PIPE_LANES', '0')),
+                    help='pp > 1: interleaved 1F1B instruction streams per stage (engine `pipe_lanes`; 1 = the reference\'s single stream).  Default 2 under pp > 1: two stages '
+                         'sharing one MI355X 14.79 vs 11.70 images/s (profiles/r5o_bench_pp2_single_device_pipe_lanes.jsonl); the engine\'s own default stays 1')
     ap.add_argument('--stack', type=int, default=int(os.environ.get('DPIPE_STACK', '1')),
                     help='run K consecutive micro-batches of a step as ONE pass of K x the size (engine `stack_micro_batches`; same samples, same gradient; default 1)')
     ap.add_argument('--torch-adamw', action='store_true', help='A/B switch: torch.optim.AdamW(fused=True) + separate lane-sum / clip / zero passes')
@@ -407,6 +408,7 @@ def main():
         raise SystemExit(f'--pp {pp} does not divide {world} ranks')
     dp = world // pp
     gas = args.gas or 8 * pp               # two micro-batches per lane and step
+    args.pipe_lanes = args.pipe_lanes or (2 if pp > 1 else 1)
     work = sdxl.SDXLWorkload(cfg, dtype=torch.bfloat16, seed=0, device=device)
     if os.environ.get('DPIPE_BENCH_ZERO_WEIGHTS', '0') == '1':
         # diagnostic: every weight zero -> every MFMA operand zero -> the same kernels and launches at a fraction of the switching power.  The
@@ -560,7 +562,7 @@ def main():
         dist.all_reduce(rl)
     g_flops, g_ms, launches, g_bytes = rl.tolist()
     traffic = None
-    tpath = next((q for q in (os.path.join(ROOT, 'profiles', f) for f in ('r4_pmc_gemm_traffic.json', 'r3_pmc_gemm_traffic.json')) if os.path.isfile(q)), '')
+    tpath = next((q for q in (os.path.join(ROOT, 'profiles', f) for f in ('r5_pmc_gemm_traffic.json', 'r4_pmc_gemm_traffic.json', 'r3_pmc_gemm_traffic.json')) if os.path.isfile(q)), '')
     # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this launch list: tools/run_gpu.sh pmc; the newest committed pass wins)
     if os.path.isfile(tpath):
         with open(tpath) as f:
@@ -804,6 +806,10 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and not (float(loss.item()) == float(loss.item()) and gnorm == gnorm):
+        # (round 5: a stacked A/B looked 20 % faster for a whole call -- on NaN losses.  A throughput line over a diverged computation is not a measurement.)
+        print('[bench] NON-FINITE loss / gradient norm in the timed steps: the throughput above is not a measurement', file=sys.stderr, flush=True)
+        sys.exit(5)
     if parity_failed:
         sys.exit(4)
 

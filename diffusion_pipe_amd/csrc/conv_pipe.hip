@@ -20,7 +20,7 @@ int ilog2_exact(int v) { return v == 1 ? 0 : v == 2 ? 1 : -1; }
 
 template <int CONV>
 int launch_conv(GemmParams& p, bool b_mc, int batch, void* ws, long ws_bytes, int tile_hint, hipStream_t s) {
-    const int force_tile = tile_hint >= 12000 ? 132 : tile_hint >= 7000 ? 257 : tile_hint >= 4000 && tile_hint < 5000 ? 129 : tile_hint >= 3000 && tile_hint < 4000 ? 128
+    const int force_tile = tile_hint >= 7000 ? 257 : tile_hint >= 4000 && tile_hint < 5000 ? 129 : tile_hint >= 3000 && tile_hint < 4000 ? 128
                          : tile_hint >= 2000 && tile_hint < 3000 ? 64 : 0;
     const int force_s = tile_hint >= 1000 ? tile_hint % 1000 : 0;
     const bool a_mc = CONV == 2;
@@ -32,12 +32,12 @@ int launch_conv(GemmParams& p, bool b_mc, int batch, void* ws, long ws_bytes, in
         if (tile == 257 || tile == 258) tile = gemm_pipe_plan(p, a_mc, b_mc, batch, ws, ws_bytes, 0, 129);      // re-plan (tile grid, split-K, slab budget) for 128^2 (258 = the half-K-step ring: plain GEMM only)
         if (CONV == 1 && !b_mc && tile == 128 && tiles128 >= 256 && tiles128 < 512 && p.splitk == 1) tile = 129;
     }
-    // the register-staged 128^2 tile (round 5): the plan names it for unsplit problems with a K-contiguous A -- the forward's and the dgrad's gathered pixel rows (CONV 1);
-    // wgrad (CONV 2: gathered K-rows) stays on the DMA ring.  Same geometry as T128R2.  DPIPE_CONV_VS=0: off (A/B)
-    static const bool conv_vs = [] { const char* e = getenv("DPIPE_CONV_VS"); return !e || atoi(e) != 0; }();
-    if (tile == 132 && (CONV != 1 || !conv_vs)) tile = 129;
+    // The register-staged 128^2 tile (round 5) stays a plain-GEMM tile.  Built for the gathered-row convolutions too and measured (profiles/r5o_conv_timing.jsonl, forward /
+    // dgrad us): its CONV = 1 instances need 142 - 146 VGPRs (the gather state on top of the register sets) = ONE workgroup per CU, and lose where the UNet spends its
+    // convolution time -- 320 -> 320 at 128 x 128 (9 per pass): 62.7 / 73.0 vs 47.9 / 50.1 on the 2-deep DMA ring; 640 -> 640 at 64 x 64: 56.1 / 66.8 vs 58.5 / 82.7 (3-deep), i.e.
+    // level; over the step's 41 convolutions 8.3 vs 6.6 ms per micro-batch forced, 6.9 vs 6.6 dispatched.  Removed again: the plan's code 132 maps back onto T128R2 here.
+    if (tile == 132) tile = 129;
     switch (tile) {
-    case 132: if constexpr (CONV == 1) return launch_pipe<T128V, CONV>(p, a_mc, b_mc, batch, s);
     case 257: return launch_pipe<T256S, CONV>(p, a_mc, b_mc, batch, s);
     case 129: return launch_pipe<T128R2, CONV>(p, a_mc, b_mc, batch, s);
     case 128: return launch_pipe<T128, CONV>(p, a_mc, b_mc, batch, s);

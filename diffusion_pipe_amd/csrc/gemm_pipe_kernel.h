@@ -133,7 +133,7 @@ template <int NLOAD, int MAXAHEAD> __device__ __forceinline__ void wait_dma_ahea
 template <int BM_, int BN_, int WM_, int WN_, int STAGES_, bool A_MC, bool B_MC, int CONV = 0, int BKT = 64, int VS = 0>
 __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, char* const lds, const int orig, const int bz) {
     using TL = Tile<BM_, BN_, WM_, WN_, STAGES_, BKT, VS>;
-    static_assert(VS == 0 || (STAGES_ == 2 && CONV != 2 && BKT == 64), "register-staged tiles: plain GEMM / gathered-row convolution on a 2-deep LDS ring of whole K-steps");
+    static_assert(VS == 0 || (STAGES_ == 2 && CONV == 0 && BKT == 64), "register-staged tile: plain GEMM on a 2-deep LDS ring of whole K-steps (the convolution form lost: conv_pipe.hip)");
     constexpr int BM = TL::BM, BN = TL::BN, STAGES = TL::STAGES, TM = TL::TM, TN = TL::TN, NLOAD = TL::NLOAD;
     constexpr int BK = BKT, KS = BKT / 16;          // (shadows the namespace default) k extent of a stage, 16-wide k-slices per stage
     static_assert(CONV == 0 || BKT == 64, "the convolution gathers are written for 64-channel K-steps");
@@ -322,25 +322,9 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, char* const 
     // (same rule as the DMA builtin: the buffer builtins only ever see non-dependent locals)
 #define VS_LOAD(r, J0, J1, LIVE)                                                                                              \
     do {                                                                                                                      \
-        const unsigned kofsB_ = (CONV == 1 && B_MC) ? (unsigned)(((long)c_kc * BK * p.ldb + (long)(c_ky * cg.kw + c_kx) * cg.b_tap_stride) * 2) : 0u; \
         _Pragma("unroll") for (int j = (J0); j < (J1); ++j) {                                                                 \
-            if (j < TL::PA) {                                                                                                 \
-                unsigned off_;                                                                                                \
-                if constexpr (CONV == 1) off_ = conv_off_a(j); else { off_ = voA[j]; voA[j] += stepA; }                       \
-                off_ = (LIVE) ? off_ : VS_OOB;                                                                                \
-                rg[r][j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off_, 0, 0);                                            \
-            } else {                                                                                                          \
-                unsigned off_;                                                                                                \
-                if constexpr (CONV == 1 && B_MC) off_ = voB[j - TL::PA] + kofsB_;                                             \
-                else { off_ = voB[j - TL::PA]; voB[j - TL::PA] += stepB; }                                                    \
-                off_ = (LIVE) ? off_ : VS_OOB;                                                                                \
-                rg[r][j] = __builtin_amdgcn_raw_buffer_load_b128(rsB, off_, 0, 0);                                            \
-            }                                                                                                                 \
-        }                                                                                                                     \
-        if ((J1) == NLOAD) {          /* the whole K-step is issued: move the gather state on by one K-step */               \
-            if constexpr (CONV == 1) {                                                                                        \
-                if (++c_kc == cg.cchunks) { c_kc = 0; if (++c_kx == cg.kw) { c_kx = 0; ++c_ky; } }                            \
-            }                                                                                                                 \
+            if (j < TL::PA) { const unsigned off_ = (LIVE) ? voA[j] : VS_OOB; voA[j] += stepA; rg[r][j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off_, 0, 0); }            \
+            else { const unsigned off_ = (LIVE) ? voB[j - TL::PA] : VS_OOB; voB[j - TL::PA] += stepB; rg[r][j] = __builtin_amdgcn_raw_buffer_load_b128(rsB, off_, 0, 0); }     \
         }                                                                                                                     \
     } while (0)
     // piece j of an operand -> LDS byte (j * NW + wid) * 1024 + 16 * lane of its image: the LDS-DMA's own lane-linear destination, so the image formats, the source

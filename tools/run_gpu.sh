@@ -18,7 +18,8 @@ for step in "$@"; do
 import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = d.get('roofline', {}); c = r.get('concurrent_lanes') or {}
-    print(f"bench {sys.argv[2]}: {d['value']} {d['unit']}, {d['ms_per_step']} ms/step, frac {r.get('frac')}, launches/step {r.get('launches_per_step')}, avg us {r.get('avg_launch_us')}, concurrent frac {c.get('frac')}, parity {d.get('parity', {}).get('grad_norm_rel')}")
+    print(f"bench {sys.argv[2]}: {d['value']} {d['unit']}, {d['ms_per_step']} ms/step, frac {r.get('frac')}, launches/step {r.get('launches_per_step')}, avg us {r.get('avg_launch_us')}, concurrent frac {c.get('frac')}, loss {d.get('loss')}, parity {d.get('parity', {}).get('grad_norm_rel')}")
+    if d.get('loss') != d.get('loss'): print(f"bench {sys.argv[2]}: *** NON-FINITE LOSS: the throughput above is not a measurement ***")
 except Exception as e:
     print(f"bench {sys.argv[2]}: no JSON line ({e})")
 PY
