@@ -48,7 +48,7 @@ int launch_conv(GemmParams& p, bool b_mc, int batch, void* ws, long ws_bytes, in
 void base_params(GemmParams& p) {
     p.bias = nullptr; p.sAo = p.sAi = p.sBo = p.sBi = p.sCo = p.sCi = 0; p.batch_inner = 1; p.alpha = 1.f; p.act = ACT_NONE; p.accumulate = 0; p.out_f32 = 0;
     p.splitk = 1; p.ksteps = p.ksteps_per_split = 0; p.slabs = nullptr; p.counters = nullptr; p.residual = nullptr; p.ldr = 0; p.colsum = nullptr; p.colsum_acc = 0;
-    p.vecA = p.vecB = 0; p.tiles_m = p.tiles_n = 0;
+    p.vecA = p.vecB = 0; p.tiles_m = p.tiles_n = 0; p.bias_rows = 0;
 }
 
 bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -75,6 +75,10 @@ int dpipe_conv2d_fwd(const void* x, long ldx, const void* w, const void* bias, c
     p.M = B * Ho * Wo; p.N = Cout; p.K = kh * kw * Cin;
     p.bias = bias; p.act = act; p.residual = residual; p.ldr = ldr;
     p.out_f32 = (flags & DPIPE_CONV_OUT_F32) ? 1 : 0; p.accumulate = (flags & DPIPE_CONV_ACCUMULATE) ? 1 : 0;
+    if (flags & DPIPE_CONV_BIAS_PER_SAMPLE) {           // bias = [B][Cout]: output pixel row m takes the bias row of its sample (the ResnetBlock's time-embedding addend at batch > 1)
+        if (!bias || Cout % 4) UNSUP("dpipe_conv2d_fwd: a per-sample bias needs a bias and Cout % 4 == 0");
+        p.bias_rows = Ho * Wo;
+    }
     p.cg = ConvGeom{Ho, Wo, H, W, kw, kh * kw, Cin / 64, sl, ul, pad, 0, 0, 0, ((long)B * H * W - 1) * ldx + Cin, 0};
     if (p.cg.a_ext * 2 >= (1L << 31) || (long)Cout * p.ldb * 2 >= (1L << 31)) UNSUP("dpipe_conv2d_fwd: operand beyond 2 GiB");
     return launch_conv<1>(p, false, 1, ws, ws_bytes, tile_hint, reinterpret_cast<hipStream_t>(stream));

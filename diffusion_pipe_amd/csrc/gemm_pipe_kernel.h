@@ -587,7 +587,7 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, char* const 
                 for (int r = 0; r < 4; ++r) v[r] = p.alpha * acc[i][j][4 * q + r];
                 const bool full = n + 3 < p.N;
                 if (p.bias) {
-                    const bf16_t* bp = reinterpret_cast<const bf16_t*>(p.bias) + n;
+                    const bf16_t* bp = reinterpret_cast<const bf16_t*>(p.bias) + (p.bias_rows ? (long)(m / p.bias_rows) * p.N : 0L) + n;
                     if (full && p.vecB >= 2) {
                         const uint2 bv = *reinterpret_cast<const uint2*>(bp);
                         v[0] += __uint_as_float(bv.x << 16); v[1] += __uint_as_float(bv.x & 0xffff0000u);

@@ -17,7 +17,7 @@ LIB_PATH = Path(os.environ.get('DPIPE_HIP_LIB') or Path(__file__).resolve().pare
 
 BF16, F32 = 0, 1
 ABI_VERSION = 6                      # DPIPE_ABI_VERSION of include/dpipe_hip.h this binding was written against
-CONV_OUT_F32, CONV_ACCUMULATE = 1, 2  # dpipe_conv2d_fwd / _dgrad `flags`
+CONV_OUT_F32, CONV_ACCUMULATE, CONV_BIAS_PER_SAMPLE = 1, 2, 4  # dpipe_conv2d_fwd / _dgrad `flags`
 OPT_ATTN_FWD_DMA, OPT_ATTN_BWD_DMA, OPT_ATTN_DQ8, OPT_ATTN_DKV_SPLIT, OPT_GEMM_SHALLOW, OPT_GEMM_BIG_TILES = 0, 1, 2, 3, 4, 5     # dpipe_set_option ids (include/dpipe_hip.h)
 ACT = {None: 0, 'none': 0, 'gelu_tanh': 1, 'gelu': 2, 'gelu_erf': 2, 'silu': 3, 'quick_gelu': 4}
 LOSS_KIND = {'mse': 0, 'huber': 1, 'smooth_l1': 2}

@@ -162,7 +162,10 @@ class Conv2d(nn.Conv2d):
 
     def forward(self, x, upsample=1, residual=None, extra_bias=None):
         bias = self.bias
-        if extra_bias is not None:                      # per-channel addend folded into the bias vector (time embedding of a resnet, batch 1)
+        if extra_bias is not None and extra_bias.dim() == 2:
+            # one addend row per sample ([B, Cout]: the time embedding of a resnet at batch > 1, i.e. under micro-batch stacking): a per-sample bias in the epilogue
+            bias = ops.bias_plus_sample(bias, extra_bias)
+        elif extra_bias is not None:                    # per-channel addend folded into the bias vector (time embedding of a resnet, batch 1)
             bias = extra_bias if bias is None else bias + extra_bias
         plain = self.padding_mode == 'zeros' and not isinstance(self.padding, str)
         if x.is_cuda and plain and ops.conv2d_eligible(x.dtype, self.weight, self.stride, self.padding, self.dilation, self.groups):

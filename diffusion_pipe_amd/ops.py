@@ -836,6 +836,24 @@ class _AddSampleChannelBiasFn(Function):
         return (gy if ctx.needs_input_grad[0] else None), gt
 
 
+class _BiasPlusSampleFn(Function):
+    """[B, C] = bias[C] + t[B, C]; the bias gradient is `column_sum` over the B rows (not autograd's broadcast reduction)."""
+
+    @staticmethod
+    def forward(ctx, bias, t):
+        ctx.dtypes = (bias.dtype, t.dtype)
+        return (bias[None, :].to(t.dtype) + t).contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        gbias = column_sum(g.contiguous()).to(ctx.dtypes[0]) if ctx.needs_input_grad[0] else None
+        return gbias, (g.to(ctx.dtypes[1]) if ctx.needs_input_grad[1] else None)
+
+
+def bias_plus_sample(bias, t):
+    return t.contiguous() if bias is None else _BiasPlusSampleFn.apply(bias, t)
+
+
 def add_sample_channel_bias(x, t):
     """x [B, C, H, W] (channels-last) + t [B, C] broadcast over the pixels; gradients without an ATen reduction (see _AddSampleChannelBiasFn)."""
     return _AddSampleChannelBiasFn.apply(x, t)
@@ -968,12 +986,17 @@ class _Conv2dNHWCFn(Function):
         ws = _splitk_workspace(x.device)
         geo = (B, H, W, Cout, kh, kw, stride, pad, upsample)
         if x.dtype == torch.float32:
+            if bias is not None and bias.dim() != 1:
+                raise DpipeHipError('conv2d: the fp32 (exact-parity) mode takes a per-channel bias only')
             (xh, xl), (wh, wl), (bh, bl) = _split_bf16(xv), _split_bf16(weight), _split_bf16(bias)
             _conv_fwd_launch(xh, Cin, wh, bh, rv, y, *geo, hip.CONV_OUT_F32, ws)
             _conv_fwd_launch(xl, Cin, wh, bl, None, y, *geo, hip.CONV_OUT_F32 | hip.CONV_ACCUMULATE, ws)
             _conv_fwd_launch(xh, Cin, wl, None, None, y, *geo, hip.CONV_OUT_F32 | hip.CONV_ACCUMULATE, ws)
         else:
-            _conv_fwd_launch(xv, Cin, weight, bias, rv, y, *geo, 0, ws)
+            per_sample = bias is not None and bias.dim() == 2          # [B, Cout]: a bias row per sample (the ResnetBlock's time-embedding addend at batch > 1)
+            if per_sample and (bias.shape != (B, Cout) or not bias.is_contiguous()):
+                raise DpipeHipError('conv2d: a per-sample bias must be a contiguous [B, Cout] tensor')
+            _conv_fwd_launch(xv, Cin, weight, bias, rv, y, *geo, hip.CONV_BIAS_PER_SAMPLE if per_sample else 0, ws)
         ctx.save_for_backward(xv, weight, bias)
         ctx.geom = (stride, pad, upsample, residual is not None)
         return y.permute(0, 3, 1, 2)
@@ -1009,6 +1032,13 @@ class _Conv2dNHWCFn(Function):
                 dxu = dxu.view(B, H, upsample, W, upsample, Cin).sum(dim=(2, 4))
             gx = dxu.permute(0, 3, 1, 2)
         need_w, need_b = ctx.needs_input_grad[1], bias is not None and ctx.needs_input_grad[2]
+        gb_rows = None
+        if need_b and bias.dim() == 2:
+            # per-sample bias: its gradient is one deterministic column sum per sample over that sample's [Ho Wo, Cout] rows of dy (no ATen reduction: see
+            # _AddSampleChannelBiasFn); the wgrad launch below then carries no fused bias gradient
+            rows = gyv.reshape(B, -1, Cout)
+            gb_rows = torch.stack([column_sum(rows[b]) for b in range(B)], 0)
+            need_b = False
         if need_w or need_b:
             tw = _accum_target_dense(weight)
             tb = _accum_target(bias) if need_b else None
@@ -1033,6 +1063,8 @@ class _Conv2dNHWCFn(Function):
                 wgrad(gyv, xv, _acc(tw), b_out, _acc(tb), 0)
             gw = None if tw is not None else w_out
             gb = None if (tb is not None or not need_b) else b_out
+        if gb_rows is not None:
+            gb = gb_rows
         gres = gy if (has_res and ctx.needs_input_grad[3]) else None
         return gx, gw, gb, gres, None, None, None
 

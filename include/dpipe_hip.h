@@ -211,6 +211,7 @@ int dpipe_lnmod_bwd(const void* x, const void* gy, const void* gamma, const void
  * parts are <= 2^-16 relative per product) -- the same MFMA kernels, no library convolution. */
 #define DPIPE_CONV_OUT_F32 1
 #define DPIPE_CONV_ACCUMULATE 2
+#define DPIPE_CONV_BIAS_PER_SAMPLE 4   /* dpipe_conv2d_fwd: `bias` is [B][Cout] (bf16, row pitch Cout, Cout % 4 == 0): every output pixel of sample b adds row b */
 int dpipe_conv2d_fwd(const void* x, long ldx, const void* w, const void* bias, const void* residual, long ldr, void* y, long ldy,
                      int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int upsample, int act, int flags,
                      void* splitk_ws, long splitk_ws_bytes, int tile_hint, void* stream);

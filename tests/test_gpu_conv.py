@@ -211,3 +211,38 @@ def test_unet_edge_convolutions_run_on_the_mfma_kernels(gpu, cin, cout):
     _close(x.grad, xr.grad, 'dgrad')
     _close(conv.weight.grad, wr.grad, 'wgrad')
     _close(conv.bias.grad, br.grad, 'bias grad')
+
+
+@pytest.mark.parametrize('case', [(2, 20, 12, 64, 192, 3, 1, 1, 1), (4, 16, 16, 320, 320, 3, 1, 1, 1), (3, 32, 32, 128, 640, 3, 1, 1, 1)], ids=lambda c: 'x'.join(map(str, c)))
+def test_conv2d_per_sample_bias_rides_the_epilogue(gpu, case):
+    """Round 5: `extra_bias` of shape [B, Cout] (the ResnetBlock's time-embedding addend at batch > 1, models/sdxl.py -> diffusers ResnetBlock2D `hidden + temb[:, :, None, None]`)
+    is added in the convolution's epilogue as a bias row PER SAMPLE (dpipe_conv2d_fwd flag DPIPE_CONV_BIAS_PER_SAMPLE); its gradient is one column sum per sample, the
+    layer's own bias gets the sum over samples -- compared with the fp32 reference.  (The hipGraph-replay side of this path -- where autograd's broadcast reduction
+    returned garbage -- is held at full size by tests/test_gpu_sdxl.py::test_stacked_micro_batches_at_full_size_stay_finite_under_graph_replay.)"""
+    from diffusion_pipe_amd import nn as dnn
+    B, H, W, Cin, Cout, k, stride, pad, ups = case
+    torch.manual_seed(sum(case))
+    conv = dnn.Conv2d(Cin, Cout, k, stride=stride, padding=pad).to(gpu, torch.bfloat16)
+    x = torch.randn(B, Cin, H, W, device=gpu).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    t = torch.randn(B, Cout, device=gpu).to(torch.bfloat16)
+    gy = torch.randn(B, Cout, H, W, device=gpu).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gx, gt = torch.zeros_like(x), torch.zeros_like(t)
+
+    def body():
+        xx, tt = x.detach().requires_grad_(True), t.detach().requires_grad_(True)
+        conv.weight.grad = None; conv.bias.grad = None
+        y = conv(xx, extra_bias=tt)
+        y.backward(gy)
+        gx.copy_(xx.grad); gt.copy_(tt.grad)
+        return y
+
+    def reference():
+        xr, tr = x.float().requires_grad_(True), t.float().requires_grad_(True)
+        wr, br = conv.weight.detach().float().contiguous().requires_grad_(True), conv.bias.detach().float().requires_grad_(True)
+        want = F.conv2d(xr, wr, br, stride=stride, padding=pad) + tr[:, :, None, None]
+        want.backward(gy.float())
+        return want, xr.grad, tr.grad, wr.grad, br.grad
+
+    y = body()
+    want, wgx, wgt, wgw, wgb = reference()
+    _close(y, want, 'forward'); _close(gx, wgx, 'dgrad'); _close(gt, wgt, 'per-sample bias grad'); _close(conv.weight.grad, wgw, 'wgrad'); _close(conv.bias.grad, wgb, 'bias grad')
