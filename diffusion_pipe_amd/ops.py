@@ -130,8 +130,12 @@ GROUP_GEMM = _os_mod.environ.get('DPIPE_GROUP_GEMM', '1') == '1'
 
 def gemm_group(problems):
     """INDEPENDENT 2-D GEMMs (`mm_problem` dicts; none reads what another writes) as few kernel launches as possible: dpipe_gemm_group puts the problems that
-    share a tile geometry into ONE launch of the LDS-DMA kernel (the dgrad and the wgrad of a Linear fill the chip together).  Results are bit-identical to
-    issuing the problems one by one.  -> the list of outputs, or None (nothing launched) when a problem asking for a fused column sum cannot take the
+    share a tile geometry into ONE launch of the pipelined kernel (the dgrad and the wgrad of a Linear fill the chip together).  Results are bit-identical to
+    issuing the problems one by one WHENEVER the group keeps each problem's own plan (same tile, same split-K: tests/test_gpu_gemm_pipe.py holds that for 13 Linear
+    shapes x 2 ring policies).  The one exception: a PAIR whose two plans name different tile geometries -- one big enough for 128^2, the other not --
+    is re-planned as a whole onto 64^2 tiles so that it still leaves as one launch (`DPIPE_GEMM_GROUP_UNIFY=0`: two launches, own plans); its results then equal the
+    64^2-forced single launches, i.e. differ from the own-plan results by fp32 summation order inside a split-K reduction only.  The register-staged and the DMA form
+    of the 128^2 tile are ONE geometry (same LDS, same arithmetic order): they share a launch and stay bit-identical.  -> the list of outputs, or None (nothing launched) when a problem asking for a fused column sum cannot take the
     pipelined kernel (the caller then takes the separate-launch route, as with `mm(..., colsum=...)` returning None)."""
     if not GROUP_GEMM:
         outs = []
