@@ -167,6 +167,30 @@ __device__ __forceinline__ float act_bwd(float x, int act) {  // d act / dx
     }
 }
 
+// Adjoint of diffusers' nearest 2x Upsample2D on a channels-last tensor: dst[b, y, x, :] = sum of the 2 x 2 block src[b, 2y .. 2y+1, 2x .. 2x+1, :] (fp32 accumulate, one
+// rounding).  Replaces `dxu.view(B, H, 2, W, 2, C).sum(dim=(2, 4))` in the convolution dgrad (round 5: the last ATen REDUCTION inside the hipGraph-replayed SDXL step --
+// an ATen reduction returned garbage under replay on the stacked path; this one had not misbehaved, it simply no longer has the chance).
+template <typename T>
+__global__ void __launch_bounds__(EW_BLOCK) upsample2x_adjoint_kernel(const T* __restrict__ src, T* __restrict__ dst, long npix, int H, int W, int C) {
+    constexpr int V = Elem<T>::VEC;
+    const int cv = C / V;
+    const long total = npix * cv;
+    const long row = (long)2 * W * C;                 // one source pixel row
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / cv; const int c0 = (int)(i - pix * cv) * V;
+        const long b = pix / ((long)H * W); const long r = pix - b * (long)H * W;
+        const long y = r / W, x = r - y * W;
+        const T* s0 = src + ((b * 2 * H + 2 * y) * 2 * W + 2 * x) * C + c0;
+        Vec16<T> a, bb, c, d;
+        a.load(s0); bb.load(s0 + C); c.load(s0 + row); d.load(s0 + row + C);
+        float fa[V], fb[V], fc[V], fd[V];
+        a.unpack(fa); bb.unpack(fb); c.unpack(fc); d.unpack(fd);
+#pragma unroll
+        for (int j = 0; j < V; ++j) fa[j] = (fa[j] + fb[j]) + (fc[j] + fd[j]);
+        a.pack(fa); a.store(dst + pix * C + c0);
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(EW_BLOCK) act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long n, int act) {
     constexpr int V = Elem<T>::VEC;
@@ -415,6 +439,18 @@ int dpipe_loss_bwd(const void* out, int dtype, const float* target, const float*
         loss_bwd_kernel<float><<<grid, EW_BLOCK, 0, STREAM(stream)>>>((const float*)out, target, mask, row_weight, grad_loss, rows, cols, kind, param, (float*)grad_out);
     else { set_last_error("dpipe_loss_bwd: dtype"); return DPIPE_ERR_UNSUPPORTED; }
     return check_launch("dpipe_loss_bwd");
+}
+
+int dpipe_upsample2x_adjoint(const void* src, void* dst, int B, int H, int W, int C, int dtype, void* stream) {
+    const int V = dtype == DPIPE_BF16 ? 8 : 4;
+    if (!src || !dst || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % V) != 0 || (reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(dst) & 15)) {
+        set_last_error("dpipe_upsample2x_adjoint: needs 16-byte aligned tensors and C a multiple of the 16-byte vector"); return DPIPE_ERR_ARG; }
+    const long npix = (long)B * H * W;
+    const int grid = stream_grid(npix * (C / V), EW_BLOCK);
+    if (dtype == DPIPE_BF16) upsample2x_adjoint_kernel<bf16_t><<<grid, EW_BLOCK, 0, STREAM(stream)>>>((const bf16_t*)src, (bf16_t*)dst, npix, H, W, C);
+    else if (dtype == DPIPE_F32) upsample2x_adjoint_kernel<float><<<grid, EW_BLOCK, 0, STREAM(stream)>>>((const float*)src, (float*)dst, npix, H, W, C);
+    else { set_last_error("dpipe_upsample2x_adjoint: dtype"); return DPIPE_ERR_UNSUPPORTED; }
+    return check_launch("dpipe_upsample2x_adjoint");
 }
 
 int dpipe_act_fwd(const void* x, void* y, long n, int dtype, int act, void* stream) {

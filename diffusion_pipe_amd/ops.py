@@ -1033,7 +1033,12 @@ class _Conv2dNHWCFn(Function):
             else:
                 dgrad(gyv, weight, 0)
             if upsample > 1:       # adjoint of the nearest up-sampling: sum over each 2 x 2 block
-                dxu = dxu.view(B, H, upsample, W, upsample, Cin).sum(dim=(2, 4))
+                if upsample == 2 and Cin % (4 if f32 else 8) == 0:
+                    dxs = torch.empty((B, H, W, Cin), device=xv.device, dtype=xv.dtype)
+                    check(lib().dpipe_upsample2x_adjoint(ptr(dxu), ptr(dxs), B, H, W, Cin, dtype_code(xv.dtype), stream()), 'upsample2x_adjoint')
+                    dxu = dxs
+                else:
+                    dxu = dxu.view(B, H, upsample, W, upsample, Cin).sum(dim=(2, 4))
             gx = dxu.permute(0, 3, 1, 2)
         need_w, need_b = ctx.needs_input_grad[1], bias is not None and ctx.needs_input_grad[2]
         gb_rows = None

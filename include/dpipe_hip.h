@@ -32,7 +32,7 @@ extern "C" {
 #define DPIPE_LOSS_SMOOTH_L1 2
 
 /* ABI version: bumped whenever a signature of this header changes; the host binding refuses a library of another version. */
-#define DPIPE_ABI_VERSION 6
+#define DPIPE_ABI_VERSION 7
 int dpipe_version(void);
 const char* dpipe_last_error(void);
 /* Kernel-selection options (process-wide; for A/B timing and for testing the fallback kernels -- every default is the measured-faster choice).
@@ -84,6 +84,9 @@ int dpipe_loss_bwd(const void* out, int dtype, const float* target, const float*
 /* ---- K6 activations ------------------------------------------------------------------------------------------
  * nn.GELU(approximate='tanh') of models/wan/model.py:270-272, nn.SiLU of wan.py time_embedding, diffusers GEGLU. */
 int dpipe_act_fwd(const void* x, void* y, long n, int dtype, int act, void* stream);
+/* (ABI 7) adjoint of the nearest 2x up-sampling folded into a convolution (diffusers Upsample2D behind models/sdxl.py:846,865): dst [B, H, W, C] = the 2 x 2 block sums of
+ * src [B, 2H, 2W, C], channels-last, fp32 accumulate; C a multiple of 8 (bf16) / 4 (fp32) */
+int dpipe_upsample2x_adjoint(const void* src, void* dst, int B, int H, int W, int C, int dtype, void* stream);
 int dpipe_act_bwd(const void* x, const void* gy, void* gx, long n, int dtype, int act, void* stream);
 /* x: [rows, 2H] -> y[rows, H] = x[:, :H] * act(x[:, H:]) */
 int dpipe_geglu_fwd(const void* x, void* y, long rows, long H, int dtype, int act, void* stream);

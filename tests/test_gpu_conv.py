@@ -246,3 +246,22 @@ def test_conv2d_per_sample_bias_rides_the_epilogue(gpu, case):
     y = body()
     want, wgx, wgt, wgw, wgb = reference()
     _close(y, want, 'forward'); _close(gx, wgx, 'dgrad'); _close(gt, wgt, 'per-sample bias grad'); _close(conv.weight.grad, wgw, 'wgrad'); _close(conv.bias.grad, wgb, 'bias grad')
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32], ids=['bf16', 'f32'])
+@pytest.mark.parametrize('shape', [(1, 64, 64, 640), (2, 9, 7, 64), (3, 5, 11, 1288)], ids=lambda s: 'x'.join(map(str, s)))
+def test_upsample2x_adjoint_is_the_block_sum_rounded_once(gpu, shape, dtype):
+    """dpipe_upsample2x_adjoint (the adjoint of diffusers' nearest 2x Upsample2D, models/sdxl.py:846,865, folded into the convolution dgrad): every output element is the
+    fp32 sum (a + b) + (c + d) of its 2 x 2 source block, rounded once to the tensor's dtype -- compared EXACTLY with the same sum in torch fp32; and the convolution's
+    backward calls it (no ATen reduction left on that path)."""
+    from diffusion_pipe_amd import hip
+    B, H, W, C = shape
+    torch.manual_seed(H * W + C)
+    src = torch.randn(B, 2 * H, 2 * W, C, device=gpu).to(dtype)
+    dst = torch.full((B, H, W, C), float('nan'), device=gpu, dtype=dtype)
+    hip.check(hip.lib().dpipe_upsample2x_adjoint(hip.ptr(src), hip.ptr(dst), B, H, W, C, hip.dtype_code(dtype), hip.stream()), 'upsample2x_adjoint')
+    v = src.float().view(B, H, 2, W, 2, C)
+    want = ((v[:, :, 0, :, 0] + v[:, :, 0, :, 1]) + (v[:, :, 1, :, 0] + v[:, :, 1, :, 1])).to(dtype)
+    assert torch.equal(dst, want)
+    # refused, not mis-run: a channel count that is not a whole number of 16-byte vectors
+    assert hip.lib().dpipe_upsample2x_adjoint(hip.ptr(src), hip.ptr(dst), B, H, W, C - 1, hip.dtype_code(dtype), hip.stream()) != 0
