@@ -181,11 +181,20 @@ __device__ __forceinline__ int nearest_code(const float* q, float x) {
 
 // ---- direct quantiser (round 5).  The library's maps are not arbitrary tables: `create_dynamic_map` lays 7 decades 10^-6 .. 10^0 side by side, decade i holding
 // 2^i (signed map) / 2^(i+1) (unsigned) EVENLY spaced values in (0.1, 1) x 10^(i-6), plus 0 and 1 (mirrored negatives in the signed map).  So the index of the code
-// nearest to x follows from 6 threshold comparisons (the decade), one multiply-add and a round (the slot) -- right to within +-1 across decade borders and rounding
-// (checked on 6 M points incl. every code, every midpoint +- ulps: oracle-side emulation in tests/test_optim_cpu.py) -- and the exact answer, ties included, is the
-// nearest of the three map entries around the guess: 3 INDEPENDENT LDS reads instead of the binary search's 9 dependent ones per moment per element (the kernel was
-// bound by that chain: 1.8 of 6.3 TB/s).  Whether a launch's maps ARE the dynamic maps is checked by the workgroup itself (one closed-form comparison per thread while it
-// stages the map into LDS); any other table keeps the search.
+// nearest to x follows from the decade (one v_log_f32, a multiply-add, a floor), one multiply-add and a round (the slot) -- right to within +-1 across decade borders and
+// rounding, whatever the last-ulp behaviour of the hardware logarithm (a misjudged decade lands on the neighbouring decade's end slot, which is the adjacent code) -- and
+// the exact answer, ties included, is the nearest of the three map entries around the guess: 3 INDEPENDENT LDS reads instead of the binary search's 9 dependent ones per
+// moment per element.  Oracle-side emulation incl. a perturbed logarithm: tests/test_optim_cpu.py.  Whether a launch's maps ARE the dynamic maps is checked by the
+// workgroup itself (one closed-form comparison per thread while it stages the map into LDS); any other table keeps the search.
+// Second pass of round 5 (the kernel had become ALU-bound: ~150 VALU operations per element against 10 bytes): the maps sit in LDS with one sentinel either side, so the
+// three candidates need no index clamps; the per-decade constants come from a 7-entry LDS table instead of two select chains; x = moment / absmax is one multiply by the
+// block's reciprocal (the exact quotient is kept for blocks whose absmax is below 1e-30, where the reciprocal would overflow); the sign rule of the first moment reduces,
+// on the dynamic map, to "code 127 (zero) for a negative moment becomes 126"; and the bf16 parameter update takes v_sqrt_f32 / v_rcp_f32 (1 ulp each; the library's own
+// kernel divides with __fdividef) -- fp32 parameters keep the correctly rounded quotient and root.
+struct Q8Lds {
+    float q1[258], q2[258];      // [k + 1] = map[k]; [0] = -3e38, [257] = +3e38
+    float4 dec1[8], dec2[8];     // decade i: {lo = 0.1 x 10^(i-6), slots_i / (0.9 x 10^(i-6)), slots_i - 1, bits of the int (first position of the decade)}: slot = (|x| - lo) * scale - 0.5
+};
 __device__ __forceinline__ float dyn_map_value(int idx, bool is_signed) {
     int pos; float sgn = 1.f;
     if (is_signed) { if (idx == 127) return 0.f; if (idx == 255) return 1.f; pos = idx < 127 ? 126 - idx : idx - 128; sgn = idx < 127 ? -1.f : 1.f; }
@@ -203,24 +212,59 @@ __device__ __forceinline__ bool is_dynamic_map(float mine, bool is_signed) {
     const float want = dyn_map_value((int)threadIdx.x, is_signed);
     return __syncthreads_and(fabsf(mine - want) <= 1e-5f * fabsf(want) + 1e-12f) != 0;
 }
+// stages both maps and the decade tables (256 threads); returns whether both are the library's dynamic maps.  Ends with the barriers of is_dynamic_map.
+__device__ __forceinline__ bool stage_maps(Q8Lds& L, const float* __restrict__ qmap1, const float* __restrict__ qmap2) {
+    const int t = threadIdx.x;
+    const float m1 = qmap1[t], m2 = qmap2[t];
+    L.q1[t + 1] = m1; L.q2[t + 1] = m2;
+    if (t == 0) { L.q1[0] = -3e38f; L.q2[0] = -3e38f; L.q1[257] = 3e38f; L.q2[257] = 3e38f; }
+    if (t < 8) {
+        const int i = t < 7 ? t : 6;
+        const float inv = i == 0 ? 1e6f : i == 1 ? 1e5f : i == 2 ? 1e4f : i == 3 ? 1e3f : i == 4 ? 1e2f : i == 5 ? 1e1f : 1e0f;
+        const float lo = 0.1f / inv;
+        L.dec1[t] = make_float4(lo, (float)(1 << i) * inv * (1.f / 0.9f), (float)((1 << i) - 1), __int_as_float((1 << i) - 1));
+        L.dec2[t] = make_float4(lo, (float)(2 << i) * inv * (1.f / 0.9f), (float)((2 << i) - 1), __int_as_float((2 << i) - 2));
+    }
+    return is_dynamic_map(m1, true) & is_dynamic_map(m2, false);
+}
+// qp = the padded map (qp[k + 1] = map[k]), dec = its decade table
 template <bool SIGNED>
-__device__ __forceinline__ int direct_code(const float* q, float x) {
+__device__ __forceinline__ int direct_code(const float* qp, const float4* dec, float x) {
     const float a = fabsf(x);
-    const int i = (a >= 1e-6f) + (a >= 1e-5f) + (a >= 1e-4f) + (a >= 1e-3f) + (a >= 1e-2f) + (a >= 1e-1f);
-    float inv = 1e6f;
-    inv = a >= 1e-6f ? 1e5f : inv; inv = a >= 1e-5f ? 1e4f : inv; inv = a >= 1e-4f ? 1e3f : inv;
-    inv = a >= 1e-3f ? 1e2f : inv; inv = a >= 1e-2f ? 1e1f : inv; inv = a >= 1e-1f ? 1e0f : inv;
-    const int nper = SIGNED ? (1 << i) : (2 << i);
-    const float t = (a * inv - 0.1f) * ((float)nper * (1.f / 0.9f)) - 0.5f;
-    const int j = min(max((int)rintf(t), 0), nper - 1);
-    const int pos = nper - (SIGNED ? 1 : 2) + j;
+    const int i = (int)__builtin_amdgcn_fmed3f(floorf(fmaf(__log2f(a), 0.30103f, 7.f)), 0.f, 6.f);      // decade [10^(i-7), 10^(i-6)): a = 0 -> -inf -> 0
+    const float4 d = dec[i];
+    const int j = (int)rintf(__builtin_amdgcn_fmed3f(fmaf(a - d.x, d.y, -0.5f), 0.f, d.z));
+    const int pos = __float_as_int(d.w) + j;                  // slots_i - base + j
     const int k = SIGNED ? (x >= 0.f ? 128 + pos : 126 - pos) : 1 + pos;
-    const int km = max(k - 1, 0), kp = min(k + 1, 255);
-    const float dm = fabsf(q[km] - x), d0 = fabsf(q[k] - x), dp = fabsf(q[kp] - x);
-    int best = km; float db = dm;
+    const float* c = qp + k;                                  // c[0 .. 2] = map[k - 1 .. k + 1] (sentinels past either end)
+    const float dm = fabsf(c[0] - x), d0 = fabsf(c[1] - x), dp = fabsf(c[2] - x);
+    int best = k - 1; float db = dm;
     if (d0 < db) { best = k; db = d0; }       // ties keep the lower index, like the search's `(q[hi] - x) < (x - q[lo]) ? hi : lo`
-    if (dp < db) best = kp;
+    if (dp < db) best = k + 1;
     return best;
+}
+// x = moment / absmax of its block (r = 1 / absmax): the exact quotient where the reciprocal would overflow
+__device__ __forceinline__ float block_scaled(float x, float amax, float r) {
+    if (__builtin_expect(amax < 1e-30f, 0)) return amax > 0.f ? x / amax : 0.f;
+    return x * r;
+}
+// the two codes of one element from x1 = m / absmax1, x2 = v / absmax2
+__device__ __forceinline__ void codes_of(const Q8Lds& L, bool dyn, float m, float x1, float x2, int& n1, int& n2) {
+    if (dyn) {
+        n1 = direct_code<true>(L.q1, L.dec1, x1);
+        n2 = direct_code<false>(L.q2, L.dec2, x2);
+        if (n1 == 127 && __float_as_int(m) < 0) n1 = 126;      // the first moment keeps its sign through quantisation (on this map only zero can lose it)
+    } else {
+        n1 = nearest_code(L.q1 + 1, x1);
+        n2 = nearest_code(L.q2 + 1, x2);
+        if (signbit(L.q1[n1 + 1]) != signbit(m)) n1 = m > 0.f ? min(n1 + 1, 255) : max(n1 - 1, 0);
+    }
+}
+// step_size * m / (sqrt(v) + correction2 * eps) without the step size
+template <typename T>
+__device__ __forceinline__ float update_ratio(float m, float v, float c2eps) {
+    if constexpr (sizeof(T) == 2) return m * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + c2eps);
+    else return m / (sqrtf(v) + c2eps);
 }
 
 template <typename T>
@@ -228,9 +272,10 @@ __global__ void __launch_bounds__(256) adamw8bit_kernel(T* __restrict__ p, const
                                                         float* __restrict__ absmax1, float* __restrict__ absmax2, const float* __restrict__ qmap1,
                                                         const float* __restrict__ qmap2, T* __restrict__ shift, long n, float beta1, float beta2, float eps,
                                                         float lr, float weight_decay, float step_size, float correction2, float gnorm_scale) {
-    __shared__ float q1[256], q2[256], red[2][4];
-    q1[threadIdx.x] = qmap1[threadIdx.x]; q2[threadIdx.x] = qmap2[threadIdx.x];
-    const bool dyn = is_dynamic_map(q1[threadIdx.x], true) & is_dynamic_map(q2[threadIdx.x], false);      // (two barriers: the maps are staged)
+    __shared__ Q8Lds L;
+    __shared__ float red[2][4];
+    const bool dyn = stage_maps(L, qmap1, qmap2);      // (two barriers: the maps are staged)
+    const float c2eps = correction2 * eps;
     const long nblocks = (n + 255) / 256;
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
@@ -241,7 +286,7 @@ __global__ void __launch_bounds__(256) adamw8bit_kernel(T* __restrict__ p, const
         float m = 0.f, v = 0.f;
         if (live && fin) {
             const float gs = gv * gnorm_scale;
-            m = q1[c1[i]] * absmax1[blk]; v = q2[c2[i]] * absmax2[blk];
+            m = L.q1[c1[i] + 1] * absmax1[blk]; v = L.q2[c2[i] + 1] * absmax2[blk];
             m = m * beta1 + (1.f - beta1) * gs;
             v = v * beta2 + (1.f - beta2) * gs * gs;
         }
@@ -258,7 +303,7 @@ __global__ void __launch_bounds__(256) adamw8bit_kernel(T* __restrict__ p, const
         T* target = shift ? shift : p;
         float t = Elem<T>::to_f(target[i]);
         if (fin) {
-            t = Elem<T>::to_f(Elem<T>::from_f(t + step_size * (m / (sqrtf(v) + correction2 * eps))));
+            t = Elem<T>::to_f(Elem<T>::from_f(t + step_size * update_ratio<T>(m, v, c2eps)));
             if (weight_decay > 0.f) t = Elem<T>::to_f(Elem<T>::from_f(t * (1.f - lr * weight_decay)));
         }
         if (shift) {
@@ -270,10 +315,8 @@ __global__ void __launch_bounds__(256) adamw8bit_kernel(T* __restrict__ p, const
         } else {
             p[i] = Elem<T>::from_f(t);
         }
-        const float x1 = new1 > 0.f ? m / new1 : 0.f, x2 = new2 > 0.f ? v / new2 : 0.f;
-        int k1 = dyn ? direct_code<true>(q1, x1) : nearest_code(q1, x1);
-        const int k2 = dyn ? direct_code<false>(q2, x2) : nearest_code(q2, x2);
-        if (signbit(q1[k1]) != signbit(m)) k1 = m > 0.f ? min(k1 + 1, 255) : max(k1 - 1, 0);   // the first moment keeps its sign through quantisation
+        int k1, k2;
+        codes_of(L, dyn, m, block_scaled(m, new1, 1.f / new1), block_scaled(v, new2, 1.f / new2), k1, k2);
         c1[i] = (uint8_t)k1; c2[i] = (uint8_t)k2;
     }
 }
@@ -290,9 +333,9 @@ __global__ void __launch_bounds__(256) adamw8bit_multi_kernel(void* const* __res
                                                               const long* __restrict__ chunk_off, const float* __restrict__ qmap1, const float* __restrict__ qmap2,
                                                               float beta1, float beta2, float eps, float lr, float weight_decay, float step_size, float correction2,
                                                               float gnorm_scale, int nchunks) {
-    __shared__ float q1[256], q2[256];
-    q1[threadIdx.x] = qmap1[threadIdx.x]; q2[threadIdx.x] = qmap2[threadIdx.x];
-    const bool dyn = is_dynamic_map(q1[threadIdx.x], true) & is_dynamic_map(q2[threadIdx.x], false);      // (two barriers: the maps are staged)
+    __shared__ Q8Lds L;
+    const bool dyn = stage_maps(L, qmap1, qmap2);      // (two barriers: the maps are staged)
+    const float c2eps = correction2 * eps;
     constexpr int E = 8;
     // grid-stride over the chunk table (round 5): a workgroup stages the two maps once and walks ~nchunks / gridDim chunks -- with one chunk per workgroup (296 k workgroups
     // for the SDXL UNet) every 20 KiB of traffic paid a map load, two barriers and a cold start of its own
@@ -346,19 +389,20 @@ __global__ void __launch_bounds__(256) adamw8bit_multi_kernel(void* const* __res
         }
     }
     const float am1 = absmax1[blk], am2 = absmax2[blk];
+    const float wdf = weight_decay > 0.f ? 1.f - lr * weight_decay : 1.f;       // (x 1 and a second rounding of an already rounded value change nothing)
     float m[E], v[E];
     bool fin[E];
     float a1 = 0.f, a2 = 0.f;
+    // no branch inside the element loops of the usual case (finite gradients, the library's maps): the eight elements' LDS reads and arithmetic interleave
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         fin[e] = isfinite(gv[e]);
-        m[e] = 0.f; v[e] = 0.f;
-        if (live[e] && fin[e]) {
-            const float gs = gv[e] * gnorm_scale;
-            m[e] = q1[k1[e]] * am1; v[e] = q2[k2[e]] * am2;
-            m[e] = m[e] * beta1 + (1.f - beta1) * gs;
-            v[e] = v[e] * beta2 + (1.f - beta2) * gs * gs;
-        }
+        const float gs = gv[e] * gnorm_scale;
+        const float mq = L.q1[k1[e] + 1] * am1, vq = L.q2[k2[e] + 1] * am2;
+        const float mn = mq * beta1 + (1.f - beta1) * gs;
+        const float vn = vq * beta2 + (1.f - beta2) * gs * gs;
+        const bool ok = live[e] && fin[e];
+        m[e] = ok ? mn : 0.f; v[e] = ok ? vn : 0.f;
         a1 = fmaxf(a1, fabsf(m[e])); a2 = fmaxf(a2, v[e]);
     }
 #pragma unroll
@@ -367,11 +411,9 @@ __global__ void __launch_bounds__(256) adamw8bit_multi_kernel(void* const* __res
     float outp[E], outs[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        float t = tv[e];
-        if (fin[e]) {
-            t = Elem<T>::to_f(Elem<T>::from_f(t + step_size * (m[e] / (sqrtf(v[e]) + correction2 * eps))));
-            if (weight_decay > 0.f) t = Elem<T>::to_f(Elem<T>::from_f(t * (1.f - lr * weight_decay)));
-        }
+        float tn = Elem<T>::to_f(Elem<T>::from_f(tv[e] + step_size * update_ratio<T>(m[e], v[e], c2eps)));
+        tn = Elem<T>::to_f(Elem<T>::from_f(tn * wdf));
+        const float t = fin[e] ? tn : tv[e];
         if (shift) {
             const float pn = Elem<T>::to_f(Elem<T>::from_f(pv[e] + t));
             const float diff = Elem<T>::to_f(Elem<T>::from_f(pv[e] - pn));
@@ -379,11 +421,22 @@ __global__ void __launch_bounds__(256) adamw8bit_multi_kernel(void* const* __res
         } else {
             outp[e] = t; outs[e] = 0.f;
         }
-        const float x1 = a1 > 0.f ? m[e] / a1 : 0.f, x2 = a2 > 0.f ? v[e] / a2 : 0.f;
-        int n1 = dyn ? direct_code<true>(q1, x1) : nearest_code(q1, x1);
-        const int n2 = dyn ? direct_code<false>(q2, x2) : nearest_code(q2, x2);
-        if (signbit(q1[n1]) != signbit(m[e])) n1 = m[e] > 0.f ? min(n1 + 1, 255) : max(n1 - 1, 0);
-        k1[e] = (uint8_t)n1; k2[e] = (uint8_t)n2;
+    }
+    const float r1 = 1.f / a1, r2 = 1.f / a2;
+    float x1[E], x2[E];
+    if (__builtin_expect((a1 < 1e-30f) | (a2 < 1e-30f), 0)) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) { x1[e] = block_scaled(m[e], a1, r1); x2[e] = block_scaled(v[e], a2, r2); }
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) { x1[e] = m[e] * r1; x2[e] = v[e] * r2; }
+    }
+    if (dyn) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) { int n1, n2; codes_of(L, true, m[e], x1[e], x2[e], n1, n2); k1[e] = (uint8_t)n1; k2[e] = (uint8_t)n2; }
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) { int n1, n2; codes_of(L, false, m[e], x1[e], x2[e], n1, n2); k1[e] = (uint8_t)n1; k2[e] = (uint8_t)n2; }
     }
     if (full) {
         if constexpr (sizeof(T) == 2) {

@@ -123,10 +123,12 @@ def test_pp2_two_pipeline_lanes_on_stage_graphs_match_one_instruction_stream(gpu
         one = _run(tmp_path, 'graph', 2, opt, total_mb=6)
         two = _run(tmp_path, 'graph', 2, opt, total_mb=6, extra={'pipe_lanes': 2})
         assert two['stage_graphs'] and two['pipe_lanes'] == 2 and one['pipe_lanes'] == 0
-        assert abs(two['res'][0][0] - one['res'][0][0]) / abs(one['res'][0][0]) < 2e-3, (one['res'], two['res'])
-        assert abs(two['res'][0][1] - one['res'][0][1]) / one['res'][0][1] < 2e-3, (one['res'], two['res'])
+        print(f"pipe lanes 2 vs 1 ({opt}): per step (loss_rel, norm_rel) =", [(abs(l1 - l0) / abs(l0), abs(n1 - n0) / n0) for (l0, n0), (l1, n1) in zip(one['res'], two['res'])])
+        # measured (profiles/r5y_tests_and_pipe_lane_distances.txt): first step loss identical, norm 1e-5 apart; steps 2 - 3 <= 1.6e-4
+        assert abs(two['res'][0][0] - one['res'][0][0]) / abs(one['res'][0][0]) < 5e-4, (one['res'], two['res'])
+        assert abs(two['res'][0][1] - one['res'][0][1]) / one['res'][0][1] < 5e-4, (one['res'], two['res'])
         for (l0, n0), (l1, n1) in zip(one['res'], two['res']):
-            assert abs(l1 - l0) / abs(l0) < 2e-2 and abs(n1 - n0) / n0 < 3e-2, (one['res'], two['res'])
+            assert abs(l1 - l0) / abs(l0) < 2e-3 and abs(n1 - n0) / n0 < 2e-3, (one['res'], two['res'])
 
 
 @pytest.mark.parametrize('opt', ['sgd', 'fused_adamw'])

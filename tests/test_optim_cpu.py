@@ -256,40 +256,69 @@ def test_grad_store_first_touch_protocol():
 
 
 def test_direct_quantiser_of_the_8bit_adamw_kernel_is_exact_on_the_dynamic_maps():
-    """csrc/optim.hip `direct_code` (round 5) restated in numpy fp32: decade by six thresholds, slot by one multiply-add and a round, then the nearest of the three map
-    entries around that guess (ties -> lower index).  Must equal the oracle's nearest-code search on both of bitsandbytes' dynamic maps for every code, every midpoint
-    between codes +- a few ulps, the decade borders and two million log-uniform / uniform points; and the guess itself must stay within one index of the answer (that
-    is what makes three entries enough)."""
+    """csrc/optim.hip `direct_code` (round 5) restated in numpy fp32: decade from one logarithm (floor(log2|x| * 0.30103 + 7), clamped to 0 .. 6), slot from the per-decade
+    table {lo, scale, slots - 1, first position} by one subtract, one multiply-add, a clamp and a round, then the nearest of the three map entries around that guess (ties ->
+    lower index; the kernel's LDS copy of the map carries a -3e38 / +3e38 sentinel either side, the same thing as clipping the candidate indices here).  Must equal the
+    oracle's nearest-code search on both of bitsandbytes' dynamic maps for every code, every midpoint between codes +- a few ulps, the decade borders, values one ulp past
+    +-1 (x = moment * (1 / absmax) can land there) and two million log-uniform / uniform points; the guess itself must stay within one index of the answer (that is what
+    makes three entries enough) -- also when the hardware logarithm (v_log_f32, 1 ulp) is off by +-4 ulps or +-3e-6 absolute."""
     import numpy as np
     from oracle.adam8bit_ref import create_dynamic_map, quantize_nearest
     f = np.float32
     rng = np.random.default_rng(0)
+    inv = np.array([1e6, 1e5, 1e4, 1e3, 1e2, 1e1, 1e0], dtype=f)
     for signed in (True, False):
         q = create_dynamic_map(signed)
+        base = 1 if signed else 2
+        slots = np.array([base << i for i in range(7)], np.int32)
+        lo = (f(0.1) / inv).astype(f)
+        scale = (slots.astype(f) * inv * f(1.0 / 0.9)).astype(f)
 
-        def guess(x):
+        def guess(x, log_ulps=0, log_abs=0.0):
             a = np.abs(x)
-            i = np.zeros(a.shape, np.int32)
-            for t in (1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1):
-                i += (a >= f(t))
-            inv = np.array([1e6, 1e5, 1e4, 1e3, 1e2, 1e1, 1e0], dtype=f)[i]
-            nper = (1 << i) if signed else (2 << i)
-            t = (a * inv - f(0.1)) * (nper.astype(f) * f(1.0 / 0.9)) - f(0.5)
-            j = np.clip(np.rint(t), 0, nper - 1).astype(np.int32)
-            pos = nper - (1 if signed else 2) + j
+            with np.errstate(divide='ignore'):
+                lg = np.log2(a.astype(np.float64)).astype(f)
+            if log_ulps:
+                fin = np.isfinite(lg)
+                lg = np.where(fin, lg + f(log_ulps) * np.spacing(np.where(fin, np.abs(lg), f(1))).astype(f), lg).astype(f)
+            lg = (lg + f(log_abs)).astype(f)
+            i = np.clip(np.floor(lg * f(0.30103) + f(7.0)), 0, 6).astype(np.int32)          # (-inf for a = 0 clips to 0)
+            t = np.clip((a - lo[i]) * scale[i] - f(0.5), 0, (slots[i] - 1).astype(f))
+            pos = slots[i] - base + np.rint(t).astype(np.int32)
             return np.where(x >= 0, 128 + pos, 126 - pos) if signed else 1 + pos
 
         mid = ((q[:-1].astype(np.float64) + q[1:]) / 2).astype(f)
-        pts = [q, np.array([0, 1, 1e-7, 1e-8, 0.1, 0.01, 1e-3, 1e-4, 1e-5, 1e-6, 0.09999999, 0.100000001], dtype=f)]
+        pts = [q, np.array([0, 1, 1e-7, 1e-8, 0.1, 0.01, 1e-3, 1e-4, 1e-5, 1e-6, 0.09999999, 0.100000001, 1.0000001, 1.0000002], dtype=f)]
         for d in (0, 1, -1, 2, -2, 7, -7):
             pts += [(mid.view(np.int32) + d).view(f), (q.view(np.int32) + d).view(f)]
         lu = (10 ** rng.uniform(-9, 0, 1_000_000)).astype(f)
-        pts += [lu, rng.uniform(-1 if signed else 0, 1, 1_000_000).astype(f)] + ([-lu] if signed else [])
+        pts += [lu, rng.uniform(-1 if signed else 0, 1, 1_000_000).astype(f)] + ([-lu, np.array([-1.0000001, -1.0000002], dtype=f)] if signed else [])
         x = np.concatenate(pts)
-        x = np.clip(x[np.isfinite(x)], -1 if signed else 0, 1).astype(f)
-        k = guess(x)
+        x = x[np.isfinite(x)].astype(f)
+        x = x[np.abs(x) <= f(1.000001)]
+        if not signed:
+            x = x[x >= 0]
         want = quantize_nearest(q, x).astype(np.int32)
-        assert np.abs(k - want).max() <= 1
-        cand = np.stack([np.clip(k - 1, 0, 255), np.clip(k, 0, 255), np.clip(k + 1, 0, 255)], 1)
-        got = cand[np.arange(len(x)), np.argmin(np.abs(q[cand] - x[:, None]), 1)]      # argmin: the first (= lowest index) of equal distances
-        assert np.array_equal(got, want)
+        for log_ulps, log_abs in ((0, 0.0), (4, 0.0), (-4, 0.0), (0, 3e-6), (0, -3e-6)):
+            k = guess(x, log_ulps, log_abs)
+            assert k.min() >= 0 and k.max() <= 255
+            assert np.abs(k - want).max() <= 1, (signed, log_ulps, log_abs)
+            cand = np.stack([np.clip(k - 1, 0, 255), np.clip(k, 0, 255), np.clip(k + 1, 0, 255)], 1)
+            got = cand[np.arange(len(x)), np.argmin(np.abs(q[cand] - x[:, None]), 1)]      # argmin: the first (= lowest index) of equal distances
+            assert np.array_equal(got, want), (signed, log_ulps, log_abs)
+        # the kernel's in-workgroup check that a launch's maps ARE these maps rests on this closed form (csrc/optim.hip dyn_map_value)
+        idx = np.arange(256)
+        if signed:
+            pos = np.where(idx < 127, 126 - idx, idx - 128)
+        else:
+            pos = idx - 1
+        pos = np.clip(pos, 0, None)
+        dec = np.floor(np.log2(pos + base)).astype(np.int32) - (0 if signed else 1)
+        nper = (1 << dec) if signed else (2 << dec)
+        val = 10.0 ** (dec - 6) * (0.1 + 0.9 * ((pos + base - nper) + 0.5) / nper)
+        if signed:
+            val = np.where(idx < 127, -val, val); val[127] = 0
+        else:
+            val[0] = 0
+        val[255] = 1
+        assert np.allclose(val, q, rtol=1e-5, atol=1e-12)
