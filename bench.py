@@ -103,9 +103,12 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the cpu_baseline / parity leg (and the other_configs leg)')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the bounded sdxl-stacked / flux / wan / hv steps the default run appends as `other_configs`')
     ap.add_argument('--no-synced-loop', action='store_true', help='skip the second timed region (a host read of the loss after every step: `value_synced_loop`)')
-    ap.add_argument('--parity-samples', type=int, default=int(os.environ.get('DPIPE_BENCH_PARITY_SAMPLES', '8')),
+    ap.add_argument('--parity-workers', type=int, default=int(os.environ.get('DPIPE_BENCH_PARITY_WORKERS', '-1')),
+                    help='child processes evaluating the oracle\'s extra parity samples (-1: 3 when the host has >= 96 hardware threads and >= 192 GB available, else one background thread)')
+    ap.add_argument('--no-reference-bf16', action='store_true', help='skip `parity.reference_bf16` (the oracle model under bf16 autocast on the GPU: what the reference itself evaluates)')
+    ap.add_argument('--parity-samples', type=int, default=int(os.environ.get('DPIPE_BENCH_PARITY_SAMPLES', '16')),
                     help='distinct micro-batches of the parity leg (timed path vs the oracle on the final weights; each costs ~20 s of host time, bounded by --parity-budget)')
-    ap.add_argument('--parity-budget', type=float, default=float(os.environ.get('DPIPE_BENCH_PARITY_BUDGET_S', '200')), help='host seconds the oracle may spend on parity samples beyond the first')
+    ap.add_argument('--parity-budget', type=float, default=float(os.environ.get('DPIPE_BENCH_PARITY_BUDGET_S', '240')), help='host seconds the oracle may spend on parity samples beyond the first')
     ap.add_argument('--light', action='store_true', help='the timed steps + the parity object only: no roofline replay legs, no fp32-kernel leg, no other_configs (the `other_configs.sdxl_stacked` child run)')
     ap.add_argument('--activation-checkpointing', action='store_true')
     ap.add_argument('--partition', default='parameters')
@@ -644,11 +647,30 @@ def main():
                 torch.cuda.synchronize()
                 gpu_l.append(float(l_.item())); gpu_n.append(float(n_.item()))
             p_loss, p_norm = gpu_l[0], gpu_n[0]
+            # Round 6: the yardstick.  The same weights and the same micro-batches through the ORACLE model with bf16 weights under torch.autocast on this
+            # GPU -- what the reference's own step evaluates (models/sdxl.py:387,636,675-988) -- so the timed path's distance from the fp32 oracle can be read beside the
+            # reference's own bf16 distance from it.  Checker only (ATen / MIOpen kernels), after the timed region.
+            ref16 = None
+            if not args.no_reference_bf16:
+                try:
+                    from oracle.gpu_reference_bf16 import sdxl_reference_bf16
+                    t_r = time.perf_counter()
+                    ref16 = sdxl_reference_bf16(cfg, state, cpu_samples, device) + (round(time.perf_counter() - t_r, 1),)
+                except Exception as e:                              # noqa: BLE001 -- reported in the line
+                    ref16 = repr(e)[:300]
+            workers = args.parity_workers
+            if workers < 0:
+                try:
+                    avail_gb = int([ln for ln in open('/proc/meminfo') if ln.startswith('MemAvailable')][0].split()[1]) / 2 ** 20
+                except Exception:                                   # noqa: BLE001
+                    avail_gb = 0
+                workers = 3 if (os.cpu_count() or 1) >= 96 and avail_gb >= 192 else 0
             from oracle.cpu_baseline import sdxl_cpu_baseline
             # the oracle times its first sample alone (= `cpu_baseline`), then evaluates the other parity samples on a background thread (~25 s of host time each) while this
             # process goes on with the GPU legs below; `finish_parity()` joins it
             out['cpu_baseline'] = cb = sdxl_cpu_baseline(cfg, latent_hw=latent, micro_batch=cpu_sample, state=state, per_parameter=detail,
-                                                         extra_micro_batches=cpu_samples[1:], extra_budget_s=args.parity_budget, extra_async=not detail)
+                                                         extra_micro_batches=cpu_samples[1:], extra_budget_s=args.parity_budget, extra_async=not detail,
+                                                         extra_workers=0 if detail else workers)
             if detail:
                 from tools.parity_report import family_table
                 family_table(gpu_rows, cb.pop('rows'), out=lambda line: print(line, file=sys.stderr, flush=True))
@@ -706,6 +728,19 @@ def main():
                                  'bounds': {'loss_rel_max': PARITY_BOUND, 'grad_norm_rel_max': PARITY_BOUND_BF16_NORM, 'grad_norm_rel_mean': PARITY_BOUND_BF16_NORM_MEAN,
                                             'grad_norm_rel_median': PARITY_BOUND_BF16_NORM_MEAN},
                                  'fp32_kernels': f32_leg}
+                if isinstance(ref16, tuple):
+                    r_n = [(g - c) / c for g, c in zip(ref16[1], cpu_n)]
+                    r_l = [abs(g - c) / abs(c) for g, c in zip(ref16[0], cpu_l)]
+                    r_mean = sum(r_n) / len(r_n)
+                    out['parity']['reference_bf16'] = {
+                        'grad_norm_rel_signed': [round(e, 6) for e in r_n], 'grad_norm_rel_mean': r_mean,
+                        'grad_norm_rel_sigma': (sum((e - r_mean) ** 2 for e in r_n) / max(len(r_n) - 1, 1)) ** 0.5,
+                        'grad_norm_rel_median': sorted(abs(e) for e in r_n)[len(r_n) // 2], 'grad_norm_rel_max': max(abs(e) for e in r_n), 'loss_rel_max': max(r_l),
+                        'seconds': ref16[2],
+                        'what': 'the yardstick: the oracle model with bf16 weights under torch.autocast(bfloat16) on this GPU (ATen kernels; loss in fp32, gradients in bf16 = '
+                                'what the reference\'s step evaluates, models/sdxl.py:387,636,675-988) vs the oracle fp32 eager path, same weights, same micro-batches'}
+                elif ref16 is not None:
+                    out['parity']['reference_bf16'] = {'error': ref16}
                 worst = max(range(n_s), key=lambda j: abs(e_n[j]))
                 if worst != 0 and eval32 is not None:
                     # the sample on which the bf16 path strayed furthest: is that distance bf16 rounding (the fp32 kernels land on the oracle) or a kernel's arithmetic?

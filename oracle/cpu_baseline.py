@@ -15,7 +15,61 @@ import torch
 from . import eager_step, sdxl_ref
 
 
-def sdxl_cpu_baseline(cfg, latent_hw=128, threads=None, micro_batch=None, state=None, per_parameter=False, extra_micro_batches=(), extra_budget_s=0.0, extra_async=False):
+def _bf16_exact(v):
+    return v.is_floating_point() and bool((v.to(torch.bfloat16).to(v.dtype) == v).all())
+
+
+def spawn_parity_workers(cfg, state, micro_batches, workers, threads):
+    """Evaluate `micro_batches` on `state` in `workers` child PROCESSES (round 6: 16 parity samples at ~25 s of host time each do not fit one background thread inside the
+    bench's few minutes; the GPU box has 256 hardware threads and the oracle runs fastest on ~32).  The weights travel once through /dev/shm (as bf16 where that is exact:
+    the product's parameters are bf16 values), worker w takes samples w, w + workers, ...  -> join() returning ([loss...], [grad_norm...]) in sample order."""
+    import subprocess
+    import sys
+    path = f'/dev/shm/dpipe_parity_{os.getpid()}.pt'
+    packed = {k: {n: (v.to(torch.bfloat16) if _bf16_exact(v) else v) for n, v in m.items()} for k, m in state.items()}
+    torch.save({'cfg': cfg, 'state': packed, 'mbs': [(tuple(t.cpu() for t in mb[0]), tuple(t.cpu() for t in mb[1])) for mb in micro_batches]}, path)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = [subprocess.Popen([sys.executable, '-m', 'oracle.cpu_baseline', path, str(w), str(workers), str(threads)], stdout=subprocess.PIPE, text=True, cwd=root)
+             for w in range(min(workers, len(micro_batches)))]
+
+    def join():
+        import json
+        got = {}
+        try:
+            for pr in procs:
+                out, _ = pr.communicate()
+                for ln in out.splitlines():
+                    if ln.startswith('{"parity_worker"'):
+                        got.update({int(k): v for k, v in json.loads(ln)['results'].items()})
+        finally:
+            if os.path.exists(path):
+                os.remove(path)
+        idx = sorted(got)
+        if idx != list(range(len(idx))):                     # a worker died: keep the contiguous prefix (the statistic says how many samples it holds)
+            idx = [i for i in range(len(micro_batches)) if all(j in got for j in range(i + 1))]
+        return [got[i][0] for i in idx], [got[i][1] for i in idx]
+    return join
+
+
+def _parity_worker_main(path, w, workers, threads):
+    import json
+    torch.set_num_threads(threads)
+    blob = torch.load(path, weights_only=False)
+    ref = sdxl_ref.SDXLRef(blob['cfg'], seed=0)
+    for k, m in ref.modules().items():
+        m.load_state_dict({n: v.to(torch.float32) if v.is_floating_point() else v for n, v in blob['state'][k].items()})
+    layers = ref.to_layers()
+    res = {}
+    for i in range(w, len(blob['mbs']), workers):
+        for p_ in ref.parameters():
+            p_.grad = None
+        l_, n_ = eager_step.eager_train_step(layers, eager_step.sdxl_loss_fn(), [blob['mbs'][i]], None, gradient_clipping=1.0, params=ref.parameters())
+        res[i] = [float(l_), float(n_)]
+    print(json.dumps({'parity_worker': w, 'results': res}), flush=True)
+
+
+def sdxl_cpu_baseline(cfg, latent_hw=128, threads=None, micro_batch=None, state=None, per_parameter=False, extra_micro_batches=(), extra_budget_s=0.0, extra_async=False,
+                      extra_workers=0):
     """-> cpu_baseline dict.  `micro_batch`: one prepared (features, label) pair as the engine receives it.  `state`: {module name: state dict}
     of the PRODUCT's weights (host tensors) -- loaded into the oracle so that its loss / gradient norm are comparable with the GPU path's on the
     same micro-batch (bench.py's `parity` object); None = the oracle's own seeded initialisation.
@@ -23,7 +77,8 @@ def sdxl_cpu_baseline(cfg, latent_hw=128, threads=None, micro_batch=None, state=
     `extra_budget_s` seconds of host time (each costs about `sample_seconds`); their losses / pre-clip gradient norms come back as `loss_all` / `grad_norm_all`
     (entry 0 = the timed sample).  `extra_async`: the extra samples are evaluated on a background thread (the caller goes on with GPU work; torch's CPU kernels release
     the GIL) -- the dict then carries `extra_join`, a callable that waits for the thread and returns (loss_all, grad_norm_all); the timed first sample is never concurrent
-    with anything."""
+    with anything.  `extra_workers` > 0 (round 6): the extra samples go to that many child processes instead (`spawn_parity_workers`), started AFTER the timed sample; this
+    process frees its own copy of the model first."""
     # many-core hosts (the GPU box has 256 hardware threads) run these mid-sized fp32 ops fastest on a subset
     threads = threads or min(os.cpu_count() or 1, int(os.environ.get('DPIPE_CPU_BASELINE_THREADS', '32')))
     prev = torch.get_num_threads()
@@ -55,7 +110,11 @@ def sdxl_cpu_baseline(cfg, latent_hw=128, threads=None, micro_batch=None, state=
                 l_, n_ = eager_step.eager_train_step(layers, eager_step.sdxl_loss_fn(), [mb], None, gradient_clipping=1.0, params=ref.parameters())
                 loss_all.append(float(l_)); norm_all.append(float(n_))
             return loss_all, norm_all
-        if extra_async and extra_micro_batches and not per_parameter:
+        worker_join = None
+        if extra_workers > 0 and extra_micro_batches and not per_parameter:
+            del ref, layers
+            worker_join = spawn_parity_workers(cfg, state, list(extra_micro_batches), extra_workers, threads)
+        elif extra_async and extra_micro_batches and not per_parameter:
             import threading
             extra_thread = threading.Thread(target=run_extras, name='oracle-parity-samples', daemon=True)
             extra_thread.start()
@@ -71,10 +130,13 @@ def sdxl_cpu_baseline(cfg, latent_hw=128, threads=None, micro_batch=None, state=
             torch.set_num_threads(prev)
 
     def extra_join():
+        if worker_join is not None:
+            l_, n_ = worker_join()
+            return loss_all + l_, norm_all + n_
         extra_thread.join()
         torch.set_num_threads(prev)
         return loss_all, norm_all
-    return {**({'rows': rows} if per_parameter else {}), **({'extra_join': extra_join} if extra_thread is not None else {}), 'value': round(1.0 / dt, 6), 'unit': 'images/s', 'cores': threads, 'kind': 'port', 'sample_seconds': round(dt, 3),
+    return {**({'rows': rows} if per_parameter else {}), **({'extra_join': extra_join} if extra_thread is not None or worker_join is not None else {}), 'value': round(1.0 / dt, 6), 'unit': 'images/s', 'cores': threads, 'kind': 'port', 'sample_seconds': round(dt, 3),
             'build_seconds': round(t_build, 1), 'loss': float(loss), 'grad_norm': float(norm), 'loss_all': loss_all, 'grad_norm_all': norm_all, 'weights': 'product state dict' if state is not None else 'oracle seed 0',
             'sample': f'oracle fp32 eager path (oracle/sdxl_ref.py + eager_step.py): ONE whole micro-batch = one {latent_hw * 8}x{latent_hw * 8} image '
                       f'through all 23 pipeline layers + loss + backward + clip (1 of the step\'s micro-batches, no optimizer step), {threads} threads'}
@@ -156,3 +218,8 @@ def dit_block_cpu_baseline(kind, step_flops_per_sample, threads=None):
             'host_tflops': round(rate / 1e12, 3), 'sample_tflop': round(sample_flops / 1e12, 2),
             'sample': f'oracle fp32 eager path, {what}, forward + backward, {threads} threads; value = measured host FLOP rate / the step\'s '
                       f'algorithmic FLOPs per sample ({step_flops_per_sample / 1e12:.1f} TFLOP) -- an extrapolation, the whole fp32 step does not fit the bound'}
+
+
+if __name__ == '__main__':          # python -m oracle.cpu_baseline <blob> <worker> <workers> <threads>   (a parity worker of spawn_parity_workers)
+    import sys
+    _parity_worker_main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))

@@ -36,6 +36,13 @@ PY
         python tools/pmc_agg.py $O/${TAG}_pmc_$c $O/${TAG}_pmc_gemm_step_$c.csv >> $O/${TAG}_pmc_$c.log 2>&1; rm -rf $O/${TAG}_pmc_$c
       done
       python tools/pmc_traffic_json.py $O/${TAG}_pmc_gemm_step_FETCH_SIZE.csv $O/${TAG}_pmc_gemm_step_WRITE_SIZE.csv $trace $div $O/${TAG}_pmc_gemm_traffic.json | tail -1;;
+    sqpmc)    # sqpmc:<name>:<command...>  -- ONE counters-only pass (8 SQ slots + GRBM) over an eager command, aggregated per kernel name
+      IFS=':' read -r name pcmd <<< "$rest"
+      ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE -f csv -d $O/${TAG}_sq_$name -o pmc -- bash -c "cd $R && $pcmd" > $O/${TAG}_sq_$name.log 2>&1 )
+      python tools/pmc_agg.py $O/${TAG}_sq_$name $O/${TAG}_pmc_${name}_sq_counters.csv | tail -1; rm -rf $O/${TAG}_sq_$name;;
+    census)   # census[:<bench args>]  -- kernel trace (no counters) of the lane bench + tools/trace_overlap.py
+      ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace -f csv -d $O/${TAG}_tr -o tr -- python $R/bench.py ${rest:---steps 4 --warmup 2 --no-cpu-baseline --no-synced-loop --light} > $O/${TAG}_census.log 2>&1 )
+      python tools/trace_overlap.py $(find $O/${TAG}_tr -name '*kernel_trace.csv' | head -1) $O/${TAG}_overlap.json --skip-frac 0.5 | head -30; rm -rf $O/${TAG}_tr;;
     cmd)      # every cmd step gets its own log: <tag>_cmd1.log, <tag>_cmd2.log, ...
       NCMD=$((${NCMD:-0} + 1))
       bash -c "$rest" > $O/${TAG}_cmd${NCMD}.log 2>&1; echo "cmd${NCMD} rc=$? $(tail -2 $O/${TAG}_cmd${NCMD}.log)";;
