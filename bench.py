@@ -516,6 +516,7 @@ def main():
         with open(timeline_path, 'w') as f:
             json.dump(rows, f, indent=1)
     engine_mod.TRACE = None
+    own_elapsed = elapsed
     t = torch.tensor([elapsed, synced_elapsed or 0.0], device=device, dtype=torch.float64)
     comm_ranks, comm_backend = 1, None
     if world > 1:
@@ -574,6 +575,23 @@ def main():
 
     parity_failed = False
     gemm_policy = (getattr(engine, 'gemm_shallow_rings', None), getattr(engine, 'gemm_big_tiles', None))
+    # Round 6: a multi-GPU run must be diagnosable from its JSON line alone (nothing above one GPU has ever been timed by the builder).  Every rank contributes: its stage,
+    # the layers it holds, the link it ended up with and how `auto` was negotiated, its own timed-region clock, peak HBM, and -- measured now, after the steps that
+    # matter -- the GPU time of one micro-batch of its captured forward + backward graphs replayed alone (`stage_ms`): gas x stage_ms / ms_per_step is the stage's busy
+    # fraction (> 1 is possible with pipe lanes: two instruction streams overlap on the chip).
+    per_rank = None
+    if world > 1:
+        own = {'rank': rank, 'stage': engine.stage_id, 'dp_rank': engine.grid.get_data_parallel_rank(), 'layers': [int(module.parts[engine.stage_id]), int(module.parts[engine.stage_id + 1])],
+               'params_m': round(sum(p_.numel() for p_ in module.parameters()) / 1e6, 1), 'own_ms_per_step': round(own_elapsed / args.steps * 1e3, 2),
+               'peak_hbm_gb': round(peak_hbm / 2 ** 30, 2), **engine.link_report(), 'stream_probe': engine.stream_probe()}
+        try:
+            sm = engine.stage_replay_ms()
+            own['stage_ms'] = round(sm, 3) if sm is not None else None
+            own['busy_frac'] = round(gas * sm / (elapsed / args.steps * 1e3), 4) if sm else None
+        except Exception as e:                                  # noqa: BLE001 -- a diagnostic never fails the run
+            own['stage_ms_error'] = repr(e)[:200]
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, own)
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         images = gas * 1 * engine.dp_world_size
@@ -594,7 +612,7 @@ def main():
                                    f'pp={pp}, GAS={gas}, AdamW, clip 1.0' + (f', {args.stack} micro-batches stacked per pass' if args.stack > 1 else '') +
                                    (' [tiny test config]' if args.config != 'full' else ''),
                        'global_batch': images, 'parallelism': f'pp{pp}' + (f' x dp{dp}' if dp > 1 else ''), 'gradient_accumulation_steps': gas,
-                       'stage_link': type(engine.link).__name__ if engine.link is not None else None,
+                       'stage_link': type(engine.link).__name__ if engine.link is not None else None, 'per_rank': per_rank,
                        'rccl_ranks': comm_ranks if comm_backend == 'nccl' else 0, 'process_group': comm_backend,
                        'graph_packet_capture': os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '1') != '0',
                        'activation_checkpointing': bool(args.activation_checkpointing), 'partition': module.parts, 'hip_graph': bool(engine.use_graph or engine.use_stage_graphs),
@@ -658,6 +676,13 @@ def main():
                     ref16 = sdxl_reference_bf16(cfg, state, cpu_samples, device) + (round(time.perf_counter() - t_r, 1),)
                 except Exception as e:                              # noqa: BLE001 -- reported in the line
                     ref16 = repr(e)[:300]
+            groups16 = None
+            if os.environ.get('DPIPE_BENCH_PARITY_GROUPS', '0') == '1':         # diagnostic: which bf16 roundings does the gradient norm react to (fp32 oracle on the GPU + rounding hooks)
+                try:
+                    from oracle.gpu_reference_bf16 import sdxl_rounding_groups
+                    groups16 = sdxl_rounding_groups(cfg, state, cpu_samples, device)
+                except Exception as e:                              # noqa: BLE001
+                    groups16 = {'error': repr(e)[:300]}
             workers = args.parity_workers
             if workers < 0:
                 try:
@@ -741,6 +766,11 @@ def main():
                                 'what the reference\'s step evaluates, models/sdxl.py:387,636,675-988) vs the oracle fp32 eager path, same weights, same micro-batches'}
                 elif ref16 is not None:
                     out['parity']['reference_bf16'] = {'error': ref16}
+                if groups16 is not None and 'none' in groups16:
+                    out['parity']['rounding_groups'] = {g: [round((v - b) / b, 6) for v, b in zip(vals, groups16['none'])] for g, vals in groups16.items() if g != 'none'}
+                    out['parity']['rounding_groups']['fp32_on_gpu_vs_cpu_oracle'] = [round((v - c) / c, 7) for v, c in zip(groups16['none'], cpu_n)]
+                elif groups16 is not None:
+                    out['parity']['rounding_groups'] = groups16
                 worst = max(range(n_s), key=lambda j: abs(e_n[j]))
                 if worst != 0 and eval32 is not None:
                     # the sample on which the bf16 path strayed furthest: is that distance bf16 rounding (the fp32 kernels land on the oracle) or a kernel's arithmetic?

@@ -48,7 +48,7 @@ int launch_conv(GemmParams& p, bool b_mc, int batch, void* ws, long ws_bytes, in
 void base_params(GemmParams& p) {
     p.bias = nullptr; p.sAo = p.sAi = p.sBo = p.sBi = p.sCo = p.sCi = 0; p.batch_inner = 1; p.alpha = 1.f; p.act = ACT_NONE; p.accumulate = 0; p.out_f32 = 0;
     p.splitk = 1; p.ksteps = p.ksteps_per_split = 0; p.slabs = nullptr; p.counters = nullptr; p.residual = nullptr; p.ldr = 0; p.colsum = nullptr; p.colsum_acc = 0;
-    p.vecA = p.vecB = 0; p.tiles_m = p.tiles_n = 0; p.bias_rows = 0;
+    p.vecA = p.vecB = 0; p.tiles_m = p.tiles_n = 0; p.bias_rows = 0; p.bias_lo = 0;
 }
 
 bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -78,6 +78,10 @@ int dpipe_conv2d_fwd(const void* x, long ldx, const void* w, const void* bias, c
     if (flags & DPIPE_CONV_BIAS_PER_SAMPLE) {           // bias = [B][Cout]: output pixel row m takes the bias row of its sample (the ResnetBlock's time-embedding addend at batch > 1)
         if (!bias || Cout % 4) UNSUP("dpipe_conv2d_fwd: a per-sample bias needs a bias and Cout % 4 == 0");
         p.bias_rows = Ho * Wo;
+    }
+    if (flags & DPIPE_CONV_BIAS_HILO) {                 // bias = a bf16 hi / lo pair of an fp32 addend ([2][Cout] or [2][B][Cout]): both sets are added in the epilogue (round 6)
+        if (!bias || Cout % 4) UNSUP("dpipe_conv2d_fwd: a hi / lo bias pair needs a bias and Cout % 4 == 0");
+        p.bias_lo = (long)Cout * ((flags & DPIPE_CONV_BIAS_PER_SAMPLE) ? B : 1);
     }
     p.cg = ConvGeom{Ho, Wo, H, W, kw, kh * kw, Cin / 64, sl, ul, pad, 0, 0, 0, ((long)B * H * W - 1) * ldx + Cin, 0};
     if (p.cg.a_ext * 2 >= (1L << 31) || (long)Cout * p.ldb * 2 >= (1L << 31)) UNSUP("dpipe_conv2d_fwd: operand beyond 2 GiB");

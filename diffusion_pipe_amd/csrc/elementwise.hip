@@ -249,6 +249,60 @@ __global__ void __launch_bounds__(EW_BLOCK) geglu_bwd_kernel(const T* __restrict
     }
 }
 
+// ------------------------------------------------------- precise row linear (round 6): fp32 per-channel addends
+// A handful of rows [R, K] of fp32 values (the SDXL time embedding `emb`, one row per sample) enter MFMA GEMMs whose results are added to EVERY pixel of a channel
+// (diffusers ResnetBlock2D: conv1(h) + time_emb_proj(silu(emb))[:, :, None, None]).  A bf16 rounding of such a row is not noise: it shifts a whole channel, and the
+// gradient norm of the network follows the mean of the residual.  So the row keeps fp32 accuracy through the bf16 MFMA path: the (activated)
+// operand is split into a bf16 hi / lo row pair (hi + lo = value to 2^-17), the GEMM runs over 2R rows with an fp32 result, and the two result rows are added
+// together with the biases in fp32 -- the result leaves either as fp32 rows or again as a hi / lo bf16 pair (a convolution's bias operand, DPIPE_CONV_BIAS_HILO).
+__global__ void __launch_bounds__(EW_BLOCK) rowsplit_fwd_kernel(const float* __restrict__ x, bf16_t* __restrict__ hl, long n, int act) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = act_fwd(x[i], act);
+        const bf16_t hi = f32_to_bf16(v);
+        hl[i] = hi;
+        hl[n + i] = f32_to_bf16(v - bf16_to_f32(hi));
+    }
+}
+// dx = d(hi + lo) * act'(x): the gradient of either row of the pair IS the gradient of their sum
+__global__ void __launch_bounds__(EW_BLOCK) rowsplit_bwd_kernel(const bf16_t* __restrict__ ds, const float* __restrict__ x, float* __restrict__ dx, long n, int act) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dx[i] = bf16_to_f32(ds[i]) * act_bwd(x[i], act);
+}
+// y[r, c] = g[r, c] + g[R + r, c] + bias[c] + extra[c]  ->  out32[r, c] and / or the pair out_hl[r, c], out_hl[R N + r N + c]
+__global__ void __launch_bounds__(EW_BLOCK) rowcombine_fwd_kernel(const float* __restrict__ g, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ extra,
+                                                                  float* __restrict__ out32, bf16_t* __restrict__ out_hl, int R, int N) {
+    const long n = (long)R * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % N);
+        float v = g[i] + g[n + i];
+        if (bias) v += bf16_to_f32(bias[c]);
+        if (extra) v += bf16_to_f32(extra[c]);
+        if (out32) out32[i] = v;
+        if (out_hl) {
+            const bf16_t hi = f32_to_bf16(v);
+            out_hl[i] = hi;
+            out_hl[n + i] = f32_to_bf16(v - bf16_to_f32(hi));
+        }
+    }
+}
+// gy[r, c] = gy[R + r, c] = bf16(gout[r, c]) (both GEMM result rows of a pair receive the gradient of their sum);  dbias[c] (+)= sum_r gout[r, c], likewise dextra
+template <typename G>
+__global__ void __launch_bounds__(EW_BLOCK) rowcombine_bwd_kernel(const G* __restrict__ gout, bf16_t* __restrict__ gy, bf16_t* __restrict__ dbias, int dbias_acc,
+                                                                  bf16_t* __restrict__ dextra, int dextra_acc, int R, int N) {
+    const long n = (long)R * N;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < N; c += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) {
+            const float v = Elem<G>::to_f(gout[(long)r * N + c]);
+            const bf16_t b = f32_to_bf16(v);
+            gy[(long)r * N + c] = b; gy[n + (long)r * N + c] = b;
+            s += v;
+        }
+        if (dbias) dbias[c] = f32_to_bf16(dbias_acc ? bf16_to_f32(dbias[c]) + s : s);
+        if (dextra) dextra[c] = f32_to_bf16(dextra_acc ? bf16_to_f32(dextra[c]) + s : s);
+    }
+}
+
 // ------------------------------------------------------- gated residual (K5)
 // out[r, :] = x[r, :] + y[r, :] * gate[r / rows_per_gate, :]   (gate may be null => plain add)
 template <typename T, typename G>
@@ -469,6 +523,33 @@ int dpipe_act_bwd(const void* x, const void* gy, void* gx, long n, int dtype, in
     else if (dtype == DPIPE_F32) act_bwd_kernel<float><<<stream_grid(n / 4 + 1, EW_BLOCK), EW_BLOCK, 0, STREAM(stream)>>>((const float*)x, (const float*)gy, (float*)gx, n, act);
     else { set_last_error("dpipe_act_bwd: dtype"); return DPIPE_ERR_UNSUPPORTED; }
     return check_launch("dpipe_act_bwd");
+}
+
+int dpipe_rowsplit_fwd(const float* x, void* hl, long n, int act, void* stream) {
+    if (!x || !hl || n <= 0) { set_last_error("dpipe_rowsplit_fwd: bad argument"); return DPIPE_ERR_ARG; }
+    rowsplit_fwd_kernel<<<stream_grid(n, EW_BLOCK), EW_BLOCK, 0, STREAM(stream)>>>(x, (bf16_t*)hl, n, act);
+    return check_launch("dpipe_rowsplit_fwd");
+}
+
+int dpipe_rowsplit_bwd(const void* ds, const float* x, float* dx, long n, int act, void* stream) {
+    if (!ds || !x || !dx || n <= 0) { set_last_error("dpipe_rowsplit_bwd: bad argument"); return DPIPE_ERR_ARG; }
+    rowsplit_bwd_kernel<<<stream_grid(n, EW_BLOCK), EW_BLOCK, 0, STREAM(stream)>>>((const bf16_t*)ds, x, dx, n, act);
+    return check_launch("dpipe_rowsplit_bwd");
+}
+
+int dpipe_rowcombine_fwd(const float* g, const void* bias, const void* extra, float* out32, void* out_hl, int R, int N, void* stream) {
+    if (!g || (!out32 && !out_hl) || R <= 0 || N <= 0) { set_last_error("dpipe_rowcombine_fwd: bad argument"); return DPIPE_ERR_ARG; }
+    rowcombine_fwd_kernel<<<stream_grid((long)R * N, EW_BLOCK), EW_BLOCK, 0, STREAM(stream)>>>(g, (const bf16_t*)bias, (const bf16_t*)extra, out32, (bf16_t*)out_hl, R, N);
+    return check_launch("dpipe_rowcombine_fwd");
+}
+
+int dpipe_rowcombine_bwd(const void* gout, int gout_dtype, void* gy, void* dbias, int dbias_accumulate, void* dextra, int dextra_accumulate, int R, int N, void* stream) {
+    if (!gout || !gy || R <= 0 || N <= 0) { set_last_error("dpipe_rowcombine_bwd: bad argument"); return DPIPE_ERR_ARG; }
+    const int grid = stream_grid(N, EW_BLOCK);
+    if (gout_dtype == DPIPE_F32) rowcombine_bwd_kernel<float><<<grid, EW_BLOCK, 0, STREAM(stream)>>>((const float*)gout, (bf16_t*)gy, (bf16_t*)dbias, dbias_accumulate, (bf16_t*)dextra, dextra_accumulate, R, N);
+    else if (gout_dtype == DPIPE_BF16) rowcombine_bwd_kernel<bf16_t><<<grid, EW_BLOCK, 0, STREAM(stream)>>>((const bf16_t*)gout, (bf16_t*)gy, (bf16_t*)dbias, dbias_accumulate, (bf16_t*)dextra, dextra_accumulate, R, N);
+    else { set_last_error("dpipe_rowcombine_bwd: dtype"); return DPIPE_ERR_UNSUPPORTED; }
+    return check_launch("dpipe_rowcombine_bwd");
 }
 
 int dpipe_geglu_fwd(const void* x, void* y, long rows, long H, int dtype, int act, void* stream) {

@@ -271,7 +271,7 @@ int dpipe_gemm_ex(int dtype, int transA, int transB, int M, int N, int K,
     p.sAo = strideA_outer; p.sAi = strideA_inner; p.sBo = strideB_outer; p.sBi = strideB_inner; p.sCo = strideC_outer; p.sCi = strideC_inner;
     p.batch_inner = batch_inner; p.alpha = alpha; p.act = act; p.accumulate = accumulate; p.out_f32 = out_f32;
     p.splitk = 1; p.ksteps = 0; p.ksteps_per_split = 0; p.slabs = nullptr; p.counters = nullptr;
-    p.residual = residual; p.ldr = ldr; p.colsum = colsum; p.colsum_acc = colsum_accumulate; p.bias_rows = 0;
+    p.residual = residual; p.ldr = ldr; p.colsum = colsum; p.colsum_acc = colsum_accumulate; p.bias_rows = 0; p.bias_lo = 0;
     if (residual && residual == C && !accumulate) { set_last_error("dpipe_gemm: residual may not alias C"); return DPIPE_ERR_ARG; }
     const int batch = batch_outer * batch_inner;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -320,7 +320,7 @@ int dpipe_gemm_group(const dpipe_gemm_desc* descs, int n, void* splitk_ws, long 
         p.sAo = p.sAi = p.sBo = p.sBi = p.sCo = p.sCi = 0;
         p.batch_inner = 1; p.alpha = d.alpha; p.act = d.act; p.accumulate = d.accumulate; p.out_f32 = d.out_f32;
         p.splitk = 1; p.ksteps = 0; p.ksteps_per_split = 0; p.slabs = nullptr; p.counters = nullptr;
-        p.residual = d.residual; p.ldr = d.ldr; p.colsum = d.colsum; p.colsum_acc = d.colsum_accumulate; p.bias_rows = 0;
+        p.residual = d.residual; p.ldr = d.ldr; p.colsum = d.colsum; p.colsum_acc = d.colsum_accumulate; p.bias_rows = 0; p.bias_lo = 0;
         pipe[i] = d.dtype == DPIPE_BF16 && gemm_pipe_eligible(p, d.transA, d.transB);
         if (d.colsum && !pipe[i]) { set_last_error("dpipe_gemm_group: fused column sum needs the pipelined kernel with a K-major A operand (transA = 1)"); return DPIPE_ERR_UNSUPPORTED; }
         if (pipe[i]) { ps[npipe] = p; ta[npipe] = d.transA; tb[npipe] = d.transB; ++npipe; }

@@ -38,6 +38,7 @@ struct GemmParams {
     const void* residual; long ldr;       // C += residual[m, n] (C's dtype, row pitch ldr, batch strides of C)
     void* colsum; int colsum_acc;          // pipelined TN kernel only: colsum[m] (+)= sum_k A[k][m]  (bias gradient of a wgrad GEMM), operand dtype
     int bias_rows;                         // 0: one bias row for every output row; r > 0: output row m takes bias row m / r (a per-sample bias of a convolution: r = Ho Wo), pitch N
+    long bias_lo;                          // 0, or the element offset from a bias row to its LO row: the bias is a bf16 hi / lo pair of an fp32 addend, both are added (round 6)
     ConvGeom cg;                           // CONV modes only
 #ifdef DPIPE_TIMELINE
     void* timeline;                        // tools/probes/gemm_timeline.hip only

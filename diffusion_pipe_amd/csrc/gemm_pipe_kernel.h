@@ -596,6 +596,11 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, char* const 
 #pragma unroll
                         for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += bf16_to_f32(bp[r]);
                     }
+                    if (p.bias_lo) {                       // the LO set of a hi / lo bias pair (an fp32 per-channel addend: DPIPE_CONV_BIAS_HILO; N % 4 == 0)
+                        const uint2 lv = *reinterpret_cast<const uint2*>(bp + p.bias_lo);
+                        v[0] += __uint_as_float(lv.x << 16); v[1] += __uint_as_float(lv.x & 0xffff0000u);
+                        v[2] += __uint_as_float(lv.y << 16); v[3] += __uint_as_float(lv.y & 0xffff0000u);
+                    }
                 }
                 if (p.act != ACT_NONE) {
 #pragma unroll

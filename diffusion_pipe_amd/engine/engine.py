@@ -401,6 +401,33 @@ class PipelineEngine:
         return self._last_grad_norm
 
     @property
+    def link_report(self):
+        """what this rank's stage link is and how `p2p_backend: 'auto'` was decided (RcclLink.negotiate: the phase a fallback was agreed at and this rank's own error,
+        if any) -- gathered per rank into the bench line so a multi-GPU run is diagnosable from its JSON alone"""
+        rep = {'link': type(self.link).__name__ if self.link is not None else None}
+        neg = getattr(RcclLink, 'last_negotiation', None)
+        if neg is not None and self.link is not None and not isinstance(self.link, HostStagedLink):
+            rep.update(negotiated=dict(neg))
+        return rep
+
+    def stage_replay_ms(self, reps=3):
+        """GPU time of ONE micro-batch of this stage's captured forward + backward graphs replayed back to back on the current stream, no exchange, no waiting on a
+        neighbour (HIP events around `reps` replays of one captured slot).  micro_batches x this / step time = the stage's busy fraction: what the 1F1B bubble, the
+        link and the slower neighbours leave of it.  Replays accumulate garbage into the gradient buffers: call it after the last step that matters.  None when the
+        stage holds no captured slot (eager path, single-stage lane path)."""
+        if self.device.type != 'cuda' or not self._stage_slots:
+            return None
+        slot = next(iter(self._stage_slots.values()))
+        torch.cuda.synchronize(self.device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        slot['fwd'].replay(); slot['bwd'].replay()
+        e0.record()
+        for _ in range(reps):
+            slot['fwd'].replay(); slot['bwd'].replay()
+        e1.record()
+        torch.cuda.synchronize(self.device)
+        return e0.elapsed_time(e1) / reps
+
     def stream_probe(self):
         """Outcome of the hardware-queue probe for this engine's lane / stage streams (engine.concurrent_streams `report`); {} before the probe ran."""
         return dict(self._probe_report)

@@ -209,6 +209,8 @@ class RcclLink(StageLink):
                 if err is not None:
                     raise err
 
+    last_negotiation = None
+
     @classmethod
     def negotiate(cls, grid, device, comm_stream=None, agree=None, log=print):
         """All-ranks-agree construction for `p2p_backend: 'auto'`: returns a connected, self-tested link on EVERY rank of the world or None on every rank.
@@ -229,10 +231,16 @@ class RcclLink(StageLink):
                 return int(flag.item()) == 1
         rank = grid.global_rank
 
+        cls.last_negotiation = {'link': 'RcclLink', 'failed_phase': None, 'local_error': None}      # per process: what THIS rank saw (bench.py gathers it per rank)
+
         def phase(name, err):
             if err is not None:
+                cls.last_negotiation['local_error'] = f'{name}: {err!r}'[:200]
                 log(f'[dpipe] rank {rank}: RCCL link unavailable at {name} ({err}); stage exchange falls back to torch.distributed isend / irecv', flush=True)
-            return agree(err is None)
+            ok = agree(err is None)
+            if not ok:
+                cls.last_negotiation.update(link='StageLink (torch isend / irecv)', failed_phase=name)
+            return ok
 
         err, link = None, None
         try:

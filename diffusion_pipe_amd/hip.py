@@ -16,8 +16,8 @@ import os
 LIB_PATH = Path(os.environ.get('DPIPE_HIP_LIB') or Path(__file__).resolve().parent / 'libdpipe_hip.so')
 
 BF16, F32 = 0, 1
-ABI_VERSION = 7                      # DPIPE_ABI_VERSION of include/dpipe_hip.h this binding was written against
-CONV_OUT_F32, CONV_ACCUMULATE, CONV_BIAS_PER_SAMPLE = 1, 2, 4  # dpipe_conv2d_fwd / _dgrad `flags`
+ABI_VERSION = 8                      # DPIPE_ABI_VERSION of include/dpipe_hip.h this binding was written against
+CONV_OUT_F32, CONV_ACCUMULATE, CONV_BIAS_PER_SAMPLE, CONV_BIAS_HILO = 1, 2, 4, 8  # dpipe_conv2d_fwd / _dgrad `flags`
 OPT_ATTN_FWD_DMA, OPT_ATTN_BWD_DMA, OPT_ATTN_DQ8, OPT_ATTN_DKV_SPLIT, OPT_GEMM_SHALLOW, OPT_GEMM_BIG_TILES = 0, 1, 2, 3, 4, 5     # dpipe_set_option ids (include/dpipe_hip.h)
 ACT = {None: 0, 'none': 0, 'gelu_tanh': 1, 'gelu': 2, 'gelu_erf': 2, 'silu': 3, 'quick_gelu': 4}
 LOSS_KIND = {'mse': 0, 'huber': 1, 'smooth_l1': 2}
@@ -52,6 +52,10 @@ _SIGNATURES = {
     'dpipe_loss_bwd': (I, [P, I, P, P, P, P, L, L, I, F, P, P]),
     'dpipe_act_fwd': (I, [P, P, L, I, I, P]),
     'dpipe_upsample2x_adjoint': (I, [P, P, I, I, I, I, I, P]),
+    'dpipe_rowsplit_fwd': (I, [P, P, L, I, P]),
+    'dpipe_rowsplit_bwd': (I, [P, P, P, L, I, P]),
+    'dpipe_rowcombine_fwd': (I, [P, P, P, P, P, I, I, P]),
+    'dpipe_rowcombine_bwd': (I, [P, I, P, P, I, P, I, I, I, P]),
     'dpipe_act_bwd': (I, [P, P, P, L, I, I, P]),
     'dpipe_geglu_fwd': (I, [P, P, L, L, I, I, P]),
     'dpipe_geglu_bwd': (I, [P, P, P, L, L, I, I, P]),

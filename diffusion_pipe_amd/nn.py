@@ -162,6 +162,12 @@ class Conv2d(nn.Conv2d):
 
     def forward(self, x, upsample=1, residual=None, extra_bias=None):
         bias = self.bias
+        if extra_bias is not None and extra_bias.dim() == 3:
+            # the bf16 hi / lo pair of an fp32 addend that already CONTAINS this convolution's bias (ops.precise_row_linear(..., extra=self.bias, pair=True))
+            if not (x.is_cuda and x.dtype == torch.bfloat16 and ops.conv2d_eligible(x.dtype, self.weight, self.stride, self.padding, self.dilation, self.groups)):
+                from .hip import DpipeHipError
+                raise DpipeHipError('Conv2d: a hi / lo bias pair needs the bf16 implicit-GEMM path')
+            return ops.conv2d_nhwc(x, self.weight, extra_bias, self.stride[0], self.padding[0], upsample, residual)
         if extra_bias is not None and extra_bias.dim() == 2:
             # one addend row per sample ([B, Cout]: the time embedding of a resnet at batch > 1, i.e. under micro-batch stacking): a per-sample bias in the epilogue
             bias = ops.bias_plus_sample(bias, extra_bias)
@@ -323,5 +329,14 @@ class TimestepEmbedding(nn.Module):
         self.act = SiLU()
         self.linear_2 = Linear(time_embed_dim, time_embed_dim, device=device, dtype=dtype)
 
+    def precise_ok(self):
+        """both projections are plain bf16 Linear layers (no adapter wrapped around them): fp32 rows may take ops.precise_row_linear"""
+        return (ops.PRECISE_ADDENDS and type(self.linear_1) is Linear and type(self.linear_2) is Linear and type(self.act) is SiLU
+                and self.linear_1.weight.dtype == torch.bfloat16 and self.linear_1.weight.is_cuda)
+
     def forward(self, sample, condition=None):
+        if sample.dtype == torch.float32 and self.precise_ok():
+            # fp32 rows in, fp32 embedding out (round 6): what leaves here is added to every pixel of a channel by each ResnetBlock2D -- a coherent error if rounded to bf16
+            h = ops.precise_row_linear(sample, self.linear_1.weight, self.linear_1.bias)
+            return ops.precise_row_linear(h, self.linear_2.weight, self.linear_2.bias, act='silu')
         return self.linear_2(self.act(self.linear_1(sample)))

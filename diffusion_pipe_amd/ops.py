@@ -522,6 +522,78 @@ def column_sum(x2, out=None, out_dtype=None, accumulate=None):
     return out
 
 
+# ---------------------------------------------------------------------------- precise row linear (round 6: fp32 per-channel addends)
+PRECISE_ADDENDS = _os.environ.get('DPIPE_PRECISE_ADDENDS', '1') == '1'      # A/B switch: 0 = the time-embedding rows in bf16 like every other activation (rounds 1 - 5)
+
+
+class _PreciseRowLinearFn(Function):
+    """y = act(x) W^T + bias (+ extra) for a FEW fp32 rows x [R, K] whose result is a per-channel addend (the SDXL time embedding: diffusers TimestepEmbedding and
+    ResnetBlock2D.time_emb_proj behind models/sdxl.py:797-865, `hidden_states + temb[:, :, None, None]`).  W / bias / extra are the bf16 parameters; the row keeps fp32
+    accuracy through the bf16 MFMA GEMM as a hi / lo bf16 row pair (csrc/elementwise.hip: rowsplit / rowcombine).  `pair` = False: fp32 [R, N]; True: the bf16 hi / lo
+    pair [2, R, N] a convolution takes as its bias (`conv2d_nhwc(..., bias=pair)`: `extra` = that convolution's own bias vector, whose gradient is taken here).
+    Why: a bf16 rounding of such a row shifts EVERY pixel of a channel together -- a coherent error the gradient norm of the network reacts to (tools/coherent_noise_probe.py:
+    rounding these rows alone moves the norm by 2 - 3e-4, every other activation of the network together by 5e-5)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, extra, act, pair):
+        require_cuda(x, weight, bias, extra)
+        if weight.dtype != torch.bfloat16:
+            raise DpipeHipError('precise_row_linear: bf16 parameters only (fp32 models take ops.linear)')
+        x32 = _contig(x.reshape(-1, x.shape[-1]))
+        if x32.dtype != torch.float32:
+            x32 = x32.float()
+        R, K = x32.shape
+        N = weight.shape[0]
+        hl = torch.empty((2 * R, K), device=x.device, dtype=torch.bfloat16)
+        check(lib().dpipe_rowsplit_fwd(ptr(x32), ptr(hl), R * K, ACT[act], stream()), 'rowsplit_fwd')
+        g = mm(hl, weight, False, True, out_dtype=torch.float32)
+        out = torch.empty((2, R, N), device=x.device, dtype=torch.bfloat16) if pair else torch.empty((R, N), device=x.device, dtype=torch.float32)
+        check(lib().dpipe_rowcombine_fwd(ptr(g), ptr(bias), ptr(extra), None if pair else ptr(out), ptr(out) if pair else None, R, N, stream()), 'rowcombine_fwd')
+        ctx.save_for_backward(x32, hl, weight, bias, extra)
+        ctx.act, ctx.pair, ctx.x_shape = act, pair, x.shape
+        return out if pair else out.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, gout):
+        x32, hl, weight, bias, extra = ctx.saved_tensors
+        R, K = x32.shape
+        N = weight.shape[0]
+        g1 = gout[0] if ctx.pair else gout.reshape(R, N)            # a pair's two rows carry the same gradient (the convolution hands back an expanded view)
+        g1 = _contig(g1)
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        tb = _accum_target(bias) if (bias is not None and ctx.needs_input_grad[2]) else None
+        te = _accum_target(extra) if (extra is not None and ctx.needs_input_grad[3]) else None
+        b_out = (tb if tb is not None else torch.empty_like(bias)) if (bias is not None and ctx.needs_input_grad[2]) else None
+        e_out = (te if te is not None else torch.empty_like(extra)) if (extra is not None and ctx.needs_input_grad[3]) else None
+        gy = torch.empty((2 * R, N), device=g1.device, dtype=torch.bfloat16)
+        check(lib().dpipe_rowcombine_bwd(ptr(g1), dtype_code(g1.dtype), ptr(gy), ptr(b_out), int(_acc(tb)), ptr(e_out), int(_acc(te)), R, N, stream()), 'rowcombine_bwd')
+        gx = gw = None
+        tw = _accum_target(weight) if need_w else None
+        acc_w = _acc(tw) if need_w else False
+        w_out = (tw if tw is not None else torch.empty_like(weight)) if need_w else None
+        ds = torch.empty((2 * R, K), device=g1.device, dtype=torch.bfloat16) if need_x else None
+        done = None
+        if need_x and need_w:
+            done = gemm_group([mm_problem(gy, weight, False, False, out=ds), mm_problem(gy, hl, True, False, out=w_out, accumulate=acc_w)])
+        if done is None:
+            if need_x:
+                mm(gy, weight, False, False, out=ds)
+            if need_w:
+                mm(gy, hl, True, False, out=w_out, accumulate=acc_w)          # dW (+)= gy^T (hi + lo): exact over the 2R rows
+        if need_x:
+            dx = torch.empty_like(x32)
+            check(lib().dpipe_rowsplit_bwd(ptr(ds), ptr(x32), ptr(dx), R * K, ACT[ctx.act], stream()), 'rowsplit_bwd')
+            gx = dx.view(ctx.x_shape)
+        if need_w and tw is None:
+            gw = w_out
+        return gx, gw, (None if tb is not None else b_out), (None if te is not None else e_out), None, None
+
+
+def precise_row_linear(x, weight, bias=None, extra=None, act=None, pair=False):
+    """see _PreciseRowLinearFn.  x: [..., K] fp32 (a few rows); -> fp32 [..., N], or with `pair` the bf16 hi / lo pair [2, R, N]."""
+    return _PreciseRowLinearFn.apply(x, weight, bias, extra, act, bool(pair))
+
+
 # ------------------------------------------------------------------------------------------- activations (K6)
 class _ActFn(Function):
     @staticmethod
@@ -997,10 +1069,13 @@ class _Conv2dNHWCFn(Function):
             _conv_fwd_launch(xl, Cin, wh, bl, None, y, *geo, hip.CONV_OUT_F32 | hip.CONV_ACCUMULATE, ws)
             _conv_fwd_launch(xh, Cin, wl, None, None, y, *geo, hip.CONV_OUT_F32 | hip.CONV_ACCUMULATE, ws)
         else:
-            per_sample = bias is not None and bias.dim() == 2          # [B, Cout]: a bias row per sample (the ResnetBlock's time-embedding addend at batch > 1)
-            if per_sample and (bias.shape != (B, Cout) or not bias.is_contiguous()):
+            hilo = bias is not None and bias.dim() == 3                # [2, R, Cout]: the bf16 hi / lo pair of an fp32 addend (precise_row_linear(..., pair=True)), R = 1 or B rows
+            if hilo and (bias.shape[0] != 2 or bias.shape[1] not in (1, B) or bias.shape[2] != Cout or not bias.is_contiguous()):
+                raise DpipeHipError('conv2d: a hi / lo bias pair must be a contiguous [2, 1 or B, Cout] tensor')
+            per_sample = bias is not None and (bias.dim() == 2 or (hilo and bias.shape[1] > 1))       # a bias row per sample (the ResnetBlock's time-embedding addend at batch > 1)
+            if per_sample and not hilo and (bias.shape != (B, Cout) or not bias.is_contiguous()):
                 raise DpipeHipError('conv2d: a per-sample bias must be a contiguous [B, Cout] tensor')
-            _conv_fwd_launch(xv, Cin, weight, bias, rv, y, *geo, hip.CONV_BIAS_PER_SAMPLE if per_sample else 0, ws)
+            _conv_fwd_launch(xv, Cin, weight, bias, rv, y, *geo, (hip.CONV_BIAS_PER_SAMPLE if per_sample else 0) | (hip.CONV_BIAS_HILO if hilo else 0), ws)
         ctx.save_for_backward(xv, weight, bias)
         ctx.geom = (stride, pad, upsample, residual is not None)
         return y.permute(0, 3, 1, 2)
@@ -1042,7 +1117,8 @@ class _Conv2dNHWCFn(Function):
             gx = dxu.permute(0, 3, 1, 2)
         need_w, need_b = ctx.needs_input_grad[1], bias is not None and ctx.needs_input_grad[2]
         gb_rows = None
-        if need_b and bias.dim() == 2:
+        hilo = bias is not None and bias.dim() == 3
+        if need_b and (bias.dim() == 2 or (hilo and bias.shape[1] > 1)):
             # per-sample bias: its gradient is one deterministic column sum per sample over that sample's [Ho Wo, Cout] rows of dy (no ATen reduction: see
             # _AddSampleChannelBiasFn); the wgrad launch below then carries no fused bias gradient
             rows = gyv.reshape(B, -1, Cout)
@@ -1052,7 +1128,7 @@ class _Conv2dNHWCFn(Function):
             tw = _accum_target_dense(weight)
             tb = _accum_target(bias) if need_b else None
             w_out = tw if tw is not None else torch.empty_like(weight)           # preserve_format: channels-last like the weight
-            b_out = (tb if tb is not None else torch.empty_like(bias)) if need_b else None
+            b_out = (tb if tb is not None else (torch.empty_like(bias[0, 0]) if hilo else torch.empty_like(bias))) if need_b else None
 
             def wgrad(g, xs, acc, bo, bacc, out_f32):
                 check(lib().dpipe_conv2d_wgrad(ptr(g), Cout, ptr(xs), Cin, ptr(w_out), ptr(bo), B, H, W, Cin, Cout, kh, kw, stride, pad, upsample,
@@ -1074,6 +1150,8 @@ class _Conv2dNHWCFn(Function):
             gb = None if (tb is not None or not need_b) else b_out
         if gb_rows is not None:
             gb = gb_rows
+        if hilo and gb is not None:
+            gb = gb.reshape(1, -1, Cout).expand(2, -1, -1)          # both rows of the pair receive the gradient of their sum (a view: precise_row_linear reads row 0)
         gres = gy if (has_res and ctx.needs_input_grad[3]) else None
         return gx, gw, gb, gres, None, None, None
 

@@ -197,7 +197,18 @@ class ResnetBlock2D(nn.Module):
 
     def forward(self, x, temb):
         x = x.contiguous(memory_format=torch.channels_last)
-        t = self.time_emb_proj(self.nonlinearity(temb))
+        if (temb.dtype == torch.float32 and x.dtype == torch.bfloat16 and x.is_cuda and ops.PRECISE_ADDENDS and type(self.time_emb_proj) is dnn.Linear
+                and type(self.conv1) is dnn.Conv2d and self.conv1.weight.shape[0] % 4 == 0
+                and ops.conv2d_eligible(x.dtype, self.conv1.weight, self.conv1.stride, self.conv1.padding, self.conv1.dilation, self.conv1.groups)):
+            # round 6: the addend time_emb_proj(silu(emb)) + conv1.bias is computed from the fp32 embedding with fp32 accuracy and enters conv1's epilogue as a bf16
+            # hi / lo pair (one row per sample) -- it shifts every pixel of a channel, so its rounding is a coherent error, not noise
+            pair = ops.precise_row_linear(temb, self.time_emb_proj.weight, self.time_emb_proj.bias, extra=self.conv1.bias, act='silu', pair=True)
+            h, x = self.norm1(x, act='silu', with_skip=True)
+            h = self.conv1(h, extra_bias=pair)
+            if self.conv_shortcut is not None:
+                x = self.conv_shortcut(x)
+            return self.conv2(self.norm2(h, act='silu'), residual=x)
+        t = self.time_emb_proj(self.nonlinearity(temb.to(x.dtype) if temb.dtype != x.dtype else temb))
         h, x = self.norm1(x, act='silu', with_skip=True)          # GroupNorm + SiLU in one pass; the skip branch's gradient is folded into its backward
         if x.shape[0] == 1:        # batch 1: the time-embedding addend is one value per channel -> it joins conv1's bias vector in the epilogue
             h = self.conv1(h, extra_bias=t.reshape(-1).to(x.dtype))
@@ -375,11 +386,15 @@ class InitialLayer(nn.Module):
 
         encoder_hidden_states, pooled = self.get_text_conditioning(input_ids, input_ids_2)
         wdtype = self.conv_in.weight.dtype
-        t_emb = self.time_proj(timestep.expand(sample.shape[0])).to(wdtype)
-        emb = self.time_embedding(t_emb)
+        # round 6: with plain bf16 embedding MLPs on the GPU the time / added-condition embedding stays fp32 from the sinusoidal features to the addend of every
+        # ResnetBlock2D (ops.precise_row_linear); otherwise (fp32 model, adapters on these layers, DPIPE_PRECISE_ADDENDS=0) it takes the model dtype as before
+        precise = sample.is_cuda and wdtype == torch.bfloat16 and self.time_embedding.precise_ok() and self.add_embedding.precise_ok()
+        t_emb = self.time_proj(timestep.expand(sample.shape[0]))
         time_embeds = self.add_time_proj(add_time_ids.flatten()).reshape(sample.shape[0], -1)
-        add_embeds = torch.cat([pooled.float(), time_embeds], dim=-1).to(wdtype)
-        emb = emb + self.add_embedding(add_embeds)
+        add_embeds = torch.cat([pooled.float(), time_embeds], dim=-1)
+        if not precise:
+            t_emb, add_embeds = t_emb.to(wdtype), add_embeds.to(wdtype)
+        emb = self.time_embedding(t_emb) + self.add_embedding(add_embeds)
         sample = self.conv_in(sample.to(wdtype))
         return make_contiguous(sample, timestep, emb, encoder_hidden_states, sample, forward_upsample_size)
 

@@ -32,7 +32,7 @@ extern "C" {
 #define DPIPE_LOSS_SMOOTH_L1 2
 
 /* ABI version: bumped whenever a signature of this header changes; the host binding refuses a library of another version. */
-#define DPIPE_ABI_VERSION 7
+#define DPIPE_ABI_VERSION 8
 int dpipe_version(void);
 const char* dpipe_last_error(void);
 /* Kernel-selection options (process-wide; for A/B timing and for testing the fallback kernels -- every default is the measured-faster choice).
@@ -88,6 +88,18 @@ int dpipe_act_fwd(const void* x, void* y, long n, int dtype, int act, void* stre
  * src [B, 2H, 2W, C], channels-last, fp32 accumulate; C a multiple of 8 (bf16) / 4 (fp32) */
 int dpipe_upsample2x_adjoint(const void* src, void* dst, int B, int H, int W, int C, int dtype, void* stream);
 int dpipe_act_bwd(const void* x, const void* gy, void* gx, long n, int dtype, int act, void* stream);
+/* (ABI 8) Precise row linear: a few rows of fp32 values that become PER-CHANNEL ADDENDS -- the SDXL time embedding through diffusers' TimestepEmbedding and
+ * ResnetBlock2D.time_emb_proj, `hidden_states + temb[:, :, None, None]` behind models/sdxl.py:797-865 -- keep fp32 accuracy through the bf16 MFMA GEMM: the
+ * (activated) operand rows are split into bf16 hi / lo pairs, the GEMM (dpipe_gemm_ex, fp32 result) runs over 2R rows, the pair of result rows is added in fp32.
+ *   rowsplit_fwd   : hl [2][R*K] bf16 <- act(x [R*K] fp32): hl[0] = bf16(v), hl[1] = bf16(v - hl[0])                    (n = R*K)
+ *   rowsplit_bwd   : dx [n] fp32 = ds [n] bf16 * act'(x [n])
+ *   rowcombine_fwd : y[r][c] = g[r][c] + g[R + r][c] + bias[c] + extra[c] (g fp32 [2R][N]; bias / extra bf16 [N] or NULL) -> out32 [R][N] fp32 and / or
+ *                    out_hl [2][R][N] bf16 (hi / lo pair: the bias operand of dpipe_conv2d_fwd under DPIPE_CONV_BIAS_HILO); either may be NULL
+ *   rowcombine_bwd : gy [2][R][N] bf16 <- gout [R][N] (fp32 or bf16, both halves equal); dbias[c] (+)= sum_r gout[r][c], dextra likewise (bf16 [N] or NULL) */
+int dpipe_rowsplit_fwd(const float* x, void* hl, long n, int act, void* stream);
+int dpipe_rowsplit_bwd(const void* ds, const float* x, float* dx, long n, int act, void* stream);
+int dpipe_rowcombine_fwd(const float* g, const void* bias, const void* extra, float* out32, void* out_hl, int R, int N, void* stream);
+int dpipe_rowcombine_bwd(const void* gout, int gout_dtype, void* gy, void* dbias, int dbias_accumulate, void* dextra, int dextra_accumulate, int R, int N, void* stream);
 /* x: [rows, 2H] -> y[rows, H] = x[:, :H] * act(x[:, H:]) */
 int dpipe_geglu_fwd(const void* x, void* y, long rows, long H, int dtype, int act, void* stream);
 int dpipe_geglu_bwd(const void* x, const void* gy, void* gx, long rows, long H, int dtype, int act, void* stream);
@@ -215,6 +227,8 @@ int dpipe_lnmod_bwd(const void* x, const void* gy, const void* gamma, const void
 #define DPIPE_CONV_OUT_F32 1
 #define DPIPE_CONV_ACCUMULATE 2
 #define DPIPE_CONV_BIAS_PER_SAMPLE 4   /* dpipe_conv2d_fwd: `bias` is [B][Cout] (bf16, row pitch Cout, Cout % 4 == 0): every output pixel of sample b adds row b */
+#define DPIPE_CONV_BIAS_HILO 8         /* (ABI 8) dpipe_conv2d_fwd: `bias` holds TWO such sets back to back, [2][Cout] or (with PER_SAMPLE) [2][B][Cout]: a bf16 hi / lo pair of an
+                                        * fp32 addend (dpipe_rowcombine_fwd), both added to the fp32 accumulator before the output is rounded; Cout % 4 == 0 */
 int dpipe_conv2d_fwd(const void* x, long ldx, const void* w, const void* bias, const void* residual, long ldr, void* y, long ldy,
                      int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int upsample, int act, int flags,
                      void* splitk_ws, long splitk_ws_bytes, int tile_hint, void* stream);

@@ -41,3 +41,68 @@ def sdxl_reference_bf16(cfg, state, micro_batches, device, dtype=torch.bfloat16)
     del ref, layers, params
     torch.cuda.empty_cache()
     return losses, norms
+
+
+def _group_of(name, mod):
+    """rounding groups of tools/coherent_noise_probe.py (which bf16 roundings move the gradient norm?)"""
+    import torch.nn as nn
+    g = set()
+    leaf = isinstance(mod, (nn.Linear, nn.Conv2d, nn.GroupNorm, nn.LayerNorm))
+    if not leaf:
+        return g
+    temb = 'time_emb_proj' in name or 'time_embedding' in name or 'add_embedding' in name
+    ctx = 'attn2.to_k' in name or 'attn2.to_v' in name or name.startswith('te')
+    g.add('all')
+    g.add('temb' if temb else 'all-temb')
+    if ctx:
+        g.add('ctx')
+    if isinstance(mod, (nn.GroupNorm, nn.LayerNorm)):
+        g.add('norms')
+    if isinstance(mod, nn.Conv2d):
+        g.add('convs')
+    if isinstance(mod, nn.Linear) and not temb:
+        g.add('linears')
+    return g
+
+
+def sdxl_rounding_groups(cfg, state, micro_batches, device, groups=('none', 'all', 'temb', 'all-temb', 'ctx', 'norms', 'convs', 'linears')):
+    """Diagnostic (DPIPE_BENCH_PARITY_GROUPS=1): the oracle model in FP32 on the GPU with forward hooks that round the outputs of one module group to bf16
+    (straight-through gradient), on the bench's own weights and parity samples -> {group: [gradient norm per sample]}.  Says which roundings of a bf16 forward the
+    global gradient norm of this network reacts to."""
+    torch.backends.cudnn.benchmark = False
+    prev_tf32 = torch.backends.cuda.matmul.allow_tf32
+    torch.backends.cuda.matmul.allow_tf32 = False
+    active = {'g': 'none'}
+    with torch.device(device):
+        ref = sdxl_ref.SDXLRef(cfg, seed=0)
+        for k, m in ref.modules().items():
+            m.load_state_dict({n: v.to(device=device, dtype=torch.float32) for n, v in state[k].items()})
+        named = [(f'unet.{k}', m) for k, m in ref.unet.named_modules()] + [(f'te1.{k}', m) for k, m in ref.text_encoder.named_modules()] + \
+                [(f'te2.{k}', m) for k, m in ref.text_encoder_2.named_modules()]
+
+        def mk(gs):
+            def hook(_m, _i, o):
+                return o.to(torch.bfloat16).to(torch.float32) if active['g'] in gs else None
+            return hook
+        for name, m in named:
+            gs = _group_of(name, m)
+            if gs:
+                m.register_forward_hook(mk(gs))
+        layers, loss_fn, params = ref.to_layers(), eager_step.sdxl_loss_fn(), ref.parameters()
+        out = {g: [] for g in groups}
+        for feats, label in micro_batches:
+            for g in groups:
+                active['g'] = g
+                for p in params:
+                    p.grad = None
+                x = tuple(t.to(device) for t in feats)
+                for layer in layers:
+                    x = layer(x)
+                loss_fn(x, tuple(t.to(device) for t in label)).backward()
+                sq = torch.stack([p.grad.detach().float().norm(2) for p in params if p.grad is not None]).square().sum()
+                out[g].append(float(sq.sqrt().item()))
+                del x
+    torch.backends.cuda.matmul.allow_tf32 = prev_tf32
+    del ref, layers, params
+    torch.cuda.empty_cache()
+    return out

@@ -161,6 +161,13 @@ def test_bench_multi_rank_path_runs_end_to_end_on_one_shared_gpu(gpu, tmp_path):
     out = json.loads(line[0])
     assert out['n_gpus'] == 2 and out['config']['parallelism'] == 'pp2' and out['config']['gradient_accumulation_steps'] == 16
     assert out['value'] > 0 and out['loss'] == out['loss'] and out['roofline']['launches_per_step'] > 0
+    # round 6: the line alone says what every rank held, which link it ended up with and how busy its stage was
+    pr = out['config']['per_rank']
+    assert [r_['rank'] for r_ in pr] == [0, 1] and [r_['stage'] for r_ in pr] == [0, 1]
+    assert pr[0]['layers'][1] == pr[1]['layers'][0] and pr[0]['layers'][0] == 0
+    assert all(r_['link'] == 'HostStagedLink' for r_ in pr)
+    assert all(r_['stage_ms'] > 0 and 0 < r_['busy_frac'] < 4 for r_ in pr), pr
+    assert all(r_['own_ms_per_step'] > 0 for r_ in pr)
 
 
 def test_bare_bench_command_self_launches_its_ranks(gpu, tmp_path):
