@@ -104,7 +104,7 @@ def parse():
     ap.add_argument('--no-other-configs', action='store_true', help='skip the bounded sdxl-stacked / flux / wan / hv steps the default run appends as `other_configs`')
     ap.add_argument('--no-synced-loop', action='store_true', help='skip the second timed region (a host read of the loss after every step: `value_synced_loop`)')
     ap.add_argument('--parity-workers', type=int, default=int(os.environ.get('DPIPE_BENCH_PARITY_WORKERS', '-1')),
-                    help='child processes evaluating the oracle\'s extra parity samples (-1: 3 when the host has >= 96 hardware threads and >= 192 GB available, else one background thread)')
+                    help='child processes evaluating the oracle\'s extra parity samples (-1: 5 / 3 when the host has >= 192 / 96 hardware threads and >= 320 / 192 GB available, else one background thread)')
     ap.add_argument('--no-reference-bf16', action='store_true', help='skip `parity.reference_bf16` (the oracle model under bf16 autocast on the GPU: what the reference itself evaluates)')
     ap.add_argument('--parity-samples', type=int, default=int(os.environ.get('DPIPE_BENCH_PARITY_SAMPLES', '16')),
                     help='distinct micro-batches of the parity leg (timed path vs the oracle on the final weights; each costs ~20 s of host time, bounded by --parity-budget)')
@@ -689,7 +689,7 @@ def main():
                     avail_gb = int([ln for ln in open('/proc/meminfo') if ln.startswith('MemAvailable')][0].split()[1]) / 2 ** 20
                 except Exception:                                   # noqa: BLE001
                     avail_gb = 0
-                workers = 3 if (os.cpu_count() or 1) >= 96 and avail_gb >= 192 else 0
+                workers = (5 if (os.cpu_count() or 1) >= 192 and avail_gb >= 320 else 3) if (os.cpu_count() or 1) >= 96 and avail_gb >= 192 else 0
             from oracle.cpu_baseline import sdxl_cpu_baseline
             # the oracle times its first sample alone (= `cpu_baseline`), then evaluates the other parity samples on a background thread (~25 s of host time each) while this
             # process goes on with the GPU legs below; `finish_parity()` joins it

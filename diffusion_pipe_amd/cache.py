@@ -30,6 +30,10 @@ from pathlib import Path
 import torch
 
 
+# The zero-copy views of a read-only shard mapping make torch.frombuffer warn "The given buffer is not writable" -- read-only is the contract.  Filtered ONCE, here, by
+# message: `warnings.catch_warnings()` around every unpickle (round 5) mutated the process-global filter list from the prefetcher's worker threads concurrently.
+warnings.filterwarnings('ignore', message='The given buffer is not writable', category=UserWarning)
+
 class _View(io.RawIOBase):
     """Read-only file object over a slice of an mmap (torch.load reads storages straight out of the mapping)."""
 
@@ -187,9 +191,7 @@ class Cache:
                         records[name.rsplit('/', 1)[1]] = (data_off, zi.file_size)
             if pkl is None:
                 raise ValueError('not a torch.save zip blob')
-            with warnings.catch_warnings():
-                warnings.simplefilter('ignore', UserWarning)          # "the given buffer is not writable": the views are read-only by contract
-                return _BlobUnpickler(io.BytesIO(m[pkl[0]:pkl[0] + pkl[1]]), m, records).load()
+            return _BlobUnpickler(io.BytesIO(m[pkl[0]:pkl[0] + pkl[1]]), m, records).load()     # ("buffer is not writable": filtered once at import, see below)
         finally:
             view.close()
 

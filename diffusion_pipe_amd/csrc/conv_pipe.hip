@@ -24,18 +24,19 @@ int launch_conv(GemmParams& p, bool b_mc, int batch, void* ws, long ws_bytes, in
                          : tile_hint >= 2000 && tile_hint < 3000 ? 64 : 0;
     const int force_s = tile_hint >= 1000 ? tile_hint % 1000 : 0;
     const bool a_mc = CONV == 2;
-    int tile = gemm_pipe_plan(p, a_mc, b_mc, batch, ws, ws_bytes, force_s, force_tile);
+    int tile = gemm_pipe_plan(p, a_mc, b_mc, batch, ws, ws_bytes, force_s, force_tile, 0, 0, /*allow_vs=*/false);
     if (force_tile == 0) {
         // measured on the SDXL convolutions (tools/conv_timing.py): the 256^2 tile loses on the UNet's 320 / 640-wide outputs (37 % of a 256-wide tile is padding:
         // 152 vs 95 us for 128^2 x 640 -> 320), and the forward's gathered A rows favour two workgroups per CU (2-deep ring) from one round of tiles on
         const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
-        if (tile == 257 || tile == 258) tile = gemm_pipe_plan(p, a_mc, b_mc, batch, ws, ws_bytes, 0, 129);      // re-plan (tile grid, split-K, slab budget) for 128^2 (258 = the half-K-step ring: plain GEMM only)
+        if (tile == 257 || tile == 258) tile = gemm_pipe_plan(p, a_mc, b_mc, batch, ws, ws_bytes, 0, 129, 0, 0, false);      // re-plan (tile grid, split-K, slab budget) for 128^2 (258 = the half-K-step ring: plain GEMM only)
         if (CONV == 1 && !b_mc && tile == 128 && tiles128 >= 256 && tiles128 < 512 && p.splitk == 1) tile = 129;
     }
     // The register-staged 128^2 tile (round 5) stays a plain-GEMM tile.  Built for the gathered-row convolutions too and measured (profiles/r5o_conv_timing.jsonl, forward /
     // dgrad us): its CONV = 1 instances need 142 - 146 VGPRs (the gather state on top of the register sets) = ONE workgroup per CU, and lose where the UNet spends its
     // convolution time -- 320 -> 320 at 128 x 128 (9 per pass): 62.7 / 73.0 vs 47.9 / 50.1 on the 2-deep DMA ring; 640 -> 640 at 64 x 64: 56.1 / 66.8 vs 58.5 / 82.7 (3-deep), i.e.
-    // level; over the step's 41 convolutions 8.3 vs 6.6 ms per micro-batch forced, 6.9 vs 6.6 dispatched.  Removed again: the plan's code 132 maps back onto T128R2 here.
+    // level; over the step's 41 convolutions 8.3 vs 6.6 ms per micro-batch forced, 6.9 vs 6.6 dispatched.  Removed again: the plan is asked without the register-staged rule
+    // (allow_vs = false; round 6, ADVICE r5: mapping its code 132 onto T128R2 afterwards had silently replaced the 128 / 129 ring choice for every big-tile convolution).
     if (tile == 132) tile = 129;
     switch (tile) {
     case 257: return launch_pipe<T256S, CONV>(p, a_mc, b_mc, batch, s);

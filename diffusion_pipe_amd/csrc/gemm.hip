@@ -342,6 +342,25 @@ int dpipe_gemm_group(const dpipe_gemm_desc* descs, int n, void* splitk_ws, long 
     return DPIPE_OK;
 }
 
+int dpipe_gemm_group_plan(const dpipe_gemm_desc* descs, int n, long splitk_ws_bytes, int* tiles_out, int* splitk_out, int* launches_out) {
+    if (!descs || !tiles_out || n <= 0 || n > 16) { set_last_error("dpipe_gemm_group_plan: 1 <= n <= 16 descriptors and a tiles_out array"); return DPIPE_ERR_ARG; }
+    GemmParams ps[16];
+    int ta[16], tb[16];
+    for (int i = 0; i < n; ++i) {
+        const dpipe_gemm_desc& d = descs[i];
+        GemmParams p;
+        p.A = d.A; p.B = d.B; p.C = d.C; p.bias = d.bias; p.M = d.M; p.N = d.N; p.K = d.K; p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc;
+        p.sAo = p.sAi = p.sBo = p.sBi = p.sCo = p.sCi = 0;
+        p.batch_inner = 1; p.alpha = d.alpha; p.act = d.act; p.accumulate = d.accumulate; p.out_f32 = d.out_f32;
+        p.splitk = 1; p.ksteps = 0; p.ksteps_per_split = 0; p.slabs = nullptr; p.counters = nullptr;
+        p.residual = d.residual; p.ldr = d.ldr; p.colsum = d.colsum; p.colsum_acc = d.colsum_accumulate; p.bias_rows = 0; p.bias_lo = 0;
+        if (d.dtype != DPIPE_BF16 || !gemm_pipe_eligible(p, d.transA, d.transB)) { set_last_error("dpipe_gemm_group_plan: a problem is not eligible for the pipelined kernel"); return DPIPE_ERR_UNSUPPORTED; }
+        ps[i] = p; ta[i] = d.transA; tb[i] = d.transB;
+    }
+    // planning only does pointer arithmetic on the workspace: any non-null base of the caller's size gives the caller's plan
+    return gemm_pipe_group(ps, ta, tb, n, reinterpret_cast<void*>(0x1000), splitk_ws_bytes, nullptr, launches_out, tiles_out, splitk_out);
+}
+
 int dpipe_gemm(int dtype, int transA, int transB, int M, int N, int K,
                const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                int batch_outer, int batch_inner,

@@ -63,9 +63,11 @@ bool gemm_pipe_try(GemmParams& p, int transA, int transB, int batch, void* ws, l
                    hipStream_t s, int* rc_out);
 // Tile / split-K choice shared by the GEMM and the convolution front ends: fills p.tiles_*, p.ksteps*, p.splitk, p.counters, p.slabs,
 // p.vecA / p.vecB (epilogue vector flags) and returns the tile code (64, 128, 129 = 128^2 2-deep ring, 256 = 256 x 128, 257 = 256^2, 63).
-int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, long ws_bytes, int force_splitk, int force_tile, int counter_base = 0, long slab_base = 0);
+// `allow_vs` = false: never the register-staged tile (132) -- the convolution front end, whose gathered-row instances of it lost their measurement (conv_pipe.hip), keeps its own 128 / 129 ring choice
+int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, long ws_bytes, int force_splitk, int force_tile, int counter_base = 0, long slab_base = 0, bool allow_vs = true);
 // n independent plain bf16 GEMMs (batch 1, all eligible for the pipelined kernel: the caller checked gemm_pipe_eligible) as few launches as possible; *launches_out = launches issued
-int gemm_pipe_group(GemmParams* ps, const int* transA, const int* transB, int n, void* ws, long ws_bytes, hipStream_t s, int* launches_out);
+// tiles_out != NULL: plan only (no launch): the tile code and split factor the launch would use, per problem (dpipe_gemm_group_plan)
+int gemm_pipe_group(GemmParams* ps, const int* transA, const int* transB, int n, void* ws, long ws_bytes, hipStream_t s, int* launches_out, int* tiles_out = nullptr, int* splitk_out = nullptr);
 bool gemm_pipe_eligible(const GemmParams& p, int transA, int transB);
 
 }  // namespace dpipe

@@ -47,14 +47,17 @@ bool gemm_pipe_try(GemmParams& p, int transA, int transB, int batch, void* ws, l
 // bit-identical results), on a private share of the split-K workspace; problems that land on the same groupable tile geometry (64^2 4-deep, 128^2 2-deep,
 // 128^2 3-deep) leave as ONE launch of up to GROUP_MAX problems, the workgroups of the problem with the longest K walk first; a dgrad / wgrad pair whose
 // geometries differ is re-planned onto the 64^2 tile when that keeps it one launch (`pair_unify`).  Everything else goes out as single launches.
-int gemm_pipe_group(GemmParams* ps, const int* transA, const int* transB, int n, void* ws, long ws_bytes, hipStream_t s, int* launches_out) {
+int gemm_pipe_group(GemmParams* ps, const int* transA, const int* transB, int n, void* ws, long ws_bytes, hipStream_t s, int* launches_out, int* tiles_out, int* splitk_out) {
+    const bool dry = tiles_out != nullptr;                 // dpipe_gemm_group_plan: plan only, report the tile code / split factor of every problem, launch nothing
     struct Plan { int tile; bool a_mc, b_mc; long tiles; int counter_base; long slab_base; };
     Plan pl[16];
     if (n > 16) { set_last_error("dpipe_gemm_group: at most 16 problems"); return DPIPE_ERR_ARG; }
     auto slab_bytes_of = [](int tile) { const long bm = (tile == 128 || tile == 129 || tile == 132) ? 128 : 64; return (bm * bm + bm) * 4L; };
-    auto plan_all = [&](int force) {
+    int force_of[16] = {};
+    auto plan_all = [&]() {
         int cbase = 0; long sbase = 0;
         for (int i = 0; i < n; ++i) {
+            const int force = force_of[i];
             GemmParams& p = ps[i];
             p.splitk = 1; p.ksteps = 0; p.ksteps_per_split = 0; p.slabs = nullptr; p.counters = nullptr;
             pl[i].a_mc = transA[i] != 0; pl[i].b_mc = transB[i] == 0;
@@ -68,11 +71,19 @@ int gemm_pipe_group(GemmParams* ps, const int* transA, const int* transB, int n,
             }
         }
     };
-    plan_all(0);
+    plan_all();
     auto groupable = [](int tile) { return tile == 64 || tile == 129 || tile == 128 || tile == 132; };
     auto geom = [](int tile) { return tile == 132 ? 129 : tile; };        // the register-staged tile shares T128R2's geometry and LDS: one grouped launch carries both
     static const bool pair_unify = [] { const char* e = getenv("DPIPE_GEMM_GROUP_UNIFY"); return !e || atoi(e) != 0; }();
-    if (pair_unify && n == 2 && geom(pl[0].tile) != geom(pl[1].tile) && groupable(pl[0].tile) && groupable(pl[1].tile)) plan_all(64);
+    if (pair_unify && n == 2 && geom(pl[0].tile) != geom(pl[1].tile) && groupable(pl[0].tile) && groupable(pl[1].tile)) {
+        // (round 6) a register-staged member (132: T128R2's geometry) next to a partner on the 3-deep 128^2 ring (128: single-lane engines, 128 .. 255 tiles)
+        // is re-planned onto its partner's ring -- both keep 128^2 tiles and leave as one T128 launch, as before the register-staged rule existed; only a pair that
+        // mixes a 64^2 member with a 128^2 one is unified onto 64^2 tiles
+        const int vs = pl[0].tile == 132 ? 0 : pl[1].tile == 132 ? 1 : -1;
+        if (vs >= 0 && pl[1 - vs].tile == 128) force_of[vs] = 128;
+        else force_of[0] = force_of[1] = 64;
+        plan_all();
+    }
     bool done[16] = {};
     int launches = 0, rc = DPIPE_OK;
     for (int i = 0; i < n && rc == DPIPE_OK; ++i) {
@@ -84,6 +95,7 @@ int gemm_pipe_group(GemmParams* ps, const int* transA, const int* transB, int n,
                 if (!done[j] && geom(pl[j].tile) == geom(pl[i].tile)) members[m++] = j;
         for (int k = 0; k < m; ++k) done[members[k]] = true;
         ++launches;
+        if (dry) continue;
         if (m == 1) { rc = launch_by_tile(pl[i].tile, ps[i], pl[i].a_mc, pl[i].b_mc, 1, s); continue; }
         // longest K walk first: its workgroups start in the first round, the short ones fill the tail
         for (int a = 1; a < m; ++a)
@@ -106,10 +118,11 @@ int gemm_pipe_group(GemmParams* ps, const int* transA, const int* transB, int n,
         }
     }
     if (launches_out) *launches_out = launches;
+    if (dry) for (int i = 0; i < n; ++i) { tiles_out[i] = pl[i].tile; if (splitk_out) splitk_out[i] = ps[i].splitk; }
     return rc;
 }
 
-int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, long ws_bytes, int force_splitk, int force_tile, int counter_base, long slab_base) {
+int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, long ws_bytes, int force_splitk, int force_tile, int counter_base, long slab_base, bool allow_vs) {
     p.ksteps = (p.K + BK - 1) / BK;
     const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
     const long tiles64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64) * batch;
@@ -193,7 +206,7 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
     // the two DMA rings on every such descriptor of the SDXL step (gemm_pipe_kernel.h has the table), split tiles included ([1024, 1280] <- 10240 NN in three slices 42.6 vs
     // 49.7 us, <- 3840 23.4 vs 25.2: profiles/r5c_gemm_desc_ledger_register_staged_and_gr.jsonl); the wgrad layouts stay on the DMA rings.  DPIPE_GEMM_VS=0: rule off (A/B).
     static const bool vs_rule = [] { const char* e = getenv("DPIPE_GEMM_VS"); return !e || atoi(e) != 0; }();
-    if (vs_rule && force_tile == 0 && big && !a_mc && p.ksteps_per_split >= 8 && batch == 1) return 132;
+    if (vs_rule && allow_vs && force_tile == 0 && big && !a_mc && p.ksteps_per_split >= 8 && batch == 1) return 132;
     if (force_tile == 129 || (force_tile == 0 && big && tiles128 >= 256 && (a_mc || b_mc || tiles128 >= 1024))) return 129;
     // DPIPE_OPT_GEMM_SHALLOW: the 128^2 tile on its 2-deep 64 KiB ring everywhere -- slower launches in isolation (step list: 23.5 vs 22.0 us average), but a 64 KiB
     // footprint lets a workgroup of ANOTHER micro-batch lane share the CU: 19.34 vs 18.93 images/s with 3 lanes (profiles/r3e_bench_variants.jsonl).  The engine sets

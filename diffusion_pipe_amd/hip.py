@@ -96,6 +96,7 @@ _SIGNATURES = {
     'dpipe_gemm': (I, [I, I, I, I, I, I, P, L, P, L, P, L, I, I, L, L, L, L, L, L, P, I, F, I, I, I, P]),
     'dpipe_gemm_ex': (I, [I, I, I, I, I, I, P, L, P, L, P, L, I, I, L, L, L, L, L, L, P, I, F, I, I, I, P, L, P, L, P, I, P]),
     'dpipe_gemm_group': (I, [POINTER(GemmDesc), I, P, L, POINTER(c_int), P]),
+    'dpipe_gemm_group_plan': (I, [P, I, L, P, P, P]),
     'dpipe_tr16_probe': (I, [P, P, P]),
     'dpipe_attn_fwd': (I, [P, P, P, P, P, P, I, I, I, I, I] + [L] * 12 + [F, I, P, P]),
     'dpipe_attn_bwd_partial_floats': (L, [I, I, I, I, I]),

@@ -212,7 +212,8 @@ class ResnetBlock2D(nn.Module):
         h, x = self.norm1(x, act='silu', with_skip=True)          # GroupNorm + SiLU in one pass; the skip branch's gradient is folded into its backward
         if x.shape[0] == 1:        # batch 1: the time-embedding addend is one value per channel -> it joins conv1's bias vector in the epilogue
             h = self.conv1(h, extra_bias=t.reshape(-1).to(x.dtype))
-        elif x.dtype == torch.bfloat16 and x.is_cuda and t.shape[1] % 4 == 0:
+        elif (x.dtype == torch.bfloat16 and x.is_cuda and t.shape[1] % 4 == 0
+              and ops.conv2d_eligible(x.dtype, self.conv1.weight, self.conv1.stride, self.conv1.padding, self.conv1.dilation, self.conv1.groups)):
             h = self.conv1(h, extra_bias=t.to(x.dtype))           # batch > 1 (stacked micro-batches): one addend row per sample in conv1's epilogue (round 5)
         else:
             h = ops.add_sample_channel_bias(self.conv1(h), t)      # (its dt is summed per sample by this repo's column_sum, not by ATen's broadcast reduction)

@@ -323,6 +323,11 @@ typedef struct dpipe_gemm_desc {
     void* colsum; int colsum_accumulate;
 } dpipe_gemm_desc;
 int dpipe_gemm_group(const dpipe_gemm_desc* descs, int n, void* splitk_ws, long splitk_ws_bytes, int* launches_out, void* stream);
+/* (ABI 8) The plan of such a call WITHOUT launching anything (host code only: no device, no dereference of the operand pointers -- they are looked at for alignment):
+ * tiles_out[i] = the tile code problem i would run on (64 = 64^2 4-deep LDS-DMA ring, 128 = 128^2 3-deep, 129 = 128^2 2-deep, 132 = 128^2 register-staged, 257 / 258 =
+ * 256^2), splitk_out[i] (optional) its K-slice count, *launches_out the kernel launches the call would issue -- under the process's current dpipe_set_option values.
+ * What the dispatcher tests hold the tile policy with (tests/test_gemm_plan_cpu.py); n = 1 is the plan of a plain dpipe_gemm_ex call. */
+int dpipe_gemm_group_plan(const dpipe_gemm_desc* descs, int n, long splitk_ws_bytes, int* tiles_out, int* splitk_out, int* launches_out);
 /* Test probe: runs ds_read_b64_tr_b16 over a 256-element i16 LDS image so the GPU tests can pin the lane mapping
  * the transposed-operand paths rely on. */
 int dpipe_tr16_probe(const void* in256_i16, void* out256_i16, void* stream);

@@ -12,11 +12,40 @@ import torch
 from . import eager_step, sdxl_ref
 
 
+class _ConvAsMatmul:
+    """Inside this context nn.Conv2d evaluates as unfold + matmul (+ bias add on the rounded output, which is also what PyTorch-ROCm's MIOpen path does: convolution, then
+    `output.add_(bias)`).  Same arithmetic class as the library convolution under autocast -- bf16 products, fp32 accumulation, one rounding of the result -- without
+    MIOpen, which compiles its kernels at first use on a fresh box (round 6, first run of this leg: 215 s for 16 samples, almost all of it MIOpen's run-time compiles)."""
+
+    def __enter__(self):
+        import torch.nn as nn
+        import torch.nn.functional as F
+        self._orig = nn.Conv2d._conv_forward
+
+        def conv_forward(mod, x, weight, bias):
+            if mod.groups != 1 or tuple(mod.dilation) != (1, 1) or isinstance(mod.padding, str) or mod.padding_mode != 'zeros':
+                return self._orig(mod, x, weight, bias)
+            B, _, H, W = x.shape
+            kh, kw = weight.shape[2:]
+            Ho = (H + 2 * mod.padding[0] - kh) // mod.stride[0] + 1
+            Wo = (W + 2 * mod.padding[1] - kw) // mod.stride[1] + 1
+            cols = F.unfold(x, (kh, kw), padding=mod.padding, stride=mod.stride)            # [B, Cin kh kw, Ho Wo]
+            y = torch.matmul(weight.flatten(1), cols.to(weight.dtype) if cols.dtype != weight.dtype and not torch.is_autocast_enabled() else cols)
+            y = y.view(B, weight.shape[0], Ho, Wo)
+            return y if bias is None else y + bias.to(y.dtype)[None, :, None, None]
+        nn.Conv2d._conv_forward = conv_forward
+        return self
+
+    def __exit__(self, *exc):
+        import torch.nn as nn
+        nn.Conv2d._conv_forward = self._orig
+        return False
+
+
 def sdxl_reference_bf16(cfg, state, micro_batches, device, dtype=torch.bfloat16):
     """-> (losses, pre-clip global gradient norms) of `micro_batches` = [(features, label), ...] (host tensors) evaluated ONE at a time on `state` =
     {module name: state dict} (the product's weights).  Eager, sequential `to_layers()`, one backward per micro-batch (GAS = 1: the parity leg's steps hold one sample)."""
-    torch.backends.cudnn.benchmark = False                     # MIOpen immediate mode: no per-shape find pass on a fresh box
-    with torch.device(device):                                  # the restatement builds its index / mask helpers with bare factory calls
+    with torch.device(device), _ConvAsMatmul():                # (torch.device: the restatement builds its index / mask helpers with bare factory calls)
         ref = sdxl_ref.SDXLRef(cfg, seed=0)
         for k, m in ref.modules().items():
             m.to(dtype)
@@ -69,11 +98,10 @@ def sdxl_rounding_groups(cfg, state, micro_batches, device, groups=('none', 'all
     """Diagnostic (DPIPE_BENCH_PARITY_GROUPS=1): the oracle model in FP32 on the GPU with forward hooks that round the outputs of one module group to bf16
     (straight-through gradient), on the bench's own weights and parity samples -> {group: [gradient norm per sample]}.  Says which roundings of a bf16 forward the
     global gradient norm of this network reacts to."""
-    torch.backends.cudnn.benchmark = False
     prev_tf32 = torch.backends.cuda.matmul.allow_tf32
     torch.backends.cuda.matmul.allow_tf32 = False
     active = {'g': 'none'}
-    with torch.device(device):
+    with torch.device(device), _ConvAsMatmul():
         ref = sdxl_ref.SDXLRef(cfg, seed=0)
         for k, m in ref.modules().items():
             m.load_state_dict({n: v.to(device=device, dtype=torch.float32) for n, v in state[k].items()})
