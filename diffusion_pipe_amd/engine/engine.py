@@ -400,7 +400,6 @@ class PipelineEngine:
     def get_global_grad_norm(self):
         return self._last_grad_norm
 
-    @property
     def link_report(self):
         """what this rank's stage link is and how `p2p_backend: 'auto'` was decided (RcclLink.negotiate: the phase a fallback was agreed at and this rank's own error,
         if any) -- gathered per rank into the bench line so a multi-GPU run is diagnosable from its JSON alone"""
@@ -428,6 +427,7 @@ class PipelineEngine:
         torch.cuda.synchronize(self.device)
         return e0.elapsed_time(e1) / reps
 
+    @property
     def stream_probe(self):
         """Outcome of the hardware-queue probe for this engine's lane / stage streams (engine.concurrent_streams `report`); {} before the probe ran."""
         return dict(self._probe_report)

@@ -184,6 +184,9 @@ class CLIPTextModel(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------------- UNet
+_DEBUG_ATEN_TEMB_ADD = os.environ.get('DPIPE_DEBUG_ATEN_TEMB_ADD', '0') == '1'      # repro switch for the round-5 graph-replay corruption (never set by the product)
+
+
 class ResnetBlock2D(nn.Module):
     def __init__(self, in_ch, out_ch, temb_ch, groups=32, eps=1e-5):
         super().__init__()
@@ -212,9 +215,11 @@ class ResnetBlock2D(nn.Module):
         h, x = self.norm1(x, act='silu', with_skip=True)          # GroupNorm + SiLU in one pass; the skip branch's gradient is folded into its backward
         if x.shape[0] == 1:        # batch 1: the time-embedding addend is one value per channel -> it joins conv1's bias vector in the epilogue
             h = self.conv1(h, extra_bias=t.reshape(-1).to(x.dtype))
-        elif (x.dtype == torch.bfloat16 and x.is_cuda and t.shape[1] % 4 == 0
+        elif (not _DEBUG_ATEN_TEMB_ADD and x.dtype == torch.bfloat16 and x.is_cuda and t.shape[1] % 4 == 0
               and ops.conv2d_eligible(x.dtype, self.conv1.weight, self.conv1.stride, self.conv1.padding, self.conv1.dilation, self.conv1.groups)):
             h = self.conv1(h, extra_bias=t.to(x.dtype))           # batch > 1 (stacked micro-batches): one addend row per sample in conv1's epilogue (round 5)
+        elif _DEBUG_ATEN_TEMB_ADD:
+            h = self.conv1(h) + t[:, :, None, None]                # DEBUG ONLY (tools/stack_debug_graph.py, tools/oob_guard_probe.py): the round-5 form whose ATen reduction went bad under replay
         else:
             h = ops.add_sample_channel_bias(self.conv1(h), t)      # (its dt is summed per sample by this repo's column_sum, not by ATen's broadcast reduction)
         if self.conv_shortcut is not None:
