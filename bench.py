@@ -27,19 +27,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# Parity bounds asserted after the line is printed (exit code 4 when missed):
+# Parity bounds asserted after the line is printed (exit code 4 when missed).  Round 6: tightened to what 16-sample statistics measured on two weight states and two
+# boxes (profiles/r6b_*, r6d_*), with the REFERENCE'S OWN bf16 arithmetic evaluated beside it (`parity.reference_bf16`: the oracle model under torch.autocast with bf16 weights
+# and gradients -- what models/sdxl.py:387,636,675-988 executes):
 #  * the HIP kernels in their exact-fp32 mode, same weights and micro-batch, vs the oracle's fp32 eager path: loss and pre-clip gradient norm within north_star's 1e-3
-#    (observed 1e-5 / 1e-4: tests/test_gpu_fullsize.py, `parity.fp32_kernels`);
-#  * the TIMED bf16 path: loss within 1e-3 (observed 1e-5 .. 5e-5); gradient norm within 5e-3.  The gradient norm of THIS random-initialised network reacts almost one
-#    to one to the MEAN of the residual out - target (tools/scale_probe.py: a constant shift of the target by 1e-3 of the residual's rms moves the norm by the amounts
-#    recorded in profiles/r4i_*), and the bf16 forward's rounding noise has a DC component of that order: across six weight states of one sample the timed path's
-#    norm landed between -3.1e-3 and +1.9e-3 of the oracle's, every parameter family moving together, while per-parameter shapes agree to <= 0.6 %
-#    (profiles/r4h_parity_scenarios.txt).  That spread is a property of bf16 activations on this configuration, not of a kernel: no single-sample
-#    bf16 evaluation can be held to 1e-3 on it, the reference's own bf16 path included.
+#    (observed 0 / 3e-5, also on the sample where the bf16 path strays furthest);
+#  * the TIMED bf16 path over 16 distinct micro-batches: loss within 1e-3 (observed <= 8e-5); gradient norm |mean| and median within 5e-4 (observed |mean| 8e-5 .. 1.4e-4,
+#    median 1.9e-4), worst single sample within 4e-3 (observed 1.5e-3 / 1.8e-3 with the fp32 per-channel addends of round 6, 3.1e-3 without them on the same weights; the
+#    yardstick's own worst on those samples: 3.0e-3 with matmul convolutions, 5.7e-3 through MIOpen, where its MEAN sits at -3.7e-3).  One bf16 evaluation of this
+#    random-initialised network cannot be held to 1e-3 on every sample -- the gradient norm follows the mean of the residual almost one to one and
+#    the reference's own bf16 step is no closer; the statistic is.
 PARITY_BOUND = 1e-3
-PARITY_BOUND_BF16_NORM = 1e-2           # worst single sample of the parity leg (round 5, 8 distinct micro-batches: seven within 5.2e-4, one at -5.1e-3 -- a sample whose fp32-kernel
-                                        # evaluation agrees with the oracle to 1e-4, `parity.fp32_kernels.worst_bf16_sample`: bf16 activation rounding, not a kernel)
-PARITY_BOUND_BF16_NORM_MEAN = 1e-3      # |mean| and median of the |signed gradient-norm error| over the parity samples: north_star's 1e-3 holds for the typical sample and on average
+PARITY_BOUND_BF16_NORM = 4e-3           # worst single sample of the parity leg (round 5: 1e-2)
+PARITY_BOUND_BF16_NORM_MEAN = 5e-4      # |mean| and median of the signed gradient-norm error over the parity samples (round 5: 1e-3)
 
 
 def _argv_int(flag, default):
@@ -105,6 +105,7 @@ def parse():
     ap.add_argument('--no-synced-loop', action='store_true', help='skip the second timed region (a host read of the loss after every step: `value_synced_loop`)')
     ap.add_argument('--parity-workers', type=int, default=int(os.environ.get('DPIPE_BENCH_PARITY_WORKERS', '-1')),
                     help='child processes evaluating the oracle\'s extra parity samples (-1: 5 / 3 when the host has >= 192 / 96 hardware threads and >= 320 / 192 GB available, else one background thread)')
+    ap.add_argument('--fp32-leg', action='store_true', help='run the exact-fp32 kernel leg of `parity` even under --light (the stacked child run of the default line)')
     ap.add_argument('--no-reference-bf16', action='store_true', help='skip `parity.reference_bf16` (the oracle model under bf16 autocast on the GPU: what the reference itself evaluates)')
     ap.add_argument('--parity-samples', type=int, default=int(os.environ.get('DPIPE_BENCH_PARITY_SAMPLES', '16')),
                     help='distinct micro-batches of the parity leg (timed path vs the oracle on the final weights; each costs ~20 s of host time, bounded by --parity-budget)')
@@ -673,7 +674,7 @@ def main():
                 try:
                     from oracle.gpu_reference_bf16 import sdxl_reference_bf16
                     t_r = time.perf_counter()
-                    ref16 = sdxl_reference_bf16(cfg, state, cpu_samples, device) + (round(time.perf_counter() - t_r, 1),)
+                    ref16 = sdxl_reference_bf16(cfg, state, cpu_samples, device, library_conv=os.environ.get('DPIPE_BENCH_YARDSTICK_MIOPEN', '0') == '1') + (round(time.perf_counter() - t_r, 1),)
                 except Exception as e:                              # noqa: BLE001 -- reported in the line
                     ref16 = repr(e)[:300]
             groups16 = None
@@ -705,7 +706,7 @@ def main():
             eval32 = None
             gc_ = __import__('gc')
             try:
-                if args.light:
+                if args.light and not args.fp32_leg:
                     raise RuntimeError('skipped (--light)')
                 del engine, module
                 ops.release_caches()                  # the fused step end's pointer tables keep parameters / states / lane gradients alive
@@ -761,7 +762,7 @@ def main():
                         'grad_norm_rel_signed': [round(e, 6) for e in r_n], 'grad_norm_rel_mean': r_mean,
                         'grad_norm_rel_sigma': (sum((e - r_mean) ** 2 for e in r_n) / max(len(r_n) - 1, 1)) ** 0.5,
                         'grad_norm_rel_median': sorted(abs(e) for e in r_n)[len(r_n) // 2], 'grad_norm_rel_max': max(abs(e) for e in r_n), 'loss_rel_max': max(r_l),
-                        'seconds': ref16[2],
+                        'seconds': ref16[2], 'convolutions': 'MIOpen' if os.environ.get('DPIPE_BENCH_YARDSTICK_MIOPEN', '0') == '1' else 'unfold + matmul (bf16 products, fp32 accumulation)',
                         'what': 'the yardstick: the oracle model with bf16 weights under torch.autocast(bfloat16) on this GPU (ATen kernels; loss in fp32, gradients in bf16 = '
                                 'what the reference\'s step evaluates, models/sdxl.py:387,636,675-988) vs the oracle fp32 eager path, same weights, same micro-batches'}
                 elif ref16 is not None:
@@ -803,8 +804,9 @@ def main():
             import subprocess
             t_wl = time.perf_counter()
             try:
-                cmd = [sys.executable, os.path.abspath(__file__), '--stack', '4', '--lanes', '2', '--steps', '10', '--warmup', '3', '--light', '--parity-samples', '2',
-                       '--parity-budget', '30', '--no-synced-loop']
+                # (round 6: the stacked line carries the same kind of parity object as the headline -- 8 samples, the yardstick, the fp32-kernel leg)
+                cmd = [sys.executable, os.path.abspath(__file__), '--stack', '4', '--lanes', '2', '--steps', '10', '--warmup', '3', '--light', '--fp32-leg', '--parity-samples', '8',
+                       '--parity-budget', '120', '--parity-workers', '3' if workers else '0', '--no-synced-loop']
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
                 line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
                 if line:
@@ -856,7 +858,7 @@ def main():
                 bad += [f'timed bf16 path {k} over {par["samples"]} samples = {abs(par[k]):.3e} > {PARITY_BOUND_BF16_NORM_MEAN:g}'
                         for k in ('grad_norm_rel_mean', 'grad_norm_rel_median') if not abs(par[k]) <= PARITY_BOUND_BF16_NORM_MEAN]
             f32 = par.get('fp32_kernels') or {}
-            if args.light:
+            if args.light and not args.fp32_leg:
                 pass
             elif 'error' in f32 or not f32:
                 bad.append(f'fp32-kernel leg did not run: {f32.get("error")}')

@@ -42,10 +42,12 @@ class _ConvAsMatmul:
         return False
 
 
-def sdxl_reference_bf16(cfg, state, micro_batches, device, dtype=torch.bfloat16):
+def sdxl_reference_bf16(cfg, state, micro_batches, device, dtype=torch.bfloat16, library_conv=False):
     """-> (losses, pre-clip global gradient norms) of `micro_batches` = [(features, label), ...] (host tensors) evaluated ONE at a time on `state` =
     {module name: state dict} (the product's weights).  Eager, sequential `to_layers()`, one backward per micro-batch (GAS = 1: the parity leg's steps hold one sample)."""
-    with torch.device(device), _ConvAsMatmul():                # (torch.device: the restatement builds its index / mask helpers with bare factory calls)
+    import contextlib
+    # `library_conv`: the convolutions through MIOpen as a PyTorch-ROCm user of the reference would run them (slow on a fresh box: run-time kernel compiles)
+    with torch.device(device), (contextlib.nullcontext() if library_conv else _ConvAsMatmul()):                # (torch.device: the restatement builds its index / mask helpers with bare factory calls)
         ref = sdxl_ref.SDXLRef(cfg, seed=0)
         for k, m in ref.modules().items():
             m.to(dtype)

@@ -343,3 +343,30 @@ def test_stacked_micro_batches_at_full_size_stay_finite_under_graph_replay(gpu):
         norm = engine.get_global_grad_norm().item()
         assert losses[-1] == losses[-1] and abs(losses[-1]) < 1e3 and norm == norm and norm < 1e6, (step, losses, norm)
     assert all(bool(torch.isfinite(p).all()) for p in module.parameters())
+
+
+def test_round5_graph_replay_corruption_is_rocm_packet_capture_not_this_repo(gpu, record_property):
+    """Round 6 root cause of the round-5 stacked-step NaN.  The old arithmetic -- `conv1(h) + temb[:, :, None, None]`, whose backward is an ATen
+    reduction with a hipMemsetAsync'ed semaphore buffer -- is kept behind a debug switch (DPIPE_DEBUG_ATEN_TEMB_ADD=1, never set by the product) and replayed as ONE
+    single-lane hipGraph at full size by tools/stack_debug_graph.py:
+      * with ROCm's graph packet capture DISABLED (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0) every gradient is finite -- asserted: the kernels, pools and capture logic of this
+        repo are sound (the guard-band / poison probe, tools/oob_guard_probe.py, finds no out-of-bounds write and no uninitialised read either);
+      * with packet capture ENABLED (the ROCm 7.2 default) the first replay returns garbage from that ATen reduction (profiles/r6_graph_replay_corruption_packet_capture_ab.txt:
+        531 of 2 375 parameters non-finite) -- recorded, not asserted: it is ROCm's behaviour and may change.  The product path holds no such node any more."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outcomes = {}
+    for capture in ('0', '1'):
+        env = dict(os.environ, DPIPE_PRECISE_ADDENDS='0', DPIPE_DEBUG_ATEN_TEMB_ADD='1', DEBUG_CLR_GRAPH_PACKET_CAPTURE=capture)
+        r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'stack_debug_graph.py'), '4', '1'], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        bad = [int(m) for m in re.findall(r'step \d+: loss \S+, (\d+) / \d+ parameters with non-finite gradients', r.stdout)]
+        assert len(bad) == 2, r.stdout[-2000:]
+        outcomes[capture] = bad
+        record_property(f'non_finite_parameters_per_step_packet_capture_{capture}', bad)
+    print('non-finite parameters per step, packet capture off / on:', outcomes)
+    assert outcomes['0'] == [0, 0], outcomes
+    assert outcomes['1'][0] == 0, outcomes              # the eager / capture step is clean either way

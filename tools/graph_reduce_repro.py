@@ -145,6 +145,27 @@ def main():
                     s1.replay(); s2.replay(); sink.append(a.clone())
         torch.cuda.synchronize()
         check('lanes_shared.a', shape, ra, want.float() * 2, report); check('lanes_shared.b', shape, rb, wantb.float() * 2, report)
+    # long: ONE capture holding a chain of 60 (matmul -> channels-last view -> pixel sum) links with their temporaries freed and reused inside the capture --
+    # the shape of a lane graph (hundreds of kernels, the reduction's staging buffer / semaphores allocated from the capture's private pool between other buffers)
+    B, C, HW = 4, 640, 64
+    w = (torch.randn(C, C, device=dev) / C ** 0.5).to(torch.bfloat16)
+    x0 = make(B, C, HW, 7)
+
+    def chain():
+        acc = torch.zeros(B, C, device=dev, dtype=torch.float32)
+        x = x0
+        for i in range(60):
+            y = torch.matmul(x.permute(0, 2, 3, 1).reshape(-1, C), w).view(B, HW, HW, C).permute(0, 3, 1, 2)          # channels-last [B, C, H, W]
+            acc = acc + y.sum(dim=(2, 3)).float() * (1.0 / (HW * HW))
+            x = (y * 0.5 + x0 * 0.5)
+        return acc
+    want_c = chain().clone()
+    torch.cuda.synchronize()
+    g, out = capture(chain)
+    res = []
+    for _ in range(40):
+        g.replay(); res.append(out.clone())
+    torch.cuda.synchronize(); check('long_chain', (B, C, HW, HW), res, want_c, report)
     bad = [r for r in report if r['mismatching_replays'] or r['non_finite_replays']]
     print(f'{len(bad)} of {len(report)} scenario / shape pairs misbehaved', flush=True)
     if len(sys.argv) > 1:

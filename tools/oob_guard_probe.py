@@ -113,7 +113,8 @@ def main():
     params = [p for m in work.modules().values() for p in m.parameters()]
     names = {id(p): f'{k}.{n}' for k, m in work.modules().items() for n, p in m.named_parameters()}
     torch.manual_seed(1234)
-    feats, label = work.prepare_inputs(sdxl.synthetic_batch(cfg, batch_size=stack, latent_hw=128, seed=100))
+    from diffusion_pipe_amd.data import split_batch
+    feats, label = split_batch(work.prepare_inputs(sdxl.synthetic_batch(cfg, batch_size=stack, latent_hw=128, seed=100)), 1)[0]      # (None mask -> empty tensor, as the engine receives it)
     report = {'stack': stack, 'precise_addends': ops.PRECISE_ADDENDS, 'aten_temb_add': sdxl._DEBUG_ATEN_TEMB_ADD, 'runs': []}
     torch.empty, torch.empty_like, torch.Tensor.new_empty = guarded_empty, guarded_empty_like, guarded_new_empty
     try:
