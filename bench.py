@@ -798,29 +798,8 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             others = {}
-            # (1) the same SDXL step with 4 micro-batches STACKED per pass on 2 lanes (engine `stack_micro_batches`): the reference's own lever for
-            # bigger GEMMs is micro_batch_size_per_gpu (train.py:396-400) -- same samples, same loss terms, every GEMM with 4 x the M.  NOT the headline (BASELINE's metric is
-            # quoted at bs = 1 per stage): a second, labelled line with its own parity object, measured by a child run of this file on the freed GPU.
             import subprocess
-            t_wl = time.perf_counter()
-            try:
-                # (round 6: the stacked line carries the same kind of parity object as the headline -- 8 samples, the yardstick, the fp32-kernel leg)
-                cmd = [sys.executable, os.path.abspath(__file__), '--stack', '4', '--lanes', '2', '--steps', '10', '--warmup', '3', '--light', '--fp32-leg', '--parity-samples', '8',
-                       '--parity-budget', '120', '--parity-workers', '3' if workers else '0', '--no-synced-loop']
-                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-                line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
-                if line:
-                    d = json.loads(line[-1])
-                    others['sdxl_stacked'] = {k: d.get(k) for k in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'data', 'loss', 'grad_norm', 'peak_hbm_gb',
-                                                                       'mfu_vs_bf16_mfma_peak', 'parity')}
-                    others['sdxl_stacked']['config'] = d['config']
-                    others['sdxl_stacked']['note'] = 'micro_batch_stacking = 4: NOT the bs = 1 headline; exit code of the child run (4 = parity miss): %d' % r.returncode
-                else:
-                    others['sdxl_stacked'] = {'error': f'child rc {r.returncode}: ' + r.stderr[-300:]}
-            except Exception as e:                          # noqa: BLE001
-                others['sdxl_stacked'] = {'error': repr(e)[:300]}
-            others['sdxl_stacked']['wall_seconds'] = round(time.perf_counter() - t_wl, 1)
-            # (3) BASELINE config 5 (HunyuanVideo 720p x 65 frames, full fine-tune, host-offloaded checkpoints: 10.9 PFLOP per step, ~22 s) as ONE warm-up + ONE timed step in a
+            # (1) BASELINE config 5 (HunyuanVideo 720p x 65 frames, full fine-tune, host-offloaded checkpoints: 10.9 PFLOP per step, ~22 s) as ONE warm-up + ONE timed step in a
             # child process of its own (128 GB of HBM and 25 GB of pinned host memory that must be gone again when it ends, whatever happens inside)
             t_wl = time.perf_counter()
             try:
@@ -833,6 +812,28 @@ def main():
             others['hv']['wall_seconds'] = round(time.perf_counter() - t_wl, 1)
             finish_parity()                                 # the oracle's background samples are (nearly) done by now; frees the fp32 model before the 232 GB Wan step
             parity_done = True
+            # (2) the same SDXL step with 4 micro-batches STACKED per pass on 2 lanes (engine `stack_micro_batches`): the reference's own lever for
+            # bigger GEMMs is micro_batch_size_per_gpu (train.py:396-400) -- same samples, same loss terms, every GEMM with 4 x the M.  NOT the headline (BASELINE's metric is
+            # quoted at bs = 1 per stage): a second, labelled line with its own parity object, measured by a child run of this file on the freed GPU.
+            t_wl = time.perf_counter()
+            try:
+                # (round 6: the stacked line carries the same kind of parity object as the headline -- six samples on the host's worker processes, which this run's own
+                # oracle workers have left by now (joined above), and the yardstick; the exact-fp32 kernel leg evaluates single samples and is not repeated here)
+                cmd = [sys.executable, os.path.abspath(__file__), '--stack', '4', '--lanes', '2', '--steps', '10', '--warmup', '3', '--light', '--parity-samples', '6' if workers else '3',
+                       '--parity-budget', '60', '--parity-workers', '5' if workers else '0', '--no-synced-loop']
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+                if line:
+                    d = json.loads(line[-1])
+                    others['sdxl_stacked'] = {k: d.get(k) for k in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'data', 'loss', 'grad_norm', 'peak_hbm_gb',
+                                                                       'mfu_vs_bf16_mfma_peak', 'parity')}
+                    others['sdxl_stacked']['config'] = d['config']
+                    others['sdxl_stacked']['note'] = 'micro_batch_stacking = 4: NOT the bs = 1 headline; exit code of the child run (4 = parity miss): %d' % r.returncode
+                else:
+                    others['sdxl_stacked'] = {'error': f'child rc {r.returncode}: ' + r.stderr[-300:]}
+            except Exception as e:                          # noqa: BLE001
+                others['sdxl_stacked'] = {'error': repr(e)[:300]}
+            others['sdxl_stacked']['wall_seconds'] = round(time.perf_counter() - t_wl, 1)
             for wl in ('flux', 'wan'):
                 a2 = copy.copy(args)
                 a2.workload, a2.steps, a2.warmup, a2.gas, a2.lanes, a2.full_ft, a2.stack = wl, 4, 2, 0, 0, False, 1
