@@ -103,10 +103,14 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the cpu_baseline / parity leg (and the other_configs leg)')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the bounded sdxl-stacked / flux / wan / hv steps the default run appends as `other_configs`')
     ap.add_argument('--no-synced-loop', action='store_true', help='skip the second timed region (a host read of the loss after every step: `value_synced_loop`)')
-    ap.add_argument('--parity-workers', type=int, default=int(os.environ.get('DPIPE_BENCH_PARITY_WORKERS', '-1')),
-                    help='child processes evaluating the oracle\'s extra parity samples (-1: 5 / 3 when the host has >= 192 / 96 hardware threads and >= 320 / 192 GB available, else one background thread)')
+    ap.add_argument('--parity-workers', type=int, default=int(os.environ.get('DPIPE_BENCH_PARITY_WORKERS', '0')),
+                    help='child processes evaluating the host oracle\'s extra parity samples (0: one background thread -- the default: on the GPU box five workers took 100 s per sample each against 25 s alone, '
+                         'its container schedules ~32 cores whatever os.cpu_count() says; -1: 5 / 3 when the host has >= 192 / 96 hardware threads and >= 320 / 192 GB available)')
     ap.add_argument('--fp32-leg', action='store_true', help='run the exact-fp32 kernel leg of `parity` even under --light (the stacked child run of the default line)')
     ap.add_argument('--no-reference-bf16', action='store_true', help='skip `parity.reference_bf16` (the oracle model under bf16 autocast on the GPU: what the reference itself evaluates)')
+    ap.add_argument('--parity-cpu-samples', type=int, default=int(os.environ.get('DPIPE_BENCH_PARITY_CPU_SAMPLES', '8')),
+                    help='how many of the parity samples the HOST oracle evaluates (25 s each on the GPU box, not parallelisable there); the others are compared with the same '
+                         'oracle code evaluated in fp32 on the GPU, whose agreement with the host evaluation on the common samples is reported')
     ap.add_argument('--parity-samples', type=int, default=int(os.environ.get('DPIPE_BENCH_PARITY_SAMPLES', '16')),
                     help='distinct micro-batches of the parity leg (timed path vs the oracle on the final weights; each costs ~20 s of host time, bounded by --parity-budget)')
     ap.add_argument('--parity-budget', type=float, default=float(os.environ.get('DPIPE_BENCH_PARITY_BUDGET_S', '240')), help='host seconds the oracle may spend on parity samples beyond the first')
@@ -684,6 +688,14 @@ def main():
                     groups16 = sdxl_rounding_groups(cfg, state, cpu_samples, device)
                 except Exception as e:                              # noqa: BLE001
                     groups16 = {'error': repr(e)[:300]}
+            gpu32 = None
+            n_cpu = max(1, min(args.parity_cpu_samples, len(cpu_samples)))
+            try:                                                    # the oracle's fp32 path on the GPU: the reference value of the samples the host does not evaluate + a cross-check on those it does
+                from oracle.gpu_reference_bf16 import sdxl_oracle_fp32_on_gpu
+                gpu32 = sdxl_oracle_fp32_on_gpu(cfg, state, cpu_samples, device)
+            except Exception as e:                                  # noqa: BLE001 -- then the statistic holds the host's samples only
+                gpu32 = repr(e)[:300]
+                n_cpu = len(cpu_samples)
             workers = args.parity_workers
             if workers < 0:
                 try:
@@ -695,7 +707,7 @@ def main():
             # the oracle times its first sample alone (= `cpu_baseline`), then evaluates the other parity samples on a background thread (~25 s of host time each) while this
             # process goes on with the GPU legs below; `finish_parity()` joins it
             out['cpu_baseline'] = cb = sdxl_cpu_baseline(cfg, latent_hw=latent, micro_batch=cpu_sample, state=state, per_parameter=detail,
-                                                         extra_micro_batches=cpu_samples[1:], extra_budget_s=args.parity_budget, extra_async=not detail,
+                                                         extra_micro_batches=cpu_samples[1:n_cpu], extra_budget_s=args.parity_budget, extra_async=not detail,
                                                          extra_workers=0 if detail else workers)
             if detail:
                 from tools.parity_report import family_table
@@ -740,6 +752,14 @@ def main():
                 """join the oracle's background samples, turn the two lists into the `parity` object, then the fp32-kernel evaluation of the worst bf16 sample"""
                 cpu_l, cpu_n = cb.pop('extra_join')() if 'extra_join' in cb else (cb['loss_all'], cb['grad_norm_all'])
                 cb.pop('loss_all', None); cb.pop('grad_norm_all', None)
+                n_host = len(cpu_n)
+                cross = None
+                if isinstance(gpu32, tuple):
+                    # samples the host oracle did not evaluate take the SAME oracle code's fp32 evaluation on the GPU as their reference; on the common samples the two evaluations
+                    # of the oracle are compared with each other (`oracle_gpu_fp32_vs_host`)
+                    cross = {'grad_norm_rel_max': max(abs(g - c) / c for g, c in zip(gpu32[1], cpu_n)), 'loss_rel_max': max(abs(g - c) / abs(c) for g, c in zip(gpu32[0], cpu_l)),
+                             'common_samples': n_host}
+                    cpu_l, cpu_n = list(cpu_l) + list(gpu32[0][n_host:]), list(cpu_n) + list(gpu32[1][n_host:])
                 n_s = len(cpu_n)
                 e_n = [(g - c) / c for g, c in zip(gpu_n, cpu_n)]
                 e_l = [abs(g - c) / abs(c) for g, c in zip(gpu_l, cpu_l)]
@@ -750,10 +770,14 @@ def main():
                                  'samples': n_s, 'grad_norm_rel_signed': [round(e, 6) for e in e_n], 'grad_norm_rel_mean': mean_n, 'grad_norm_rel_sigma': sig_n,
                                  'grad_norm_rel_median': sorted(abs(e) for e in e_n)[n_s // 2], 'grad_norm_rel_max': max(abs(e) for e in e_n), 'loss_rel_max': max(e_l),
                                  'what': 'timed path (bf16 kernels, hipGraph, lanes) vs the oracle fp32 eager path: same weights (the product state dict after the '
-                                         'timed steps), `samples` distinct micro-batches (entry 0 = the fields above); pre-clip global gradient norm, signed relative error',
+                                         'timed steps), `samples` distinct micro-batches (entry 0 = the fields above); pre-clip global gradient norm, signed relative error.  The first '
+                                         '`oracle_evaluated_on.host_cpu_fp32` samples are referenced to the oracle evaluated on the host cores, the others to the same oracle code '
+                                         'evaluated in fp32 on the GPU (`oracle_gpu_fp32_vs_host`: how far those two evaluations of the oracle are apart on the common samples)',
                                  'bounds': {'loss_rel_max': PARITY_BOUND, 'grad_norm_rel_max': PARITY_BOUND_BF16_NORM, 'grad_norm_rel_mean': PARITY_BOUND_BF16_NORM_MEAN,
                                             'grad_norm_rel_median': PARITY_BOUND_BF16_NORM_MEAN},
-                                 'fp32_kernels': f32_leg}
+                                 'fp32_kernels': f32_leg,
+                                 'oracle_evaluated_on': {'host_cpu_fp32': n_host, 'gpu_fp32_same_oracle_code': n_s - n_host},
+                                 'oracle_gpu_fp32_vs_host': cross if cross is not None else ({'error': gpu32} if gpu32 is not None else None)}
                 if isinstance(ref16, tuple):
                     r_n = [(g - c) / c for g, c in zip(ref16[1], cpu_n)]
                     r_l = [abs(g - c) / abs(c) for g, c in zip(ref16[0], cpu_l)]
@@ -817,10 +841,10 @@ def main():
             # quoted at bs = 1 per stage): a second, labelled line with its own parity object, measured by a child run of this file on the freed GPU.
             t_wl = time.perf_counter()
             try:
-                # (round 6: the stacked line carries the same kind of parity object as the headline -- six samples on the host's worker processes, which this run's own
-                # oracle workers have left by now (joined above), and the yardstick; the exact-fp32 kernel leg evaluates single samples and is not repeated here)
-                cmd = [sys.executable, os.path.abspath(__file__), '--stack', '4', '--lanes', '2', '--steps', '10', '--warmup', '3', '--light', '--parity-samples', '6' if workers else '3',
-                       '--parity-budget', '60', '--parity-workers', '5' if workers else '0', '--no-synced-loop']
+                # (round 6: the stacked line carries the same kind of parity object as the headline -- eight samples (two through the host oracle, six through the same oracle in
+                # fp32 on the GPU) and the yardstick; the exact-fp32 kernel leg evaluates single samples and is not repeated here)
+                cmd = [sys.executable, os.path.abspath(__file__), '--stack', '4', '--lanes', '2', '--steps', '10', '--warmup', '3', '--light', '--parity-samples', '8',
+                       '--parity-cpu-samples', '2', '--parity-budget', '40', '--no-synced-loop']
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
                 line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
                 if line:

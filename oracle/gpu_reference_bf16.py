@@ -96,6 +96,36 @@ def _group_of(name, mod):
     return g
 
 
+def sdxl_oracle_fp32_on_gpu(cfg, state, micro_batches, device):
+    """The ORACLE's fp32 eager path (oracle/sdxl_ref.py + eager_step's loss) evaluated on the GPU through ATen in fp32 -- the same code the host evaluates for `cpu_baseline`,
+    on another processor.  -> (losses, pre-clip gradient norms).  bench.py uses it for the parity samples beyond what the host cores can evaluate inside the run (the GPU
+    box's container gives ~32 effective cores: 25 s per sample, no speed-up from parallel workers) and reports its agreement with the host evaluation on the samples both
+    see (observed <= 4.2e-5 on the gradient norm, 16 samples: profiles/r6b_*)."""
+    prev_tf32 = torch.backends.cuda.matmul.allow_tf32
+    torch.backends.cuda.matmul.allow_tf32 = False
+    losses, norms = [], []
+    with torch.device(device), _ConvAsMatmul():
+        ref = sdxl_ref.SDXLRef(cfg, seed=0)
+        for k, m in ref.modules().items():
+            m.load_state_dict({n: v.to(device=device, dtype=torch.float32) for n, v in state[k].items()})
+        layers, loss_fn, params = ref.to_layers(), eager_step.sdxl_loss_fn(), ref.parameters()
+        for feats, label in micro_batches:
+            for p in params:
+                p.grad = None
+            x = tuple(t.to(device) for t in feats)
+            for layer in layers:
+                x = layer(x)
+            loss = loss_fn(x, tuple(t.to(device) for t in label))
+            loss.backward()
+            sq = torch.stack([p.grad.detach().double().norm(2) for p in params if p.grad is not None]).square().sum()
+            losses.append(float(loss.item())); norms.append(float(sq.sqrt().item()))
+            del x, loss
+    torch.backends.cuda.matmul.allow_tf32 = prev_tf32
+    del ref, layers, params
+    torch.cuda.empty_cache()
+    return losses, norms
+
+
 def sdxl_rounding_groups(cfg, state, micro_batches, device, groups=('none', 'all', 'temb', 'all-temb', 'ctx', 'norms', 'convs', 'linears')):
     """Diagnostic (DPIPE_BENCH_PARITY_GROUPS=1): the oracle model in FP32 on the GPU with forward hooks that round the outputs of one module group to bf16
     (straight-through gradient), on the bench's own weights and parity samples -> {group: [gradient norm per sample]}.  Says which roundings of a bf16 forward the

@@ -183,6 +183,7 @@ def main():
     chain = {'flux': flux_chain, 'wan': wan_chain, 'hv': hv_chain}[which](max_blocks)
     rows, what, t0 = [], None, time.perf_counter()
     try:
+        torch.set_default_device(DEV)           # the oracle's helpers build their index / mask tensors with bare factory calls
         item = next(chain)
         while True:
             what, name, layer, module, ofn, params, x, changed = item
