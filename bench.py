@@ -841,10 +841,10 @@ def main():
             # quoted at bs = 1 per stage): a second, labelled line with its own parity object, measured by a child run of this file on the freed GPU.
             t_wl = time.perf_counter()
             try:
-                # (round 6: the stacked line carries the same kind of parity object as the headline -- eight samples (two through the host oracle, six through the same oracle in
+                # (round 6: the stacked line carries the same kind of parity object as the headline -- eight samples (one through the host oracle, seven through the same oracle in
                 # fp32 on the GPU) and the yardstick; the exact-fp32 kernel leg evaluates single samples and is not repeated here)
                 cmd = [sys.executable, os.path.abspath(__file__), '--stack', '4', '--lanes', '2', '--steps', '10', '--warmup', '3', '--light', '--parity-samples', '8',
-                       '--parity-cpu-samples', '2', '--parity-budget', '40', '--no-synced-loop']
+                       '--parity-cpu-samples', '1', '--parity-budget', '40', '--no-synced-loop']
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
                 line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
                 if line:

@@ -15,6 +15,21 @@ import torch
 from . import eager_step, sdxl_ref
 
 
+def cpu_quota_cores():
+    """CPU time the container may use, in cores (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unknown.  The GPU box reports 256 hardware threads and a quota of 16."""
+    try:
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        return None if q == 'max' else float(q) / float(p)
+    except Exception:                                    # noqa: BLE001
+        pass
+    try:
+        q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        p = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        return None if q <= 0 else q / p
+    except Exception:                                    # noqa: BLE001
+        return None
+
+
 def _bf16_exact(v):
     return v.is_floating_point() and bool((v.to(torch.bfloat16).to(v.dtype) == v).all())
 
@@ -137,6 +152,7 @@ def sdxl_cpu_baseline(cfg, latent_hw=128, threads=None, micro_batch=None, state=
         torch.set_num_threads(prev)
         return loss_all, norm_all
     return {**({'rows': rows} if per_parameter else {}), **({'extra_join': extra_join} if extra_thread is not None or worker_join is not None else {}), 'value': round(1.0 / dt, 6), 'unit': 'images/s', 'cores': threads, 'kind': 'port', 'sample_seconds': round(dt, 3),
+            'host': {'hardware_threads': os.cpu_count(), 'cgroup_cpu_quota_cores': cpu_quota_cores(), 'threads_used': threads},
             'build_seconds': round(t_build, 1), 'loss': float(loss), 'grad_norm': float(norm), 'loss_all': loss_all, 'grad_norm_all': norm_all, 'weights': 'product state dict' if state is not None else 'oracle seed 0',
             'sample': f'oracle fp32 eager path (oracle/sdxl_ref.py + eager_step.py): ONE whole micro-batch = one {latent_hw * 8}x{latent_hw * 8} image '
                       f'through all 23 pipeline layers + loss + backward + clip (1 of the step\'s micro-batches, no optimizer step), {threads} threads'}

@@ -43,7 +43,8 @@ def run_pair(name, product_layer, product_module, oracle_fn, oracle_params, inpu
         p.grad = None
     pout = product_layer(pin)
     oin = tuple((_to32(t).requires_grad_(True) if (torch.is_tensor(t) and t.is_floating_point() and i in changed) else _to32(t)) for i, t in enumerate(inputs))
-    oout = oracle_fn(oin)
+    with torch.device(DEV):                     # the oracle's helpers build their index / mask tensors with bare factory calls
+        oout = oracle_fn(oin)
     gen = torch.Generator(device=DEV).manual_seed(seed)
     row = {'block': name}
     gs_p, gs_o, outs_p, outs_o = [], [], [], []
@@ -183,7 +184,6 @@ def main():
     chain = {'flux': flux_chain, 'wan': wan_chain, 'hv': hv_chain}[which](max_blocks)
     rows, what, t0 = [], None, time.perf_counter()
     try:
-        torch.set_default_device(DEV)           # the oracle's helpers build their index / mask tensors with bare factory calls
         item = next(chain)
         while True:
             what, name, layer, module, ofn, params, x, changed = item
