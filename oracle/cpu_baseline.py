@@ -30,6 +30,19 @@ def cpu_quota_cores():
         return None
 
 
+def default_threads():
+    """threads of the oracle's CPU legs: DPIPE_CPU_BASELINE_THREADS if set; else at most 32 (these mid-sized fp32 ops run fastest on a subset of a many-core host) and at most
+    the container's CPU quota -- on the GPU box (256 hardware threads, quota 16) 16 threads evaluate one sample in 18.6 s, 32 threads in 26.4 - 26.9 s (call r6i: throttled
+    OpenMP teams wait at every barrier)."""
+    if 'DPIPE_CPU_BASELINE_THREADS' in os.environ:
+        return max(1, min(os.cpu_count() or 1, int(os.environ['DPIPE_CPU_BASELINE_THREADS'])))
+    n = min(os.cpu_count() or 1, 32)
+    q = cpu_quota_cores()
+    if q:
+        n = max(1, min(n, int(q + 0.999)))
+    return n
+
+
 def _bf16_exact(v):
     return v.is_floating_point() and bool((v.to(torch.bfloat16).to(v.dtype) == v).all())
 
@@ -95,7 +108,7 @@ def sdxl_cpu_baseline(cfg, latent_hw=128, threads=None, micro_batch=None, state=
     with anything.  `extra_workers` > 0 (round 6): the extra samples go to that many child processes instead (`spawn_parity_workers`), started AFTER the timed sample; this
     process frees its own copy of the model first."""
     # many-core hosts (the GPU box has 256 hardware threads) run these mid-sized fp32 ops fastest on a subset
-    threads = threads or min(os.cpu_count() or 1, int(os.environ.get('DPIPE_CPU_BASELINE_THREADS', '32')))
+    threads = threads or default_threads()
     prev = torch.get_num_threads()
     torch.set_num_threads(threads)
     extra_thread = None
@@ -166,7 +179,7 @@ def dit_block_cpu_baseline(kind, step_flops_per_sample, threads=None):
     extrapolation is stated in `sample`."""
     import torch.nn.functional as F
     from . import blocks_ref as br, flux_ref
-    threads = threads or min(os.cpu_count() or 1, int(os.environ.get('DPIPE_CPU_BASELINE_THREADS', '32')))
+    threads = threads or default_threads()
     prev = torch.get_num_threads()
     torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(0)
