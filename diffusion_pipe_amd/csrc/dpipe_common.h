@@ -83,6 +83,37 @@ template <> __device__ __forceinline__ void Vec16<bf16_t>::pack(const float* f) 
     raw.z = pack_bf16x2(f[4], f[5]); raw.w = pack_bf16x2(f[6], f[7]);
 }
 
+// V consecutive values of a per-column operand (norm weights, modulation rows, biases) as fp32, read by 16-byte loads and BRANCH-FREE: an absent operand
+// (null pointer) reads a zero pad and the caller selects the identity value per element.  Why this exists (round 6): `w ? to_f(w[c + j]) : 1.f` per element makes
+// hipcc branch around every 2-byte load and wait `vmcnt(0)` behind each one -- a chain of V dependent round trips per vector (cdna_hip_programming.md section 5, trap (c)).
+// `p + idx` must be 16-byte aligned (the launchers check the base pointers; idx is a multiple of V).
+static __device__ uint4 g_param_pad[2];   // zero-initialised; NOT const: a constant-address-space object would turn the pointer select in PVec::load into flat loads
+template <typename W, int V> struct PVec {
+    static_assert(V * sizeof(W) == 16 || V * sizeof(W) == 32, "PVec: 8 bf16, 4 fp32 or 8 fp32 values");
+    static constexpr int NR = V * (int)sizeof(W) / 16;
+    uint4 raw[NR];
+    __device__ __forceinline__ void load(const W* p, long idx) {
+        const uint4* q = p ? reinterpret_cast<const uint4*>(p + idx) : g_param_pad;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) raw[r] = q[r];
+    }
+    __device__ __forceinline__ void unpack(float* f) const {
+        if constexpr (sizeof(W) == 4) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                f[4 * r + 0] = __uint_as_float(raw[r].x); f[4 * r + 1] = __uint_as_float(raw[r].y);
+                f[4 * r + 2] = __uint_as_float(raw[r].z); f[4 * r + 3] = __uint_as_float(raw[r].w);
+            }
+        } else {
+            f[0] = __uint_as_float(raw[0].x << 16); f[1] = __uint_as_float(raw[0].x & 0xffff0000u);
+            f[2] = __uint_as_float(raw[0].y << 16); f[3] = __uint_as_float(raw[0].y & 0xffff0000u);
+            f[4] = __uint_as_float(raw[0].z << 16); f[5] = __uint_as_float(raw[0].z & 0xffff0000u);
+            f[6] = __uint_as_float(raw[0].w << 16); f[7] = __uint_as_float(raw[0].w & 0xffff0000u);
+        }
+    }
+};
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
 // ---- wave64 / block reductions -------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

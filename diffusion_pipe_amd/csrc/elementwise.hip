@@ -315,9 +315,10 @@ __global__ void __launch_bounds__(EW_BLOCK) gated_residual_fwd_kernel(
         const long r = i / dv, c = (i - r * dv) * V;
         Vec16<T> vx, vy; vx.load(x + r * D + c); vy.load(y + r * D + c);
         float fx[V], fy[V]; vx.unpack(fx); vy.unpack(fy);
-        const G* g = gate ? gate + (r / rows_per_gate) * D + c : nullptr;
+        PVec<G, V> pg; pg.load(gate, (r / rows_per_gate) * D + c);          // 16-byte, branch-free gate read (dpipe_common.h, PVec)
+        float fgt[V]; pg.unpack(fgt);
 #pragma unroll
-        for (int j = 0; j < V; ++j) fx[j] += fy[j] * (g ? Elem<G>::to_f(g[j]) : 1.f);
+        for (int j = 0; j < V; ++j) fx[j] += fy[j] * (gate ? fgt[j] : 1.f);
         vx.pack(fx); vx.store(out + r * D + c);
     }
 }
@@ -573,7 +574,7 @@ int dpipe_geglu_bwd(const void* x, const void* gy, void* gx, long rows, long H, 
 int dpipe_gated_residual_fwd(const void* x, const void* y, const void* gate, void* out, long rows, long D, long rows_per_gate,
                              int dtype, int gate_dtype, void* stream) {
     const int V = dtype == DPIPE_BF16 ? 8 : 4;
-    if (!x || !y || !out || rows <= 0 || D <= 0 || (D % V) != 0 || rows_per_gate <= 0) { set_last_error("dpipe_gated_residual_fwd: bad argument"); return DPIPE_ERR_ARG; }
+    if (!x || !y || !out || rows <= 0 || D <= 0 || (D % V) != 0 || rows_per_gate <= 0 || !aligned16(gate)) { set_last_error("dpipe_gated_residual_fwd: bad argument (or a gate that is not 16-byte aligned)"); return DPIPE_ERR_ARG; }
     int grid = stream_grid(rows * (D / V), EW_BLOCK);
     hipStream_t s = STREAM(stream);
     if (dtype == DPIPE_BF16 && gate_dtype == DPIPE_BF16) gated_residual_fwd_kernel<bf16_t, bf16_t><<<grid, EW_BLOCK, 0, s>>>((const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)gate, (bf16_t*)out, rows, D, rows_per_gate);

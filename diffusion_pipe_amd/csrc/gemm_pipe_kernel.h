@@ -572,6 +572,83 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, char* const 
     // for each q = e >> 2 the lane holds 4 consecutive n of one output row.
     const long coff = zo * p.sCo + zi * p.sCi;
     const int h = lane >> 5;
+    // Batched epilogue (round 6), taken by every bf16-output launch whose rows allow 8-byte accesses (N % 4 == 0: the 4 columns a lane owns are inside or outside together):
+    // the operand reads of a 32 x 32 accumulator tile -- bias (hi / lo), residual, the old C of an accumulating launch: 4 lane groups x up to 4 reads of 8 bytes --
+    // are ALL issued before the first is used, and the next tile's reads before this tile's stores.  The general form below wraps every read in a wave-uniform `if`
+    // (operand present? vector legal?), which hipcc compiles to a branch with `s_waitcnt vmcnt(0)` behind each load: 8 groups x (bias + residual + old C) = up to 24
+    // DEPENDENT round trips per lane after the K loop, each also waiting for the previous group's store to be acknowledged (gfx9 counts stores in vmcnt) -- 5 - 12 us of a
+    // 25 - 60 us launch (ISA: profiles/r6m_gemm_epilogue_isa_before_after.txt).  Here an absent operand reads the zero pad (branch-free pointer select), rows past M are
+    // clamped to M - 1 and columns past N to 0 for the reads and skipped for the stores; the arithmetic order (alpha, bias hi, bias lo, activation, residual, old C) is the
+    // general form's, so results are bit-identical.
+    if (!p.out_f32 && p.vecA >= 2 && (p.N & 3) == 0 && (!p.bias || p.vecB >= 2) && (!p.residual || p.vecA >= 3)) {
+        const bool hb = p.bias != nullptr, hl = hb && p.bias_lo != 0, hr = p.residual != nullptr, ha = p.accumulate != 0;
+        const uint2* pad = reinterpret_cast<const uint2*>(g_param_pad);
+        const bf16_t* biasp = reinterpret_cast<const bf16_t*>(p.bias);
+        const bf16_t* resp = reinterpret_cast<const bf16_t*>(p.residual);
+        bf16_t* cp = reinterpret_cast<bf16_t*>(p.C);
+        const int brows = p.bias_rows ? p.bias_rows : 0x7fffffff;       // one bias row for every output row: row index 0
+        constexpr int U = TM * TN;
+        struct EpiOps { uint2 b[4], l[4], r[4], o[4]; long idx[4]; bool ok[4]; };
+        EpiOps ops[2];
+        auto issue = [&](EpiOps& e, int u) {
+            const int i = u / TN, j = u % TN;
+            const int m = m0 + wm0 + i * 32 + (lane & 31);
+            const bool mok = m < p.M;
+            const int mm = mok ? m : p.M - 1;
+            const long brow = (long)(mm / brows) * p.N;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn0 + j * 32 + 8 * q + 4 * h;
+                const bool nok = n < p.N;
+                const int nn = nok ? n : 0;
+                e.ok[q] = mok && nok;
+                e.idx[q] = coff + (long)mm * p.ldc + nn;
+                e.b[q] = *(hb ? reinterpret_cast<const uint2*>(biasp + brow + nn) : pad);
+                e.l[q] = *(hl ? reinterpret_cast<const uint2*>(biasp + brow + nn + p.bias_lo) : pad);
+                e.r[q] = *(hr ? reinterpret_cast<const uint2*>(resp + coff + (long)mm * p.ldr + nn) : pad);
+                e.o[q] = *(ha ? reinterpret_cast<const uint2*>(cp + e.idx[q]) : pad);
+            }
+        };
+        auto finish = [&](const EpiOps& e, int u) {
+            const int i = u / TN, j = u % TN;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = p.alpha * acc[i][j][4 * q + r];
+                if (hb) {
+                    v[0] += __uint_as_float(e.b[q].x << 16); v[1] += __uint_as_float(e.b[q].x & 0xffff0000u);
+                    v[2] += __uint_as_float(e.b[q].y << 16); v[3] += __uint_as_float(e.b[q].y & 0xffff0000u);
+                }
+                if (hl) {
+                    v[0] += __uint_as_float(e.l[q].x << 16); v[1] += __uint_as_float(e.l[q].x & 0xffff0000u);
+                    v[2] += __uint_as_float(e.l[q].y << 16); v[3] += __uint_as_float(e.l[q].y & 0xffff0000u);
+                }
+                if (p.act != ACT_NONE) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = epilogue_act(v[r], p.act);
+                }
+                if (hr) {
+                    v[0] += __uint_as_float(e.r[q].x << 16); v[1] += __uint_as_float(e.r[q].x & 0xffff0000u);
+                    v[2] += __uint_as_float(e.r[q].y << 16); v[3] += __uint_as_float(e.r[q].y & 0xffff0000u);
+                }
+                if (ha) {
+                    v[0] += __uint_as_float(e.o[q].x << 16); v[1] += __uint_as_float(e.o[q].x & 0xffff0000u);
+                    v[2] += __uint_as_float(e.o[q].y << 16); v[3] += __uint_as_float(e.o[q].y & 0xffff0000u);
+                }
+                if (e.ok[q]) *reinterpret_cast<uint2*>(cp + e.idx[q]) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            }
+        };
+        issue(ops[0], 0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (u + 1 < U) issue(ops[(u + 1) & 1], u + 1);
+            __builtin_amdgcn_sched_barrier(0);          // the reads above stay above: the machine scheduler would sink them next to their uses
+            finish(ops[u & 1], u);
+        }
+        TL_STAMP(3);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm0 + i * 32 + (lane & 31);

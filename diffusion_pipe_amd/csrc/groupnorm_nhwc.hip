@@ -134,13 +134,15 @@ __global__ void __launch_bounds__(NB) gn_nhwc_apply_kernel(const T* __restrict__
         const int v = tv + i * l.vpb;
         if (v >= l.nvec) break;
         float ga[V], be[V];
+        PVec<W, V> pg, pb; pg.load(gamma, (long)v * V); pb.load(beta, (long)v * V);      // 16-byte, branch-free operand reads (dpipe_common.h, PVec)
+        pg.unpack(ga); pb.unpack(be);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             const int c = v * V + j;
             const long row = n * G + c / cpg;
             const float rs = rstd[row];
-            ga[j] = (gamma ? Elem<W>::to_f(gamma[c]) : 1.f) * rs;
-            be[j] = (beta ? Elem<W>::to_f(beta[c]) : 0.f) - mean[row] * ga[j];
+            ga[j] = (gamma ? ga[j] : 1.f) * rs;
+            be[j] = (beta ? be[j] : 0.f) - mean[row] * ga[j];
         }
         const T* xp = x + (n * HW) * C + (long)v * V;
         T* yp = y + (n * HW) * C + (long)v * V;
@@ -186,12 +188,14 @@ __global__ void __launch_bounds__(NB) gn_nhwc_bwd_partial_kernel(const T* __rest
         for (int j = 0; j < V; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
         if (live && v < l.nvec) {
             float mu[V], rs[V], ga[V], be[V];
+            PVec<W, V> pg, pb; pg.load(gamma, (long)v * V); pb.load(beta, (long)v * V);
+            pg.unpack(ga); pb.unpack(be);
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 const int c = v * V + j;
                 const long row = n * G + c / cpg;
                 mu[j] = mean[row]; rs[j] = rstd[row];
-                ga[j] = gamma ? Elem<W>::to_f(gamma[c]) : 1.f; be[j] = beta ? Elem<W>::to_f(beta[c]) : 0.f;
+                ga[j] = gamma ? ga[j] : 1.f; be[j] = beta ? be[j] : 0.f;
             }
             const T* xp = x + (n * HW) * C + (long)v * V;
             const T* gp = dy + (n * HW) * C + (long)v * V;
@@ -287,55 +291,48 @@ __global__ void __launch_bounds__(NB) gn_nhwc_bwd_apply_kernel(const T* __restri
         const int v = tv + i * l.vpb;
         if (v >= l.nvec) break;
         float mu[V], rs[V], ga[V], be[V], ca[V], cb[V];
+        PVec<W, V> pg, pb; pg.load(gamma, (long)v * V); pb.load(beta, (long)v * V);
+        pg.unpack(ga); pb.unpack(be);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             const int c = v * V + j;
             const long row = n * G + c / cpg;
             mu[j] = mean[row]; rs[j] = rstd[row];
-            ga[j] = gamma ? Elem<W>::to_f(gamma[c]) : 1.f; be[j] = beta ? Elem<W>::to_f(beta[c]) : 0.f;
+            ga[j] = gamma ? ga[j] : 1.f; be[j] = beta ? be[j] : 0.f;
             ca[j] = ab[row * 2] * inv_m; cb[j] = ab[row * 2 + 1] * inv_m;
         }
         const T* xp = x + (n * HW) * C + (long)v * V;
         const T* gp = dy + (n * HW) * C + (long)v * V;
         T* op = dx + (n * HW) * C + (long)v * V;
-        const T* ap = dadd ? dadd + (n * HW) * C + (long)v * V : nullptr;     // gradient that reached x around the norm (residual branch)
+        // gradient that reached x around the norm (residual branch): read with the x / dy loads of its row, branch-free (absent: the zero pad, row pitch 0)
+        const bool ha = dadd != nullptr;
+        const T* ap = ha ? dadd + (n * HW) * C + (long)v * V : reinterpret_cast<const T*>(g_param_pad);
+        const long apitch = ha ? C : 0;
         long r = r0 + rlane;
         for (; r + (long)l.rl < r1; r += 2L * l.rl) {
-            Vec16<T> a[2], b[2];
+            Vec16<T> a[2], b[2], e[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) { a[u].load(xp + (r + (long)u * l.rl) * C); b[u].load(gp + (r + (long)u * l.rl) * C); }
+            for (int u = 0; u < 2; ++u) { a[u].load(xp + (r + (long)u * l.rl) * C); b[u].load(gp + (r + (long)u * l.rl) * C); e[u].load(ap + (r + (long)u * l.rl) * apitch); }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                float fx[V], fg[V]; a[u].unpack(fx); b[u].unpack(fg);
+                float fx[V], fg[V], fe[V]; a[u].unpack(fx); b[u].unpack(fg); e[u].unpack(fe);
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
                     const float xh = (fx[j] - mu[j]) * rs[j];
                     const float dz = ACT ? fg[j] * silu_grad(xh * ga[j] + be[j]) : fg[j];
-                    fx[j] = rs[j] * (ga[j] * dz - ca[j] - xh * cb[j]);
-                }
-                if (ap) {
-                    Vec16<T> e; e.load(ap + (r + (long)u * l.rl) * C);
-                    float fe[V]; e.unpack(fe);
-#pragma unroll
-                    for (int j = 0; j < V; ++j) fx[j] += fe[j];
+                    fx[j] = rs[j] * (ga[j] * dz - ca[j] - xh * cb[j]) + (ha ? fe[j] : 0.f);
                 }
                 Vec16<T> o; o.pack(fx); o.store(op + (r + (long)u * l.rl) * C);
             }
         }
         for (; r < r1; r += l.rl) {
-            Vec16<T> a, b; a.load(xp + r * C); b.load(gp + r * C);
-            float fx[V], fg[V]; a.unpack(fx); b.unpack(fg);
+            Vec16<T> a, b, e; a.load(xp + r * C); b.load(gp + r * C); e.load(ap + r * apitch);
+            float fx[V], fg[V], fe[V]; a.unpack(fx); b.unpack(fg); e.unpack(fe);
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 const float xh = (fx[j] - mu[j]) * rs[j];
                 const float dz = ACT ? fg[j] * silu_grad(xh * ga[j] + be[j]) : fg[j];
-                fx[j] = rs[j] * (ga[j] * dz - ca[j] - xh * cb[j]);
-            }
-            if (ap) {
-                Vec16<T> e; e.load(ap + r * C);
-                float fe[V]; e.unpack(fe);
-#pragma unroll
-                for (int j = 0; j < V; ++j) fx[j] += fe[j];
+                fx[j] = rs[j] * (ga[j] * dz - ca[j] - xh * cb[j]) + (ha ? fe[j] : 0.f);
             }
             Vec16<T> o; o.pack(fx); o.store(op + r * C);
         }
@@ -369,7 +366,7 @@ int dpipe_groupnorm_nhwc_fwd(const void* x, const void* gamma, const void* beta,
     if (!x || !y || !mean || !rstd || !workspace || N <= 0 || C <= 0 || HW <= 0 || G <= 0 || C % G) BAD("dpipe_groupnorm_nhwc_fwd: bad argument");
     const int V = dtype == DPIPE_BF16 ? 8 : 4;
     if ((dtype != DPIPE_BF16 && dtype != DPIPE_F32) || (wdtype != DPIPE_BF16 && wdtype != DPIPE_F32)) BAD("dpipe_groupnorm_nhwc_fwd: dtype");
-    if (C % V || C / V > NB * MAXVI || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) BAD("dpipe_groupnorm_nhwc_fwd: C must be a multiple of the 16-byte vector (<= 8192 channels), 16-byte aligned tensors");
+    if (C % V || C / V > NB * MAXVI || ((uintptr_t)x & 15) || ((uintptr_t)y & 15) || !aligned16(gamma) || !aligned16(beta)) BAD("dpipe_groupnorm_nhwc_fwd: C must be a multiple of the 16-byte vector (<= 8192 channels), 16-byte aligned tensors");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rpb, chunks; plan(C, HW, N, V, rpb, chunks);
     dim3 grid(chunks, (unsigned)N);
@@ -391,7 +388,7 @@ int dpipe_groupnorm_nhwc_bwd(const void* x, const void* dy, const void* gamma, c
     if (!x || !dy || !dx || !mean || !rstd || !workspace || N <= 0 || C <= 0 || HW <= 0 || G <= 0 || C % G) BAD("dpipe_groupnorm_nhwc_bwd: bad argument");
     const int V = dtype == DPIPE_BF16 ? 8 : 4;
     if ((dtype != DPIPE_BF16 && dtype != DPIPE_F32) || (wdtype != DPIPE_BF16 && wdtype != DPIPE_F32)) BAD("dpipe_groupnorm_nhwc_bwd: dtype");
-    if (C % V || C / V > NB * MAXVI || C / G > NB || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || ((uintptr_t)dx & 15)) BAD("dpipe_groupnorm_nhwc_bwd: alignment / channel count");
+    if (C % V || C / V > NB * MAXVI || C / G > NB || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || ((uintptr_t)dx & 15) || !aligned16(gamma) || !aligned16(beta) || !aligned16(dx_add)) BAD("dpipe_groupnorm_nhwc_bwd: alignment / channel count");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rpb, chunks; plan(C, HW, N, V, rpb, chunks);
     dim3 grid(chunks, (unsigned)N);

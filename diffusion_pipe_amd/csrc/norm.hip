@@ -54,11 +54,12 @@ __global__ void __launch_bounds__(NB) rmsnorm_fwd_kernel(const T* __restrict__ x
     T* yr = y + row * (long)cols;
     for (int c = sub * V; c < cols; c += LPR * V) {
         Vec16<T> v; v.load(xr + c);
-        float f[V]; v.unpack(f);
+        PVec<W, V> pw; pw.load(w, c);                                  // 16-byte, branch-free weight read (dpipe_common.h, PVec)
+        float f[V], fw[V]; v.unpack(f); pw.unpack(fw);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             float n = Elem<T>::to_f(Elem<T>::from_f(f[j] * rstd));  // ".type_as(x)" rounding point of the reference
-            f[j] = w ? n * Elem<W>::to_f(w[c + j]) : n;
+            f[j] = w ? n * fw[j] : n;
         }
         v.pack(f); v.store(yr + c);
     }
@@ -78,18 +79,20 @@ __global__ void __launch_bounds__(NB) rmsnorm_bwd_dx_kernel(const T* __restrict_
     float dot = 0.f;
     for (int c = sub * V; c < cols; c += LPR * V) {
         Vec16<T> vx, vg; vx.load(xr + c); vg.load(gr + c);
-        float fx[V], fg[V]; vx.unpack(fx); vg.unpack(fg);
+        PVec<W, V> pw; pw.load(w, c);
+        float fx[V], fg[V], fw[V]; vx.unpack(fx); vg.unpack(fg); pw.unpack(fw);
 #pragma unroll
-        for (int j = 0; j < V; ++j) dot += fg[j] * (w ? Elem<W>::to_f(w[c + j]) : 1.f) * fx[j] * rstd;
+        for (int j = 0; j < V; ++j) dot += fg[j] * (w ? fw[j] : 1.f) * fx[j] * rstd;
     }
     dot = group_sum<LPR>(dot) / (float)cols;
     if (!live) return;
     T* o = gx + row * (long)cols;
     for (int c = sub * V; c < cols; c += LPR * V) {
         Vec16<T> vx, vg; vx.load(xr + c); vg.load(gr + c);
-        float fx[V], fg[V]; vx.unpack(fx); vg.unpack(fg);
+        PVec<W, V> pw; pw.load(w, c);
+        float fx[V], fg[V], fw[V]; vx.unpack(fx); vg.unpack(fg); pw.unpack(fw);
 #pragma unroll
-        for (int j = 0; j < V; ++j) fg[j] = rstd * (fg[j] * (w ? Elem<W>::to_f(w[c + j]) : 1.f) - fx[j] * rstd * dot);
+        for (int j = 0; j < V; ++j) fg[j] = rstd * (fg[j] * (w ? fw[j] : 1.f) - fx[j] * rstd * dot);
         vg.pack(fg); vg.store(o + c);
     }
 }
@@ -130,12 +133,13 @@ __global__ void __launch_bounds__(NB) rmsnorm_rope_fwd_kernel(const T* __restric
     T* yr = y + row * (long)cols;
     for (int c = sub * V; c < cols; c += LPR * V) {
         Vec16<T> v; v.load(xr + c);
-        float f[V]; v.unpack(f);
+        PVec<W, V> pw; pw.load(w, c);
+        float f[V], fw[V]; v.unpack(f); pw.unpack(fw);
         const int cd = c % rg.D;
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             const float n = Elem<T>::to_f(Elem<T>::from_f(f[j] * rstd));  // ".type_as(x)" rounding point of the reference norm
-            f[j] = w ? n * Elem<W>::to_f(w[c + j]) : n;
+            f[j] = w ? n * fw[j] : n;
         }
         if (rot) {
 #pragma unroll
@@ -179,20 +183,22 @@ __global__ void __launch_bounds__(NB) rmsnorm_rope_bwd_dx_kernel(const T* __rest
     float dot = 0.f;
     for (int c = sub * V; c < cols; c += LPR * V) {
         Vec16<T> vx, vg; vx.load(xr + c); vg.load(gr + c);
-        float fx[V], fg[V]; vx.unpack(fx); vg.unpack(fg);
+        PVec<W, V> pw; pw.load(w, c);
+        float fx[V], fg[V], fw[V]; vx.unpack(fx); vg.unpack(fg); pw.unpack(fw);
         unrotate(fg, c);
 #pragma unroll
-        for (int j = 0; j < V; ++j) dot += fg[j] * (w ? Elem<W>::to_f(w[c + j]) : 1.f) * fx[j] * rstd;
+        for (int j = 0; j < V; ++j) dot += fg[j] * (w ? fw[j] : 1.f) * fx[j] * rstd;
     }
     dot = group_sum<LPR>(dot) / (float)cols;
     if (!live) return;
     T* o = gx + row * (long)cols;
     for (int c = sub * V; c < cols; c += LPR * V) {
         Vec16<T> vx, vg; vx.load(xr + c); vg.load(gr + c);
-        float fx[V], fg[V]; vx.unpack(fx); vg.unpack(fg);
+        PVec<W, V> pw; pw.load(w, c);
+        float fx[V], fg[V], fw[V]; vx.unpack(fx); vg.unpack(fg); pw.unpack(fw);
         unrotate(fg, c);
 #pragma unroll
-        for (int j = 0; j < V; ++j) fg[j] = rstd * (fg[j] * (w ? Elem<W>::to_f(w[c + j]) : 1.f) - fx[j] * rstd * dot);
+        for (int j = 0; j < V; ++j) fg[j] = rstd * (fg[j] * (w ? fw[j] : 1.f) - fx[j] * rstd * dot);
         vg.pack(fg); vg.store(o + c);
     }
 }
@@ -271,12 +277,17 @@ __global__ void __launch_bounds__(NB) colreduce_kernel(const T* __restrict__ x, 
     const long rps = cdiv(rows_per_group, slabs);
     const long r0 = blockIdx.y * rps, r1 = min(r0 + rps, rows_per_group);
     float a0[V], a1[V], fgam[V], fbet[V], fsc[V];
+    {
+        const long cs = live ? c : 0;                                   // 16-byte, branch-free operand reads (dpipe_common.h, PVec)
+        PVec<W, V> pg, pb; PVec<M, V> ps; pg.load(gamma, cs); pb.load(beta, cs); ps.load(scale, grp * cols + cs);
+        pg.unpack(fgam); pb.unpack(fbet); ps.unpack(fsc);
+    }
 #pragma unroll
     for (int j = 0; j < V; ++j) {
         a0[j] = 0.f; a1[j] = 0.f;
-        fgam[j] = (live && gamma) ? Elem<W>::to_f(gamma[c + j]) : 1.f;
-        fbet[j] = (live && beta) ? Elem<W>::to_f(beta[c + j]) : 0.f;
-        fsc[j] = (live && scale) ? 1.f + Elem<M>::to_f(scale[grp * cols + c + j]) : 1.f;
+        fgam[j] = gamma ? fgam[j] : 1.f;
+        fbet[j] = beta ? fbet[j] : 0.f;
+        fsc[j] = scale ? 1.f + fsc[j] : 1.f;
     }
     if (live) {
 #pragma unroll 4
@@ -381,7 +392,14 @@ __global__ void __launch_bounds__(NB) slabsum_kernel(const float* __restrict__ p
 
 // ------------------------------------------------- LayerNorm + AdaLN modulate
 // n = (x - mean) * rstd [* gamma + beta] ;  y = n * (1 + scale[b]) + shift[b]
-template <typename T, typename W, typename M, int LPR>
+//
+// Round 6: the per-column operands (gamma, beta, scale, shift) are read as 16-byte vectors through PVec -- BRANCH-FREE, an absent operand reads a zero
+// pad -- and every load of a row (x, the operands, the statistics) is issued before the first use.  The previous form `gamma ? to_f(gamma[c + j]) : 1.f`
+// per element compiled to a branch around every 2-byte load with `s_waitcnt vmcnt(0)` behind it: 160 DEPENDENT round trips per wave in the forward, 128 - 640
+// in the backward (ISA counts in profiles/r6m_norm_isa_before_after.txt); the kernels were bound by that chain, not by HBM.
+// NK > 0: the row fits NK vectors per lane (cols <= LPR * V * NK, NK <= 4: every SDXL width) and stays in registers across the passes; lanes past the end
+// of the row read column 0 and are masked.  NK = 0: any width, three passes over the row (L2-resident re-reads).
+template <typename T, typename W, typename M, int LPR, int NK>
 __global__ void __launch_bounds__(NB) lnmod_fwd_kernel(const T* __restrict__ x, const W* __restrict__ gamma, const W* __restrict__ beta,
                                                        const M* __restrict__ scale, const M* __restrict__ shift, T* __restrict__ y,
                                                        float* __restrict__ mean_out, float* __restrict__ rstd_out,
@@ -391,158 +409,213 @@ __global__ void __launch_bounds__(NB) lnmod_fwd_kernel(const T* __restrict__ x, 
     const int sub = threadIdx.x % LPR;
     const long row = (long)blockIdx.x * RPB + threadIdx.x / LPR;
     const bool live = row < rows;
-    const T* xr = x + (live ? row : 0) * (long)cols;
-    // rows of up to RC vectors per lane (cols <= 2048 bf16 / 1024 fp32: every SDXL width) stay in registers across the three passes: one global read
-    // instead of three dependent load -> reduce round trips (the kernel is latency-bound: 4 rows per workgroup, one workgroup per CU)
-    constexpr int RC = 4;
-    const bool cached = cols <= LPR * V * RC;
-    Vec16<T> rv[RC];
-    float s = 0.f;
-    if (cached) {
+    const long r = live ? row : 0;
+    const T* xr = x + r * (long)cols;
+    T* yr = y + r * (long)cols;
+    const long mb = (r / rows_per_mod) * (long)cols;
+    const bool hg = gamma != nullptr, hb = beta != nullptr, hs = scale != nullptr, hh = shift != nullptr;
+    auto affine = [&](float* f, const PVec<W, V>& pg, const PVec<W, V>& pb, const PVec<M, V>& ps, const PVec<M, V>& ph, float mu, float rstd) {
+        float g[V], bt[V], sc[V], sh[V];
+        pg.unpack(g); pb.unpack(bt); ps.unpack(sc); ph.unpack(sh);
 #pragma unroll
-        for (int k = 0; k < RC; ++k) {
+        for (int j = 0; j < V; ++j) {
+            float n = (f[j] - mu) * rstd;
+            n = hg ? n * g[j] + (hb ? bt[j] : 0.f) : n;
+            n = hs ? n * (1.f + sc[j]) : n;
+            n = hh ? n + sh[j] : n;
+            f[j] = n;
+        }
+    };
+    if constexpr (NK > 0) {
+        Vec16<T> rv[NK]; PVec<W, V> pg[NK], pb[NK]; PVec<M, V> ps[NK], ph[NK];
+        bool in[NK]; int cc[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
             const int c = (sub + k * LPR) * V;
-            if (c < cols) { rv[k].load(xr + c); float f[V]; rv[k].unpack(f);
+            in[k] = c < cols; cc[k] = in[k] ? c : 0;
+            rv[k].load(xr + cc[k]);
+        }
 #pragma unroll
-                for (int j = 0; j < V; ++j) s += f[j]; }
+        for (int k = 0; k < NK; ++k) { pg[k].load(gamma, cc[k]); pb[k].load(beta, cc[k]); ps[k].load(scale, mb + cc[k]); ph[k].load(shift, mb + cc[k]); }
+        __builtin_amdgcn_sched_barrier(0);   // every load of the row is in flight before the first use (the machine scheduler would otherwise delay some behind the arithmetic)
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            float f[V]; rv[k].unpack(f);
+#pragma unroll
+            for (int j = 0; j < V; ++j) s += in[k] ? f[j] : 0.f;
+        }
+        const float mu = group_sum<LPR>(s) / (float)cols;
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            float f[V]; rv[k].unpack(f);
+#pragma unroll
+            for (int j = 0; j < V; ++j) { const float d = f[j] - mu; ss += in[k] ? d * d : 0.f; }
+        }
+        const float rstd = rsqrtf(group_sum<LPR>(ss) / (float)cols + eps);
+        if (!live) return;
+        if (sub == 0) { if (mean_out) mean_out[row] = mu; if (rstd_out) rstd_out[row] = rstd; }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            float f[V]; rv[k].unpack(f);
+            affine(f, pg[k], pb[k], ps[k], ph[k], mu, rstd);
+            rv[k].pack(f);
+            if (in[k]) rv[k].store(yr + cc[k]);
         }
     } else {
+        float s = 0.f;
         for (int c = sub * V; c < cols; c += LPR * V) {
             Vec16<T> v; v.load(xr + c); float f[V]; v.unpack(f);
 #pragma unroll
             for (int j = 0; j < V; ++j) s += f[j];
         }
-    }
-    const float mu = group_sum<LPR>(s) / (float)cols;
-    float ss = 0.f;
-    if (cached) {
-#pragma unroll
-        for (int k = 0; k < RC; ++k) {
-            const int c = (sub + k * LPR) * V;
-            if (c < cols) { float f[V]; rv[k].unpack(f);
-#pragma unroll
-                for (int j = 0; j < V; ++j) { float d = f[j] - mu; ss += d * d; } }
-        }
-    } else {
+        const float mu = group_sum<LPR>(s) / (float)cols;
+        float ss = 0.f;
         for (int c = sub * V; c < cols; c += LPR * V) {
             Vec16<T> v; v.load(xr + c); float f[V]; v.unpack(f);
 #pragma unroll
-            for (int j = 0; j < V; ++j) { float d = f[j] - mu; ss += d * d; }
+            for (int j = 0; j < V; ++j) { const float d = f[j] - mu; ss += d * d; }
         }
-    }
-    const float rstd = rsqrtf(group_sum<LPR>(ss) / (float)cols + eps);
-    if (!live) return;
-    if (sub == 0) { if (mean_out) mean_out[row] = mu; if (rstd_out) rstd_out[row] = rstd; }
-    const long b = row / rows_per_mod;
-    T* yr = y + row * (long)cols;
-    auto emit = [&](int c, Vec16<T>& v) {
-        float f[V]; v.unpack(f);
-#pragma unroll
-        for (int j = 0; j < V; ++j) {
-            float n = (f[j] - mu) * rstd;
-            if (gamma) n = n * Elem<W>::to_f(gamma[c + j]) + (beta ? Elem<W>::to_f(beta[c + j]) : 0.f);
-            if (scale) n = n * (1.f + Elem<M>::to_f(scale[b * cols + c + j]));
-            if (shift) n += Elem<M>::to_f(shift[b * cols + c + j]);
-            f[j] = n;
+        const float rstd = rsqrtf(group_sum<LPR>(ss) / (float)cols + eps);
+        if (!live) return;
+        if (sub == 0) { if (mean_out) mean_out[row] = mu; if (rstd_out) rstd_out[row] = rstd; }
+        for (int c = sub * V; c < cols; c += LPR * V) {
+            Vec16<T> v; PVec<W, V> pg, pb; PVec<M, V> ps, ph;
+            v.load(xr + c); pg.load(gamma, c); pb.load(beta, c); ps.load(scale, mb + c); ph.load(shift, mb + c);
+            float f[V]; v.unpack(f);
+            affine(f, pg, pb, ps, ph, mu, rstd);
+            v.pack(f); v.store(yr + c);
         }
-        v.pack(f); v.store(yr + c);
-    };
-    if (cached) {
-#pragma unroll
-        for (int k = 0; k < RC; ++k) {
-            const int c = (sub + k * LPR) * V;
-            if (c < cols) emit(c, rv[k]);
-        }
-    } else {
-        for (int c = sub * V; c < cols; c += LPR * V) { Vec16<T> v; v.load(xr + c); emit(c, v); }
     }
 }
 // dxhat = gy * (1+scale) * gamma ;  dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)) (+ gadd: the gradient that reached x
 // through the residual branch around this norm, added here instead of by a separate elementwise kernel)
 //
-// FUSE != 0 (rows that fit the register cache, cols <= 64 * V * RC): the per-column parameter-gradient sums ride this pass as well -- every lane keeps
+// FUSE != 0 (NK > 0 only: rows that fit the register cache): the per-column parameter-gradient sums ride this pass as well -- every lane keeps
 // fp32 accumulators for the columns it owns over the RW rows its wave walks, the block's waves combine through LDS and ONE partial row per block goes
-// to the workspace (p0 / p1, [groups][slabs][cols]); slabsum2 then finishes.  The separate column-reduction launch, which re-read x and gy, is gone:
+// to the workspace (p0 / p1, [groups][slabs][cols]); slabsum2p then finishes.  The separate column-reduction launch, which re-read x and gy, is gone:
 //   FUSE 1: (dgamma, dbeta):  p0 += dn * xhat, p1 += dn         with dn = gy * (1 + scale)
 //   FUSE 2: (dscale, dshift): p0 += gy * (xhat * gamma + beta), p1 += gy
-template <typename T, typename W, typename M, int LPR, int FUSE = 0, int RW = 1>
+// Operand loads: see lnmod_fwd_kernel (vectors, branch-free, all issued ahead of the first use; gamma / beta once per block, the rest once per row).
+template <typename T, typename W, typename M, int LPR, int NK, int FUSE = 0, int RW = 1>
 __global__ void __launch_bounds__(NB) lnmod_bwd_dx_kernel(const T* __restrict__ x, const T* __restrict__ gy, const W* __restrict__ gamma,
                                                           const M* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           T* __restrict__ gx, const T* __restrict__ gadd, long rows, int cols, long rows_per_mod,
                                                           const W* __restrict__ beta = nullptr, float* __restrict__ p0 = nullptr, float* __restrict__ p1 = nullptr,
                                                           int slabs = 1) {
+    static_assert(FUSE == 0 || NK > 0, "the fused column partials need the register-cached row");
     constexpr int V = Elem<T>::VEC;
     constexpr int RPB = NB / LPR;
-    constexpr int RC = 4;                         // see lnmod_fwd_kernel: rows that fit stay in registers between the two passes
+    constexpr int NA = NK > 0 ? NK : 1;
     const int sub = threadIdx.x % LPR;
     const int wave = threadIdx.x / LPR;
-    const bool cached = FUSE != 0 || cols <= LPR * V * RC;
-    float a0[FUSE ? RC : 1][V], a1[FUSE ? RC : 1][V];
+    const bool hg = gamma != nullptr, hs = scale != nullptr, hb = beta != nullptr, ha = gadd != nullptr;
+    float a0[FUSE ? NA : 1][V], a1[FUSE ? NA : 1][V];
     if (FUSE) {
 #pragma unroll
-        for (int k = 0; k < RC; ++k)
+        for (int k = 0; k < NA; ++k)
 #pragma unroll
             for (int j = 0; j < V; ++j) { a0[k][j] = 0.f; a1[k][j] = 0.f; }
     }
+    if constexpr (NK > 0) {
+        bool in[NK]; int cc[NK];
+        PVec<W, V> pg[NK], pb[NK];
 #pragma unroll
-    for (int t = 0; t < RW; ++t) {
-        const long row = ((long)blockIdx.x * RW + t) * RPB + wave;
+        for (int k = 0; k < NK; ++k) {
+            const int c = (sub + k * LPR) * V;
+            in[k] = c < cols; cc[k] = in[k] ? c : 0;
+            pg[k].load(gamma, cc[k]);
+            if (FUSE == 2) pb[k].load(beta, cc[k]);
+        }
+#pragma unroll
+        for (int t = 0; t < RW; ++t) {
+            const long row = ((long)blockIdx.x * RW + t) * RPB + wave;
+            const bool live = row < rows;
+            const long r = live ? row : 0;
+            const T* xr = x + r * (long)cols; const T* gr = gy + r * (long)cols;
+            const long mb = (r / rows_per_mod) * (long)cols;
+            Vec16<T> rx[NK], rg[NK], ra[NK]; PVec<M, V> ps[NK];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) { rx[k].load(xr + cc[k]); rg[k].load(gr + cc[k]); }
+            const float mu = mean[r], rs = rstd[r];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                ps[k].load(scale, mb + cc[k]);
+                ra[k].raw = *(ha ? reinterpret_cast<const uint4*>(gadd + r * (long)cols + cc[k]) : &g_param_pad[0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // (see lnmod_fwd_kernel)
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                float fx[V], fg[V], g[V], sc[V]; rx[k].unpack(fx); rg[k].unpack(fg); pg[k].unpack(g); ps[k].unpack(sc);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const float d = fg[j] * (hs ? 1.f + sc[j] : 1.f) * (hg ? g[j] : 1.f);
+                    s1 += in[k] ? d : 0.f; s2 += in[k] ? d * (fx[j] - mu) * rs : 0.f;
+                }
+            }
+            // gadd is `const __restrict__`: its loads may move across anything, and LLVM sinks them behind the reductions (a second dependent round trip).
+            // A register use here pins them ahead; x / gy, issued before them, were waited for above, so this adds no wait of its own.
+#pragma unroll
+            for (int k = 0; k < NK; ++k) asm volatile("" : "+v"(ra[k].raw.x), "+v"(ra[k].raw.y), "+v"(ra[k].raw.z), "+v"(ra[k].raw.w));
+            s1 = group_sum<LPR>(s1) / (float)cols;
+            s2 = group_sum<LPR>(s2) / (float)cols;
+            if (!live) continue;                       // (wave-uniform: a wave owns whole rows)
+            T* o = gx + row * (long)cols;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                float fx[V], fg[V], g[V], sc[V], bt[V], fa[V];
+                rx[k].unpack(fx); rg[k].unpack(fg); pg[k].unpack(g); ps[k].unpack(sc); ra[k].unpack(fa);
+                if (FUSE == 2) pb[k].unpack(bt);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const float scv = hs ? 1.f + sc[j] : 1.f;
+                    const float gm = hg ? g[j] : 1.f;
+                    const float xhat = (fx[j] - mu) * rs;
+                    if (FUSE == 1) { const float dn = fg[j] * scv; a0[FUSE ? k : 0][j] += in[k] ? dn * xhat : 0.f; a1[FUSE ? k : 0][j] += in[k] ? dn : 0.f; }
+                    if (FUSE == 2) { a0[FUSE ? k : 0][j] += in[k] ? fg[j] * (xhat * gm + (hb ? bt[j] : 0.f)) : 0.f; a1[FUSE ? k : 0][j] += in[k] ? fg[j] : 0.f; }
+                    const float d = fg[j] * scv * gm;
+                    fg[j] = rs * (d - s1 - xhat * s2) + (ha ? fa[j] : 0.f);
+                }
+                rg[k].pack(fg);
+                if (in[k]) rg[k].store(o + cc[k]);
+            }
+        }
+    } else {
+        const long row = (long)blockIdx.x * RPB + wave;
         const bool live = row < rows;
         const long r = live ? row : 0;
         const T* xr = x + r * (long)cols; const T* gr = gy + r * (long)cols;
         const float mu = mean[r], rs = rstd[r];
-        const long b = r / rows_per_mod;
-        Vec16<T> rx[RC], rg[RC];
+        const long mb = (r / rows_per_mod) * (long)cols;
         float s1 = 0.f, s2 = 0.f;
-        auto pass1 = [&](int c, const Vec16<T>& vx, const Vec16<T>& vg) {
-            float fx[V], fg[V]; vx.unpack(fx); vg.unpack(fg);
+        for (int c = sub * V; c < cols; c += LPR * V) {
+            Vec16<T> vx, vg; PVec<W, V> pg; PVec<M, V> ps;
+            vx.load(xr + c); vg.load(gr + c); pg.load(gamma, c); ps.load(scale, mb + c);
+            float fx[V], fg[V], g[V], sc[V]; vx.unpack(fx); vg.unpack(fg); pg.unpack(g); ps.unpack(sc);
 #pragma unroll
             for (int j = 0; j < V; ++j) {
-                float d = fg[j] * (scale ? 1.f + Elem<M>::to_f(scale[b * cols + c + j]) : 1.f) * (gamma ? Elem<W>::to_f(gamma[c + j]) : 1.f);
+                const float d = fg[j] * (hs ? 1.f + sc[j] : 1.f) * (hg ? g[j] : 1.f);
                 s1 += d; s2 += d * (fx[j] - mu) * rs;
             }
-        };
-        if (cached) {
-#pragma unroll
-            for (int k = 0; k < RC; ++k) {
-                const int c = (sub + k * LPR) * V;
-                if (c < cols) { rx[k].load(xr + c); rg[k].load(gr + c); pass1(c, rx[k], rg[k]); }
-            }
-        } else {
-            for (int c = sub * V; c < cols; c += LPR * V) { Vec16<T> vx, vg; vx.load(xr + c); vg.load(gr + c); pass1(c, vx, vg); }
         }
         s1 = group_sum<LPR>(s1) / (float)cols;
         s2 = group_sum<LPR>(s2) / (float)cols;
-        if (!live) continue;                       // (wave-uniform: a wave owns whole rows)
+        if (!live) return;
         T* o = gx + row * (long)cols;
-        auto pass2 = [&](int c, int k, const Vec16<T>& vx, Vec16<T>& vg) {
-            float fx[V], fg[V]; vx.unpack(fx); vg.unpack(fg);
+        for (int c = sub * V; c < cols; c += LPR * V) {
+            Vec16<T> vx, vg, va; PVec<W, V> pg; PVec<M, V> ps;
+            vx.load(xr + c); vg.load(gr + c); pg.load(gamma, c); ps.load(scale, mb + c);
+            va.raw = *(ha ? reinterpret_cast<const uint4*>(gadd + row * (long)cols + c) : &g_param_pad[0]);
+            float fx[V], fg[V], g[V], sc[V], fa[V]; vx.unpack(fx); vg.unpack(fg); pg.unpack(g); ps.unpack(sc); va.unpack(fa);
 #pragma unroll
             for (int j = 0; j < V; ++j) {
-                const float sc = scale ? 1.f + Elem<M>::to_f(scale[b * cols + c + j]) : 1.f;
-                const float gm = gamma ? Elem<W>::to_f(gamma[c + j]) : 1.f;
                 const float xhat = (fx[j] - mu) * rs;
-                if (FUSE == 1) { const float dn = fg[j] * sc; a0[FUSE ? k : 0][j] += dn * xhat; a1[FUSE ? k : 0][j] += dn; }
-                if (FUSE == 2) { a0[FUSE ? k : 0][j] += fg[j] * (xhat * gm + (beta ? Elem<W>::to_f(beta[c + j]) : 0.f)); a1[FUSE ? k : 0][j] += fg[j]; }
-                const float d = fg[j] * sc * gm;
-                fg[j] = rs * (d - s1 - xhat * s2);
-            }
-            if (gadd) {
-                Vec16<T> va; va.load(gadd + row * (long)cols + c);
-                float fa[V]; va.unpack(fa);
-#pragma unroll
-                for (int j = 0; j < V; ++j) fg[j] += fa[j];
+                const float d = fg[j] * (hs ? 1.f + sc[j] : 1.f) * (hg ? g[j] : 1.f);
+                fg[j] = rs * (d - s1 - xhat * s2) + (ha ? fa[j] : 0.f);
             }
             vg.pack(fg); vg.store(o + c);
-        };
-        if (cached) {
-#pragma unroll
-            for (int k = 0; k < RC; ++k) {
-                const int c = (sub + k * LPR) * V;
-                if (c < cols) pass2(c, k, rx[k], rg[k]);
-            }
-        } else {
-            for (int c = sub * V; c < cols; c += LPR * V) { Vec16<T> vx, vg; vx.load(xr + c); vg.load(gr + c); pass2(c, 0, vx, vg); }
         }
     }
     if (FUSE) {
@@ -554,18 +627,17 @@ __global__ void __launch_bounds__(NB) lnmod_bwd_dx_kernel(const T* __restrict__ 
         float* o0 = p0 + (grp * slabs + slab) * (long)cols;
         float* o1 = p1 + (grp * slabs + slab) * (long)cols;
 #pragma unroll
-        for (int k = 0; k < RC; ++k) {
-            if (k * LPR * V >= cols) break;           // block-uniform
+        for (int k = 0; k < NA; ++k) {
             if (k) __syncthreads();
 #pragma unroll
             for (int j = 0; j < V; ++j) { red[0][wave][sub * V + j] = a0[k][j]; red[1][wave][sub * V + j] = a1[k][j]; }
             __syncthreads();
-            for (int cc = threadIdx.x; cc < LPR * V; cc += NB) {
-                const int c = k * LPR * V + cc;
+            for (int cc2 = threadIdx.x; cc2 < LPR * V; cc2 += NB) {
+                const int c = k * LPR * V + cc2;
                 if (c < cols) {
                     float u0 = 0.f, u1 = 0.f;
 #pragma unroll
-                    for (int w = 0; w < RPB; ++w) { u0 += red[0][w][cc]; u1 += red[1][w][cc]; }
+                    for (int w = 0; w < RPB; ++w) { u0 += red[0][w][cc2]; u1 += red[1][w][cc2]; }
                     o0[c] = u0; o1[c] = u1;
                 }
             }
@@ -700,7 +772,7 @@ int dpipe_norm_slabs(long rows_per_group) {
 
 int dpipe_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, long rows, int cols, float eps, int dtype, int wdtype, void* stream) {
     const int V = dtype == DPIPE_BF16 ? 8 : 4;
-    if (!x || !y || rows <= 0 || cols <= 0 || (cols % V) != 0) BAD("dpipe_rmsnorm_fwd: cols must be a multiple of the 16-byte vector");
+    if (!x || !y || rows <= 0 || cols <= 0 || (cols % V) != 0 || !aligned16(w)) BAD("dpipe_rmsnorm_fwd: cols must be a multiple of the 16-byte vector, the weight 16-byte aligned");
     hipStream_t s = STREAM(stream);
     const int lpr = pick_lpr(cols, V);
     const unsigned grid = (unsigned)cdiv(rows, NB / lpr);
@@ -715,7 +787,7 @@ int dpipe_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, long r
 int dpipe_rmsnorm_bwd(const void* x, const void* w, const void* gy, const float* rstd, void* gx, void* dw, float* workspace,
                       long rows, int cols, int dtype, int wdtype, int accumulate_params, void* stream) {
     const int V = dtype == DPIPE_BF16 ? 8 : 4;
-    if (!x || !gy || !rstd || !gx || rows <= 0 || cols <= 0 || (cols % V) != 0) BAD("dpipe_rmsnorm_bwd: bad argument");
+    if (!x || !gy || !rstd || !gx || rows <= 0 || cols <= 0 || (cols % V) != 0 || !aligned16(w)) BAD("dpipe_rmsnorm_bwd: bad argument");
     if (dw && !workspace) BAD("dpipe_rmsnorm_bwd: workspace required for dw");
     hipStream_t s = STREAM(stream);
     const int lpr = pick_lpr(cols, V);
@@ -746,7 +818,7 @@ int dpipe_rmsnorm_rope_fwd(const void* x, const void* w, const float* cos_t, con
                            int groups_per_token, long token_offset, long rope_tokens, long x_token_stride, float eps, int dtype, int wdtype, void* stream) {
     const int V = dtype == DPIPE_BF16 ? 8 : 4;
     RopeGeom rg;
-    if (!x || !y || rows <= 0 || cols <= 0 || (cols % V) != 0 || (head_dim % V) != 0 || (x_token_stride % V) != 0 ||
+    if (!x || !y || rows <= 0 || cols <= 0 || (cols % V) != 0 || (head_dim % V) != 0 || (x_token_stride % V) != 0 || !aligned16(w) ||
         !rope_geom(rg, cos_t, sin_t, rows, cols, head_dim, S, groups_per_token, token_offset, rope_tokens, x_token_stride)) BAD("dpipe_rmsnorm_rope_fwd: bad argument");
     hipStream_t s = STREAM(stream);
     const int lpr = pick_lpr(cols, V);
@@ -764,7 +836,7 @@ int dpipe_rmsnorm_rope_bwd(const void* x, const void* w, const void* gy, const f
                            int wdtype, int accumulate_params, void* stream) {
     const int V = dtype == DPIPE_BF16 ? 8 : 4;
     RopeGeom rg;
-    if (!x || !gy || !rstd || !gx || rows <= 0 || cols <= 0 || (cols % V) != 0 || (head_dim % V) != 0 || (x_token_stride % V) != 0 ||
+    if (!x || !gy || !rstd || !gx || rows <= 0 || cols <= 0 || (cols % V) != 0 || (head_dim % V) != 0 || (x_token_stride % V) != 0 || !aligned16(w) ||
         !rope_geom(rg, cos_t, sin_t, rows, cols, head_dim, S, groups_per_token, token_offset, rope_tokens, x_token_stride)) BAD("dpipe_rmsnorm_rope_bwd: bad argument");
     if (dw && !workspace) BAD("dpipe_rmsnorm_rope_bwd: workspace required for dw");
     hipStream_t s = STREAM(stream);
@@ -789,8 +861,12 @@ int dpipe_lnmod_fwd(const void* x, const void* gamma, const void* beta, const vo
     const int V = dtype == DPIPE_BF16 ? 8 : 4;
     if (!x || !y || rows <= 0 || cols <= 0 || (cols % V) != 0 || rows_per_mod <= 0) BAD("dpipe_lnmod_fwd: bad argument");
     hipStream_t s = STREAM(stream);
+    if (!aligned16(x) || !aligned16(y) || !aligned16(gamma) || !aligned16(beta) || !aligned16(scale) || !aligned16(shift)) BAD("dpipe_lnmod_fwd: operands must be 16-byte aligned");
     const unsigned grid = (unsigned)cdiv(rows, NB / 64);
-#define LNFWD(TT, WW, MM) lnmod_fwd_kernel<TT, WW, MM, 64><<<grid, NB, 0, s>>>((const TT*)x, (const WW*)gamma, (const WW*)beta, (const MM*)scale, (const MM*)shift, (TT*)y, mean, rstd, rows, cols, rows_per_mod, eps)
+    const int nk = cols <= 64 * V * 4 ? (int)cdiv(cols, 64 * V) : 0;      // vectors per lane when the row stays in registers (see lnmod_fwd_kernel)
+#define LNFWD_K(TT, WW, MM, KK) lnmod_fwd_kernel<TT, WW, MM, 64, KK><<<grid, NB, 0, s>>>((const TT*)x, (const WW*)gamma, (const WW*)beta, (const MM*)scale, (const MM*)shift, (TT*)y, mean, rstd, rows, cols, rows_per_mod, eps)
+#define LNFWD(TT, WW, MM) do { switch (nk) { case 1: LNFWD_K(TT, WW, MM, 1); break; case 2: LNFWD_K(TT, WW, MM, 2); break; case 3: LNFWD_K(TT, WW, MM, 3); break; \
+    case 4: LNFWD_K(TT, WW, MM, 4); break; default: LNFWD_K(TT, WW, MM, 0); } } while (0)
     if (dtype == DPIPE_BF16) {
         if (wdtype == DPIPE_BF16 && mdtype == DPIPE_BF16) LNFWD(bf16_t, bf16_t, bf16_t);
         else if (wdtype == DPIPE_BF16) LNFWD(bf16_t, bf16_t, float);
@@ -799,6 +875,7 @@ int dpipe_lnmod_fwd(const void* x, const void* gamma, const void* beta, const vo
     } else if (dtype == DPIPE_F32 && wdtype == DPIPE_F32 && mdtype == DPIPE_F32) LNFWD(float, float, float);
     else { set_last_error("dpipe_lnmod_fwd: dtype combination"); return DPIPE_ERR_UNSUPPORTED; }
 #undef LNFWD
+#undef LNFWD_K
     return check_launch("dpipe_lnmod_fwd");
 }
 
@@ -811,6 +888,9 @@ int dpipe_lnmod_bwd(const void* x, const void* gy, const void* gamma, const void
     if (!x || !gy || !mean || !rstd || !gx || rows <= 0 || cols <= 0 || (cols % V) != 0 || rows_per_mod <= 0 || (rows % rows_per_mod) != 0)
         BAD("dpipe_lnmod_bwd: bad argument");
     if ((dgamma || dscale) && !workspace) BAD("dpipe_lnmod_bwd: workspace required");
+    if (!aligned16(x) || !aligned16(gy) || !aligned16(gx) || !aligned16(gx_add) || !aligned16(gamma) || !aligned16(beta) || !aligned16(scale))
+        BAD("dpipe_lnmod_bwd: operands must be 16-byte aligned");
+    const int nk = cols <= 64 * V * 4 ? (int)cdiv(cols, 64 * V) : 0;
     hipStream_t s = STREAM(stream);
     const unsigned grid = (unsigned)cdiv(rows, NB / 64);
     const long groups = rows / rows_per_mod;
@@ -824,17 +904,22 @@ int dpipe_lnmod_bwd(const void* x, const void* gy, const void* gamma, const void
     const int rw = rw_env == 1 || rw_env == 4 ? rw_env : (rows_per_mod > 2048 ? 4 : 1);
     const bool fuse_ok = cols <= vec_cols && ((dgamma != nullptr) != (dscale != nullptr)) && (groups == 1 || rows_per_mod % (4 * rw) == 0) && lnmod_fuse_enabled();
     const int fslabs = fuse_ok ? (int)cdiv(rows_per_mod, 4 * rw) : 0;
+#define LNBWD_FUSED_K(TT, WW, MM, FU, RWW, KK) \
+    lnmod_bwd_dx_kernel<TT, WW, MM, 64, KK, FU, RWW><<<(unsigned)cdiv(rows, 4 * RWW), NB, 0, s>>>((const TT*)x, (const TT*)gy, (const WW*)gamma, (const MM*)scale, mean, rstd, (TT*)gx, \
+        (const TT*)gx_add, rows, cols, rows_per_mod, (const WW*)beta, p0, p1, fslabs)
 #define LNBWD_FUSED(TT, WW, MM, FU, RWW) do { \
     float* p0 = workspace; float* p1 = workspace + groups * fslabs * (long)cols; \
-    lnmod_bwd_dx_kernel<TT, WW, MM, 64, FU, RWW><<<(unsigned)cdiv(rows, 4 * RWW), NB, 0, s>>>((const TT*)x, (const TT*)gy, (const WW*)gamma, (const MM*)scale, mean, rstd, (TT*)gx, \
-        (const TT*)gx_add, rows, cols, rows_per_mod, (const WW*)beta, p0, p1, fslabs); \
+    switch (nk) { case 1: LNBWD_FUSED_K(TT, WW, MM, FU, RWW, 1); break; case 2: LNBWD_FUSED_K(TT, WW, MM, FU, RWW, 2); break; \
+                  case 3: LNBWD_FUSED_K(TT, WW, MM, FU, RWW, 3); break; default: LNBWD_FUSED_K(TT, WW, MM, FU, RWW, 4); } \
     if (FU == 1) slabsum2p_kernel<WW><<<dim3((unsigned)cdiv(cols, 32), 1), NB, 0, s>>>(p0, p1, (WW*)dgamma, (WW*)dbeta, cols, (int)(groups * fslabs), accumulate_params); \
     else slabsum2p_kernel<MM><<<dim3((unsigned)cdiv(cols, 32), (unsigned)groups), NB, 0, s>>>(p0, p1, (MM*)dscale, (MM*)dshift, cols, fslabs, 0); \
     } while (0)
+#define LNBWD_DX_K(TT, WW, MM, KK) lnmod_bwd_dx_kernel<TT, WW, MM, 64, KK><<<grid, NB, 0, s>>>((const TT*)x, (const TT*)gy, (const WW*)gamma, (const MM*)scale, mean, rstd, (TT*)gx, (const TT*)gx_add, rows, cols, rows_per_mod)
 #define LNBWD(TT, WW, MM) do { \
     if (fuse_ok && dgamma) { if (rw == 4) LNBWD_FUSED(TT, WW, MM, 1, 4); else LNBWD_FUSED(TT, WW, MM, 1, 1); break; } \
     if (fuse_ok && dscale) { if (rw == 4) LNBWD_FUSED(TT, WW, MM, 2, 4); else LNBWD_FUSED(TT, WW, MM, 2, 1); break; } \
-    lnmod_bwd_dx_kernel<TT, WW, MM, 64><<<grid, NB, 0, s>>>((const TT*)x, (const TT*)gy, (const WW*)gamma, (const MM*)scale, mean, rstd, (TT*)gx, (const TT*)gx_add, rows, cols, rows_per_mod); \
+    switch (nk) { case 1: LNBWD_DX_K(TT, WW, MM, 1); break; case 2: LNBWD_DX_K(TT, WW, MM, 2); break; case 3: LNBWD_DX_K(TT, WW, MM, 3); break; \
+                  case 4: LNBWD_DX_K(TT, WW, MM, 4); break; default: LNBWD_DX_K(TT, WW, MM, 0); } \
     if (dscale) { \
         float* p0 = workspace; float* p1 = workspace + groups * slabs_mod * (long)cols; \
         dim3 g2((unsigned)cdiv(cols / V, CR_CT), slabs_mod, (unsigned)groups); \
@@ -858,6 +943,8 @@ int dpipe_lnmod_bwd(const void* x, const void* gy, const void* gamma, const void
     else { set_last_error("dpipe_lnmod_bwd: dtype combination"); return DPIPE_ERR_UNSUPPORTED; }
 #undef LNBWD
 #undef LNBWD_FUSED
+#undef LNBWD_FUSED_K
+#undef LNBWD_DX_K
     return check_launch("dpipe_lnmod_bwd");
 }
 

@@ -17,6 +17,13 @@ def _contig(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _al(t):
+    """Read-only per-column operand (norm weight / bias, modulation row, gate, bypass gradient) at a 16-byte aligned address: the kernels read these as
+    16-byte vectors (csrc/dpipe_common.h, PVec).  Parameters and fresh tensors are aligned already; an odd view (a slice at an offset that is not a multiple
+    of 8 elements) is copied once."""
+    return t if t is None or t.data_ptr() % 16 == 0 else t.clone()
+
+
 def _rows2d(x):
     """View x as [rows, cols] with a contiguous last dim and uniform row stride."""
     x2 = x.reshape(-1, x.shape[-1])
@@ -674,7 +681,7 @@ class _GatedResidualFn(Function):
             gc = _contig(gate).reshape(-1, D)
             rows_per_gate = rows // gc.shape[0]
         out = torch.empty_like(xc)
-        check(lib().dpipe_gated_residual_fwd(ptr(xc), ptr(yc), ptr(gc), ptr(out), rows, D, rows_per_gate,
+        check(lib().dpipe_gated_residual_fwd(ptr(xc), ptr(yc), ptr(_al(gc)), ptr(out), rows, D, rows_per_gate,
                                              dtype_code(xc.dtype), dtype_code(gc.dtype) if gc is not None else dtype_code(xc.dtype),
                                              stream()), 'gated_residual_fwd')
         ctx.save_for_backward(yc, gc)
@@ -716,7 +723,7 @@ class _RMSNormFn(Function):
         y = torch.empty_like(x2)
         rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
         wd = dtype_code(weight.dtype) if weight is not None else dtype_code(x.dtype)
-        check(lib().dpipe_rmsnorm_fwd(ptr(x2), ptr(weight), ptr(y), ptr(rstd), rows, cols, eps, dtype_code(x.dtype), wd, stream()), 'rmsnorm_fwd')
+        check(lib().dpipe_rmsnorm_fwd(ptr(x2), ptr(_al(weight)), ptr(y), ptr(rstd), rows, cols, eps, dtype_code(x.dtype), wd, stream()), 'rmsnorm_fwd')
         ctx.save_for_backward(x2, weight, rstd)
         ctx.shape = x.shape
         return y.view(x.shape)
@@ -736,7 +743,7 @@ class _RMSNormFn(Function):
                 dw = torch.empty_like(weight)
             ws = torch.empty(lib().dpipe_norm_slabs(rows) * cols, device=x2.device, dtype=torch.float32)
         wd = dtype_code(weight.dtype) if weight is not None else dtype_code(x2.dtype)
-        check(lib().dpipe_rmsnorm_bwd(ptr(x2), ptr(weight), ptr(gy2), ptr(rstd), ptr(gx), ptr(dw), ptr(ws), rows, cols,
+        check(lib().dpipe_rmsnorm_bwd(ptr(x2), ptr(_al(weight)), ptr(gy2), ptr(rstd), ptr(gx), ptr(dw), ptr(ws), rows, cols,
                                       dtype_code(x2.dtype), wd, _acc_all(fused, dw), stream()), 'rmsnorm_bwd')
         return gx.view(ctx.shape), (None if fused else dw), None
 
@@ -770,7 +777,7 @@ class _LNModFn(Function):
         y = torch.empty_like(x2)
         mean = torch.empty(rows, device=x.device, dtype=torch.float32)
         rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
-        check(lib().dpipe_lnmod_fwd(ptr(x2), ptr(gamma), ptr(beta), ptr(sc), ptr(sh), ptr(y), ptr(mean), ptr(rstd), rows, cols,
+        check(lib().dpipe_lnmod_fwd(ptr(x2), ptr(_al(gamma)), ptr(_al(beta)), ptr(_al(sc)), ptr(_al(sh)), ptr(y), ptr(mean), ptr(rstd), rows, cols,
                                     rows_per_mod, eps, dtype_code(x.dtype), wdt, mdt, stream()), 'lnmod_fwd')
         ctx.save_for_backward(x2, gamma, beta, sc, mean, rstd)
         ctx.meta = (x.shape, None if scale is None else scale.shape, None if shift is None else shift.shape,
@@ -812,9 +819,9 @@ class _LNModFn(Function):
         ws = None
         if dgamma is not None or need_mod:
             ws = torch.empty(lib().dpipe_lnmod_workspace_floats(rows, cols, rows_per_mod), device=x2.device, dtype=torch.float32)
-        check(lib().dpipe_lnmod_bwd(ptr(x2), ptr(gy2), ptr(gamma), ptr(beta), ptr(sc), ptr(mean), ptr(rstd), ptr(gx),
+        check(lib().dpipe_lnmod_bwd(ptr(x2), ptr(gy2), ptr(_al(gamma)), ptr(_al(beta)), ptr(_al(sc)), ptr(mean), ptr(rstd), ptr(gx),
                                     ptr(dgamma), ptr(dbeta), ptr(dscale), ptr(dshift), ptr(ws), rows, cols, rows_per_mod,
-                                    dtype_code(x2.dtype), wdt, mdt, _acc_all(fused, dgamma, dbeta), ptr(gadd), stream()), 'lnmod_bwd')
+                                    dtype_code(x2.dtype), wdt, mdt, _acc_all(fused, dgamma, dbeta), ptr(_al(gadd)), stream()), 'lnmod_bwd')
         g_scale = dscale.view(scale_shape) if scale_shape is not None else None
         g_shift = dshift.view(shift_shape) if shift_shape is not None else None
         if fused:
@@ -961,7 +968,7 @@ class _GroupNormNHWCFn(Function):
         rstd = torch.empty_like(mean)
         ws = torch.empty(lib().dpipe_groupnorm_nhwc_workspace_floats(N, C, HW, num_groups), device=x.device, dtype=torch.float32)
         wdt = dtype_code(weight.dtype) if weight is not None else dtype_code(x.dtype)
-        check(lib().dpipe_groupnorm_nhwc_fwd(ptr(xv), ptr(weight), ptr(bias), ptr(y), ptr(mean), ptr(rstd), ptr(ws), N, C, HW, num_groups, float(eps),
+        check(lib().dpipe_groupnorm_nhwc_fwd(ptr(xv), ptr(_al(weight)), ptr(_al(bias)), ptr(y), ptr(mean), ptr(rstd), ptr(ws), N, C, HW, num_groups, float(eps),
                                              ACT[act], dtype_code(x.dtype), wdt, stream()), 'groupnorm_nhwc_fwd')
         ctx.save_for_backward(xv, weight, bias, mean, rstd)
         ctx.meta = (num_groups, act, wdt)
@@ -993,8 +1000,8 @@ class _GroupNormNHWCFn(Function):
                 dgamma = torch.empty_like(weight)
                 dbeta = torch.empty_like(bias) if bias is not None else None
         ws = torch.empty(lib().dpipe_groupnorm_nhwc_workspace_floats(N, C, H * W, G), device=xv.device, dtype=torch.float32)
-        check(lib().dpipe_groupnorm_nhwc_bwd(ptr(xv), ptr(gyv), ptr(weight), ptr(bias), ptr(mean), ptr(rstd), ptr(gx), ptr(dgamma), ptr(dbeta), ptr(ws),
-                                             N, C, H * W, G, ACT[act], dtype_code(xv.dtype), wdt, _acc_all(fused, dgamma, dbeta), ptr(gadd), stream()), 'groupnorm_nhwc_bwd')
+        check(lib().dpipe_groupnorm_nhwc_bwd(ptr(xv), ptr(gyv), ptr(_al(weight)), ptr(_al(bias)), ptr(mean), ptr(rstd), ptr(gx), ptr(dgamma), ptr(dbeta), ptr(ws),
+                                             N, C, H * W, G, ACT[act], dtype_code(xv.dtype), wdt, _acc_all(fused, dgamma, dbeta), ptr(_al(gadd)), stream()), 'groupnorm_nhwc_bwd')
         if fused:
             dgamma = dbeta = None
         return gx.permute(0, 3, 1, 2), None, dgamma, dbeta, None, None, None
@@ -1228,7 +1235,7 @@ class _RMSNormRopeFn(Function):
         y = torch.empty((B, S, H, D), device=x.device, dtype=x.dtype)
         rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
         wd = dtype_code(weight.dtype) if weight is not None else dtype_code(x.dtype)
-        check(lib().dpipe_rmsnorm_rope_fwd(ptr(x), ptr(weight), ptr(cos), ptr(sin), ptr(y), ptr(rstd), rows, cols, D, S, groups, int(token_offset), rt, x.stride(1), float(eps),
+        check(lib().dpipe_rmsnorm_rope_fwd(ptr(x), ptr(_al(weight)), ptr(cos), ptr(sin), ptr(y), ptr(rstd), rows, cols, D, S, groups, int(token_offset), rt, x.stride(1), float(eps),
                                            dtype_code(x.dtype), wd, stream()), 'rmsnorm_rope_fwd')
         ctx.save_for_backward(x, weight, rstd, cos, sin)
         ctx.meta = (rows, cols, D, S, groups, int(token_offset), rt)
@@ -1249,7 +1256,7 @@ class _RMSNormRopeFn(Function):
                 dw = torch.empty_like(weight)
             ws = torch.empty(lib().dpipe_norm_slabs(rows) * cols, device=gy.device, dtype=torch.float32)
         wd = dtype_code(weight.dtype) if weight is not None else dtype_code(x.dtype)
-        check(lib().dpipe_rmsnorm_rope_bwd(ptr(x), ptr(weight), ptr(gy), ptr(rstd), ptr(cos), ptr(sin), ptr(gx), ptr(dw), ptr(ws), rows, cols, D, S, groups, tok_off, rt,
+        check(lib().dpipe_rmsnorm_rope_bwd(ptr(x), ptr(_al(weight)), ptr(gy), ptr(rstd), ptr(cos), ptr(sin), ptr(gx), ptr(dw), ptr(ws), rows, cols, D, S, groups, tok_off, rt,
                                            x.stride(1), dtype_code(x.dtype), wd, _acc_all(fused, dw), stream()), 'rmsnorm_rope_bwd')
         return gx, (None if fused else dw), None, None, None, None, None, None
 
