@@ -1069,6 +1069,7 @@ int dpipe_attn_fwd(const void* q, const void* k, const void* v, void* o, float* 
                    long v_ss, long v_sh, long o_sb, long o_ss, long o_sh, float scale, int causal, float* o_f32, void* stream) {
     if (!q || !k || !v || !o || !lse || B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) { set_last_error("dpipe_attn_fwd: bad argument"); return DPIPE_ERR_ARG; }
     if (D != 64 && D != 128) { set_last_error("dpipe_attn_fwd: head dim must be 64 or 128"); return DPIPE_ERR_UNSUPPORTED; }
+    if (ablated(ABL_ATTN)) return DPIPE_OK;                                        // (debug switch: runtime.hip)
     if (!strides_ok(q, q_sb, q_ss, q_sh) || !strides_ok(k, k_sb, k_ss, k_sh) || !strides_ok(v, v_sb, v_ss, v_sh) || !strides_ok(o, o_sb, o_ss, o_sh)) {
         set_last_error("dpipe_attn_fwd: tensors must be 16-byte aligned with strides multiple of 8 elements"); return DPIPE_ERR_ARG; }
     AttnParams p = {};
@@ -1126,6 +1127,7 @@ int dpipe_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
     if (!q || !k || !v || !o || !dout || !lse || !delta || !dq || !dk || !dv || B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0) {
         set_last_error("dpipe_attn_bwd: bad argument"); return DPIPE_ERR_ARG; }
     if (D != 64 && D != 128) { set_last_error("dpipe_attn_bwd: head dim must be 64 or 128"); return DPIPE_ERR_UNSUPPORTED; }
+    if (ablated(ABL_ATTN)) return DPIPE_OK;
     if (!strides_ok(q, q_sb, q_ss, q_sh) || !strides_ok(k, k_sb, k_ss, k_sh) || !strides_ok(v, v_sb, v_ss, v_sh) || !strides_ok(o, o_sb, o_ss, o_sh) ||
         !strides_ok(dout, do_sb, do_ss, do_sh) || !strides_ok(dq, dq_sb, dq_ss, dq_sh) || !strides_ok(dk, dk_sb, dk_ss, dk_sh) || !strides_ok(dv, dv_sb, dv_ss, dv_sh)) {
         set_last_error("dpipe_attn_bwd: tensors must be 16-byte aligned with strides multiple of 8 elements"); return DPIPE_ERR_ARG; }

@@ -65,6 +65,7 @@ int dpipe_conv2d_fwd(const void* x, long ldx, const void* w, const void* bias, c
                      int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int upsample, int act, int flags,
                      void* ws, long ws_bytes, int tile_hint, void* stream) {
     if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || pad < 0) BAD("dpipe_conv2d_fwd: bad argument");
+    if (ablated(ABL_CONV)) return DPIPE_OK;
     const int sl = ilog2_exact(stride), ul = ilog2_exact(upsample);
     if (sl < 0 || ul < 0) UNSUP("dpipe_conv2d_fwd: stride and upsample must be 1 or 2");
     if (Cin % 64 || ldx % 8 || ldy % 4 || !al16(x) || !al16(w)) UNSUP("dpipe_conv2d_fwd: needs Cin % 64 == 0, 16-byte aligned operands, ldx % 8 == 0");
@@ -93,6 +94,7 @@ int dpipe_conv2d_dgrad(const void* dy, long lddy, const void* w, void* dx, long 
                        int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int flags,
                        void* ws, long ws_bytes, int tile_hint, void* stream) {
     if (!dy || !w || !dx || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || pad < 0) BAD("dpipe_conv2d_dgrad: bad argument");
+    if (ablated(ABL_CONV)) return DPIPE_OK;
     const int sl = ilog2_exact(stride);
     if (sl < 0) UNSUP("dpipe_conv2d_dgrad: stride must be 1 or 2");
     if (Cout % 64 || Cin % 8 || lddy % 8 || lddx % 4 || !al16(dy) || !al16(w)) UNSUP("dpipe_conv2d_dgrad: needs Cout % 64 == 0, Cin % 8 == 0, aligned operands");
@@ -111,6 +113,7 @@ int dpipe_conv2d_wgrad(const void* dy, long lddy, const void* x, long ldx, void*
                        int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int upsample,
                        int accumulate, int bias_accumulate, int out_f32, void* ws, long ws_bytes, int tile_hint, void* stream) {
     if (!dy || !x || !dw || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || pad < 0) BAD("dpipe_conv2d_wgrad: bad argument");
+    if (ablated(ABL_CONV)) return DPIPE_OK;
     const int sl = ilog2_exact(stride), ul = ilog2_exact(upsample);
     if (sl < 0 || ul < 0) UNSUP("dpipe_conv2d_wgrad: stride and upsample must be 1 or 2");
     if (Cin % 8 || Cout % 8 || lddy % 8 || ldx % 8 || !al16(dy) || !al16(x)) UNSUP("dpipe_conv2d_wgrad: needs Cin % 8 == 0, Cout % 8 == 0, aligned operands");

@@ -25,6 +25,10 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 void set_last_error(const char* msg);
 int option(int id, int dflt);          // runtime.hip: dpipe_set_option value, else the option's environment variable, else dflt
 int check_launch(const char* what);
+// debug ablation switches (runtime.hip): classes 1 GEMM, 2 convolution, 4 attention, 8 LayerNorm / RMSNorm, 16 GroupNorm, 32 element-wise, 64 step end
+enum { ABL_GEMM = 1, ABL_CONV = 2, ABL_ATTN = 4, ABL_LN = 8, ABL_GN = 16, ABL_EW = 32, ABL_STEP = 64 };
+bool ablated(int cls);
+int ablate_gemm_kdiv();
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
     return __uint_as_float(((uint32_t)v) << 16);

@@ -510,7 +510,7 @@ int dpipe_upsample2x_adjoint(const void* src, void* dst, int B, int H, int W, in
 
 int dpipe_act_fwd(const void* x, void* y, long n, int dtype, int act, void* stream) {
     if (!x || !y || n < 0) { set_last_error("dpipe_act_fwd: bad argument"); return DPIPE_ERR_ARG; }
-    if (n == 0) return DPIPE_OK;
+    if (n == 0 || ablated(ABL_EW)) return DPIPE_OK;
     if (dtype == DPIPE_BF16) act_fwd_kernel<bf16_t><<<stream_grid(n / 8 + 1, EW_BLOCK), EW_BLOCK, 0, STREAM(stream)>>>((const bf16_t*)x, (bf16_t*)y, n, act);
     else if (dtype == DPIPE_F32) act_fwd_kernel<float><<<stream_grid(n / 4 + 1, EW_BLOCK), EW_BLOCK, 0, STREAM(stream)>>>((const float*)x, (float*)y, n, act);
     else { set_last_error("dpipe_act_fwd: dtype"); return DPIPE_ERR_UNSUPPORTED; }
@@ -519,7 +519,7 @@ int dpipe_act_fwd(const void* x, void* y, long n, int dtype, int act, void* stre
 
 int dpipe_act_bwd(const void* x, const void* gy, void* gx, long n, int dtype, int act, void* stream) {
     if (!x || !gy || !gx || n < 0) { set_last_error("dpipe_act_bwd: bad argument"); return DPIPE_ERR_ARG; }
-    if (n == 0) return DPIPE_OK;
+    if (n == 0 || ablated(ABL_EW)) return DPIPE_OK;
     if (dtype == DPIPE_BF16) act_bwd_kernel<bf16_t><<<stream_grid(n / 8 + 1, EW_BLOCK), EW_BLOCK, 0, STREAM(stream)>>>((const bf16_t*)x, (const bf16_t*)gy, (bf16_t*)gx, n, act);
     else if (dtype == DPIPE_F32) act_bwd_kernel<float><<<stream_grid(n / 4 + 1, EW_BLOCK), EW_BLOCK, 0, STREAM(stream)>>>((const float*)x, (const float*)gy, (float*)gx, n, act);
     else { set_last_error("dpipe_act_bwd: dtype"); return DPIPE_ERR_UNSUPPORTED; }
@@ -556,6 +556,7 @@ int dpipe_rowcombine_bwd(const void* gout, int gout_dtype, void* gy, void* dbias
 int dpipe_geglu_fwd(const void* x, void* y, long rows, long H, int dtype, int act, void* stream) {
     const int V = dtype == DPIPE_BF16 ? 8 : 4;
     if (!x || !y || rows <= 0 || H <= 0 || (H % V) != 0) { set_last_error("dpipe_geglu_fwd: H must be a multiple of the 16-byte vector"); return DPIPE_ERR_ARG; }
+    if (ablated(ABL_EW)) return DPIPE_OK;
     int grid = stream_grid(rows * (H / V), EW_BLOCK);
     if (dtype == DPIPE_BF16) geglu_fwd_kernel<bf16_t><<<grid, EW_BLOCK, 0, STREAM(stream)>>>((const bf16_t*)x, (bf16_t*)y, rows, H, act);
     else geglu_fwd_kernel<float><<<grid, EW_BLOCK, 0, STREAM(stream)>>>((const float*)x, (float*)y, rows, H, act);
@@ -565,6 +566,7 @@ int dpipe_geglu_fwd(const void* x, void* y, long rows, long H, int dtype, int ac
 int dpipe_geglu_bwd(const void* x, const void* gy, void* gx, long rows, long H, int dtype, int act, void* stream) {
     const int V = dtype == DPIPE_BF16 ? 8 : 4;
     if (!x || !gy || !gx || rows <= 0 || H <= 0 || (H % V) != 0) { set_last_error("dpipe_geglu_bwd: bad argument"); return DPIPE_ERR_ARG; }
+    if (ablated(ABL_EW)) return DPIPE_OK;
     int grid = stream_grid(rows * (H / V), EW_BLOCK);
     if (dtype == DPIPE_BF16) geglu_bwd_kernel<bf16_t><<<grid, EW_BLOCK, 0, STREAM(stream)>>>((const bf16_t*)x, (const bf16_t*)gy, (bf16_t*)gx, rows, H, act);
     else geglu_bwd_kernel<float><<<grid, EW_BLOCK, 0, STREAM(stream)>>>((const float*)x, (const float*)gy, (float*)gx, rows, H, act);

@@ -265,6 +265,8 @@ int dpipe_gemm_ex(int dtype, int transA, int transB, int M, int N, int K,
                   void* stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch_outer <= 0 || batch_inner <= 0) { set_last_error("dpipe_gemm: bad argument"); return DPIPE_ERR_ARG; }
     if (dtype != DPIPE_BF16 && dtype != DPIPE_F32) { set_last_error("dpipe_gemm: dtype"); return DPIPE_ERR_UNSUPPORTED; }
+    if (ablated(ABL_GEMM)) return DPIPE_OK;                                        // (debug switch: runtime.hip)
+    if (ablate_gemm_kdiv() > 1 && K >= 128) { K = (K / ablate_gemm_kdiv() + 63) / 64 * 64; }
     const int V = dtype == DPIPE_BF16 ? 8 : 4;
     GemmParams p;
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
@@ -306,6 +308,7 @@ int dpipe_gemm_ex(int dtype, int transA, int transB, int M, int N, int K,
 
 int dpipe_gemm_group(const dpipe_gemm_desc* descs, int n, void* splitk_ws, long splitk_ws_bytes, int* launches_out, void* stream) {
     if (!descs || n <= 0 || n > 16) { set_last_error("dpipe_gemm_group: 1 <= n <= 16 descriptors"); return DPIPE_ERR_ARG; }
+    if (ablated(ABL_GEMM)) { if (launches_out) *launches_out = 0; return DPIPE_OK; }      // (debug switch: runtime.hip)
     GemmParams ps[16];
     int ta[16], tb[16];
     bool pipe[16];
@@ -316,7 +319,8 @@ int dpipe_gemm_group(const dpipe_gemm_desc* descs, int n, void* splitk_ws, long 
         if (d.dtype != DPIPE_BF16 && d.dtype != DPIPE_F32) { set_last_error("dpipe_gemm_group: dtype"); return DPIPE_ERR_UNSUPPORTED; }
         if (d.residual && d.residual == d.C && !d.accumulate) { set_last_error("dpipe_gemm_group: residual may not alias C"); return DPIPE_ERR_ARG; }
         GemmParams p;
-        p.A = d.A; p.B = d.B; p.C = d.C; p.bias = d.bias; p.M = d.M; p.N = d.N; p.K = d.K; p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc;
+        p.A = d.A; p.B = d.B; p.C = d.C; p.bias = d.bias; p.M = d.M; p.N = d.N; p.K = d.K; p.lda = d.lda;
+        if (ablate_gemm_kdiv() > 1 && p.K >= 128) p.K = (p.K / ablate_gemm_kdiv() + 63) / 64 * 64; p.ldb = d.ldb; p.ldc = d.ldc;
         p.sAo = p.sAi = p.sBo = p.sBi = p.sCo = p.sCi = 0;
         p.batch_inner = 1; p.alpha = d.alpha; p.act = d.act; p.accumulate = d.accumulate; p.out_f32 = d.out_f32;
         p.splitk = 1; p.ksteps = 0; p.ksteps_per_split = 0; p.slabs = nullptr; p.counters = nullptr;

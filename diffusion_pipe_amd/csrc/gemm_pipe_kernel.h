@@ -527,17 +527,49 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, char* const 
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        for (int s = 0; s < p.splitk; ++s) {
-            const float4* sl = slab0 + (long)s * TL::SLAB_F4;
+        // the slices' slabs, summed in slice order (deterministic).  Round 6: SLB slices per pass with every read of the pass in flight before the first add (the
+        // one-slice-per-iteration loop was a dependent round trip per slice: 4 - 8 of them in the last arriver of a 77-token linear); a pass past the last slice
+        // re-reads the last slab and skips the add.  SLB = 4 on the 64^2 tile (the split tiles of the step are almost all 64^2: 4 x 16 VGPRs of reads).
+        constexpr int SLB = TL::ACC_F4 <= 4 ? 4 : 1;      // (two slices per pass on the 128^2 tiles: 104 -> 108 VGPRs, a register allocation step the lanes feel -- left at one)
+        if constexpr (SLB == 1) {
+            for (int s = 0; s < p.splitk; ++s) {
+                const float4* sl = slab0 + (long)s * TL::SLAB_F4;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+                    for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 v = sl[((i * TN + j) * 4 + q) * TL::NT + threadIdx.x];
-                        acc[i][j][4 * q] += v.x; acc[i][j][4 * q + 1] += v.y; acc[i][j][4 * q + 2] += v.z; acc[i][j][4 * q + 3] += v.w;
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 v = sl[((i * TN + j) * 4 + q) * TL::NT + threadIdx.x];
+                            acc[i][j][4 * q] += v.x; acc[i][j][4 * q + 1] += v.y; acc[i][j][4 * q + 2] += v.z; acc[i][j][4 * q + 3] += v.w;
+                        }
+            }
+        } else {
+            for (int s = 0; s < p.splitk; s += SLB) {
+                float4 sv[SLB][TM * TN * 4];
+#pragma unroll
+                for (int t = 0; t < SLB; ++t) {
+                    const int ss = s + t < p.splitk ? s + t : p.splitk - 1;
+                    const float4* sl = slab0 + (long)ss * TL::SLAB_F4;
+#pragma unroll
+                    for (int x = 0; x < TM * TN * 4; ++x) sv[t][x] = sl[x * TL::NT + threadIdx.x];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < SLB; ++t) {
+                    if (s + t < p.splitk) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const float4 v = sv[t][(i * TN + j) * 4 + q];
+                                    acc[i][j][4 * q] += v.x; acc[i][j][4 * q + 1] += v.y; acc[i][j][4 * q + 2] += v.z; acc[i][j][4 * q + 3] += v.w;
+                                }
                     }
+                }
+            }
         }
     }
 
@@ -572,45 +604,46 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, char* const 
     // for each q = e >> 2 the lane holds 4 consecutive n of one output row.
     const long coff = zo * p.sCo + zi * p.sCi;
     const int h = lane >> 5;
-    // Batched epilogue (round 6), taken by every bf16-output launch whose rows allow 8-byte accesses (N % 4 == 0: the 4 columns a lane owns are inside or outside together):
-    // the operand reads of a 32 x 32 accumulator tile -- bias (hi / lo), residual, the old C of an accumulating launch: 4 lane groups x up to 4 reads of 8 bytes --
-    // are ALL issued before the first is used, and the next tile's reads before this tile's stores.  The general form below wraps every read in a wave-uniform `if`
-    // (operand present? vector legal?), which hipcc compiles to a branch with `s_waitcnt vmcnt(0)` behind each load: 8 groups x (bias + residual + old C) = up to 24
-    // DEPENDENT round trips per lane after the K loop, each also waiting for the previous group's store to be acknowledged (gfx9 counts stores in vmcnt) -- 5 - 12 us of a
-    // 25 - 60 us launch (ISA: profiles/r6m_gemm_epilogue_isa_before_after.txt).  Here an absent operand reads the zero pad (branch-free pointer select), rows past M are
-    // clamped to M - 1 and columns past N to 0 for the reads and skipped for the stores; the arithmetic order (alpha, bias hi, bias lo, activation, residual, old C) is the
-    // general form's, so results are bit-identical.
-    if (!p.out_f32 && p.vecA >= 2 && (p.N & 3) == 0 && (!p.bias || p.vecB >= 2) && (!p.residual || p.vecA >= 3)) {
-        const bool hb = p.bias != nullptr, hl = hb && p.bias_lo != 0, hr = p.residual != nullptr, ha = p.accumulate != 0;
+    // Batched epilogue (round 6), taken by the bf16-output launches of the 64^2 / 128^2 tiles that READ something in the epilogue (a bias, a residual, the old C of an
+    // accumulating launch) and whose rows allow 8-byte accesses (N % 4 == 0: the 4 columns a lane owns are inside or outside together): the reads of a 32 x 32
+    // accumulator tile -- 4 lane groups x up to 4 operands x 8 bytes -- are all issued before the first is used, and NO store is issued before the last read has
+    // returned (gfx9 counts stores in vmcnt: a read behind a store waits for the store's acknowledgement as well).  The general form below wraps every read in a
+    // wave-uniform `if` (operand present? vector legal?), which hipcc compiles to a branch with `s_waitcnt vmcnt(0)` behind each load: per lane 8 groups x (bias +
+    // residual + old C) dependent round trips, each behind the previous group's store (ISA: profiles/r6n_gemm_epilogue_isa.txt).  An absent operand reads the zero
+    // pad (branch-free pointer select), rows past M are clamped to M - 1 and columns past N to 0 for the reads and skipped for the stores; the arithmetic order
+    // (alpha, bias hi, bias lo, activation, residual, old C) is the general form's, so results are bit-identical.  A launch that reads nothing keeps the general
+    // form: its stores are fire-and-forget, and a first version that sent it through here (16 pad reads per tile ahead of the stores) cost every plain launch
+    // 1 - 4 us (profiles/r6n_gemm_ledger_epilogue_v1_{base,new}.jsonl: the ledger +4 %).
+    if (TM * TN <= 2 && !p.out_f32 && p.vecA >= 2 && (p.N & 3) == 0 && (!p.bias || p.vecB >= 2) && (!p.residual || p.vecA >= 3) &&
+        (p.bias || p.residual || p.accumulate)) {
+        const bool hb = p.bias != nullptr, hl = CONV != 0 && hb && p.bias_lo != 0, hr = p.residual != nullptr, ha = p.accumulate != 0;     // (hi / lo bias pairs: convolutions only)
         const uint2* pad = reinterpret_cast<const uint2*>(g_param_pad);
         const bf16_t* biasp = reinterpret_cast<const bf16_t*>(p.bias);
         const bf16_t* resp = reinterpret_cast<const bf16_t*>(p.residual);
         bf16_t* cp = reinterpret_cast<bf16_t*>(p.C);
         const int brows = p.bias_rows ? p.bias_rows : 0x7fffffff;       // one bias row for every output row: row index 0
-        constexpr int U = TM * TN;
-        struct EpiOps { uint2 b[4], l[4], r[4], o[4]; long idx[4]; bool ok[4]; };
-        EpiOps ops[2];
-        auto issue = [&](EpiOps& e, int u) {
+        constexpr int U = TM * TN <= 2 ? TM * TN : 1;
+        struct EpiOps { uint2 b[4], l[4], r[4], o[4]; };
+        uint2 outv[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
             const int i = u / TN, j = u % TN;
             const int m = m0 + wm0 + i * 32 + (lane & 31);
-            const bool mok = m < p.M;
-            const int mm = mok ? m : p.M - 1;
+            const int mm = m < p.M ? m : p.M - 1;
             const long brow = (long)(mm / brows) * p.N;
+            const int nb = n0 + wn0 + j * 32 + 4 * h;                  // group q covers columns nb + 8 q .. + 3
+            const long crow = coff + (long)mm * p.ldc, rrow = coff + (long)mm * p.ldr;
+            EpiOps e;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn0 + j * 32 + 8 * q + 4 * h;
-                const bool nok = n < p.N;
-                const int nn = nok ? n : 0;
-                e.ok[q] = mok && nok;
-                e.idx[q] = coff + (long)mm * p.ldc + nn;
+                const int n = nb + 8 * q;
+                const int nn = n < p.N ? n : 0;
                 e.b[q] = *(hb ? reinterpret_cast<const uint2*>(biasp + brow + nn) : pad);
-                e.l[q] = *(hl ? reinterpret_cast<const uint2*>(biasp + brow + nn + p.bias_lo) : pad);
-                e.r[q] = *(hr ? reinterpret_cast<const uint2*>(resp + coff + (long)mm * p.ldr + nn) : pad);
-                e.o[q] = *(ha ? reinterpret_cast<const uint2*>(cp + e.idx[q]) : pad);
+                if constexpr (CONV != 0) e.l[q] = *(hl ? reinterpret_cast<const uint2*>(biasp + brow + nn + p.bias_lo) : pad);
+                e.r[q] = *(hr ? reinterpret_cast<const uint2*>(resp + rrow + nn) : pad);
+                e.o[q] = *(ha ? reinterpret_cast<const uint2*>(cp + crow + nn) : pad);
             }
-        };
-        auto finish = [&](const EpiOps& e, int u) {
-            const int i = u / TN, j = u % TN;
+            __builtin_amdgcn_sched_barrier(0);          // the reads above stay above: the machine scheduler would sink them next to their uses
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float v[4];
@@ -620,7 +653,7 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, char* const 
                     v[0] += __uint_as_float(e.b[q].x << 16); v[1] += __uint_as_float(e.b[q].x & 0xffff0000u);
                     v[2] += __uint_as_float(e.b[q].y << 16); v[3] += __uint_as_float(e.b[q].y & 0xffff0000u);
                 }
-                if (hl) {
+                if constexpr (CONV != 0) if (hl) {
                     v[0] += __uint_as_float(e.l[q].x << 16); v[1] += __uint_as_float(e.l[q].x & 0xffff0000u);
                     v[2] += __uint_as_float(e.l[q].y << 16); v[3] += __uint_as_float(e.l[q].y & 0xffff0000u);
                 }
@@ -636,15 +669,19 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, char* const 
                     v[0] += __uint_as_float(e.o[q].x << 16); v[1] += __uint_as_float(e.o[q].x & 0xffff0000u);
                     v[2] += __uint_as_float(e.o[q].y << 16); v[3] += __uint_as_float(e.o[q].y & 0xffff0000u);
                 }
-                if (e.ok[q]) *reinterpret_cast<uint2*>(cp + e.idx[q]) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                outv[u][q] = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
             }
-        };
-        issue(ops[0], 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (u + 1 < U) issue(ops[(u + 1) & 1], u + 1);
-            __builtin_amdgcn_sched_barrier(0);          // the reads above stay above: the machine scheduler would sink them next to their uses
-            finish(ops[u & 1], u);
+            const int i = u / TN, j = u % TN;
+            const int m = m0 + wm0 + i * 32 + (lane & 31);
+            const int nb = n0 + wn0 + j * 32 + 4 * h;
+            bf16_t* crow = cp + coff + (long)m * p.ldc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (m < p.M && nb + 8 * q < p.N) *reinterpret_cast<uint2*>(crow + nb + 8 * q) = outv[u][q];
         }
         TL_STAMP(3);
         return;

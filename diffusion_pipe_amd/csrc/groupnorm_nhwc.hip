@@ -364,6 +364,7 @@ long dpipe_groupnorm_nhwc_workspace_floats(long N, int C, long HW, int G) {
 int dpipe_groupnorm_nhwc_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd, float* workspace,
                              long N, int C, long HW, int G, float eps, int act, int dtype, int wdtype, void* stream) {
     if (!x || !y || !mean || !rstd || !workspace || N <= 0 || C <= 0 || HW <= 0 || G <= 0 || C % G) BAD("dpipe_groupnorm_nhwc_fwd: bad argument");
+    if (ablated(ABL_GN)) return DPIPE_OK;
     const int V = dtype == DPIPE_BF16 ? 8 : 4;
     if ((dtype != DPIPE_BF16 && dtype != DPIPE_F32) || (wdtype != DPIPE_BF16 && wdtype != DPIPE_F32)) BAD("dpipe_groupnorm_nhwc_fwd: dtype");
     if (C % V || C / V > NB * MAXVI || ((uintptr_t)x & 15) || ((uintptr_t)y & 15) || !aligned16(gamma) || !aligned16(beta)) BAD("dpipe_groupnorm_nhwc_fwd: C must be a multiple of the 16-byte vector (<= 8192 channels), 16-byte aligned tensors");
@@ -386,6 +387,7 @@ int dpipe_groupnorm_nhwc_bwd(const void* x, const void* dy, const void* gamma, c
                              void* dx, void* dgamma, void* dbeta, float* workspace, long N, int C, long HW, int G, int act, int dtype, int wdtype,
                              int accumulate_params, const void* dx_add, void* stream) {
     if (!x || !dy || !dx || !mean || !rstd || !workspace || N <= 0 || C <= 0 || HW <= 0 || G <= 0 || C % G) BAD("dpipe_groupnorm_nhwc_bwd: bad argument");
+    if (ablated(ABL_GN)) return DPIPE_OK;
     const int V = dtype == DPIPE_BF16 ? 8 : 4;
     if ((dtype != DPIPE_BF16 && dtype != DPIPE_F32) || (wdtype != DPIPE_BF16 && wdtype != DPIPE_F32)) BAD("dpipe_groupnorm_nhwc_bwd: dtype");
     if (C % V || C / V > NB * MAXVI || C / G > NB || ((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || ((uintptr_t)dx & 15) || !aligned16(gamma) || !aligned16(beta) || !aligned16(dx_add)) BAD("dpipe_groupnorm_nhwc_bwd: alignment / channel count");

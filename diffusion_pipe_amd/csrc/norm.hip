@@ -860,6 +860,7 @@ int dpipe_lnmod_fwd(const void* x, const void* gamma, const void* beta, const vo
                     int dtype, int wdtype, int mdtype, void* stream) {
     const int V = dtype == DPIPE_BF16 ? 8 : 4;
     if (!x || !y || rows <= 0 || cols <= 0 || (cols % V) != 0 || rows_per_mod <= 0) BAD("dpipe_lnmod_fwd: bad argument");
+    if (ablated(ABL_LN)) return DPIPE_OK;
     hipStream_t s = STREAM(stream);
     if (!aligned16(x) || !aligned16(y) || !aligned16(gamma) || !aligned16(beta) || !aligned16(scale) || !aligned16(shift)) BAD("dpipe_lnmod_fwd: operands must be 16-byte aligned");
     const unsigned grid = (unsigned)cdiv(rows, NB / 64);
@@ -887,6 +888,7 @@ int dpipe_lnmod_bwd(const void* x, const void* gy, const void* gamma, const void
     const int V = dtype == DPIPE_BF16 ? 8 : 4;
     if (!x || !gy || !mean || !rstd || !gx || rows <= 0 || cols <= 0 || (cols % V) != 0 || rows_per_mod <= 0 || (rows % rows_per_mod) != 0)
         BAD("dpipe_lnmod_bwd: bad argument");
+    if (ablated(ABL_LN)) return DPIPE_OK;
     if ((dgamma || dscale) && !workspace) BAD("dpipe_lnmod_bwd: workspace required");
     if (!aligned16(x) || !aligned16(gy) || !aligned16(gx) || !aligned16(gx_add) || !aligned16(gamma) || !aligned16(beta) || !aligned16(scale))
         BAD("dpipe_lnmod_bwd: operands must be 16-byte aligned");

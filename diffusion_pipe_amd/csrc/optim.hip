@@ -93,7 +93,10 @@ __device__ __forceinline__ void kahan_apply(float& p, float& shift, float old) {
     p = pn;
 }
 
-template <typename T>
+// LN > 0: the lane count is static -- every read of a 16-byte element group (LN gradient vectors, p, m, v, the Kahan buffer) is issued before the first is
+// used (round 6: the runtime lane loop waited for each lane's load before it issued the next, five dependent round trips per group with 16 bytes per thread in
+// flight -- 4.5 - 4.7 TB/s; the pointers come from tables, i.e. these are flat loads, which count on both wait counters).  LN = 0: any lane count, the old loop.
+template <typename T, int LN>
 __global__ void __launch_bounds__(OPT_BLOCK) adamw_step_kernel(void* const* __restrict__ p_ptrs, void* const* __restrict__ m_ptrs, void* const* __restrict__ v_ptrs,
                                                               void* const* __restrict__ s_ptrs, void* const* __restrict__ g_ptrs, int lanes, const int* __restrict__ chunk_tensor,
                                                               const long* __restrict__ chunk_off, const int* __restrict__ chunk_len,
@@ -122,19 +125,38 @@ __global__ void __launch_bounds__(OPT_BLOCK) adamw_step_kernel(void* const* __re
             float gs[V];
 #pragma unroll
             for (int j = 0; j < V; ++j) gs[j] = 0.f;
-            for (int l = 0; l < lanes; ++l) {
-                Vec16<T> gv; gv.load(g[l] + e);
-                float f[V]; gv.unpack(f);
+            Vec16<T> pv, mv, vv, sv;
+            if constexpr (LN > 0) {
+                Vec16<T> gv[LN];
 #pragma unroll
-                for (int j = 0; j < V; ++j) gs[j] += f[j];
-                if (zero_grads) zero.store(g[l] + e);
+                for (int l = 0; l < LN; ++l) gv[l].load(g[l] + e);
+                pv.load(p + e); mv.load(m + e); vv.load(v + e);
+                sv.load(sh ? sh + e : p + e);                      // (no Kahan buffer: a second read of the parameter vector, branch-free)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int l = 0; l < LN; ++l) {
+                    float f[V]; gv[l].unpack(f);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) gs[j] += f[j];
+                }
+                if (zero_grads) {
+#pragma unroll
+                    for (int l = 0; l < LN; ++l) zero.store(g[l] + e);
+                }
+            } else {
+                for (int l = 0; l < lanes; ++l) {
+                    Vec16<T> gv; gv.load(g[l] + e);
+                    float f[V]; gv.unpack(f);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) gs[j] += f[j];
+                    if (zero_grads) zero.store(g[l] + e);
+                }
+                pv.load(p + e); mv.load(m + e); vv.load(v + e);
+                if (sh) sv.load(sh + e);
             }
-            Vec16<T> pv, mv, vv;
-            pv.load(p + e); mv.load(m + e); vv.load(v + e);
             float pf[V], mf[V], vf[V];
             pv.unpack(pf); mv.unpack(mf); vv.unpack(vf);
             if (sh) {
-                Vec16<T> sv; sv.load(sh + e);
                 float sf[V]; sv.unpack(sf);
 #pragma unroll
                 for (int j = 0; j < V; ++j) { const float old = pf[j]; adamw_update(pf[j], mf[j], vf[j], gs[j] * coef, h); kahan_apply<T>(pf[j], sf[j], old); }
@@ -474,6 +496,7 @@ extern "C" {
 int dpipe_adamw_sumsq(const void* const* g_ptrs, int lanes, const int* chunk_tensor, const long* chunk_off, const int* chunk_len, int nchunks,
                       int dtype, float* partials, float* out_sumsq, int accumulate, void* stream) {
     if (!partials || !out_sumsq || nchunks < 0 || lanes < 1 || lanes > MAX_LANES) { set_last_error("dpipe_adamw_sumsq: bad argument"); return DPIPE_ERR_ARG; }
+    if (ablated(ABL_STEP)) return DPIPE_OK;                                        // (debug switch: runtime.hip)
     hipStream_t s = STREAM(stream);
     if (nchunks > 0) {
         if (!g_ptrs || !chunk_tensor || !chunk_off || !chunk_len) { set_last_error("dpipe_adamw_sumsq: null table"); return DPIPE_ERR_ARG; }
@@ -489,18 +512,22 @@ static int adamw_step_impl(void* const* p_ptrs, void* const* m_ptrs, void* const
                            const long* chunk_off, const int* chunk_len, int nchunks, int dtype, float lr, float beta1, float beta2, float eps,
                            float weight_decay, float bias_correction1, float bias_correction2, const float* total_sumsq, float max_norm,
                            int zero_grads, void* stream) {
-    if (nchunks <= 0) return DPIPE_OK;
+    if (nchunks <= 0 || ablated(ABL_STEP)) return DPIPE_OK;
     if (!p_ptrs || !m_ptrs || !v_ptrs || !g_ptrs || !chunk_tensor || !chunk_off || !chunk_len || lanes < 1 || lanes > MAX_LANES ||
         bias_correction1 <= 0.f || bias_correction2 <= 0.f) {
         set_last_error("dpipe_adamw_step: bad argument"); return DPIPE_ERR_ARG;
     }
     AdamHyper h{lr, beta1, beta2, eps, weight_decay, bias_correction1, sqrtf(bias_correction2), max_norm};
     hipStream_t s = STREAM(stream);
-    if (dtype == DPIPE_BF16)
-        adamw_step_kernel<bf16_t><<<nchunks, OPT_BLOCK, 0, s>>>(p_ptrs, m_ptrs, v_ptrs, s_ptrs, g_ptrs, lanes, chunk_tensor, chunk_off, chunk_len, total_sumsq, h, zero_grads);
-    else if (dtype == DPIPE_F32)
-        adamw_step_kernel<float><<<nchunks, OPT_BLOCK, 0, s>>>(p_ptrs, m_ptrs, v_ptrs, s_ptrs, g_ptrs, lanes, chunk_tensor, chunk_off, chunk_len, total_sumsq, h, zero_grads);
+    static const bool static_lanes = [] { const char* e = getenv("DPIPE_ADAMW_STATIC_LANES"); return !e || atoi(e) != 0; }();     // =0: the runtime lane loop (A/B)
+#define ADAMW_STEP(TT, LL) adamw_step_kernel<TT, LL><<<nchunks, OPT_BLOCK, 0, s>>>(p_ptrs, m_ptrs, v_ptrs, s_ptrs, g_ptrs, lanes, chunk_tensor, chunk_off, chunk_len, total_sumsq, h, zero_grads)
+#define ADAMW_STEP_L(TT) do { switch (static_lanes ? lanes : 0) { case 1: ADAMW_STEP(TT, 1); break; case 2: ADAMW_STEP(TT, 2); break; case 3: ADAMW_STEP(TT, 3); break; \
+    case 4: ADAMW_STEP(TT, 4); break; case 6: ADAMW_STEP(TT, 6); break; case 8: ADAMW_STEP(TT, 8); break; default: ADAMW_STEP(TT, 0); } } while (0)
+    if (dtype == DPIPE_BF16) ADAMW_STEP_L(bf16_t);
+    else if (dtype == DPIPE_F32) ADAMW_STEP_L(float);
     else { set_last_error("dpipe_adamw_step: dtype"); return DPIPE_ERR_UNSUPPORTED; }
+#undef ADAMW_STEP_L
+#undef ADAMW_STEP
     return check_launch("dpipe_adamw_step");
 }
 

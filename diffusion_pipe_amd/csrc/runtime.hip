@@ -30,6 +30,17 @@ int option(int id, int dflt) {
     const char* e = getenv(g_option_env[id]);
     return e ? atoi(e) : dflt;
 }
+// DEBUG ONLY (never set by the product; results are garbage): DPIPE_DEBUG_ABLATE = bit mask of kernel classes whose launches are SKIPPED, DPIPE_DEBUG_GEMM_KDIV = d
+// shortens every plain GEMM's K loop d-fold.  tools/run_gpu.sh `ablate` times the four-lane step with one class removed / halved at a time: the step's sensitivity to
+// each class under concurrency, which no serialising profiler can measure.
+bool ablated(int cls) {
+    static const int mask = [] { const char* e = getenv("DPIPE_DEBUG_ABLATE"); return e ? atoi(e) : 0; }();
+    return (mask & cls) != 0;
+}
+int ablate_gemm_kdiv() {
+    static const int d = [] { const char* e = getenv("DPIPE_DEBUG_GEMM_KDIV"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
+    return d;
+}
 }  // namespace dpipe
 
 extern "C" {

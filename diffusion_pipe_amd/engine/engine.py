@@ -91,16 +91,24 @@ def concurrent_streams(device, n, main=None, candidates=12, report=None):
             t1 = statistics.median(spin([main], cycles) for _ in range(3))
         report['spin_ms'] = round(t1 * 1e3, 3)
         chosen = []
-        for _ in range(candidates):
-            if len(chosen) == n:
-                break
-            cand = torch.cuda.Stream(device)
-            group = [main] + chosen + [cand]
-            t = statistics.median(spin(group, cycles) for _ in range(3))
-            report['candidates_tried'] += 1
-            report['ratios'].append(round(t / t1, 2))
-            if t < 1.5 * t1:                                    # all of them overlapped; a shared queue gives >= 2 x
-                chosen.append(cand)
+        # normal-priority candidates first; when they run out of hardware queues (4 on ROCm 7.2) and more lanes are wanted, HIGH-priority candidates: the runtime
+        # keeps a separate pool of hardware queues per stream priority (round 6: how a 5th .. 8th lane gets a queue of its own; DPIPE_LANE_PRIORITY_STREAMS=0: off)
+        passes = [0] + ([-1] if n > 3 and os.environ.get('DPIPE_LANE_PRIORITY_STREAMS', '1') != '0' else [])
+        report['priority_streams'] = 0
+        for prio in passes:
+            for _ in range(candidates):
+                if len(chosen) == n:
+                    break
+                cand = torch.cuda.Stream(device, priority=prio) if prio else torch.cuda.Stream(device)
+                group = [main] + chosen + [cand]
+                t = statistics.median(spin(group, cycles) for _ in range(3))
+                report['candidates_tried'] += 1
+                report['ratios'].append(round(t / t1, 2))
+                if t < 1.5 * t1:                                    # all of them overlapped; a shared queue gives >= 2 x
+                    chosen.append(cand)
+                    report['priority_streams'] += int(prio != 0)
+                elif prio:
+                    break                                           # (the priority pool is exhausted too)
         report['probed_ok'] = len(chosen)
         report['unprobed_fallback'] = n - len(chosen)
         if len(chosen) < n and int(os.environ.get('RANK', '0')) == 0:
@@ -217,6 +225,7 @@ class PipelineEngine:
         self.clip_grad_fn = None           # optional whole-function override (the reference patches this, patches.py:429)
         self.grad_kernels = None           # provider of grads_sumsq / grads_clip_scale_; None = HIP kernels (ops.py)
         self.dp_bucket_bytes = int(self._config.get('dp_bucket_bytes', 512 << 20))
+        self.dp_direct_min_bytes = int(self._config.get('dp_direct_min_bytes', 1 << 20))     # gradients outside an arena: averaged in place from this size on (below: staged buckets)
         # flat gradient arenas (one buffer per dtype per lane / stage) whenever gradients are persistent (hipGraph paths) and replicas exist to
         # reduce over; 'flat_grads': True forces them on a single replica as well (tests, lane summation in one launch per dtype)
         self.flat_grads = bool(self._config.get('flat_grads', self.dp_world_size > 1))
@@ -1123,8 +1132,8 @@ class PipelineEngine:
 
     def _exec_reduce_grads(self, skip_storages=None):
         """Data-parallel gradient average.  Persistent-gradient paths keep the gradients in flat arenas (flatten_grads) and reduce those in
-        place, in buckets sized for xGMI / 288 GB HBM; gradients outside an arena (eager path: autograd allocates them per step) are bucketed through a
-        staging concatenation."""
+        place, in buckets sized for xGMI / 288 GB HBM; gradients outside an arena (eager path: autograd allocates them per step) are averaged in place when
+        large and bucketed through a staging concatenation when small."""
         if not self.is_data_parallel:
             return
         group = self.grid.get_data_parallel_group()
@@ -1137,8 +1146,17 @@ class PipelineEngine:
                 dt = self.communication_data_type or p.grad.dtype
                 by_dtype.setdefault((dt, p.grad.dtype), []).append(p.grad)
         for (comm_dt, _), grads in by_dtype.items():
+            # (round 6) a gradient of dp_direct_min_bytes or more is averaged IN PLACE, as its own collective: no concatenation, no copy back --
+            # staging is for the small tensors only (biases, norm weights: a collective each would be latency-bound).  Every rank walks the same parameter list, so the
+            # sequence of collectives is the same everywhere.
+            small = []
+            for g in grads:
+                if g.is_contiguous() and g.numel() * g.element_size() >= self.dp_direct_min_bytes:
+                    self._dp_reduce_(g.view(-1), group)
+                else:
+                    small.append(g)
             bucket, size = [], 0
-            for g in grads + [None]:
+            for g in small + [None]:
                 if g is not None:
                     bucket.append(g); size += g.numel() * g.element_size()
                 if bucket and (g is None or size >= self.dp_bucket_bytes):

@@ -167,9 +167,10 @@ def _worker(rank, world, port, mode, outdir):
         elif mode == 'flat_dp4':
             _flat_reduce_worker(rank, world, outdir)
             return
-        else:  # dp2: each replica sees its own micro-batches
+        else:  # dp2: each replica sees its own micro-batches (dp2_direct: every gradient averaged in place, no staging bucket)
             batches = [make_batches(2 * gas, 2, 100 + s)[rank * gas:(rank + 1) * gas] for s in range(steps)]
-            losses, params, engine = engine_run(steps, gas, 0.5, batches, num_stages=1)
+            losses, params, engine = engine_run(steps, gas, 0.5, batches, num_stages=1, extra={'dp_direct_min_bytes': 0} if mode == 'dp2_direct' else None)
+            assert engine.dp_direct_min_bytes == (0 if mode == 'dp2_direct' else 1 << 20)
         start, stop = engine.module.local_layer_range()
         torch.save({'losses': losses, 'range': (start, stop), 'params': [p.detach() for p in params]}, os.path.join(outdir, f'r{rank}.pt'))
     finally:
@@ -348,6 +349,19 @@ def test_engine_dp2_gloo_matches_oracle():
     batches = [make_batches(2 * gas, 2, 100 + s) for s in range(steps)]
     want_l, want_p = oracle_run(steps, 2 * gas, 0.5, batches)
     res = _spawn('dp2')
+    for r in res:
+        assert r['losses'] == pytest.approx(want_l, rel=1e-5)
+        for a, b in zip(r['params'], want_p):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+def test_engine_dp2_in_place_average_of_large_gradients_matches_staged_buckets():
+    """gradients outside an arena are averaged in place from `dp_direct_min_bytes` on (no concatenation, no copy back); with the
+    threshold at 0 every gradient takes that route -- same losses and parameters as the staged buckets of the default."""
+    steps, gas = 2, 4
+    batches = [make_batches(2 * gas, 2, 100 + s) for s in range(steps)]
+    want_l, want_p = oracle_run(steps, 2 * gas, 0.5, batches)
+    res = _spawn('dp2_direct')
     for r in res:
         assert r['losses'] == pytest.approx(want_l, rel=1e-5)
         for a, b in zip(r['params'], want_p):

@@ -43,6 +43,29 @@ PY
     census)   # census[:<bench args>]  -- kernel trace (no counters) of the lane bench + tools/trace_overlap.py
       ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace -f csv -d $O/${TAG}_tr -o tr -- python $R/bench.py ${rest:---steps 4 --warmup 2 --no-cpu-baseline --no-synced-loop --light} > $O/${TAG}_census.log 2>&1 )
       python tools/trace_overlap.py $(find $O/${TAG}_tr -name '*kernel_trace.csv' | head -1) $O/${TAG}_overlap.json --skip-frac 0.5 | head -30; rm -rf $O/${TAG}_tr;;
+    ablate)   # ablate:<mask,mask,...>[:kdiv]  -- DEBUG sensitivity census: the light four-lane bench with one kernel class's launches SKIPPED per run (results are garbage, only the
+              # clock counts; csrc/runtime.hip: 1 GEMM, 2 convolution, 4 attention, 8 LayerNorm, 16 GroupNorm, 32 element-wise, 64 step end), and, with :kdiv, one run with every GEMM's K loop d-fold shorter
+      IFS=':' read -r masks kdiv <<< "$rest"
+      for m in ${masks//,/ }; do
+        ( export DPIPE_DEBUG_ABLATE=$m; timeout 600 python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-synced-loop --light > $O/${TAG}_ablate_$m.log 2>&1 )
+        python - "$O/${TAG}_ablate_$m.log" "$m" >> $O/${TAG}_ablation.jsonl <<'PY'
+import json, sys
+line = [l for l in open(sys.argv[1]) if l.startswith('{"metric"')]
+d = json.loads(line[-1]) if line else {}
+print(json.dumps({'ablate_mask': int(sys.argv[2]), 'gemm_kdiv': 1, 'ms_per_step': d.get('ms_per_step'), 'images_per_s': d.get('value')}))
+PY
+        tail -1 $O/${TAG}_ablation.jsonl
+      done
+      if [ -n "$kdiv" ]; then
+        ( export DPIPE_DEBUG_GEMM_KDIV=$kdiv; timeout 600 python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-synced-loop --light > $O/${TAG}_ablate_kdiv$kdiv.log 2>&1 )
+        python - "$O/${TAG}_ablate_kdiv$kdiv.log" "$kdiv" >> $O/${TAG}_ablation.jsonl <<'PY'
+import json, sys
+line = [l for l in open(sys.argv[1]) if l.startswith('{"metric"')]
+d = json.loads(line[-1]) if line else {}
+print(json.dumps({'ablate_mask': 0, 'gemm_kdiv': int(sys.argv[2]), 'ms_per_step': d.get('ms_per_step'), 'images_per_s': d.get('value')}))
+PY
+        tail -1 $O/${TAG}_ablation.jsonl
+      fi;;
     cmd)      # every cmd step gets its own log: <tag>_cmd1.log, <tag>_cmd2.log, ...
       NCMD=$((${NCMD:-0} + 1))
       bash -c "$rest" > $O/${TAG}_cmd${NCMD}.log 2>&1; echo "cmd${NCMD} rc=$? $(tail -2 $O/${TAG}_cmd${NCMD}.log)";;
