@@ -46,6 +46,19 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu);
 }
 
+// Phi(x) = 0.5 (1 + erf(x / sqrt 2)) of the exact ("erf") GELU and E = exp(-x^2 / 2), branch-free (round 6): Abramowitz-Stegun 7.1.26 with the complementary
+// form on the negative side (no cancellation), one v_exp_f32 and one v_rcp_f32 -- |Phi error| <= 3.0e-7, |gelu error| <= 4.3e-7, |gelu' error| <= 3.2e-7 over
+// [-12, 12] in fp32 (tests/test_optim_cpu.py::test_gelu_erf_approximation; torch's own fp32 erf GELU is 1.2e-6 off the fp64 value).  ocml's erff costs ~3 x the
+// instructions and a divergent branch per element: the GEGLU kernels were VALU-bound on it next to 50 MB of traffic (165 branches in geglu_bwd's ISA).
+__device__ __forceinline__ float gelu_erf_cdf(float x, float& E) {
+    const float z = fabsf(x) * 0.7071067811865476f;
+    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * z);
+    E = __expf(-0.5f * x * x);
+    const float P = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float half = 0.5f * P * E;
+    return x >= 0.f ? 1.f - half : half;
+}
+
 // Element traits so that HBM-bound kernels can be instantiated for bf16 and fp32.
 template <typename T> struct Elem;
 template <> struct Elem<float> {

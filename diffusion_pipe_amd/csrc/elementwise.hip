@@ -135,7 +135,7 @@ __device__ __forceinline__ float act_fwd(float x, int act) {
         float u = k0 * (x + k1 * x * x * x);
         return 0.5f * x * (1.f + tanhf(u));
     }
-    case ACT_GELU_ERF: return 0.5f * x * (1.f + erff(x * 0.7071067811865476f));
+    case ACT_GELU_ERF: { float E; return x * gelu_erf_cdf(x, E); }
     case ACT_SILU: return x / (1.f + __expf(-x));
     case ACT_QUICK_GELU: return x / (1.f + __expf(-1.702f * x));       // HF CLIP quick_gelu: x * sigmoid(1.702 x)
     default: return x;
@@ -151,9 +151,9 @@ __device__ __forceinline__ float act_bwd(float x, int act) {  // d act / dx
         return 0.5f * (1.f + th) + 0.5f * x * (1.f - th * th) * du;
     }
     case ACT_GELU_ERF: {
-        float cdf = 0.5f * (1.f + erff(x * 0.7071067811865476f));
-        float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-        return cdf + x * pdf;
+        float E;
+        const float cdf = gelu_erf_cdf(x, E);
+        return cdf + x * (0.3989422804014327f * E);
     }
     case ACT_SILU: {
         float s = 1.f / (1.f + __expf(-x));
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(EW_BLOCK) upsample2x_adjoint_kernel(const T* _
     }
 }
 
-template <typename T>
+template <typename T, int ACTC>
 __global__ void __launch_bounds__(EW_BLOCK) act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long n, int act) {
     constexpr int V = Elem<T>::VEC;
     const long nv = n / V;
@@ -199,13 +199,13 @@ __global__ void __launch_bounds__(EW_BLOCK) act_fwd_kernel(const T* __restrict__
         Vec16<T> v; v.load(x + i * V);
         float f[V]; v.unpack(f);
 #pragma unroll
-        for (int j = 0; j < V; ++j) f[j] = act_fwd(f[j], act);
+        for (int j = 0; j < V; ++j) f[j] = act_fwd(f[j], ACTC);
         v.pack(f); v.store(y + i * V);
     }
     for (long i = nv * V + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        y[i] = Elem<T>::from_f(act_fwd(Elem<T>::to_f(x[i]), act));
+        y[i] = Elem<T>::from_f(act_fwd(Elem<T>::to_f(x[i]), ACTC));
 }
-template <typename T>
+template <typename T, int ACTC>
 __global__ void __launch_bounds__(EW_BLOCK) act_bwd_kernel(const T* __restrict__ x, const T* __restrict__ gy, T* __restrict__ gx, long n, int act) {
     constexpr int V = Elem<T>::VEC;
     const long nv = n / V;
@@ -213,15 +213,17 @@ __global__ void __launch_bounds__(EW_BLOCK) act_bwd_kernel(const T* __restrict__
         Vec16<T> vx, vg; vx.load(x + i * V); vg.load(gy + i * V);
         float fx[V], fg[V]; vx.unpack(fx); vg.unpack(fg);
 #pragma unroll
-        for (int j = 0; j < V; ++j) fg[j] *= act_bwd(fx[j], act);
+        for (int j = 0; j < V; ++j) fg[j] *= act_bwd(fx[j], ACTC);
         vg.pack(fg); vg.store(gx + i * V);
     }
     for (long i = nv * V + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        gx[i] = Elem<T>::from_f(Elem<T>::to_f(gy[i]) * act_bwd(Elem<T>::to_f(x[i]), act));
+        gx[i] = Elem<T>::from_f(Elem<T>::to_f(gy[i]) * act_bwd(Elem<T>::to_f(x[i]), ACTC));
 }
 
 // GEGLU (diffusers GEGLU: h, gate = proj.chunk(2, -1); h * gelu(gate)).  x: [rows, 2H], y: [rows, H]
-template <typename T>
+// (round 6: the activation is a TEMPLATE parameter of the act / GEGLU kernels -- with a runtime code the 5-way switch sat inside the unrolled element loop, 9 scalar
+//  branches per element: 165 in geglu_bwd; the launchers dispatch.  The kernels keep the `act` argument for the launch signature only.)
+template <typename T, int ACTC>
 __global__ void __launch_bounds__(EW_BLOCK) geglu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long rows, long H, int act) {
     constexpr int V = Elem<T>::VEC;
     const long hv = H / V, total = rows * hv;
@@ -230,11 +232,11 @@ __global__ void __launch_bounds__(EW_BLOCK) geglu_fwd_kernel(const T* __restrict
         Vec16<T> vh, vg; vh.load(x + r * 2 * H + c); vg.load(x + r * 2 * H + H + c);
         float fh[V], fg[V]; vh.unpack(fh); vg.unpack(fg);
 #pragma unroll
-        for (int j = 0; j < V; ++j) fh[j] *= act_fwd(fg[j], act);
+        for (int j = 0; j < V; ++j) fh[j] *= act_fwd(fg[j], ACTC);
         vh.pack(fh); vh.store(y + r * H + c);
     }
 }
-template <typename T>
+template <typename T, int ACTC>
 __global__ void __launch_bounds__(EW_BLOCK) geglu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ gy, T* __restrict__ gx, long rows, long H, int act) {
     constexpr int V = Elem<T>::VEC;
     const long hv = H / V, total = rows * hv;
@@ -243,7 +245,7 @@ __global__ void __launch_bounds__(EW_BLOCK) geglu_bwd_kernel(const T* __restrict
         Vec16<T> vh, vg, vy; vh.load(x + r * 2 * H + c); vg.load(x + r * 2 * H + H + c); vy.load(gy + r * H + c);
         float fh[V], fg[V], fy[V], dh[V], dg[V]; vh.unpack(fh); vg.unpack(fg); vy.unpack(fy);
 #pragma unroll
-        for (int j = 0; j < V; ++j) { dh[j] = fy[j] * act_fwd(fg[j], act); dg[j] = fy[j] * fh[j] * act_bwd(fg[j], act); }
+        for (int j = 0; j < V; ++j) { dh[j] = fy[j] * act_fwd(fg[j], ACTC); dg[j] = fy[j] * fh[j] * act_bwd(fg[j], ACTC); }
         vh.pack(dh); vh.store(gx + r * 2 * H + c);
         vg.pack(dg); vg.store(gx + r * 2 * H + H + c);
     }
@@ -457,6 +459,8 @@ __global__ void __launch_bounds__(EW_BLOCK) multi_clip_scale_kernel(void* const*
 
 }  // namespace
 
+#define ACT_SWITCH(act, LAUNCH) switch (act) { case ACT_GELU_TANH: { LAUNCH(ACT_GELU_TANH); } break; case ACT_GELU_ERF: { LAUNCH(ACT_GELU_ERF); } break; \
+    case ACT_SILU: { LAUNCH(ACT_SILU); } break; case ACT_QUICK_GELU: { LAUNCH(ACT_QUICK_GELU); } break; default: { LAUNCH(ACT_NONE); } }
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
 
 extern "C" {
@@ -511,18 +515,26 @@ int dpipe_upsample2x_adjoint(const void* src, void* dst, int B, int H, int W, in
 int dpipe_act_fwd(const void* x, void* y, long n, int dtype, int act, void* stream) {
     if (!x || !y || n < 0) { set_last_error("dpipe_act_fwd: bad argument"); return DPIPE_ERR_ARG; }
     if (n == 0 || ablated(ABL_EW)) return DPIPE_OK;
-    if (dtype == DPIPE_BF16) act_fwd_kernel<bf16_t><<<stream_grid(n / 8 + 1, EW_BLOCK), EW_BLOCK, 0, STREAM(stream)>>>((const bf16_t*)x, (bf16_t*)y, n, act);
-    else if (dtype == DPIPE_F32) act_fwd_kernel<float><<<stream_grid(n / 4 + 1, EW_BLOCK), EW_BLOCK, 0, STREAM(stream)>>>((const float*)x, (float*)y, n, act);
+#define L_BF(A) act_fwd_kernel<bf16_t, A><<<stream_grid(n / 8 + 1, EW_BLOCK), EW_BLOCK, 0, STREAM(stream)>>>((const bf16_t*)x, (bf16_t*)y, n, act)
+#define L_F32(A) act_fwd_kernel<float, A><<<stream_grid(n / 4 + 1, EW_BLOCK), EW_BLOCK, 0, STREAM(stream)>>>((const float*)x, (float*)y, n, act)
+    if (dtype == DPIPE_BF16) ACT_SWITCH(act, L_BF)
+    else if (dtype == DPIPE_F32) ACT_SWITCH(act, L_F32)
     else { set_last_error("dpipe_act_fwd: dtype"); return DPIPE_ERR_UNSUPPORTED; }
+#undef L_BF
+#undef L_F32
     return check_launch("dpipe_act_fwd");
 }
 
 int dpipe_act_bwd(const void* x, const void* gy, void* gx, long n, int dtype, int act, void* stream) {
     if (!x || !gy || !gx || n < 0) { set_last_error("dpipe_act_bwd: bad argument"); return DPIPE_ERR_ARG; }
     if (n == 0 || ablated(ABL_EW)) return DPIPE_OK;
-    if (dtype == DPIPE_BF16) act_bwd_kernel<bf16_t><<<stream_grid(n / 8 + 1, EW_BLOCK), EW_BLOCK, 0, STREAM(stream)>>>((const bf16_t*)x, (const bf16_t*)gy, (bf16_t*)gx, n, act);
-    else if (dtype == DPIPE_F32) act_bwd_kernel<float><<<stream_grid(n / 4 + 1, EW_BLOCK), EW_BLOCK, 0, STREAM(stream)>>>((const float*)x, (const float*)gy, (float*)gx, n, act);
+#define L_BF(A) act_bwd_kernel<bf16_t, A><<<stream_grid(n / 8 + 1, EW_BLOCK), EW_BLOCK, 0, STREAM(stream)>>>((const bf16_t*)x, (const bf16_t*)gy, (bf16_t*)gx, n, act)
+#define L_F32(A) act_bwd_kernel<float, A><<<stream_grid(n / 4 + 1, EW_BLOCK), EW_BLOCK, 0, STREAM(stream)>>>((const float*)x, (const float*)gy, (float*)gx, n, act)
+    if (dtype == DPIPE_BF16) ACT_SWITCH(act, L_BF)
+    else if (dtype == DPIPE_F32) ACT_SWITCH(act, L_F32)
     else { set_last_error("dpipe_act_bwd: dtype"); return DPIPE_ERR_UNSUPPORTED; }
+#undef L_BF
+#undef L_F32
     return check_launch("dpipe_act_bwd");
 }
 
@@ -558,8 +570,12 @@ int dpipe_geglu_fwd(const void* x, void* y, long rows, long H, int dtype, int ac
     if (!x || !y || rows <= 0 || H <= 0 || (H % V) != 0) { set_last_error("dpipe_geglu_fwd: H must be a multiple of the 16-byte vector"); return DPIPE_ERR_ARG; }
     if (ablated(ABL_EW)) return DPIPE_OK;
     int grid = stream_grid(rows * (H / V), EW_BLOCK);
-    if (dtype == DPIPE_BF16) geglu_fwd_kernel<bf16_t><<<grid, EW_BLOCK, 0, STREAM(stream)>>>((const bf16_t*)x, (bf16_t*)y, rows, H, act);
-    else geglu_fwd_kernel<float><<<grid, EW_BLOCK, 0, STREAM(stream)>>>((const float*)x, (float*)y, rows, H, act);
+#define L_BF(A) geglu_fwd_kernel<bf16_t, A><<<grid, EW_BLOCK, 0, STREAM(stream)>>>((const bf16_t*)x, (bf16_t*)y, rows, H, act)
+#define L_F32(A) geglu_fwd_kernel<float, A><<<grid, EW_BLOCK, 0, STREAM(stream)>>>((const float*)x, (float*)y, rows, H, act)
+    if (dtype == DPIPE_BF16) ACT_SWITCH(act, L_BF)
+    else ACT_SWITCH(act, L_F32)
+#undef L_BF
+#undef L_F32
     return check_launch("dpipe_geglu_fwd");
 }
 
@@ -568,8 +584,12 @@ int dpipe_geglu_bwd(const void* x, const void* gy, void* gx, long rows, long H, 
     if (!x || !gy || !gx || rows <= 0 || H <= 0 || (H % V) != 0) { set_last_error("dpipe_geglu_bwd: bad argument"); return DPIPE_ERR_ARG; }
     if (ablated(ABL_EW)) return DPIPE_OK;
     int grid = stream_grid(rows * (H / V), EW_BLOCK);
-    if (dtype == DPIPE_BF16) geglu_bwd_kernel<bf16_t><<<grid, EW_BLOCK, 0, STREAM(stream)>>>((const bf16_t*)x, (const bf16_t*)gy, (bf16_t*)gx, rows, H, act);
-    else geglu_bwd_kernel<float><<<grid, EW_BLOCK, 0, STREAM(stream)>>>((const float*)x, (const float*)gy, (float*)gx, rows, H, act);
+#define L_BF(A) geglu_bwd_kernel<bf16_t, A><<<grid, EW_BLOCK, 0, STREAM(stream)>>>((const bf16_t*)x, (const bf16_t*)gy, (bf16_t*)gx, rows, H, act)
+#define L_F32(A) geglu_bwd_kernel<float, A><<<grid, EW_BLOCK, 0, STREAM(stream)>>>((const float*)x, (const float*)gy, (float*)gx, rows, H, act)
+    if (dtype == DPIPE_BF16) ACT_SWITCH(act, L_BF)
+    else ACT_SWITCH(act, L_F32)
+#undef L_BF
+#undef L_F32
     return check_launch("dpipe_geglu_bwd");
 }
 

@@ -292,6 +292,7 @@ int dpipe_gemm_ex(int dtype, int transA, int transB, int M, int N, int K,
         if (tile_hint >= 1000) { set_last_error("dpipe_gemm: problem not eligible for the pipelined kernel"); return DPIPE_ERR_UNSUPPORTED; }
     }
     if (tile_hint >= 1000) { set_last_error("dpipe_gemm: pipelined kernel is bf16 only"); return DPIPE_ERR_UNSUPPORTED; }
+    if (act & ACT_GEGLU_BWD) { set_last_error("dpipe_gemm: DPIPE_ACT_GEGLU_BWD needs the pipelined bf16 kernel (aligned h / dh, N % 4 == 0, no bias, no accumulation)"); return DPIPE_ERR_UNSUPPORTED; }
     if (colsum) { set_last_error("dpipe_gemm: fused column sum needs the pipelined kernel with a K-major A operand (transA = 1)"); return DPIPE_ERR_UNSUPPORTED; }
     // 16-byte loads need an aligned base and vector-multiple strides; ragged edges are handled per vector in load_tile.
     auto vec_ok = [&](const void* ptr, long ld, long so, long si) {

@@ -45,14 +45,36 @@ struct GemmParams {
 #endif
 };
 
-enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_SILU = 3, ACT_QUICK_GELU = 4 };
+enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_SILU = 3, ACT_QUICK_GELU = 4,
+       ACT_GEGLU_BWD = 16 };     // flag on top of an activation code (DPIPE_ACT_GEGLU_BWD): the GEGLU backward rides this dgrad GEMM's epilogue, see gemm_pipe_kernel.h
 __device__ __forceinline__ float epilogue_act(float x, int act) {
     switch (act) {
     case ACT_GELU_TANH: { const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x); return 0.5f * x * (1.f + tanhf(u)); }
-    case ACT_GELU_ERF: return 0.5f * x * (1.f + erff(x * 0.7071067811865476f));
+    case ACT_GELU_ERF: { float E; return x * gelu_erf_cdf(x, E); }
     case ACT_SILU: return x / (1.f + __expf(-x));
     case ACT_QUICK_GELU: return x / (1.f + __expf(-1.702f * x));
     default: return x;
+    }
+}
+
+// d act / dx (the formulas of elementwise.hip's act_bwd)
+__device__ __forceinline__ float epilogue_act_grad(float x, int act) {
+    switch (act) {
+    case ACT_GELU_TANH: {
+        const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+        const float u = k0 * (x + k1 * x * x * x);
+        const float th = tanhf(u);
+        const float du = k0 * (1.f + 3.f * k1 * x * x);
+        return 0.5f * (1.f + th) + 0.5f * x * (1.f - th * th) * du;
+    }
+    case ACT_GELU_ERF: {
+        float E;
+        const float cdf = gelu_erf_cdf(x, E);
+        return cdf + x * (0.3989422804014327f * E);
+    }
+    case ACT_SILU: { const float s = 1.f / (1.f + __expf(-x)); return s * (1.f + x * (1.f - s)); }
+    case ACT_QUICK_GELU: { const float s = 1.f / (1.f + __expf(-1.702f * x)); return s * (1.f + 1.702f * x * (1.f - s)); }
+    default: return 1.f;
     }
 }
 

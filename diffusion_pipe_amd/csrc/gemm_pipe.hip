@@ -15,6 +15,10 @@ static bool pipe_eligible(const GemmParams& p, bool a_mc, bool b_mc) {
     if (p.lda % 8 || p.ldb % 8 || p.sAo % 8 || p.sAi % 8 || p.sBo % 8 || p.sBi % 8) return false;
     if ((!a_mc || !b_mc) && (p.K % BK) != 0) return false;
     if (p.colsum && !a_mc) return false;                      // fused column sums read the K-major A image only
+    if (p.act & ACT_GEGLU_BWD) {                               // the GEGLU-backward epilogue exists in the batched bf16 form only (gemm_pipe_kernel.h)
+        const auto al8 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 7) == 0; };
+        if (!p.residual || p.bias || p.accumulate || p.out_f32 || (p.N & 3) || (p.ldr & 3) || (p.ldc & 3) || (p.sCo & 3) || (p.sCi & 3) || !al8(p.residual) || !al8(p.C)) return false;
+    }
     const long kpad = (long)((p.K + BK - 1) / BK) * BK, mpad = (long)((p.M + 255) / 256) * 256, npad = (long)((p.N + 255) / 256) * 256;
     const long ext_a = a_mc ? kpad * p.lda + mpad : mpad * p.lda + kpad;
     const long ext_b = b_mc ? kpad * p.ldb + npad : npad * p.ldb + kpad;
@@ -146,7 +150,7 @@ int gemm_pipe_plan(GemmParams& p, bool a_mc, bool b_mc, int batch, void* ws, lon
     // ... and on the 4-deep ring of half K-steps (T256K) when B is MN-contiguous (dgrad): its DMA pieces are whole k-rows either way, and three half steps in
     // flight shorten the vmcnt wait: +5 .. +6 % (9216 x 5120 x 13824 NN: 996 vs 940 TFLOP/s).  A K-contiguous operand pays for half steps with 64-byte pieces
     // (half a cache line per row per step) and twice the barriers: NT is 8 % slower on T256K and stays on T256S (8192^3: 1 292 vs 1 184)
-    if (force_tile == 0 && !a_mc && p.ksteps >= 64 && tiles256 >= 128) force_tile = b_mc ? 258 : 257;
+    if (force_tile == 0 && !a_mc && p.ksteps >= 64 && tiles256 >= 128 && !(p.act & ACT_GEGLU_BWD)) force_tile = b_mc ? 258 : 257;       // (the GEGLU epilogue: 64^2 / 128^2 tiles)
     // (Round 4 negative result, profiles/r4h_bench_tile_policy.jsonl: the 256^2 tile for SDXL-sized forward / dgrad problems under four lanes -- from 16 / 48 tiles and 16 K-steps on --
     //  19.62 / 20.72 images/s against 21.10 with the 128^2 rule below, same box: one 128 KiB workgroup per CU leaves no room for another lane's workgroup.)
     // (Removed in round 5 after losing twice: the occupancy-style 4-wave tile for short-K forwards (DPIPE_GEMM_Q3: single-stream list +0.7 %, four-lane step -0.8 %) and the

@@ -616,6 +616,12 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, char* const 
     // 1 - 4 us (profiles/r6n_gemm_ledger_epilogue_v1_{base,new}.jsonl: the ledger +4 %).
     if (TM * TN <= 2 && !p.out_f32 && p.vecA >= 2 && (p.N & 3) == 0 && (!p.bias || p.vecB >= 2) && (!p.residual || p.vecA >= 3) &&
         (p.bias || p.residual || p.accumulate)) {
+        // GEGLU backward in this epilogue (DPIPE_ACT_GEGLU_BWD | activation; plain GEMMs only): the GEMM is the dgrad of the Linear BEHIND a GEGLU, acc = dy [M, N];
+        // `residual` = the GEGLU's input h [M, 2 N] (value | gate halves), C = dh [M, 2 N]:  dh[m, n] = dy * act(gate),  dh[m, N + n] = dy * value * act'(gate).
+        // dy never reaches memory and the separate geglu_bwd pass (3 reads + 2 writes of [M, N]-sized tensors, the most expensive element-wise kernel of the SDXL
+        // step under the lanes: profiles/r6p_ablation_census_four_lane_step.jsonl) is gone.  The gate vectors travel in the `l` slots, the second result in outw.
+        const bool gg = CONV == 0 && (p.act & ACT_GEGLU_BWD) != 0;
+        const int iact = p.act & 15;
         const bool hb = p.bias != nullptr, hl = CONV != 0 && hb && p.bias_lo != 0, hr = p.residual != nullptr, ha = p.accumulate != 0;     // (hi / lo bias pairs: convolutions only)
         const uint2* pad = reinterpret_cast<const uint2*>(g_param_pad);
         const bf16_t* biasp = reinterpret_cast<const bf16_t*>(p.bias);
@@ -624,7 +630,7 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, char* const 
         const int brows = p.bias_rows ? p.bias_rows : 0x7fffffff;       // one bias row for every output row: row index 0
         constexpr int U = TM * TN <= 2 ? TM * TN : 1;
         struct EpiOps { uint2 b[4], l[4], r[4], o[4]; };
-        uint2 outv[U][4];
+        uint2 outv[U][4], outw[CONV == 0 ? U : 1][4];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = u / TN, j = u % TN;
@@ -640,6 +646,7 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, char* const 
                 const int nn = n < p.N ? n : 0;
                 e.b[q] = *(hb ? reinterpret_cast<const uint2*>(biasp + brow + nn) : pad);
                 if constexpr (CONV != 0) e.l[q] = *(hl ? reinterpret_cast<const uint2*>(biasp + brow + nn + p.bias_lo) : pad);
+                else e.l[q] = *(gg ? reinterpret_cast<const uint2*>(resp + rrow + p.N + nn) : pad);
                 e.r[q] = *(hr ? reinterpret_cast<const uint2*>(resp + rrow + nn) : pad);
                 e.o[q] = *(ha ? reinterpret_cast<const uint2*>(cp + crow + nn) : pad);
             }
@@ -657,9 +664,21 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, char* const 
                     v[0] += __uint_as_float(e.l[q].x << 16); v[1] += __uint_as_float(e.l[q].x & 0xffff0000u);
                     v[2] += __uint_as_float(e.l[q].y << 16); v[3] += __uint_as_float(e.l[q].y & 0xffff0000u);
                 }
-                if (p.act != ACT_NONE) {
+                if constexpr (CONV == 0) if (gg) {
+                    float vl[4], gt[4], w[4];
+                    vl[0] = __uint_as_float(e.r[q].x << 16); vl[1] = __uint_as_float(e.r[q].x & 0xffff0000u);
+                    vl[2] = __uint_as_float(e.r[q].y << 16); vl[3] = __uint_as_float(e.r[q].y & 0xffff0000u);
+                    gt[0] = __uint_as_float(e.l[q].x << 16); gt[1] = __uint_as_float(e.l[q].x & 0xffff0000u);
+                    gt[2] = __uint_as_float(e.l[q].y << 16); gt[3] = __uint_as_float(e.l[q].y & 0xffff0000u);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = epilogue_act(v[r], p.act);
+                    for (int r = 0; r < 4; ++r) { w[r] = v[r] * vl[r] * epilogue_act_grad(gt[r], iact); v[r] = v[r] * epilogue_act(gt[r], iact); }
+                    outv[u][q] = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                    outw[u][q] = make_uint2(pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3]));
+                    continue;
+                }
+                if (iact != ACT_NONE) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = epilogue_act(v[r], iact);
                 }
                 if (hr) {
                     v[0] += __uint_as_float(e.r[q].x << 16); v[1] += __uint_as_float(e.r[q].x & 0xffff0000u);
@@ -681,7 +700,10 @@ __device__ __forceinline__ void gemm_pipe_body(const GemmParams& p, char* const 
             bf16_t* crow = cp + coff + (long)m * p.ldc;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (m < p.M && nb + 8 * q < p.N) *reinterpret_cast<uint2*>(crow + nb + 8 * q) = outv[u][q];
+                if (m < p.M && nb + 8 * q < p.N) {
+                    *reinterpret_cast<uint2*>(crow + nb + 8 * q) = outv[u][q];
+                    if constexpr (CONV == 0) if (gg) *reinterpret_cast<uint2*>(crow + p.N + nb + 8 * q) = outw[u][q];
+                }
         }
         TL_STAMP(3);
         return;

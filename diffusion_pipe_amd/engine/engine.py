@@ -92,8 +92,10 @@ def concurrent_streams(device, n, main=None, candidates=12, report=None):
         report['spin_ms'] = round(t1 * 1e3, 3)
         chosen = []
         # normal-priority candidates first; when they run out of hardware queues (4 on ROCm 7.2) and more lanes are wanted, HIGH-priority candidates: the runtime
-        # keeps a separate pool of hardware queues per stream priority (round 6: how a 5th .. 8th lane gets a queue of its own; DPIPE_LANE_PRIORITY_STREAMS=0: off)
-        passes = [0] + ([-1] if n > 3 and os.environ.get('DPIPE_LANE_PRIORITY_STREAMS', '1') != '0' else [])
+        # keeps a separate pool of hardware queues per stream priority, so a 5th .. 8th lane CAN get a queue of its own (DPIPE_LANE_PRIORITY_STREAMS=1).  OFF by default:
+        # measured in round 6 (profiles/r6q_bench_lanes_priority_streams.jsonl, same box), 8 lanes that genuinely overlap (probe ratios 1.03 - 1.08) run the SDXL step at
+        # 20.6 images/s, 6 lanes at 15.2, 8 lanes sharing the four normal queues at 22.6 -- against 23.3 with four lanes: the chip is full at four, the queue count is not the bound
+        passes = [0] + ([-1] if n > 3 and os.environ.get('DPIPE_LANE_PRIORITY_STREAMS', '0') != '0' else [])
         report['priority_streams'] = 0
         for prio in passes:
             for _ in range(candidates):

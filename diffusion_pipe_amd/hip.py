@@ -16,10 +16,11 @@ import os
 LIB_PATH = Path(os.environ.get('DPIPE_HIP_LIB') or Path(__file__).resolve().parent / 'libdpipe_hip.so')
 
 BF16, F32 = 0, 1
-ABI_VERSION = 8                      # DPIPE_ABI_VERSION of include/dpipe_hip.h this binding was written against
+ABI_VERSION = 9                      # DPIPE_ABI_VERSION of include/dpipe_hip.h this binding was written against
 CONV_OUT_F32, CONV_ACCUMULATE, CONV_BIAS_PER_SAMPLE, CONV_BIAS_HILO = 1, 2, 4, 8  # dpipe_conv2d_fwd / _dgrad `flags`
 OPT_ATTN_FWD_DMA, OPT_ATTN_BWD_DMA, OPT_ATTN_DQ8, OPT_ATTN_DKV_SPLIT, OPT_GEMM_SHALLOW, OPT_GEMM_BIG_TILES = 0, 1, 2, 3, 4, 5     # dpipe_set_option ids (include/dpipe_hip.h)
 ACT = {None: 0, 'none': 0, 'gelu_tanh': 1, 'gelu': 2, 'gelu_erf': 2, 'silu': 3, 'quick_gelu': 4}
+ACT_GEGLU_BWD = 16                   # DPIPE_ACT_GEGLU_BWD: flag on top of an activation code (the GEGLU backward in a dgrad GEMM's epilogue, ABI 9)
 LOSS_KIND = {'mse': 0, 'huber': 1, 'smooth_l1': 2}
 
 P, I, L, F = c_void_p, c_int, c_long, c_float

@@ -258,8 +258,12 @@ class FeedForward(nn.Module):
         self.net = nn.ModuleList([GEGLU(dim, inner, device=device, dtype=dtype), Identity(), Linear(inner, dim, device=device, dtype=dtype)])
 
     def forward(self, x, residual=None):
-        x = self.net[0](x)
-        return self.net[2](x, residual)         # net[1] is the (identity) dropout slot; the block's residual add rides the epilogue
+        g, out = self.net[0], self.net[2]
+        if type(g) is GEGLU and type(out) is Linear and type(self.net[1]) is Identity:
+            # GEGLU's multiply + the output Linear as one autograd node: the GEGLU backward rides the Linear's dgrad epilogue (ops.geglu_linear, round 6)
+            return ops.geglu_linear(g.proj(x), out.weight, out.bias, residual)
+        x = g(x)
+        return out(x, residual)                 # net[1] is the (identity) dropout slot; the block's residual add rides the epilogue
 
 
 class Attention(nn.Module):

@@ -174,15 +174,15 @@ def gemm_group(problems):
         any_bf16 = any_bf16 or dt == hip.BF16
         d.dtype, d.transA, d.transB, d.M, d.N, d.K = dt, q['ta'], q['tb'], q['M'], q['N'], q['K']
         d.A, d.lda, d.B, d.ldb, d.C, d.ldc = a.data_ptr(), q['lda'], b.data_ptr(), q['ldb'], out.data_ptr(), q['ldc']
-        d.bias, d.act, d.alpha, d.accumulate, d.out_f32 = (bias.data_ptr() if bias is not None else None), ACT[q['act']], float(q['alpha']), int(q['acc']), out_f32
+        d.bias, d.act, d.alpha, d.accumulate, d.out_f32 = (bias.data_ptr() if bias is not None else None), (q['act'] if isinstance(q['act'], int) else ACT[q['act']]), float(q['alpha']), int(q['acc']), out_f32
         d.residual, d.ldr = (res.data_ptr() if res is not None else None), q['ldr']
         d.colsum, d.colsum_accumulate = (q['colsum'].data_ptr() if q['colsum'] is not None else None), int(q['colsum_acc'])
         q['_dt'], q['_out_f32'] = dt, out_f32
     ws = _splitk_workspace(problems[0]['a'].device) if any_bf16 else None
     launches = hip.c_int(0)
     rc = lib().dpipe_gemm_group(descs, n, ptr(ws), ws.numel() if ws is not None else 0, hip.ctypes.byref(launches), stream())
-    if rc == -2 and any(q['colsum'] is not None for q in problems):
-        return None
+    if rc == -2 and any(q['colsum'] is not None or (isinstance(q['act'], int) and q['act'] >= hip.ACT_GEGLU_BWD) for q in problems):
+        return None          # (fused column sum / GEGLU epilogue not available for this problem: the caller takes the separate-launch route)
     check(rc, 'dpipe_gemm_group')
     if GEMM_TRACE is not None:
         for i, q in enumerate(problems):
@@ -663,6 +663,112 @@ class _GegluFn(Function):
 
 def geglu(x, act='gelu_erf'):
     return _GegluFn.apply(x, act)
+
+
+# DPIPE_FUSE_GEGLU_BWD=1: the GEGLU backward in the epilogue of the output Linear's dgrad GEMM (DPIPE_ACT_GEGLU_BWD).  OFF by default -- measured, round 6, same box, two
+# pairs (profiles/r6s_bench_geglu_bwd_epilogue_ab.jsonl): 355.5 / 355.0 ms per step fused against 353.0 / 352.7 with the separate pass (r6r, before the cheaper GELU:
+# 358.1 / 358.0 against 355.9 / 356.3).  The fusion saves the dy round trip and a launch, but moves the GELU / GELU' arithmetic of 5 M elements per call from an element-wise
+# kernel that the other lanes' GEMMs run NEXT TO (VALU work under their MFMA work) into the tail of GEMM workgroups, where it holds the CU's LDS and registers
+# while the matrix pipe idles.  Parity-tested either way (tests/test_gpu_geglu_linear.py).
+FUSE_GEGLU_BWD = _os_mod.environ.get('DPIPE_FUSE_GEGLU_BWD', '0') == '1'
+
+
+class _GegluLinearFn(Function):
+    """out = Linear(geglu(h)) (+ residual): diffusers FeedForward's [GEGLU's multiply, Dropout, Linear] tail as ONE autograd node, so that the backward of the
+    GEGLU rides the epilogue of the Linear's dgrad GEMM (DPIPE_ACT_GEGLU_BWD): dy = dout . W never reaches memory, dh = [dy * act(gate) | dy * value * act'(gate)]
+    is written by the GEMM itself -- the element-wise geglu_bwd pass (3 reads + 2 writes of [rows, H]-sized tensors) is gone.  Grouped with the wgrad
+    dW (+)= dout^T . y as in _LinearFn.  Falls back to the two-pass route whenever the fused launch is refused (fp32 parity mode, odd shapes)."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, residual, act):
+        h2 = _contig(_rows2d(h))
+        H = h2.shape[1] // 2
+        y = torch.empty((h2.shape[0], H), device=h.device, dtype=h.dtype)
+        check(lib().dpipe_geglu_fwd(ptr(h2), ptr(y), h2.shape[0], H, dtype_code(h.dtype), ACT[act], stream()), 'geglu_fwd')
+        if y.dtype != weight.dtype:
+            y = y.to(weight.dtype)
+        res2 = None
+        if residual is not None:
+            res2 = _rows2d(residual)
+            if res2.dtype != weight.dtype:
+                res2 = res2.to(weight.dtype)
+        out = mm(y, weight, False, True, bias=bias, residual=res2)
+        ctx.save_for_backward(h2, y, weight, bias)
+        ctx.act, ctx.h_shape, ctx.has_bias, ctx.has_res = act, h.shape, bias is not None, residual is not None
+        return out.view(*h.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, gout):
+        h2, y, weight, bias = ctx.saved_tensors
+        go2 = _rows2d(gout)
+        if go2.dtype != weight.dtype:
+            go2 = go2.to(weight.dtype)
+        need_h, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        gres = gout if (ctx.has_res and ctx.needs_input_grad[3]) else None
+        tw = _accum_target(weight) if need_w else None
+        tb = _accum_target(bias) if need_b else None
+        acc_w = _acc(tw) if need_w else False
+        acc_b = _acc(tb) if need_b else False
+        H = h2.shape[1] // 2
+        gh = gw = gb = None
+        fused_ok = FUSE_GEGLU_BWD and need_h and go2.dtype == torch.bfloat16 and h2.dtype == torch.bfloat16
+        if fused_ok:
+            gh2 = torch.empty_like(h2)
+            dgrad = mm_problem(go2, weight, False, False, out=gh2, residual=h2, act=ACT[ctx.act] | hip.ACT_GEGLU_BWD)
+            if need_w:
+                w_out = tw if tw is not None else torch.empty(weight.shape, device=weight.device, dtype=weight.dtype)
+                fuse_b = FUSE_BIAS_GRAD and need_b
+                b_out = (tb if tb is not None else torch.empty(bias.shape, device=bias.device, dtype=bias.dtype)) if fuse_b else None
+                done = gemm_group([dgrad, mm_problem(go2, y, True, False, out=w_out, accumulate=acc_w, colsum=b_out, colsum_accumulate=acc_b if fuse_b else False)])
+                if done is not None:
+                    gw = None if tw is not None else w_out
+                    if fuse_b:
+                        gb = None if tb is not None else b_out
+                    elif need_b:
+                        gb = column_sum(go2, out=tb, accumulate=acc_b)
+                        if tb is not None:
+                            gb = None
+                    return gh2.view(ctx.h_shape), gw, gb, gres, None
+            else:
+                done = gemm_group([dgrad])
+                if done is not None:
+                    gb = None
+                    if need_b:
+                        gb = column_sum(go2, out=tb, accumulate=acc_b)
+                        if tb is not None:
+                            gb = None
+                    return gh2.view(ctx.h_shape), None, gb, gres, None
+        # two-pass route: plain dgrad, then the element-wise GEGLU backward
+        if need_h:
+            gy = mm(go2, weight, False, False)
+            if gy.dtype != h2.dtype:
+                gy = gy.to(h2.dtype)
+            gh2 = torch.empty_like(h2)
+            check(lib().dpipe_geglu_bwd(ptr(h2), ptr(_contig(gy)), ptr(gh2), h2.shape[0], H, dtype_code(h2.dtype), ACT[ctx.act], stream()), 'geglu_bwd')
+            gh = gh2.view(ctx.h_shape)
+        if need_w:
+            if FUSE_BIAS_GRAD and need_b and go2.dtype == torch.bfloat16:
+                w_out = tw if tw is not None else torch.empty(weight.shape, device=weight.device, dtype=weight.dtype)
+                b_out = tb if tb is not None else torch.empty(bias.shape, device=bias.device, dtype=bias.dtype)
+                if mm(go2, y, True, False, out=w_out, accumulate=acc_w, colsum=b_out, colsum_accumulate=acc_b) is not None:
+                    return gh, (None if tw is not None else w_out), (None if tb is not None else b_out), gres, None
+            if tw is not None:
+                mm(go2, y, True, False, out=tw, accumulate=acc_w)
+            else:
+                gw = mm(go2, y, True, False)
+        if need_b:
+            gb = column_sum(go2, out=tb, accumulate=acc_b)
+            if tb is not None:
+                gb = None
+        return gh, gw, gb, gres, None
+
+
+def geglu_linear(h, weight, bias=None, residual=None, act='gelu_erf'):
+    """Linear(geglu(h)) (+ residual) with the GEGLU backward fused into the dgrad GEMM's epilogue (see _GegluLinearFn)."""
+    if residual is not None and not FUSE_RESIDUAL:
+        return gated_residual(residual, _GegluLinearFn.apply(h, weight, bias, None, act))
+    return _GegluLinearFn.apply(h, weight, bias, residual, act)
 
 
 # ----------------------------------------------------------------------------------------- gated residual (K5)

@@ -26,13 +26,18 @@ extern "C" {
 #define DPIPE_ACT_GELU_ERF 2
 #define DPIPE_ACT_SILU 3
 #define DPIPE_ACT_QUICK_GELU 4
+/* dpipe_gemm_ex / dpipe_gemm_group only (ABI 9): `act` = DPIPE_ACT_GEGLU_BWD | activation turns the epilogue into the backward of a GEGLU that FEEDS the Linear whose
+ * dgrad this GEMM is (diffusers FeedForward behind models/sdxl.py:797-865: net = [GEGLU, Dropout, Linear]):  acc = dy [M, N];  `residual` = the GEGLU's input
+ * h [M, 2 N] (value | gate halves, pitch ldr), C = dh [M, 2 N] (pitch ldc):  dh[m, n] = dy * act(gate),  dh[m, N + n] = dy * value * act'(gate).  bf16, N % 4 == 0,
+ * 8-byte aligned h / dh, no bias, no accumulation; otherwise DPIPE_ERR_UNSUPPORTED (the caller runs dpipe_geglu_bwd after a plain dgrad). */
+#define DPIPE_ACT_GEGLU_BWD 16
 
 #define DPIPE_LOSS_MSE 0
 #define DPIPE_LOSS_HUBER 1
 #define DPIPE_LOSS_SMOOTH_L1 2
 
 /* ABI version: bumped whenever a signature of this header changes; the host binding refuses a library of another version. */
-#define DPIPE_ABI_VERSION 8
+#define DPIPE_ABI_VERSION 9
 int dpipe_version(void);
 const char* dpipe_last_error(void);
 /* Kernel-selection options (process-wide; for A/B timing and for testing the fallback kernels -- every default is the measured-faster choice).

@@ -322,3 +322,28 @@ def test_direct_quantiser_of_the_8bit_adamw_kernel_is_exact_on_the_dynamic_maps(
             val[0] = 0
         val[255] = 1
         assert np.allclose(val, q, rtol=1e-5, atol=1e-12)
+
+
+def test_gelu_erf_approximation():
+    """csrc/dpipe_common.h `gelu_erf_cdf` (round 6): the branch-free Phi(x) the exact-GELU kernels evaluate instead of ocml's erff -- Abramowitz-Stegun 7.1.26 with the
+    complementary form on the negative side -- restated here in fp32 numpy and held against the fp64 erf: the bounds quoted in the header."""
+    import math
+
+    import numpy as np
+    from scipy.special import erf
+    f32 = np.float32
+    x = np.linspace(-12, 12, 400001).astype(f32)
+    z = np.abs(x) * f32(0.7071067811865476)
+    t = f32(1) / (f32(1) + f32(0.3275911) * z)
+    E = np.exp(-(f32(0.5) * x * x)).astype(f32)
+    P = t * (f32(0.254829592) + t * (f32(-0.284496736) + t * (f32(1.421413741) + t * (f32(-1.453152027) + t * f32(1.061405429)))))
+    half = f32(0.5) * P * E
+    cdf = np.where(x >= 0, f32(1) - half, half).astype(f32)
+    xd = x.astype(np.float64)
+    cdf_t = 0.5 * (1 + erf(xd / math.sqrt(2)))
+    assert np.abs(cdf - cdf_t).max() <= 3.0e-7
+    assert np.abs(x * cdf - xd * cdf_t).max() <= 4.3e-7
+    d = cdf + x * f32(0.3989422804014327) * E
+    d_t = cdf_t + xd * np.exp(-0.5 * xd * xd) / math.sqrt(2 * math.pi)
+    assert np.abs(d - d_t).max() <= 3.2e-7
+    assert (cdf[x < 0] >= 0).all() and (cdf <= 1).all()          # no cancellation on the negative side: Phi stays in [0, 1]
