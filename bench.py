@@ -572,7 +572,7 @@ def main():
         dist.all_reduce(rl)
     g_flops, g_ms, launches, g_bytes = rl.tolist()
     traffic = None
-    tpath = next((q for q in (os.path.join(ROOT, 'profiles', f) for f in ('r5_pmc_gemm_traffic.json', 'r4_pmc_gemm_traffic.json', 'r3_pmc_gemm_traffic.json')) if os.path.isfile(q)), '')
+    tpath = next((q for q in (os.path.join(ROOT, 'profiles', f) for f in ('r6_pmc_gemm_traffic.json', 'r5_pmc_gemm_traffic.json', 'r4_pmc_gemm_traffic.json', 'r3_pmc_gemm_traffic.json')) if os.path.isfile(q)), '')
     # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this launch list: tools/run_gpu.sh pmc; the newest committed pass wins)
     if os.path.isfile(tpath):
         with open(tpath) as f:
