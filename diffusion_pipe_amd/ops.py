@@ -739,7 +739,25 @@ class _GegluLinearFn(Function):
                         if tb is not None:
                             gb = None
                     return gh2.view(ctx.h_shape), None, gb, gres, None
-        # two-pass route: plain dgrad, then the element-wise GEGLU backward
+        # two-pass route: plain dgrad, then the element-wise GEGLU backward -- the dgrad still leaves in ONE grouped launch with the wgrad (as in _LinearFn)
+        if need_h and need_w and go2.dtype == torch.bfloat16 and h2.dtype == torch.bfloat16:
+            w_out = tw if tw is not None else torch.empty(weight.shape, device=weight.device, dtype=weight.dtype)
+            fuse_b = FUSE_BIAS_GRAD and need_b
+            b_out = (tb if tb is not None else torch.empty(bias.shape, device=bias.device, dtype=bias.dtype)) if fuse_b else None
+            gy = torch.empty((go2.shape[0], H), device=go2.device, dtype=go2.dtype)
+            done = gemm_group([mm_problem(go2, weight, False, False, out=gy),
+                               mm_problem(go2, y, True, False, out=w_out, accumulate=acc_w, colsum=b_out, colsum_accumulate=acc_b if fuse_b else False)])
+            if done is not None:
+                gh2 = torch.empty_like(h2)
+                check(lib().dpipe_geglu_bwd(ptr(h2), ptr(gy), ptr(gh2), h2.shape[0], H, dtype_code(h2.dtype), ACT[ctx.act], stream()), 'geglu_bwd')
+                gw = None if tw is not None else w_out
+                if fuse_b:
+                    gb = None if tb is not None else b_out
+                elif need_b:
+                    gb = column_sum(go2, out=tb, accumulate=acc_b)
+                    if tb is not None:
+                        gb = None
+                return gh2.view(ctx.h_shape), gw, gb, gres, None
         if need_h:
             gy = mm(go2, weight, False, False)
             if gy.dtype != h2.dtype:
