@@ -379,11 +379,18 @@ __global__ void __launch_bounds__(256) adamw8bit_multi_kernel(void* const* __res
     float gv[E], tv[E], pv[E];
     uint8_t k1[E], k2[E];
     bool live[E];
+    // (round 6) the block's two absmax values are read ahead of the branchy load phase, and the bf16 full-vector path issues all of its reads (gradient, target,
+    // parameter, both code words) back to back with nothing conditional in between: these are flat loads through table pointers, and a load behind a branch waits for
+    // everything in flight (the pattern tools/isa_census.py found in the norm kernels)
+    const float am1 = absmax1[blk], am2 = absmax2[blk];
+    uint2 u1pre = make_uint2(0u, 0u), u2pre = make_uint2(0u, 0u);
     if (full) {
         if constexpr (sizeof(T) == 2) {
-            Vec16<T> vg; vg.load(g + i0); vg.unpack(gv);
-            Vec16<T> vt; vt.load((shift ? shift : p) + i0); vt.unpack(tv);
-            if (shift) { Vec16<T> vp; vp.load(p + i0); vp.unpack(pv); }
+            Vec16<T> vg, vt, vp;
+            vg.load(g + i0); vt.load((shift ? shift : p) + i0); vp.load(p + i0);          // (no Kahan buffer: the parameter vector twice, the second read an L1 hit)
+            u1pre = *reinterpret_cast<const uint2*>(c1 + i0); u2pre = *reinterpret_cast<const uint2*>(c2 + i0);
+            __builtin_amdgcn_sched_barrier(0);
+            vg.unpack(gv); vt.unpack(tv); vp.unpack(pv);
         } else {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -392,7 +399,7 @@ __global__ void __launch_bounds__(256) adamw8bit_multi_kernel(void* const* __res
                 if (shift) { Vec16<T> vp; vp.load(p + i0 + 4 * h); vp.unpack(pv + 4 * h); }
             }
         }
-        const uint2 u1 = *reinterpret_cast<const uint2*>(c1 + i0), u2 = *reinterpret_cast<const uint2*>(c2 + i0);
+        const uint2 u1 = sizeof(T) == 2 ? u1pre : *reinterpret_cast<const uint2*>(c1 + i0), u2 = sizeof(T) == 2 ? u2pre : *reinterpret_cast<const uint2*>(c2 + i0);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             k1[e] = (uint8_t)(((e < 4 ? u1.x : u1.y) >> (8 * (e & 3))) & 0xff);
@@ -410,7 +417,6 @@ __global__ void __launch_bounds__(256) adamw8bit_multi_kernel(void* const* __res
             k1[e] = c1[i]; k2[e] = c2[i];
         }
     }
-    const float am1 = absmax1[blk], am2 = absmax2[blk];
     const float wdf = weight_decay > 0.f ? 1.f - lr * weight_decay : 1.f;       // (x 1 and a second rounding of an already rounded value change nothing)
     float m[E], v[E];
     bool fin[E];
@@ -519,7 +525,10 @@ static int adamw_step_impl(void* const* p_ptrs, void* const* m_ptrs, void* const
     }
     AdamHyper h{lr, beta1, beta2, eps, weight_decay, bias_correction1, sqrtf(bias_correction2), max_norm};
     hipStream_t s = STREAM(stream);
-    static const bool static_lanes = [] { const char* e = getenv("DPIPE_ADAMW_STATIC_LANES"); return !e || atoi(e) != 0; }();     // =0: the runtime lane loop (A/B)
+    // DPIPE_ADAMW_STATIC_LANES=1: the static-lane form.  OFF: measured level with the runtime loop -- 343.8 / 343.2 vs 344.6 ms per step in the bench (r6q), and in isolation
+    // (tools/optim_timing.py, r6x, two pairs) 2.65 / 2.39 vs 2.34 / 2.39 ms at one lane, 3.49 / 3.93 vs 3.41 / 3.47 at three: the step end already streams at 5.2 - 5.3 TB/s with
+    // three or more lanes' reads per group, more reads in flight per thread buy nothing.
+    static const bool static_lanes = [] { const char* e = getenv("DPIPE_ADAMW_STATIC_LANES"); return e && atoi(e) != 0; }();
 #define ADAMW_STEP(TT, LL) adamw_step_kernel<TT, LL><<<nchunks, OPT_BLOCK, 0, s>>>(p_ptrs, m_ptrs, v_ptrs, s_ptrs, g_ptrs, lanes, chunk_tensor, chunk_off, chunk_len, total_sumsq, h, zero_grads)
 #define ADAMW_STEP_L(TT) do { switch (static_lanes ? lanes : 0) { case 1: ADAMW_STEP(TT, 1); break; case 2: ADAMW_STEP(TT, 2); break; case 3: ADAMW_STEP(TT, 3); break; \
     case 4: ADAMW_STEP(TT, 4); break; case 6: ADAMW_STEP(TT, 6); break; case 8: ADAMW_STEP(TT, 8); break; default: ADAMW_STEP(TT, 0); } } while (0)
