@@ -360,8 +360,8 @@ __global__ void __launch_bounds__(NB) slabsum2p_kernel(const float* __restrict__
     const long g = blockIdx.y;
     float a = 0.f, b = 0.f;
     if (c < cols) {
-#pragma unroll 8
-        for (int s = sl; s < slabs; s += 8) {
+#pragma unroll 16
+        for (int s = sl; s < slabs; s += 8) {                 // (16 x 2 loads in flight per lane: 256 slabs in two round trips)
             a += p0[(g * slabs + s) * cols + c];
             b += p1[(g * slabs + s) * cols + c];
         }
@@ -903,6 +903,8 @@ int dpipe_lnmod_bwd(const void* x, const void* gy, const void* gamma, const void
     // rows per wave: 1 (4 rows per block) up to 2 048 rows -- the kernel is latency-bound and wants the blocks; 4 beyond (measured on MI355X, tools/norm_timing.py:
     // [1024, 1280] backward 35.8 us at 4 rows per wave vs 24.4 us unfused; [4096, 640] 33.3 vs 34.3).  DPIPE_LNMOD_RW = 1 / 4 forces one for A/B.
     static const int rw_env = [] { const char* e = getenv("DPIPE_LNMOD_RW"); return e ? atoi(e) : 0; }();
+    // (round 6, after the operand-load rewrite: 4 rows per wave from 1 024 rows on measured level with this policy -- 345.6 / 347.0 vs 346.8 / 346.2 ms per step, call r6z;
+    //  344.9 vs 345.7 / 346.0 in call r6t, profiles/r6t_bench_lnmod_rows_per_wave.jsonl -- the threshold stays)
     const int rw = rw_env == 1 || rw_env == 4 ? rw_env : (rows_per_mod > 2048 ? 4 : 1);
     const bool fuse_ok = cols <= vec_cols && ((dgamma != nullptr) != (dscale != nullptr)) && (groups == 1 || rows_per_mod % (4 * rw) == 0) && lnmod_fuse_enabled();
     const int fslabs = fuse_ok ? (int)cdiv(rows_per_mod, 4 * rw) : 0;
