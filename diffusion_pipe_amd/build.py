@@ -21,7 +21,8 @@ CFLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wno-unused-r
 # move to scratch): the 256^2 tiles exceed LLVM's default pragma-unroll cost cap (16 384).  Round 5: with the default cap the 8-wave 256^2 kernels (the DiT-sized GEMMs of
 # Flux / Wan / HunyuanVideo) carried 100 - 324 bytes of scratch per lane, the 4-wave 256^2 tile 1 088; with the cap raised: 0 - 8.  Every other instantiation is unchanged
 # (same register counts, profiles/r5_kernel_resources.csv).
-EXTRA_CFLAGS = {'gemm_pipe.hip': ['-mllvm', '-pragma-unroll-threshold=200000'], 'conv_pipe.hip': ['-mllvm', '-pragma-unroll-threshold=200000']}
+_UNROLL = ['-mllvm', '-pragma-unroll-threshold=200000']
+EXTRA_CFLAGS = {'gemm_pipe.hip': _UNROLL, 'gemm_pipe_group.hip': _UNROLL, 'gemm_pipe_256.hip': _UNROLL, 'conv_pipe.hip': _UNROLL}
 
 
 def _sources():

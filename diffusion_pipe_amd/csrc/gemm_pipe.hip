@@ -8,6 +8,10 @@ using namespace dpipe_pipe;
 
 namespace dpipe {
 
+// the largest instantiations live in translation units of their own (build wall time)
+int gemm_pipe_launch_group(int geom, const GemmGroup& g, int total_wg, hipStream_t s);      // gemm_pipe_group.hip
+int gemm_pipe_launch_256(int tile, const GemmParams& p, bool a_mc, bool b_mc, int batch, hipStream_t s);      // gemm_pipe_256.hip
+
 // eligibility for the LDS-DMA kernel: 16-byte DMA pieces, K-contiguous operands need whole K-steps, 32-bit buffer offsets
 static bool pipe_eligible(const GemmParams& p, bool a_mc, bool b_mc) {
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -27,8 +31,7 @@ static bool pipe_eligible(const GemmParams& p, bool a_mc, bool b_mc) {
 
 static int launch_by_tile(int tile, const GemmParams& p, bool a_mc, bool b_mc, int batch, hipStream_t s) {
     switch (tile) {
-    case 257: return launch_pipe<T256S>(p, a_mc, b_mc, batch, s);
-    case 258: return launch_pipe<T256K>(p, a_mc, b_mc, batch, s);
+    case 257: case 258: return gemm_pipe_launch_256(tile, p, a_mc, b_mc, batch, s);       // (gemm_pipe_256.hip)
     case 129: return launch_pipe<T128R2>(p, a_mc, b_mc, batch, s);
     case 128: return launch_pipe<T128>(p, a_mc, b_mc, batch, s);
     case 132: return launch_pipe<T128V>(p, a_mc, b_mc, batch, s);
@@ -115,11 +118,7 @@ int gemm_pipe_group(GemmParams* ps, const int* transA, const int* transB, int n,
                 at += (g.nwg[k] + 7) & ~7;
             } else { g.p[k] = ps[members[0]]; g.mode[k] = 0; g.start[k] = at; g.nwg[k] = 0; }
         }
-        switch (geom(pl[i].tile)) {
-        case 129: rc = launch_pipe_group<T128R2>(g, at, s); break;
-        case 128: rc = launch_pipe_group<T128>(g, at, s); break;
-        default: rc = launch_pipe_group<T64>(g, at, s); break;
-        }
+        rc = gemm_pipe_launch_group(geom(pl[i].tile), g, at, s);                                // (gemm_pipe_group.hip)
     }
     if (launches_out) *launches_out = launches;
     if (dry) for (int i = 0; i < n; ++i) { tiles_out[i] = pl[i].tile; if (splitk_out) splitk_out[i] = ps[i].splitk; }
