@@ -65,3 +65,17 @@ def test_no_cpu_fallback():
         ops.rms_norm(x)
 
 
+
+
+def test_debug_ablation_switches_are_never_set_by_the_product():
+    """csrc/runtime.hip reads DPIPE_DEBUG_ABLATE / DPIPE_DEBUG_GEMM_KDIV (skip a kernel class's launches / shorten the GEMM K loops: the ablation census of DESIGN.md
+    section 4.1c -- results are garbage by construction).  Nothing under the package or in bench.py may set or even name them: only tools/run_gpu.sh does."""
+    import pathlib
+    root = pathlib.Path(__file__).resolve().parent.parent
+    offenders = []
+    for path in list((root / 'diffusion_pipe_amd').rglob('*.py')) + [root / 'bench.py', root / '__graft_entry__.py']:
+        text = path.read_text()
+        if 'DPIPE_DEBUG_ABLATE' in text or 'DPIPE_DEBUG_GEMM_KDIV' in text:
+            offenders.append(str(path))
+    assert not offenders, offenders
+    assert 'DPIPE_DEBUG_ABLATE' in (root / 'tools' / 'run_gpu.sh').read_text()
