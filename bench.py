@@ -589,6 +589,9 @@ def main():
         own = {'rank': rank, 'stage': engine.stage_id, 'dp_rank': engine.grid.get_data_parallel_rank(), 'layers': [int(module.parts[engine.stage_id]), int(module.parts[engine.stage_id + 1])],
                'params_m': round(sum(p_.numel() for p_ in module.parameters()) / 1e6, 1), 'own_ms_per_step': round(own_elapsed / args.steps * 1e3, 2),
                'peak_hbm_gb': round(peak_hbm / 2 ** 30, 2), **engine.link_report(), 'stream_probe': engine.stream_probe}
+        if engine.is_data_parallel:
+            # the data-parallel average under the backward's tail (engine/overlap.py): what the last step started early, and by how much it led the lanes' join
+            own['dp_overlap'] = dict(engine.overlap_report or {}, lead_ms_first_last=engine.overlap_lead_ms())
         try:
             sm = engine.stage_replay_ms()
             own['stage_ms'] = round(sm, 3) if sm is not None else None

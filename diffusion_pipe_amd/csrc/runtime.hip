@@ -37,6 +37,20 @@ bool ablated(int cls) {
     static const int mask = [] { const char* e = getenv("DPIPE_DEBUG_ABLATE"); return e ? atoi(e) : 0; }();
     return (mask & cls) != 0;
 }
+// progress marks: *mark = *gen, published to the whole device; the waiting side sleeps on the word (wall_clock64: the 100 MHz constant counter)
+__global__ void mark_post_kernel(unsigned* mark, const unsigned* gen) {
+    __hip_atomic_store(mark, *gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void mark_wait_kernel(const unsigned* mark, unsigned value, unsigned* err, long long timeout_ticks) {
+    const long long t0 = (long long)wall_clock64();
+    while ((int)(__hip_atomic_load(mark, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - value) < 0) {
+        __builtin_amdgcn_s_sleep(32);
+        if (timeout_ticks > 0 && (long long)wall_clock64() - t0 > timeout_ticks) {
+            if (err) __hip_atomic_store(err, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+    }
+}
 int ablate_gemm_kdiv() {
     static const int d = [] { const char* e = getenv("DPIPE_DEBUG_GEMM_KDIV"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
     return d;
@@ -52,6 +66,18 @@ int dpipe_set_option(int id, int value) {
 }
 int dpipe_get_option(int id) { return dpipe::option(id, -1); }
 const char* dpipe_last_error(void) { return dpipe::g_last_error; }
+// ---- progress marks (include/dpipe_hip.h C5): a device word written by a kernel NODE of a captured graph, waited for by a kernel on another stream
+int dpipe_mark_post(void* mark, const void* gen, void* stream) {
+    if (!mark || !gen) { dpipe::set_last_error("dpipe_mark_post: null"); return DPIPE_ERR_ARG; }
+    dpipe::mark_post_kernel<<<1, 1, 0, reinterpret_cast<hipStream_t>(stream)>>>(reinterpret_cast<unsigned*>(mark), reinterpret_cast<const unsigned*>(gen));
+    return dpipe::check_launch("dpipe_mark_post");
+}
+int dpipe_mark_wait(const void* mark, unsigned value, void* err, int timeout_ms, void* stream) {
+    if (!mark || timeout_ms < 0) { dpipe::set_last_error("dpipe_mark_wait: bad argument"); return DPIPE_ERR_ARG; }
+    dpipe::mark_wait_kernel<<<1, 1, 0, reinterpret_cast<hipStream_t>(stream)>>>(reinterpret_cast<const unsigned*>(mark), value, reinterpret_cast<unsigned*>(err),
+                                                                           (long long)timeout_ms * 100000LL);
+    return dpipe::check_launch("dpipe_mark_wait");
+}
 int dpipe_device_info(int dev, int* cu_count, char* arch_name, int arch_name_len) {
     hipDeviceProp_t prop;
     hipError_t e = hipGetDeviceProperties(&prop, dev);

@@ -351,6 +351,22 @@ class PipelineEngine:
         self._eval_mode = False
         self.pipe_buffers = {}
         self._force_grad_boundary = False
+        # Data-parallel average UNDER the tail of the step's last backward (engine/overlap.py): `dp_overlap` (default on with replicas),
+        # `dp_overlap_marks` layer boundaries at most, none with fewer than `dp_overlap_min_bytes` of gradients behind it.
+        self.dp_overlap = bool(self._config.get('dp_overlap', True)) and self.is_data_parallel
+        self._marks = None
+        self._fwd_count = self._bwd_count = 0
+        self._early = None                 # eager path: what the marks of the running last backward have started ({'done': ids, 'pending': [...], ...})
+        self.overlap_report = {}           # last step: marks that fired, collectives / bytes started before the backward had finished
+        self._overlap_events = None
+        self._mark_err = None
+        self.dp_mark_timeout_ms = int(self._config.get('dp_mark_timeout_ms', 20000))
+        if self.dp_overlap:
+            from .overlap import BackwardMarks
+            self._marks = BackwardMarks(self.module, max_marks=int(self._config.get('dp_overlap_marks', 6)),
+                                        min_bytes=int(self._config.get('dp_overlap_min_bytes', 1 << 20)))
+            if not self._marks.boundaries:
+                self._marks, self.dp_overlap = None, False
         if self.is_data_parallel:
             self._broadcast_model()
 
@@ -474,6 +490,10 @@ class PipelineEngine:
         self._eval_mode = False
         self.total_loss = None
         self._data_iter = data_iter
+        self._fwd_count = self._bwd_count = 0
+        self._early = None
+        self.overlap_report = {}
+        self._overlap_events = None
         if self.stack_micro_batches > 1 and data_iter is not None:
             from ..data import StackedIterator
             self._data_iter = StackedIterator(data_iter, self.stack_micro_batches)
@@ -707,13 +727,31 @@ class PipelineEngine:
                     _trace(('launch', self.global_steps, i, lane['id']), lane['stream'])
                 first = store_first and lane['id'] not in started and entry.get('graph_first') is not None
                 started.add(lane['id'])
+                if self._marks is not None:
+                    # this replay's number: what its progress marks will hold (a mark written by an earlier replay can never satisfy a wait for this one)
+                    lane['marked_step'] = bool(entry.get('marked')) and 'gen' in lane
+                    lane['fired_step'] = set(entry.get('fired', ()))
+                    if lane['marked_step']:
+                        lane['gen_host'] += 1
+                        lane['gen'].fill_(lane['gen_host'])
                 (entry['graph_first'] if first else entry['graph']).replay()
                 _trace(('replay', self.global_steps, i, lane['id']), lane['stream'])
+        base = lanes[0]
+        flat_ok = bool(base['arena']) and all(set(l['arena']) == set(base['arena']) and all(l['arena'][d].numel() == base['arena'][d].numel() for d in base['arena'])
+                                              for l in lanes[1:])
+        marked_stop = None
+        if self._marks is not None and flat_ok and self.is_data_parallel:
+            # every replay of the step is launched: the communication stream follows the lanes' progress marks and averages the gradients of the late layers
+            # over the replicas while the graphs are still in the backward of the early ones
+            marked_stop = self._reduce_flat_marked(lanes, params)
         for lane in lanes:
             main.wait_stream(lane['stream'])
         if TRACE_TIMING:
             _trace(('lanes_joined', self.global_steps), main)
-        base = lanes[0]
+        if marked_stop is not None and self._overlap_events is not None:
+            joined = torch.cuda.Event(enable_timing=True)
+            joined.record(main)
+            self._overlap_events[2] = joined
         _ops.WS_LANE = None
         if self._fused_step_end() and not self.is_data_parallel:
             # the lanes' accumulators go straight into the fused step end: summed, clipped, applied and zeroed in one pass
@@ -729,8 +767,6 @@ class PipelineEngine:
             _trace(('step_end', self.global_steps - 1), main)
             return
         # lane 0 owns the step's gradients; add the other lanes' accumulators and losses into it
-        flat_ok = bool(base['arena']) and all(set(l['arena']) == set(base['arena']) and all(l['arena'][d].numel() == base['arena'][d].numel() for d in base['arena'])
-                                              for l in lanes[1:])
         covered = set()
         if flat_ok:
             covered = {dt: (a.untyped_storage().data_ptr()) for dt, a in base['arena'].items()}
@@ -746,7 +782,7 @@ class PipelineEngine:
         self.total_loss = base['loss']
         self._exec_reduce_tied_grads()
         if flat_ok:
-            self._reduce_flat(base['arena'], [l['arena'] for l in lanes[1:]])
+            self._reduce_flat(base['arena'], [l['arena'] for l in lanes[1:]], stop=marked_stop)
         self._exec_reduce_grads(skip_storages=set(covered.values()) if flat_ok else None)
         self._exec_optimizer_step()                              # zeroes lane 0's buffers (p.grad)
         for lane in lanes[1:]:
@@ -781,6 +817,8 @@ class PipelineEngine:
             return t.requires_grad_(True) if (ckpt and t.is_floating_point()) else t
 
         def body():
+            if self._marks is not None:
+                self._marks.begin()
             x = leaf(static_in[0]) if single else tuple(leaf(t) for t in static_in)
             out = self.module(x)
             loss = self.module.loss_fn(out, static_lab[0] if single_label else static_lab)
@@ -811,8 +849,18 @@ class PipelineEngine:
         cur.wait_stream(side)
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode=_capture_mode()):
-            body()
+        if self._marks is not None:
+            # data-parallel replicas: the backward's progress marks become event-record nodes of this lane's graph (engine/overlap.py, _reduce_flat_marked)
+            self._marks.sink = self._mark_sink(lane)
+        fired = ()
+        try:
+            with torch.cuda.graph(graph, capture_error_mode=_capture_mode()):
+                body()
+            if self._marks is not None:
+                fired = tuple(sorted(self._marks._fired))         # the boundaries whose mark IS a node of this graph (a boundary without a non-leaf float input has none)
+        finally:
+            if self._marks is not None:
+                self._marks.sink = None
         graph_first = None
         if want_first:
             # the lane's first-micro-batch-of-a-step graph: the gradient buffers no fused kernel first-touches (autograd's own accumulation: embedding tables; found by
@@ -841,7 +889,7 @@ class PipelineEngine:
         lane['loss'].copy_(saved_loss)
         _ops.WS_LANE = None
         _offload.POOL_TAG = None
-        return {'graph': graph, 'graph_first': graph_first, 'inputs': static_in, 'labels': static_lab}
+        return {'graph': graph, 'graph_first': graph_first, 'inputs': static_in, 'labels': static_lab, 'marked': self._marks is not None, 'fired': fired}
 
     # ------------------------------------------------------------------------- hipGraph path, pipeline stages
     def _stage_slot(self, buffer_id, inputs, labels):
@@ -1019,6 +1067,13 @@ class PipelineEngine:
         if self.use_stage_graphs and not self._eval_mode:
             return self._exec_forward_pass_graphed(buffer_id)
         inputs = self.pipe_buffers['inputs'][buffer_id]
+        if self._marks is not None and not self._eval_mode:
+            # the step's LAST forward registers the backward progress marks (its backward is the step's last one: 1F1B runs a stage's backwards in forward order)
+            self._fwd_count += 1
+            self._marks.sink = None
+            if self._fwd_count == self.micro_batches:
+                self._marks.begin()
+                self._marks.sink = self._eager_mark
         outputs = self.module(inputs)
         if self.is_last_stage():
             if self.module.loss_fn is not None:
@@ -1037,6 +1092,7 @@ class PipelineEngine:
         if self.use_stage_graphs:
             return self._exec_backward_pass_graphed(buffer_id)
         outputs = self.pipe_buffers['outputs'][buffer_id]
+        self._bwd_count += 1
         if self.is_last_stage():
             (outputs / self.micro_batches).backward()
         else:
@@ -1085,10 +1141,11 @@ class PipelineEngine:
     def _exec_reduce_tied_grads(self):
         pass   # the reference's adapters register no tied layers
 
-    def _dp_reduce_(self, chunk, group):
+    def _dp_reduce_(self, chunk, group, async_op=False):
         """in-place data-parallel AVERAGE of one contiguous bucket.  One all-reduce with the averaging folded in (ReduceOp.AVG) where the backend has it (RCCL;
         the gloo of this torch build), else sum + scale; `communication_data_type` (DeepSpeed's knob, honoured by the bucketed path too) reduces a cast copy
-        of the bucket and writes the result back."""
+        of the bucket and writes the result back.  `async_op` (host-side backends under the backward's tail): the collective is started and a `finish()` that
+        waits for it and completes the average is returned."""
         comm_dt = self.communication_data_type
         buf = chunk if (comm_dt is None or comm_dt == chunk.dtype) else chunk.to(comm_dt)
         if self._dp_avg_ok is None:
@@ -1096,19 +1153,27 @@ class PipelineEngine:
             # collective lets a single failing rank issue a second all-reduce its peers never post -- a hang instead of an error).  RCCL / NCCL have AVG; gloo
             # takes sum + scale (exact for the power-of-two world sizes the CPU tests use, and never a capability question).
             self._dp_avg_ok = str(dist.get_backend(group)).lower() == 'nccl'
-        if self._dp_avg_ok:
-            dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=group)
-        else:
-            dist.all_reduce(buf, group=group)
-            buf.div_(self.dp_world_size)
-        if buf is not chunk:
-            chunk.copy_(buf)
+        avg = self._dp_avg_ok
+        work = dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=group, async_op=async_op) if avg else dist.all_reduce(buf, group=group, async_op=async_op)
 
-    def _reduce_flat(self, base, others):
+        def finish():
+            if async_op:
+                work.wait()
+            if not avg:
+                buf.div_(self.dp_world_size)
+            if buf is not chunk:
+                chunk.copy_(buf)
+        if async_op:
+            return finish
+        finish()
+        return None
+
+    def _reduce_flat(self, base, others, stop=None):
         """Lane summation + data-parallel average over flat gradient arenas, bucket by bucket: bucket k's lane sum runs on the compute
         stream, its all-reduce on the communication stream behind an event -- so the all-reduce of bucket k overlaps the summation of bucket k + 1 and
         the xGMI links start moving data as soon as the first bucket is summed.  No staging concatenation, no copy back: the buckets are views of the
-        arenas the wgrad kernels accumulated into.  base: {dtype: flat}; others: the other lanes' arenas (same layout)."""
+        arenas the wgrad kernels accumulated into.  base: {dtype: flat}; others: the other lanes' arenas (same layout); `stop` ({dtype: element count}):
+        only arena[:stop] -- the tail was reduced under the backward (_reduce_flat_marked)."""
         group = self.grid.get_data_parallel_group() if self.is_data_parallel else None
         cuda = self.device.type == 'cuda'
         if cuda and group is not None and self._dp_stream is None:
@@ -1116,10 +1181,11 @@ class PipelineEngine:
         cur = torch.cuda.current_stream(self.device) if cuda else None
         for dt, flat in base.items():
             step = max(1, self.dp_bucket_bytes // flat.element_size())
-            for off in range(0, flat.numel(), step):
-                chunk = flat[off:off + step]
+            end = flat.numel() if stop is None else min(flat.numel(), stop.get(dt, flat.numel()))
+            for off in range(0, end, step):
+                chunk = flat[off:min(off + step, end)]
                 for o in others:
-                    chunk.add_(o[dt][off:off + step])
+                    chunk.add_(o[dt][off:min(off + step, end)])
                 if group is None:
                     continue
                 if cuda:
@@ -1132,42 +1198,198 @@ class PipelineEngine:
         if cuda and group is not None:
             cur.wait_stream(self._dp_stream)
 
+    def _lane_marks(self, lane):
+        """The lane's progress marks: one device word per boundary (written by a kernel node of every graph the lane captures, include/dpipe_hip.h C5), the word
+        that names the replay in flight (`gen`, set on the lane's stream before every replay) and its host copy."""
+        if 'marks' not in lane:
+            lane['marks'] = torch.zeros(len(self._marks.boundaries), dtype=torch.int32, device=self.device)
+            lane['gen'] = torch.zeros(1, dtype=torch.int32, device=self.device)
+            lane['gen_host'] = 0
+        return lane['marks']
+
+    def _mark_sink(self, lane):
+        """Sink of BackwardMarks while a lane graph is being captured: boundary j -> a `mark = gen` kernel node on the capturing stream."""
+        from .. import hip as _hip
+        words = self._lane_marks(lane)
+        index = {j: i for i, j in enumerate(self._marks.boundaries)}
+
+        def sink(j):
+            _hip.check(_hip.lib().dpipe_mark_post(words.data_ptr() + 4 * index[j], lane['gen'].data_ptr(), torch.cuda.current_stream(self.device).cuda_stream), 'mark_post')
+        return sink
+
+    def _reduce_flat_marked(self, lanes, params):
+        """The data-parallel average UNDER the tail of the lanes' last replays (hipGraph lane path; called when every replay of the step has been launched, before
+        the lanes are joined).  For the boundaries j in descending order: the communication stream waits for mark j of EVERY lane -- recorded inside the lane's graph
+        once the backward has left layer j, i.e. arena[offset_j:] of that lane is final -- then sums the lanes' arena ranges into lane 0's and averages them over the
+        replicas, while the graphs are still running the backward of the earlier layers.  Returns {dtype: element count still to do} for _reduce_flat, or None
+        when the arenas are not laid out in layer order (nothing started)."""
+        from .. import hip as _hip
+        base = lanes[0]
+        key = tuple(sorted((str(dt), l['arena'][dt].data_ptr()) for l in lanes for dt in l['arena']))
+        cached = getattr(self, '_marked_bounds', None)
+        if cached is None or cached[0] != key:
+            per_lane = [self._marks.arena_bounds(params, l['arena'], grad_of=lambda p, l=l: l['grads'].get(id(p))) for l in lanes]
+            bounds = per_lane[0] if all(b == per_lane[0] for b in per_lane[1:]) else None
+            self._marked_bounds = cached = (key, bounds)
+        bounds = cached[1]
+        if not bounds or not any(bounds.values()) or any('marks' not in l or not l.get('marked_step', False) for l in lanes):
+            return None
+        if self._mark_err is None:
+            self._mark_err = torch.zeros(1, dtype=torch.int32).pin_memory()       # written by a waiting kernel that gave up (a lost mark), read here one step later
+        elif int(self._mark_err[0]) != 0:
+            raise RuntimeError('data-parallel overlap: a progress mark of an earlier step never arrived (dpipe_mark_wait timed out); gradients of that step were reduced early')
+        index = {j: i for i, j in enumerate(self._marks.boundaries)}
+        group = self.grid.get_data_parallel_group()
+        if self._dp_stream is None:
+            self._dp_stream = torch.cuda.Stream(self.device)
+        dps = self._dp_stream
+        stop = {dt: a.numel() for dt, a in base['arena'].items()}
+        report = {'path': 'graph lanes', 'marks': [], 'early_collectives': 0, 'early_bytes': 0, 'total_bytes': sum(a.numel() * a.element_size() for a in base['arena'].values())}
+        lib = _hip.lib()
+        usable = set.intersection(*[l.get('fired_step', set()) for l in lanes])
+        for j in sorted(bounds, reverse=True):
+            offs = {dt: off for dt, off in bounds[j].items() if off < stop[dt]}
+            if not offs or j not in usable:
+                continue
+            for l in lanes:       # the replay numbered gen_host is the lane's last one of this step: behind its mark j the lane's arena[offset_j:] is final
+                _hip.check(lib.dpipe_mark_wait(l['marks'].data_ptr() + 4 * index[j], l['gen_host'] & 0xffffffff, self._mark_err.data_ptr(), self.dp_mark_timeout_ms,
+                                               dps.cuda_stream), 'mark_wait')
+            with torch.cuda.stream(dps):
+                for dt, off in offs.items():
+                    flat = base['arena'][dt]
+                    step = max(1, self.dp_bucket_bytes // flat.element_size())
+                    for o0 in range(off, stop[dt], step):
+                        o1 = min(o0 + step, stop[dt])
+                        chunk = flat[o0:o1]
+                        for l in lanes[1:]:
+                            chunk.add_(l['arena'][dt][o0:o1])
+                        self._dp_reduce_(chunk, group)
+                        report['early_collectives'] += 1
+                        report['early_bytes'] += (o1 - o0) * flat.element_size()
+                    stop[dt] = off
+            report['marks'].append(j)
+            if len(report['marks']) == 1:
+                first_done = torch.cuda.Event(enable_timing=True)
+                first_done.record(dps)
+        if report['marks']:
+            last_done = torch.cuda.Event(enable_timing=True)
+            last_done.record(dps)
+            self._overlap_events = [first_done, last_done, None]
+        self.overlap_report = report
+        return stop
+
+    def overlap_lead_ms(self):
+        """(hipGraph lane path, after a step; synchronises) how long before the lanes' graphs had all finished the average of the FIRST / LAST marked gradient range
+        was complete on the communication stream: positive = that much of the reduction ran under the backward."""
+        ev = self._overlap_events
+        if not ev or ev[2] is None:
+            return None
+        ev[2].synchronize()
+        return round(ev[0].elapsed_time(ev[2]), 3), round(ev[1].elapsed_time(ev[2]), 3)
+
+    def _eager_mark(self, j):
+        """Sink of BackwardMarks on the eager path (called from inside the step's last backward): the gradients of the layers >= j are final -- start their average."""
+        if self._bwd_count != self.micro_batches or not self.is_data_parallel:
+            return
+        st = self._early
+        if st is None:
+            st = self._early = {'done': set(), 'finish': [], 'marks': [], 'collectives': 0, 'bytes': 0, 'streamed': False}
+        layer_of = self._marks.layer_of
+        grads = []
+        for p in self._trainable_params():
+            if p.grad is not None and id(p) not in st['done'] and layer_of.get(id(p), -1) >= j:
+                st['done'].add(id(p))
+                grads.append(p.grad)
+        st['marks'].append(j)
+        if grads:
+            self._reduce_grad_tensors(grads, self.grid.get_data_parallel_group(), early=st)
+
+    def _reduce_grad_tensors(self, grads, group, early=None):
+        """Average gradient tensors over the replicas in place: a gradient of dp_direct_min_bytes or more as its own collective, the small ones through staged buckets.
+        `early` (the eager overlap state): the collectives are STARTED here -- on the communication stream behind an event (GPU) or as asynchronous operations
+        (gloo) -- and completed by _exec_reduce_grads."""
+        cuda = self.device.type == 'cuda'
+        by_dtype = OrderedDict()
+        for g in grads:
+            dt = self.communication_data_type or g.dtype
+            by_dtype.setdefault((dt, g.dtype), []).append(g)
+        async_op = early is not None and not cuda
+        ctx = None
+        if early is not None and cuda:
+            if self._dp_stream is None:
+                self._dp_stream = torch.cuda.Stream(self.device)
+            ev = torch.cuda.current_stream(self.device).record_event()
+            self._dp_stream.wait_event(ev)
+            ctx = torch.cuda.stream(self._dp_stream)
+            ctx.__enter__()
+            early['streamed'] = True
+        try:
+            for (comm_dt, _), gs in by_dtype.items():
+                # (round 6, VERDICT round 5 weak 13) a gradient of dp_direct_min_bytes or more is averaged IN PLACE, as its own collective: no concatenation, no copy back --
+                # staging is for the small tensors only (biases, norm weights: a collective each would be latency-bound).  Every rank walks the same parameter list, so the
+                # sequence of collectives is the same everywhere.
+                small = []
+                for g in gs:
+                    if g.is_contiguous() and g.numel() * g.element_size() >= self.dp_direct_min_bytes:
+                        fin = self._dp_reduce_(g.view(-1), group, async_op=async_op)
+                        if early is not None:
+                            early['collectives'] += 1; early['bytes'] += g.numel() * g.element_size()
+                            if fin is not None:
+                                early['finish'].append(fin)
+                    else:
+                        small.append(g)
+                bucket, size = [], 0
+                for g in small + [None]:
+                    if g is not None:
+                        bucket.append(g); size += g.numel() * g.element_size()
+                    if bucket and (g is None or size >= self.dp_bucket_bytes):
+                        flat = torch.cat([b.reshape(-1).to(comm_dt) for b in bucket])
+                        fin = self._dp_reduce_(flat, group, async_op=async_op)
+
+                        def copy_back(flat=flat, bucket=bucket, fin=fin):
+                            if fin is not None:
+                                fin()
+                            off = 0
+                            for b in bucket:
+                                b.copy_(flat[off:off + b.numel()].view_as(b)); off += b.numel()
+                        if async_op:
+                            early['finish'].append(copy_back)
+                        else:
+                            copy_back()
+                        if early is not None:
+                            early['collectives'] += 1; early['bytes'] += size
+                        bucket, size = [], 0
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
+
     def _exec_reduce_grads(self, skip_storages=None):
         """Data-parallel gradient average.  Persistent-gradient paths keep the gradients in flat arenas (flatten_grads) and reduce those in
         place, in buckets sized for xGMI / 288 GB HBM; gradients outside an arena (eager path: autograd allocates them per step) are averaged in place when
-        large and bucketed through a staging concatenation when small."""
+        large and bucketed through a staging concatenation when small.  What the marks of the step's last backward already started (eager path, _eager_mark)
+        is completed first and not repeated."""
+        if self._marks is not None:
+            self._marks.sink = None
         if not self.is_data_parallel:
             return
         group = self.grid.get_data_parallel_group()
+        early, self._early = self._early, None
+        done = set()
+        if early is not None:
+            for fin in early['finish']:
+                fin()
+            if early['streamed']:
+                torch.cuda.current_stream(self.device).wait_stream(self._dp_stream)
+            done = early['done']
+            self.overlap_report = {'path': 'eager', 'marks': early['marks'], 'early_collectives': early['collectives'], 'early_bytes': early['bytes'],
+                                   'total_bytes': sum(p.grad.numel() * p.grad.element_size() for p in self._trainable_params() if p.grad is not None)}
         if skip_storages is None and self._stage_arena:
             self._reduce_flat(self._stage_arena, [])
             skip_storages = {a.untyped_storage().data_ptr() for a in self._stage_arena.values()}
-        by_dtype = OrderedDict()
-        for p in self._trainable_params():
-            if p.grad is not None and not (skip_storages and p.grad.untyped_storage().data_ptr() in skip_storages):
-                dt = self.communication_data_type or p.grad.dtype
-                by_dtype.setdefault((dt, p.grad.dtype), []).append(p.grad)
-        for (comm_dt, _), grads in by_dtype.items():
-            # (round 6, VERDICT round 5 weak 13) a gradient of dp_direct_min_bytes or more is averaged IN PLACE, as its own collective: no concatenation, no copy back --
-            # staging is for the small tensors only (biases, norm weights: a collective each would be latency-bound).  Every rank walks the same parameter list, so the
-            # sequence of collectives is the same everywhere.
-            small = []
-            for g in grads:
-                if g.is_contiguous() and g.numel() * g.element_size() >= self.dp_direct_min_bytes:
-                    self._dp_reduce_(g.view(-1), group)
-                else:
-                    small.append(g)
-            bucket, size = [], 0
-            for g in small + [None]:
-                if g is not None:
-                    bucket.append(g); size += g.numel() * g.element_size()
-                if bucket and (g is None or size >= self.dp_bucket_bytes):
-                    flat = torch.cat([b.reshape(-1).to(comm_dt) for b in bucket])
-                    self._dp_reduce_(flat, group)
-                    off = 0
-                    for b in bucket:
-                        b.copy_(flat[off:off + b.numel()].view_as(b)); off += b.numel()
-                    bucket, size = [], 0
+        grads = [p.grad for p in self._trainable_params()
+                 if p.grad is not None and id(p) not in done and not (skip_storages and p.grad.untyped_storage().data_ptr() in skip_storages)]
+        if grads:
+            self._reduce_grad_tensors(grads, group)
 
     def clip_fp32_gradients(self):
         """Reference `clip_grad_norm_` (utils/patches.py:175-246) on the HIP multi-tensor kernels, no host sync."""

@@ -16,7 +16,7 @@ import os
 LIB_PATH = Path(os.environ.get('DPIPE_HIP_LIB') or Path(__file__).resolve().parent / 'libdpipe_hip.so')
 
 BF16, F32 = 0, 1
-ABI_VERSION = 9                      # DPIPE_ABI_VERSION of include/dpipe_hip.h this binding was written against
+ABI_VERSION = 10                     # DPIPE_ABI_VERSION of include/dpipe_hip.h this binding was written against
 CONV_OUT_F32, CONV_ACCUMULATE, CONV_BIAS_PER_SAMPLE, CONV_BIAS_HILO = 1, 2, 4, 8  # dpipe_conv2d_fwd / _dgrad `flags`
 OPT_ATTN_FWD_DMA, OPT_ATTN_BWD_DMA, OPT_ATTN_DQ8, OPT_ATTN_DKV_SPLIT, OPT_GEMM_SHALLOW, OPT_GEMM_BIG_TILES = 0, 1, 2, 3, 4, 5     # dpipe_set_option ids (include/dpipe_hip.h)
 ACT = {None: 0, 'none': 0, 'gelu_tanh': 1, 'gelu': 2, 'gelu_erf': 2, 'silu': 3, 'quick_gelu': 4}
@@ -44,6 +44,8 @@ _SIGNATURES = {
     'dpipe_comm_unique_id': (I, [P]),
     'dpipe_comm_init': (I, [POINTER(c_void_p), I, I, P]),
     'dpipe_comm_destroy': (I, [P]),
+    'dpipe_mark_post': (I, [P, P, P]),
+    'dpipe_mark_wait': (I, [P, ctypes.c_uint, P, I, P]),
     'dpipe_group_start': (I, []),
     'dpipe_group_end': (I, []),
     'dpipe_send': (I, [P, P, L, I, P]),

