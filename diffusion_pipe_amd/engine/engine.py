@@ -360,6 +360,8 @@ class PipelineEngine:
         self.overlap_report = {}           # last step: marks that fired, collectives / bytes started before the backward had finished
         self._overlap_events = None
         self._mark_err = None
+        self._stage_lane = {'id': -1, 'arena': {}, 'grads': None}      # stage-graph path without pipeline lanes: the 'lane' the stage's progress marks belong to
+        self._stage_marked_stop = None
         self.dp_mark_timeout_ms = int(self._config.get('dp_mark_timeout_ms', 20000))
         if self.dp_overlap:
             from .overlap import BackwardMarks
@@ -494,6 +496,7 @@ class PipelineEngine:
         self._early = None
         self.overlap_report = {}
         self._overlap_events = None
+        self._stage_marked_stop = None
         if self.stack_micro_batches > 1 and data_iter is not None:
             from ..data import StackedIterator
             self._data_iter = StackedIterator(data_iter, self.stack_micro_batches)
@@ -644,9 +647,19 @@ class PipelineEngine:
             self._exec_reduce_grads()
             self._exec_optimizer_step()
             return
+        base = lanes[0]
+        flat_ok = bool(base['arena']) and all(set(l['arena']) == set(base['arena']) and all(l['arena'][d].numel() == base['arena'][d].numel() for d in base['arena'])
+                                              for l in lanes[1:])
+        marked_stop = None
+        if self._marks is not None and flat_ok and self.is_data_parallel:
+            # every instruction of the step is issued: the communication stream follows the progress marks of each lane's last backward replay
+            marked_stop = self._reduce_flat_marked(lanes, [p for p in self.module.parameters() if p.requires_grad])
         for lane in lanes[1:]:
             main.wait_stream(lane['stream'])
-        base = lanes[0]
+        if marked_stop is not None and self._overlap_events is not None:
+            joined = torch.cuda.Event(enable_timing=True)
+            joined.record(main)
+            self._overlap_events[2] = joined
         for p in self.module.parameters():
             p.grad = base['grads'].get(id(p))
         if self.is_last_stage():
@@ -657,12 +670,16 @@ class PipelineEngine:
         if self._fused_step_end() and not self.is_data_parallel:
             self._exec_optimizer_step(lane_grads=[lane['grads'] for lane in lanes])      # lanes summed, clipped, applied and zeroed in one pass
             return
+        covered = {dt: a.untyped_storage().data_ptr() for dt, a in base['arena'].items()} if flat_ok else {}
         for lane in lanes[1:]:
             ks = [k for k in lane['grads'] if k in base['grads']]
+            if flat_ok:       # gradients outside the arenas one by one; the arenas themselves in _reduce_flat (bucket-wise lane sums + all-reduce, minus what ran under the backward)
+                ks = [k for k in ks if covered.get(base['grads'][k].dtype) != base['grads'][k].untyped_storage().data_ptr()]
             if ks:
                 torch._foreach_add_([base['grads'][k] for k in ks], [lane['grads'][k] for k in ks])
-        self._stage_arena = base['arena']
-        self._exec_reduce_grads()
+        if flat_ok:
+            self._reduce_flat(base['arena'], [l['arena'] for l in lanes[1:]], stop=marked_stop)
+        self._exec_reduce_grads(skip_storages=set(covered.values()) if flat_ok else set())
         self._exec_optimizer_step()                              # zeroes lane 0's buffers (p.grad)
         for lane in lanes[1:]:
             if lane['grads']:
@@ -970,12 +987,24 @@ class PipelineEngine:
         # forward graphs of the two forward streams and the backward graph replay at the same time: they must not share split-K ticket counters / slabs.
         # A pipeline lane replays its forward and backward graphs on ONE stream: one workspace per lane.
         _ops.WS_LANE = ('pipe-lane', lane['id']) if lane is not None else ('stage-fwd', self._capturing_buffer % max(1, len(self._fwd_streams)))
-        with torch.cuda.graph(fwd_graph, capture_error_mode=_capture_mode()):
-            out = forward(static_in)
-        static_gout = None if last else grads_like(out)
-        _ops.WS_LANE = ('pipe-lane', lane['id']) if lane is not None else 'stage-bwd'
-        with torch.cuda.graph(bwd_graph, pool=fwd_graph.pool(), capture_error_mode=_capture_mode()):
-            backward(out, static_gout)
+        fired = ()
+        if self._marks is not None:
+            # data-parallel replicas: the forward capture registers the layer-boundary hooks, the backward capture turns each into a `mark = gen` kernel node of the
+            # backward graph (engine/overlap.py); the communication stream follows them after the step's last backward replay (_reduce_flat_marked)
+            self._marks.begin()
+            self._marks.sink = self._mark_sink(lane if lane is not None else self._stage_lane)
+        try:
+            with torch.cuda.graph(fwd_graph, capture_error_mode=_capture_mode()):
+                out = forward(static_in)
+            static_gout = None if last else grads_like(out)
+            _ops.WS_LANE = ('pipe-lane', lane['id']) if lane is not None else 'stage-bwd'
+            with torch.cuda.graph(bwd_graph, pool=fwd_graph.pool(), capture_error_mode=_capture_mode()):
+                backward(out, static_gout)
+            if self._marks is not None:
+                fired = tuple(sorted(self._marks._fired))
+        finally:
+            if self._marks is not None:
+                self._marks.sink = None
         _ops.WS_LANE = None
         # undo the side effects of warm-up / capture on the accumulators
         for p in params:
@@ -991,7 +1020,7 @@ class PipelineEngine:
                     lane['grads'][id(p)] = p.grad                # persistent: their addresses are baked into this lane's backward graphs
         _offload.POOL_TAG = None
         return {'fwd': fwd_graph, 'bwd': bwd_graph, 'inputs': static_in, 'labels': static_lab, 'out': out, 'gout': static_gout,
-                'single_in': single_in, 'fwd_done': None, 'bwd_done': None}
+                'single_in': single_in, 'fwd_done': None, 'bwd_done': None, 'marked': self._marks is not None, 'fired': fired}
 
     def _exec_forward_pass_graphed(self, buffer_id):
         inputs = self.pipe_buffers['inputs'][buffer_id]
@@ -1028,9 +1057,22 @@ class PipelineEngine:
                     if src.data_ptr() != dst.data_ptr():
                         dst.copy_(src, non_blocking=True)
             self.pipe_buffers['grads'][buffer_id] = None
+        self._bwd_count += 1
+        mlane = None
+        if self._marks is not None:
+            mlane = self._cur_pipe_lane if self._cur_pipe_lane is not None else self._stage_lane
+            mlane['marked_step'] = bool(slot.get('marked')) and 'gen' in mlane
+            mlane['fired_step'] = set(slot.get('fired', ()))
+            if mlane['marked_step']:
+                mlane['gen_host'] += 1                  # this replay's number: what its progress marks will hold
+                mlane['gen'].fill_(mlane['gen_host'])
         slot['bwd'].replay()
         slot['bwd_done'] = cur.record_event()
         self.pipe_buffers['outputs'][buffer_id] = None
+        if mlane is self._stage_lane and mlane is not None and self._bwd_count == self.micro_batches and self.is_data_parallel and self._stage_arena:
+            # the step's last backward is launched: average the late layers' gradients over the replicas while it is still running
+            self._stage_lane['arena'] = self._stage_arena
+            self._stage_marked_stop = self._reduce_flat_marked([self._stage_lane], [p for p in self.module.parameters() if p.requires_grad])
 
     # ----------------------------------------------------------------------------------------- instructions
     def _next_batch(self):
@@ -1228,7 +1270,7 @@ class PipelineEngine:
         key = tuple(sorted((str(dt), l['arena'][dt].data_ptr()) for l in lanes for dt in l['arena']))
         cached = getattr(self, '_marked_bounds', None)
         if cached is None or cached[0] != key:
-            per_lane = [self._marks.arena_bounds(params, l['arena'], grad_of=lambda p, l=l: l['grads'].get(id(p))) for l in lanes]
+            per_lane = [self._marks.arena_bounds(params, l['arena'], grad_of=(lambda p, l=l: l['grads'].get(id(p))) if l.get('grads') else None) for l in lanes]
             bounds = per_lane[0] if all(b == per_lane[0] for b in per_lane[1:]) else None
             self._marked_bounds = cached = (key, bounds)
         bounds = cached[1]
@@ -1244,7 +1286,7 @@ class PipelineEngine:
             self._dp_stream = torch.cuda.Stream(self.device)
         dps = self._dp_stream
         stop = {dt: a.numel() for dt, a in base['arena'].items()}
-        report = {'path': 'graph lanes', 'marks': [], 'early_collectives': 0, 'early_bytes': 0, 'total_bytes': sum(a.numel() * a.element_size() for a in base['arena'].values())}
+        report = {'path': 'graph lanes' if self.use_graph else 'stage graphs', 'marks': [], 'early_collectives': 0, 'early_bytes': 0, 'total_bytes': sum(a.numel() * a.element_size() for a in base['arena'].values())}
         lib = _hip.lib()
         usable = set.intersection(*[l.get('fired_step', set()) for l in lanes])
         for j in sorted(bounds, reverse=True):
@@ -1373,6 +1415,10 @@ class PipelineEngine:
         if not self.is_data_parallel:
             return
         group = self.grid.get_data_parallel_group()
+        if self._overlap_events is not None and self._overlap_events[2] is None and self.device.type == 'cuda':
+            joined = torch.cuda.Event(enable_timing=True)       # stage-graph path: the step's last backward has been joined into the caller's stream by now
+            joined.record(torch.cuda.current_stream(self.device))
+            self._overlap_events[2] = joined
         early, self._early = self._early, None
         done = set()
         if early is not None:
@@ -1384,7 +1430,7 @@ class PipelineEngine:
             self.overlap_report = {'path': 'eager', 'marks': early['marks'], 'early_collectives': early['collectives'], 'early_bytes': early['bytes'],
                                    'total_bytes': sum(p.grad.numel() * p.grad.element_size() for p in self._trainable_params() if p.grad is not None)}
         if skip_storages is None and self._stage_arena:
-            self._reduce_flat(self._stage_arena, [])
+            self._reduce_flat(self._stage_arena, [], stop=self._stage_marked_stop)
             skip_storages = {a.untyped_storage().data_ptr() for a in self._stage_arena.values()}
         grads = [p.grad for p in self._trainable_params()
                  if p.grad is not None and id(p) not in done and not (skip_storages and p.grad.untyped_storage().data_ptr() in skip_storages)]

@@ -30,10 +30,11 @@ if world > 1:
     dist.init_process_group('gloo', rank=rank, world_size=world)
 cfg = sdxl.tiny_config()
 dp_mode = len(sys.argv) > 4 and sys.argv[4] == 'dp'          # every rank a whole replica (pp = 1, dp = world) instead of a pipeline stage
+ppdp_mode = len(sys.argv) > 4 and sys.argv[4] == 'ppdp'      # 2 pipeline stages x (world / 2) replicas
 total_mb = int(sys.argv[5]) if len(sys.argv) > 5 else 4      # micro-batches per optimizer step over all replicas
-gas = total_mb // world if dp_mode else total_mb
+gas = total_mb // world if dp_mode else (total_mb // (world // 2) if ppdp_mode else total_mb)
 work = sdxl.SDXLWorkload(cfg, model_config={'min_snr_gamma': 5.0}, dtype=torch.bfloat16, seed=2, device=dev)
-module = ManualPipelineModule(layers=work.to_layers(), num_stages=1 if dp_mode else world, partition_method='parameters', loss_fn=work.get_loss_fn(), dynamic_shape=True)
+module = ManualPipelineModule(layers=work.to_layers(), num_stages=1 if dp_mode else (2 if ppdp_mode else world), partition_method='parameters', loss_fn=work.get_loss_fn(), dynamic_shape=True)
 extra = {'graph_lanes': 2, 'flat_grads': True, 'dp_bucket_bytes': 1 << 20} if (dp_mode or (len(sys.argv) > 4 and sys.argv[4] == 'flat')) else {}
 extra.update(json.loads(os.environ.get('DPIPE_TEST_EXTRA_CONFIG', '{}')))
 engine, _, _, _ = initialize(model=module, config={'train_micro_batch_size_per_gpu': 1, 'gradient_accumulation_steps': gas, 'gradient_clipping': 1.0,
@@ -53,6 +54,9 @@ for step in range(3):
     micro = split_batch((feats, label), total_mb)
     if dp_mode:
         micro = micro[rank * gas:(rank + 1) * gas]            # replica r trains on its slice of the global batch
+    if ppdp_mode:
+        d = engine.grid.get_data_parallel_rank()
+        micro = micro[d * gas:(d + 1) * gas]
     need = engine.is_first_stage() or engine.is_last_stage()
     engine.reset_activation_shape()
     loss = engine.train_batch(iter(micro) if need else None)
@@ -164,6 +168,20 @@ def test_dp2_average_under_the_lanes_last_replays_matches_the_reduction_after_th
         assert abs(l1 - l0) <= 1e-6 * abs(l0) and abs(n1 - n0) <= 1e-5 * n0, (plain['res'], early['res'])
     # the first marked range was averaged before the lanes' graphs had finished (gloo moves the bytes through the host here: the lead is what the marks give, not a rate)
     assert early['overlap_lead_ms'] is not None and early['overlap_lead_ms'][0] > 0.0, early['overlap_lead_ms']
+
+
+@pytest.mark.parametrize('lanes', [1, 2])
+def test_pp2_dp2_average_under_the_last_backward_graph_matches_the_reduction_after_it(gpu, tmp_path, lanes):
+    """The same on per-stage hipGraphs (2 stages x 2 replicas = four processes on cuda:0): the marks are kernel nodes of every slot's BACKWARD graph; after the step's
+    last backward replay (of each pipeline lane) is launched the communication stream averages the stage's late-layer gradients under it.  Against `dp_overlap: false`."""
+    common = {'flat_grads': True, 'dp_bucket_bytes': 1 << 20, **({'pipe_lanes': 2} if lanes == 2 else {})}
+    plain = _run(tmp_path, 'graph', 4, 'sgd', 'ppdp', 8, extra={**common, 'dp_overlap': False})
+    early = _run(tmp_path, 'graph', 4, 'sgd', 'ppdp', 8, extra={**common, 'dp_overlap_min_bytes': 0, 'dp_overlap_marks': 3})
+    ov = early['overlap']
+    print(f'pp2 x dp2, pipe lanes {lanes}: overlap report (stage 0):', ov, 'lead (first, last) ms:', early['overlap_lead_ms'])
+    assert early['stage_graphs'] and early['boundaries'] and ov['path'] == 'stage graphs' and ov['marks'] and 0 < ov['early_bytes'] <= ov['total_bytes']
+    for (l0, n0), (l1, n1) in zip(plain['res'], early['res']):
+        assert abs(l1 - l0) <= 1e-6 * abs(l0) and abs(n1 - n0) <= 1e-5 * n0, (plain['res'], early['res'])
 
 
 def test_bench_multi_rank_path_runs_end_to_end_on_one_shared_gpu(gpu, tmp_path):
