@@ -241,7 +241,8 @@ def _flat_reduce_worker(rank, world, outdir):
     from diffusion_pipe_amd.engine.engine import flatten_grads
     layers, params = _flat_case(rank, 0)
     module = ManualPipelineModule(layers=layers, num_stages=1, partition_method='uniform', loss_fn=None)
-    engine, _, _, _ = initialize(model=module, config={'gradient_accumulation_steps': 2, 'dp_bucket_bytes': 256}, device='cpu')
+    engine, _, _, _ = initialize(model=module, config={'gradient_accumulation_steps': 2, 'dp_bucket_bytes': 256, 'dp_overlap': outdir.endswith('marked'),
+                                                         'dp_overlap_min_bytes': 0, 'dp_overlap_marks': 2}, device='cpu')
     assert engine.dp_world_size == world and engine.flat_grads
     base = flatten_grads(params)
     assert list(base) == [torch.float32] and base[torch.float32].numel() >= sum(p.numel() for p in params)
@@ -249,14 +250,28 @@ def _flat_reduce_worker(rank, world, outdir):
         assert p.grad.untyped_storage().data_ptr() == base[torch.float32].untyped_storage().data_ptr()
     _, lane1_params = _flat_case(rank, 1)
     other = flatten_grads(lane1_params)
-    engine._reduce_flat(base, [other])
+    if engine._marks is not None:
+        # as engine._reduce_flat_marked does under the last backward: the arena's tail behind the LAST mark first (lane sum + average), the rest -- arena[:offset] --
+        # through _reduce_flat(stop=...)
+        bounds = engine._marks.arena_bounds(params, base)
+        off = bounds[max(bounds)][torch.float32]
+        assert 0 < off < base[torch.float32].numel()
+        tail = base[torch.float32][off:]
+        tail.add_(other[torch.float32][off:])
+        engine._dp_reduce_(tail, engine.grid.get_data_parallel_group())
+        engine._reduce_flat(base, [other], stop={torch.float32: off})
+    else:
+        engine._reduce_flat(base, [other])
     engine._exec_reduce_grads(skip_storages={base[torch.float32].untyped_storage().data_ptr()})     # nothing left outside the arena: a no-op
     torch.save({'grads': [p.grad.clone() for p in params]}, os.path.join(outdir, f'r{rank}.pt'))
 
 
-def test_flat_gradient_arenas_lane_sum_and_dp_average_gloo_ws4():
+@pytest.mark.parametrize('marked', [False, True])
+def test_flat_gradient_arenas_lane_sum_and_dp_average_gloo_ws4(marked):
+    """marked: the arena's tail behind the last progress mark is summed and averaged first, the head through `_reduce_flat(stop=...)` -- the split the overlapped
+    path makes (engine._reduce_flat_marked)"""
     world = 4
-    with tempfile.TemporaryDirectory() as d:
+    with tempfile.TemporaryDirectory(suffix='marked' if marked else '') as d:
         mp.spawn(_worker, args=(world, _free_port(), 'flat_dp4', d), nprocs=world, join=True)
         res = [torch.load(os.path.join(d, f'r{r}.pt')) for r in range(world)]
     want = None
