@@ -11,8 +11,8 @@ included) has executed by then.  Leaf inputs are never used: their AccumulateGra
 `BackwardMarks` installs one forward pre-hook per chosen layer boundary; while a `sink` is set, the forward registers the tensor hooks and the
 backward calls `sink(j)` ONCE per boundary, in descending j.  Three sinks exist (engine.py):
   * eager path (CPU / gloo, GPU without graphs): starts the asynchronous average of the gradients of layers >= j;
-  * hipGraph lanes / stage graphs: `dpipe_mark_record` -- an event-record NODE in the captured graph (include/dpipe_hip.h C5), which the communication
-    stream waits for after the step's last replays were launched.
+  * hipGraph lanes / stage graphs: `dpipe_mark_post` -- a one-thread KERNEL NODE of the captured graph that writes the replay's number into the mark's
+    device word (include/dpipe_hip.h C5); after the step's last replays were launched the communication stream runs `dpipe_mark_wait` on it.
 Boundaries are chosen by gradient bytes: at most `max_marks` of them, none before `min_bytes` of gradients are behind it."""
 import torch
 from torch import nn
