@@ -874,7 +874,7 @@ class PipelineEngine:
             with torch.cuda.graph(graph, capture_error_mode=_capture_mode()):
                 body()
             if self._marks is not None:
-                fired = tuple(sorted(self._marks._fired))         # the boundaries whose mark IS a node of this graph (a boundary without a non-leaf float input has none)
+                fired = self._marks.fired()         # the boundaries whose mark IS a node of this graph (a boundary without a non-leaf float input has none)
         finally:
             if self._marks is not None:
                 self._marks.sink = None
@@ -1001,7 +1001,7 @@ class PipelineEngine:
             with torch.cuda.graph(bwd_graph, pool=fwd_graph.pool(), capture_error_mode=_capture_mode()):
                 backward(out, static_gout)
             if self._marks is not None:
-                fired = tuple(sorted(self._marks._fired))
+                fired = self._marks.fired()
         finally:
             if self._marks is not None:
                 self._marks.sink = None

@@ -70,6 +70,11 @@ class BackwardMarks:
         self._generation += 1
         self._fired = set()
 
+    def fired(self):
+        """The boundaries whose mark the backward since the last begin() has reported (under a graph capture: the marks that ARE nodes of that graph -- a boundary
+        whose layer received no non-leaf float input has none)."""
+        return tuple(sorted(self._fired))
+
     def _make_pre_hook(self, j):
         def pre_hook(_layer, args):
             sink = self.sink
