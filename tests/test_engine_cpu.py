@@ -176,6 +176,11 @@ def _worker(rank, world, port, mode, outdir):
                 extra['dp_direct_min_bytes'] = 0
             losses, params, engine = engine_run(steps, gas, 0.5, batches, num_stages=1, extra=extra)
             overlap = dict(engine.overlap_report, boundaries=list(engine._marks.boundaries) if engine._marks is not None else None)
+        elif mode == 'dp4_overlap':
+            gas = 2
+            batches = [make_batches(4 * gas, 2, 100 + s)[rank * gas:(rank + 1) * gas] for s in range(steps)]
+            losses, params, engine = engine_run(steps, gas, 0.5, batches, num_stages=1, extra={'dp_overlap_min_bytes': 0, 'dp_overlap_marks': 3, 'dp_bucket_bytes': 1500})
+            overlap = dict(engine.overlap_report, boundaries=list(engine._marks.boundaries))
         elif mode == 'pp2dp2_overlap':   # 2 stages x 2 replicas, two pipeline lanes, marks on both stages
             d = engine_dp_rank(rank)
             batches = [make_batches(2 * gas, 2, 100 + s)[d * gas:(d + 1) * gas] for s in range(steps)]
@@ -444,6 +449,58 @@ def test_backward_marks_fire_in_descending_order_when_the_later_layers_gradients
     out = module(batches[0][0])
     oracle.default_loss_fn()(out, (batches[0][1][0], torch.tensor([]))).backward()
     assert not seen                                     # closed: no hooks left on the layers
+
+
+def test_backward_marks_choose_boundaries_by_gradient_bytes_and_refuse_arenas_out_of_layer_order():
+    """`BackwardMarks._choose`: at most max_marks boundaries, ascending, each with about total / (max_marks + 1) bytes of gradients between it and the next one, none
+    at layer 0 and none with nothing in front of it; `arena_bounds` names an offset only for an arena whose gradients lie in layer order (else nothing may start early)."""
+    from diffusion_pipe_amd.engine.overlap import BackwardMarks
+    from diffusion_pipe_amd.engine.engine import flatten_grads
+    for n_mid, max_marks in ((4, 3), (9, 2), (9, 6), (1, 6), (4, 0)):
+        layers = make_layers(n_mid=n_mid)
+        module = ManualPipelineModule(layers=layers, num_stages=1, partition_method='uniform', loss_fn=None)
+        marks = BackwardMarks(module, max_marks=max_marks, min_bytes=0)
+        b = marks.boundaries
+        per_layer = (D * D + D) * 4
+        assert len(b) <= max_marks and b == sorted(set(b)) and all(1 <= j < len(layers) for j in b)
+        want = (len(layers) * per_layer) // (max_marks + 1) if max_marks else 0
+        edges = b + [len(layers)]
+        for lo, hi in zip(edges, edges[1:]):
+            assert (hi - lo) * per_layer >= want                 # every marked range carries its share
+            assert (hi - lo - 1) * per_layer < max(want, 1)      # ... and not a layer more than needed
+        marks.close()
+    # a huge min_bytes: no boundary qualifies -> the engine switches the overlap off
+    marks = BackwardMarks(module, max_marks=3, min_bytes=1 << 30)
+    assert marks.boundaries == []
+    # arena geometry: in layer order -> suffix offsets; gradients re-homed in REVERSED parameter order -> no offsets for that arena
+    layers = make_layers(n_mid=4)
+    module = ManualPipelineModule(layers=layers, num_stages=1, partition_method='uniform', loss_fn=None)
+    marks = BackwardMarks(module, max_marks=3, min_bytes=0)
+    params = [p for l in layers for p in l.parameters()]
+    for p in params:
+        p.grad = torch.ones_like(p)
+    ordered = marks.arena_bounds(params, flatten_grads(params))
+    assert all(torch.float32 in ordered[j] for j in marks.boundaries)
+    offs = [ordered[j][torch.float32] for j in marks.boundaries]
+    assert offs == sorted(offs) and len(set(offs)) == len(offs)
+    for p in params:
+        p.grad = torch.ones_like(p)
+    shuffled = marks.arena_bounds(params, flatten_grads(list(reversed(params))))
+    assert all(shuffled[j] == {} for j in marks.boundaries)
+    marks.close()
+
+
+def test_engine_dp4_eager_overlap_matches_oracle():
+    """four replicas (gloo ring: the bucket a value travels in may change its summation order, so against the oracle with a tolerance, not bitwise)"""
+    steps, gas = 2, 2
+    batches = [make_batches(4 * gas, 2, 100 + s) for s in range(steps)]
+    want_l, want_p = oracle_run(steps, 4 * gas, 0.5, batches)
+    res = _spawn('dp4_overlap', world=4)
+    for r in res:
+        assert r['losses'] == pytest.approx(want_l, rel=1e-5)
+        for a, b in zip(r['params'], want_p):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+        assert r['overlap']['early_collectives'] > 0 and r['overlap']['marks'] == [4, 2]
 
 
 def test_engine_dp2_average_under_the_last_backward_matches_the_reduction_after_it():
